@@ -1,0 +1,251 @@
+""" TEST INFRASTRUCTURE ONLY -- numpy fp64 restatement of the *kernel-side* mathematics.
+
+The reference obtains du/dx_i and d2u/dx_i2 by nested reverse-mode autograd (model_torch.py:174-178) and the
+parameter gradient by one more reverse sweep (`loss.backward()`, :460). The HIP engine computes the same
+quantities by forward Taylor-mode "jets" through the MLP plus one hand-written reverse sweep (DESIGN.md
+section 3). This file is the plain-numpy, double-precision statement of exactly those formulas; the tests use it
+(a) to prove the formulas equal the reference's nested autograd (vs `oracle.pinn_oracle` in fp64) and
+(b) as the fp64 arbiter for the fp32 kernels.
+
+Stream order (shared with the kernels): index 0 = value; 1..ND = first derivative along direction k;
+1+ND..ND+N2 = second derivative along direction k < N2 (directions that need a second derivative come first).
+`dir_cols[k]` is the input column that direction k differentiates.
+"""
+import numpy as np
+
+
+def act_derivs(z, act):
+    """ activation value and its first three derivatives. """
+    if act == 'tanh':
+        t = np.tanh(z)
+        d1 = 1.0 - t * t
+        d2 = -2.0 * t * d1
+        d3 = d1 * (6.0 * t * t - 2.0)
+        return t, d1, d2, d3
+    if act == 'sigmoid':
+        s = 1.0 / (1.0 + np.exp(-z))
+        d1 = s * (1.0 - s)
+        d2 = d1 * (1.0 - 2.0 * s)
+        d3 = d1 * ((1.0 - 2.0 * s) ** 2 - 2.0 * d1)
+        return s, d1, d2, d3
+    raise ValueError(act)
+
+
+class Spec:
+    """ Problem descriptor: network, ansatz and requested derivative streams. """
+    def __init__(self, weights, biases, act, ndims, nparams=0, has_bc=False, bc_value=0.0, has_ic=False,
+                 domain=None, log_scale=0.0, dir_cols=(), n2=0):
+        self.W = [np.asarray(w, dtype=np.float64) for w in weights]     # [out, in] per layer (nn.Linear layout)
+        self.b = [np.asarray(b, dtype=np.float64) for b in biases]
+        self.act = act.lower()
+        self.ndims, self.nparams = ndims, nparams
+        self.has_bc, self.bc_value, self.has_ic = has_bc, float(bc_value), has_ic
+        self.nsp = ndims - 1 if has_ic else ndims
+        self.domain = [tuple(map(float, d)) for d in (domain or [(0.0, 1.0)] * ndims)]
+        self.log_scale = float(log_scale)
+        self.dir_cols, self.nd, self.n2 = list(dir_cols), len(dir_cols), n2
+        self.S = 1 + self.nd + self.n2
+
+
+def mlp_jet_forward(sp, xs):
+    """ xs [N,d] -> net streams [S,N]; cache for the reverse sweep. """
+    N = xs.shape[0]
+    L = len(sp.W)
+    cache = []
+    # layer 1: z0 = W x + b ; z_k = W[:, col_k] ; z_kk = 0
+    W, b = sp.W[0], sp.b[0]
+    z = np.zeros((sp.S, N, W.shape[0]))
+    z[0] = xs @ W.T + b
+    for k, c in enumerate(sp.dir_cols):
+        z[1 + k] = W[:, c][None, :]
+    h_prev = None
+    for l in range(L - 1):
+        if l > 0:
+            W, b = sp.W[l], sp.b[l]
+            z = np.einsum('snk,ok->sno', h_prev, W)
+            z[0] += b
+        t, d1, d2, d3 = act_derivs(z[0], sp.act)
+        h = np.zeros_like(z)
+        h[0] = t
+        for k in range(sp.nd):
+            h[1 + k] = d1 * z[1 + k]
+        for k in range(sp.n2):
+            h[1 + sp.nd + k] = d2 * z[1 + k] ** 2 + d1 * z[1 + sp.nd + k]
+        cache.append((h_prev, z, d1, d2, d3))
+        h_prev = h
+    W, b = sp.W[L - 1], sp.b[L - 1]
+    net = np.einsum('snk,ok->sno', h_prev, W)[:, :, 0]
+    net[0] += b[0]
+    return net, (cache, h_prev, xs)
+
+
+def mlp_jet_backward(sp, gnet, fwd_cache):
+    """ gnet [S,N] = dLoss/dnet streams -> (dW list, db list). """
+    cache, h_last, xs = fwd_cache
+    L = len(sp.W)
+    dW = [None] * L
+    db = [None] * L
+    dW[L - 1] = np.einsum('sn,snk->k', gnet, h_last)[None, :]
+    db[L - 1] = np.array([gnet[0].sum()])
+    gh = gnet[:, :, None] * sp.W[L - 1][0][None, None, :]
+    for l in range(L - 2, -1, -1):
+        h_prev, z, d1, d2, d3 = cache[l]
+        gz = np.zeros_like(gh)
+        acc = d1 * gh[0]
+        for k in range(sp.nd):
+            zk = z[1 + k]
+            gz[1 + k] = d1 * gh[1 + k]
+            acc = acc + d2 * zk * gh[1 + k]
+            if k < sp.n2:
+                zkk, ghkk = z[1 + sp.nd + k], gh[1 + sp.nd + k]
+                gz[1 + sp.nd + k] = d1 * ghkk
+                gz[1 + k] += 2.0 * d2 * zk * ghkk
+                acc = acc + (d3 * zk * zk + d2 * zkk) * ghkk
+        gz[0] = acc
+        db[l] = gz[0].sum(axis=0)
+        if l > 0:
+            dW[l] = np.einsum('sno,snk->ok', gz, h_prev)
+            gh = np.einsum('sno,ok->snk', gz, sp.W[l])
+        else:
+            g = gz[0].T @ xs                                             # value stream: z0 = W x + b
+            for k, c in enumerate(sp.dir_cols):
+                g[:, c] += gz[1 + k].sum(axis=0)                         # z_k = W[:, col_k]
+            dW[0] = g
+    return dW, db
+
+
+def _bc_factors(sp, xs):
+    """ P and, per direction, dP/dx_c and d2P/dx_c2 (zero unless the direction is a spatial column). """
+    N = xs.shape[0]
+    p = np.ones((sp.nsp, N)); p1 = np.zeros((sp.nsp, N)); p2 = np.zeros((sp.nsp, N))
+    for j in range(sp.nsp):
+        lo, hi = sp.domain[j]
+        w = hi - lo
+        p[j] = ((xs[:, j] - lo) / w) * ((hi - xs[:, j]) / w)
+        p1[j] = (lo + hi - 2.0 * xs[:, j]) / (w * w)
+        p2[j] = -2.0 / (w * w)
+    P = np.prod(p, axis=0) if sp.nsp else np.ones(N)
+    Pk = np.zeros((sp.nd, N)); Pkk = np.zeros((sp.nd, N))
+    for k, c in enumerate(sp.dir_cols):
+        if c < sp.nsp:
+            rest = np.ones(N)
+            for j in range(sp.nsp):
+                if j != c:
+                    rest = rest * p[j]
+            Pk[k] = p1[c] * rest
+            Pkk[k] = p2[c] * rest
+    return P, Pk, Pkk
+
+
+def _ic_gate(sp, xs):
+    """ G = sigmoid(tau) - 1/2, its t-derivatives per direction and its log_scale-derivatives. """
+    N = xs.shape[0]
+    tcol = sp.ndims - 1
+    t0 = sp.domain[-1][0]
+    es = np.exp(-sp.log_scale)
+    tau = (xs[:, tcol] - t0) * es
+    s, d1, d2, d3 = act_derivs(tau, 'sigmoid')
+    G = s - 0.5
+    Gk = np.zeros((sp.nd, N)); Gkk = np.zeros((sp.nd, N))
+    dG_ds = -tau * d1
+    dGk_ds = np.zeros((sp.nd, N)); dGkk_ds = np.zeros((sp.nd, N))
+    for k, c in enumerate(sp.dir_cols):
+        if c == tcol:
+            Gk[k] = d1 * es
+            Gkk[k] = d2 * es * es
+            dGk_ds[k] = es * (-tau * d2 - d1)
+            dGkk_ds[k] = es * es * (-tau * d3 - 2.0 * d2)
+    return G, Gk, Gkk, dG_ds, dGk_ds, dGkk_ds
+
+
+def ansatz_forward(sp, net, xs, ic_streams=None):
+    """ net streams [S,N] -> u streams [S,N] (reference model_torch.py:107-128 + product rule). """
+    nd, n2 = sp.nd, sp.n2
+    Q = net.copy()
+    bc = None
+    if sp.has_bc:
+        P, Pk, Pkk = _bc_factors(sp, xs)
+        bc = (P, Pk, Pkk)
+        Q[0] = net[0] * P + sp.bc_value
+        for k in range(nd):
+            Q[1 + k] = net[1 + k] * P + net[0] * Pk[k]
+        for k in range(n2):
+            Q[1 + nd + k] = net[1 + nd + k] * P + 2.0 * net[1 + k] * Pk[k] + net[0] * Pkk[k]
+    u = Q.copy()
+    gate = None
+    if sp.has_ic:
+        gate = _ic_gate(sp, xs)
+        G, Gk, Gkk = gate[:3]
+        u[0] = G * Q[0]
+        for k in range(nd):
+            u[1 + k] = Gk[k] * Q[0] + G * Q[1 + k]
+        for k in range(n2):
+            u[1 + nd + k] = Gkk[k] * Q[0] + 2.0 * Gk[k] * Q[1 + k] + G * Q[1 + nd + k]
+        if ic_streams is not None:
+            u = u + ic_streams
+    return u, (net, Q, bc, gate)
+
+
+def ansatz_backward(sp, gu, cache):
+    """ gu [S,N] -> (gnet [S,N], d log_scale). """
+    net, Q, bc, gate = cache
+    nd, n2 = sp.nd, sp.n2
+    gQ = gu.copy()
+    g_ls = 0.0
+    if sp.has_ic:
+        G, Gk, Gkk, dG, dGk, dGkk = gate
+        gG = gu[0] * Q[0]
+        gQ[0] = gu[0] * G
+        for k in range(nd):
+            gG = gG + gu[1 + k] * Q[1 + k]
+            gGk = gu[1 + k] * Q[0]
+            gQ[0] = gQ[0] + gu[1 + k] * Gk[k]
+            gQ[1 + k] = gu[1 + k] * G
+            if k < n2:
+                gkk = gu[1 + nd + k]
+                gG = gG + gkk * Q[1 + nd + k]
+                gGk = gGk + 2.0 * gkk * Q[1 + k]
+                g_ls += np.sum(gkk * Q[0] * dGkk[k])
+                gQ[0] = gQ[0] + gkk * Gkk[k]
+                gQ[1 + k] = gQ[1 + k] + 2.0 * gkk * Gk[k]
+                gQ[1 + nd + k] = gkk * G
+            g_ls += np.sum(gGk * dGk[k])
+        g_ls += np.sum(gG * dG)
+    gnet = gQ.copy()
+    if sp.has_bc:
+        P, Pk, Pkk = bc
+        gnet[0] = gQ[0] * P
+        for k in range(nd):
+            gnet[0] = gnet[0] + gQ[1 + k] * Pk[k]
+            gnet[1 + k] = gQ[1 + k] * P
+            if k < n2:
+                gkk = gQ[1 + nd + k]
+                gnet[0] = gnet[0] + gkk * Pkk[k]
+                gnet[1 + k] = gnet[1 + k] + 2.0 * gkk * Pk[k]
+                gnet[1 + nd + k] = gkk * P
+    return gnet, g_ls
+
+
+def step(sp, xs, residual, ic_streams=None, n_global=None):
+    """ One residual + grad evaluation.  `residual(u_streams, xs) -> (r [N], dr/du_streams [S,N])`.
+    Returns dict(u, r, loss, dW, db, dlog_scale, u_streams). """
+    xs = np.asarray(xs, dtype=np.float64)
+    n_global = n_global or xs.shape[0]
+    net, fcache = mlp_jet_forward(sp, xs)
+    u, acache = ansatz_forward(sp, net, xs, ic_streams)
+    r, dr_du = residual(u, xs)
+    loss = np.sum(r * r) / n_global
+    gu = dr_du * (2.0 * r / n_global)[None, :]
+    gnet, g_ls = ansatz_backward(sp, gu, acache)
+    dW, db = mlp_jet_backward(sp, gnet, fcache)
+    return dict(u=u[0], r=r, loss=loss, dW=dW, db=db, dlog_scale=g_ls, u_streams=u, gu=gu)
+
+
+def adam_update(p, g, m, v, step_no, lr=0.005, b1=0.9, b2=0.999, eps=1e-8):
+    """ torch.optim.Adam single-tensor form (defaults: no weight decay, no amsgrad). """
+    m[:] = b1 * m + (1 - b1) * g
+    v[:] = b2 * v + (1 - b2) * g * g
+    bc1 = 1 - b1 ** step_no
+    bc2 = 1 - b2 ** step_no
+    denom = np.sqrt(v) / np.sqrt(bc2) + eps
+    p[:] = p - (lr / bc1) * m / denom

@@ -1,0 +1,61 @@
+""" The five BASELINE.json workloads in pydens form (equation callable + Solver kwargs + point sampler).
+
+Neutral module: depends on neither the product package nor the oracle. `D` and `torch` are passed in so the
+same definitions drive the reference, the oracle and the HIP engine. Column order is pydens' (spatial..., t,
+params...) -- reference model_torch.py:111 -- so BASELINE's "(t,x,y)" heat config is (x,y,t) here.
+"""
+import math
+import numpy as np
+
+PI = math.pi
+
+
+def mlp(depth, width):
+    return dict(layout='fa' * depth + 'f', features=[width] * depth + [1], activation='Tanh')
+
+
+def make_config(name, D, torch):
+    """ -> dict(equation, solver_kwargs, n_points, low, high, dir_cols, n2) """
+    if name in ('cfg1', 'cfg2'):
+        def equation(f, x, y):                                   # reference README.md:36-37
+            return D(D(f, x), x) + D(D(f, y), y) - 5 * torch.sin(PI * (x + y))
+        net = (dict(layout='fa fa fa f', features=[10, 12, 15, 1], activation='Tanh') if name == 'cfg1'
+               else mlp(4, 64))
+        return dict(equation=equation, solver_kwargs=dict(ndims=2, boundary_condition=1, **net),
+                    n_points=100 if name == 'cfg1' else 65536, low=[0, 0], high=[1, 1])
+    if name == 'cfg3':
+        def equation(f, x, y, t):                                # tutorial heat equation with a == 1
+            return D(D(f, x), x) + D(D(f, y), y) - D(f, t)
+        return dict(equation=equation,
+                    solver_kwargs=dict(ndims=3, boundary_condition=0,
+                                       initial_condition=lambda x, y: 10 * x * y * (1 - x) * (1 - y), **mlp(5, 128)),
+                    n_points=262144, low=[0, 0, 0], high=[1, 1, 1])
+    if name == 'cfg4':
+        def equation(f, x, e):                                   # reference README.md:78-79
+            return D(f, x) - e * PI * torch.cos(e * PI * x)
+        return dict(equation=equation, solver_kwargs=dict(ndims=1, nparams=1, initial_condition=1, **mlp(4, 64)),
+                    n_points=1048576, low=[0, 1], high=[1, 5])
+    if name == 'cfg5':
+        def equation(f, x, t):                                   # reference model_torch.py:237-239 (IC docstring)
+            return D(D(f, t), t) - D(D(f, x), x)
+        return dict(equation=equation,
+                    solver_kwargs=dict(ndims=2, boundary_condition=0, initial_condition=lambda x: x * (1 - x),
+                                       **mlp(6, 256)),
+                    n_points=1048576, low=[0, 0], high=[1, 1])
+    if name == 'ode_sigmoid':                                    # tutorial cells 28-31: default net [20,30,1] Sigmoid
+        def equation(f, x, e):
+            return D(f, x) - e * PI * torch.cos(e * PI * x)
+        return dict(equation=equation, solver_kwargs=dict(ndims=1, nparams=1, initial_condition=2.0),
+                    n_points=700, low=[0, .5], high=[1, 5.5])
+    raise KeyError(name)
+
+
+CONFIG_NAMES = ('cfg1', 'cfg2', 'cfg3', 'cfg4', 'cfg5')
+
+
+def sample_points(cfg, n, seed, steps=None):
+    """ U[low, high)^d fp32 points, [n,d] or [steps,n,d]. """
+    rng = np.random.RandomState(seed)
+    low, high = np.asarray(cfg['low'], dtype=np.float64), np.asarray(cfg['high'], dtype=np.float64)
+    shape = (n, len(low)) if steps is None else (steps, n, len(low))
+    return (low + (high - low) * rng.rand(*shape)).astype(np.float32)
