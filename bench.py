@@ -1,0 +1,170 @@
+""" bench.py -- collocation-points/sec of the full residual + grad + Adam step (BASELINE.json metric).
+
+Workload at every N: BASELINE config 2 (2D Poisson, 4x64 Tanh MLP, batch 65 536 points PER GPU, weak scaling);
+a "step" = one fused pinn_residual_step (forward jets, ansatz, residual, MSE, reverse sweep) + gradient
+all-reduce over RCCL (N > 1) + pinn_adam_step, on point batches already resident in HBM.
+
+    python bench.py --gpus 1 --steps 100 --warmup 20
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
+        bench.py --gpus N --steps K --warmup W
+
+Prints ONE JSON line (rank 0). `roofline`: algorithmic FLOPs of the dominant kernel (pinn_tile_kernel) per launch
+= F * points, F = 6*S*sum_{l>=2}(in*out) + 4*d*H1, over its mean launch duration measured with HIP
+events on the launch stream (pinn_profile_tile), against the fp32 MFMA peak of MI355X (157.3 TFLOP/s).
+`cpu_baseline`: the oracle restatement of the reference step (oracle/pinn_oracle.py, torch CPU ops, all host
+cores) timed in the same run on a bounded sample of the same workload.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+import numpy as np      # noqa: E402
+import torch            # noqa: E402
+
+import pinn_configs as pc       # noqa: E402
+
+PEAK_FP32_MFMA_TFLOPS = 157.3   # /opt/skills/guides/MI355X_MICROARCH.md "Peak FP32 (matrix)"
+WORKLOAD = 'cfg2'
+BATCH_PER_GPU = 65536
+POOL = 8                        # distinct pre-generated point batches cycled through
+
+
+def flops_per_point(layer_dims, n_streams):
+    d, h1 = layer_dims[0], layer_dims[1]
+    inner = sum(a * b for a, b in zip(layer_dims[1:-1], layer_dims[2:]))
+    return 6 * n_streams * inner + 4 * d * h1
+
+
+def cpu_baseline(n_points, steps):
+    """ oracle (port of the reference step) on the host cores; bounded sample of the same workload. """
+    from oracle import pinn_oracle as po
+    torch.set_num_threads(os.cpu_count() or 1)
+    cfg = pc.make_config(WORKLOAD, po.D, torch)
+    solver = po.OracleSolver(cfg['equation'], **cfg['solver_kwargs'])
+    pts = pc.sample_points(cfg, n_points, seed=0, steps=steps + 1)
+    solver.fit(niters=1, batch_size=n_points, points=pts[:1])
+    t0 = time.perf_counter()
+    solver.fit(niters=steps, batch_size=n_points, points=pts[1:])
+    dt = time.perf_counter() - t0
+    return dict(value=n_points * steps / dt, unit='points/s', cores=torch.get_num_threads(), kind='port',
+                sample=f'{steps} Solver.fit iterations of {WORKLOAD} at batch {n_points} '
+                       f'(oracle/pinn_oracle.py, torch {torch.__version__} CPU ops, fp32), {dt:.1f} s')
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--gpus', type=int, default=1)
+    ap.add_argument('--steps', type=int, default=100)
+    ap.add_argument('--warmup', type=int, default=20)
+    ap.add_argument('--batch', type=int, default=BATCH_PER_GPU)
+    ap.add_argument('--no-cpu-baseline', action='store_true')
+    args = ap.parse_args()
+
+    import pydens_amd as pa
+
+    world = int(os.environ.get('WORLD_SIZE', '1'))
+    rank = int(os.environ.get('RANK', '0'))
+    local_rank = int(os.environ.get('LOCAL_RANK', '0'))
+    if args.gpus != world:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit('launch with torch.distributed.run --nproc-per-node N for --gpus N')
+    torch.cuda.set_device(local_rank)
+    device = torch.device('cuda', local_rank)
+    dist = torch.distributed
+    if world > 1:
+        dist.init_process_group('nccl', device_id=device)
+
+    torch.manual_seed(0)
+    cfg = pc.make_config(WORKLOAD, pa.D, torch)
+    solver = pa.Solver(cfg['equation'], **cfg['solver_kwargs'], device=device)
+    assert solver.program is not None, solver.program_error
+    model, spec = solver.model, solver.spec
+    lay = model.net.layout
+    n = args.batch
+    gen = torch.Generator(device=device)
+    gen.manual_seed(1234 + rank)
+    pool = [torch.rand((n, model.total), dtype=torch.float32, device=device, generator=gen) for _ in range(POOL)]
+
+    from pydens_amd.solver import FlatAdam
+    solver.optimizer = FlatAdam(model, lr=0.005)
+    solver.optimizer.refresh()
+    if world > 1:
+        dist.broadcast(model.flat, src=0)
+
+    def step(i):
+        solver._fused_step(pool[i % POOL], world)
+        if world > 1:
+            dist.all_reduce(solver.grads)
+        solver.optimizer.step(solver.grads)
+
+    for i in range(args.warmup):
+        step(i)
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for i in range(args.steps):
+        step(i)
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    t = torch.tensor([dt], dtype=torch.float64, device=device)
+    if world > 1:
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    dt = float(t.item())
+    loss = float(solver.grads[lay.off_loss].item())
+
+    # dominant-kernel duration, measured live with HIP events around the tile-kernel launch (separate pass)
+    tile_ms = None
+    if rank == 0:
+        lib = model.net.lib
+        lib.pinn_profile_tile(1)
+        samples = []
+        for i in range(min(args.steps, 50)):
+            solver._fused_step(pool[i % POOL], world)
+            samples.append(float(lib.pinn_last_tile_ms()))
+        lib.pinn_profile_tile(0)
+        tile_ms = float(np.mean(samples))
+    if world > 1:
+        dist.barrier()
+
+    if rank == 0:
+        f_pt = flops_per_point(model.layer_dims, spec.n_streams)
+        achieved = f_pt * n / (tile_ms * 1e-3) / 1e12
+        out = {
+            'metric': 'collocation-points/sec (residual+grad+Adam step)',
+            'value': n * world * args.steps / dt,
+            'unit': 'points/s',
+            'n_gpus': world,
+            'steps': args.steps,
+            'warmup': args.warmup,
+            'ms_per_step': dt / args.steps * 1e3,
+            'higher_is_better': True,
+            'scaling': 'weak',
+            'vs_baseline': None,
+            'dtype': 'f32',
+            'data': 'synthetic (U[0,1)^2 points resident in HBM, PyTorch-default random-init weights, seed 0)',
+            'config': {'workload': 'BASELINE cfg2: 2D Poisson u_xx+u_yy=5sin(pi(x+y)), BC=1, 4x64 Tanh MLP, '
+                                   f'{n} collocation points per GPU per step, Adam lr 0.005',
+                       'points_per_gpu': n, 'global_points': n * world, 'streams': spec.n_streams,
+                       'parallelism': f'dp{world}', 'step_path': 'fused'},
+            'final_loss': loss,
+            'roofline': {'bound': 'mfma', 'kernel': 'pinn_tile_kernel<64,2,2,1>', 'achieved': achieved,
+                         'peak': PEAK_FP32_MFMA_TFLOPS, 'unit': 'TFLOP/s', 'frac': achieved / PEAK_FP32_MFMA_TFLOPS,
+                         'flops_per_point': f_pt, 'kernel_ms': tile_ms, 'traffic': None},
+        }
+        if not args.no_cpu_baseline:
+            out['cpu_baseline'] = cpu_baseline(65536, 15)
+        print(json.dumps(out))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == '__main__':
+    main()

@@ -1,0 +1,143 @@
+/* pinn.h -- C-ABI of the MI355X-native PINN step engine (libpinn_hip.so).
+ *
+ * Drop-in boundary for the hot path of pydens `Solver.fit` / `Solver.predict`
+ * (reference pydens/model_torch.py:426-464 and :466-487).  The reference has no FFI of its own: every
+ * FLOP of its step is an ATen CPU op driven from Python.  Each entry point below names the reference
+ * lines whose arithmetic it replaces; the Python host (`pydens_amd`) binds them with ctypes
+ * (`pydens_amd/engine.py`), INTEGRATION.md shows the stub a pydens maintainer would add.
+ *
+ * Conventions
+ *   - plain pointers and sizes only; every pointer is DEVICE memory owned by the caller (torch tensors
+ *     in the Python host); the library allocates nothing on the step path and never synchronises;
+ *   - all work is enqueued on `stream` (a hipStream_t passed as void*; NULL = default stream);
+ *   - return value 0 = ok, non-zero = error, text via pinn_last_error(); nothing throws across the ABI;
+ *   - all arithmetic is IEEE fp32 (the reference computes in fp32: model_torch.py:35,113,167,353-359,433).
+ *
+ * Parameter buffer ("flat padded layout", all fp32, described by pinn_layout()):
+ *     W1 [HP][d]  b1 [HP]  { Wh_l [HP][HP]  bh_l [HP] } l=0..LH-1   WL [HP]  bL  log_scale  loss_slot  pad
+ *     followed by PINN_EXTRA_SLOTS user slots (trainable V(...) scalars, model_torch.py:180-188).
+ *   HP = hidden width rounded up to a multiple of 16 (MFMA tile), LH = number of hidden->hidden layers.
+ *   nn.Linear's [out,in] row-major weight of every layer is the top-left block of its padded matrix, so the
+ *   host exposes per-layer nn.Parameter views into this one buffer; padded entries stay zero (Adam mask).
+ *   Gradient buffers use the same layout; `loss_slot` receives sum(r^2)/N of the step.
+ *
+ * Derivative streams (what D(...) needs, model_torch.py:174-178): stream 0 = u; 1..nd = du/dx_c along
+ * direction k (input column dir_cols[k]); 1+nd..nd+n2 = d2u/dx_c2 for the first n2 directions.
+ * Stream arrays are stream-major: [S][N], S = 1 + nd + n2.
+ */
+#ifndef PINN_H
+#define PINN_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define PINN_MAX_LAYERS   16   /* linear layers */
+#define PINN_MAX_INPUTS   8    /* ndims + nparams */
+#define PINN_MAX_DIRS     3    /* differentiated input columns */
+#define PINN_EXTRA_SLOTS  16
+#define PINN_MAX_OPS      64   /* residual program length */
+#define PINN_MAX_CONSTS   32
+#define PINN_MAX_REGS     40   /* residual program registers (inputs included) */
+
+#define PINN_ACT_TANH     0
+#define PINN_ACT_SIGMOID  1
+
+typedef struct pinn_net pinn_t;
+
+typedef struct pinn_layout {
+    int hp;             /* padded hidden width */
+    int lh;             /* hidden->hidden layers */
+    int d;              /* input columns */
+    int off_w1, off_b1; /* first layer: W1 row stride = d */
+    int off_wh;         /* first hidden block; block l at off_wh + l*hidden_stride; W row stride = hp, bias at +hp*hp */
+    int hidden_stride;
+    int off_wl, off_bl; /* last layer (out = 1) */
+    int off_log_scale, off_loss;
+    int p_core;         /* floats up to and including loss_slot + pad (what the kernels reduce) */
+    int off_extra;      /* first user slot */
+    int p_total;        /* p_core + PINN_EXTRA_SLOTS: length of params / grads / Adam-state buffers */
+} pinn_layout_t;
+
+/* Residual program: the user's equation (model_torch.py:447-448 `criterion(equation(u_hat, *xs), 0)`) traced
+ * by the host into straight-line code over per-point registers.  Registers 0..S-1 hold the u streams,
+ * S..S+d-1 the input columns; instruction i writes register S+d+i... (dst is explicit).  The value of the
+ * last instruction is the residual r.  word = op | dst<<8 | a<<16 | b<<24; PINN_OP_CONST reads consts[a]. */
+enum pinn_op {
+    PINN_OP_CONST = 0, PINN_OP_ADD, PINN_OP_SUB, PINN_OP_MUL, PINN_OP_DIV, PINN_OP_NEG,
+    PINN_OP_SIN, PINN_OP_COS, PINN_OP_EXP, PINN_OP_LOG, PINN_OP_TANH, PINN_OP_SQRT,
+    PINN_OP_POW,      /* a ** consts[b] */
+    PINN_OP_ABS, PINN_OP_SIGMOID, PINN_OP_RECIP, PINN_OP_COPY
+};
+
+typedef struct pinn_program {
+    int n_ops;
+    int n_consts;
+    uint32_t code[PINN_MAX_OPS];
+    float consts[PINN_MAX_CONSTS];
+} pinn_program_t;
+
+/* Descriptor of network + ansatz.  Replaces ConvBlockModel.__init__/TorchModel.__init__ bookkeeping
+ * (model_torch.py:19-50, :158-168).  layer_dims[0] = ndims+nparams, layer_dims[n_layers] = 1.
+ * dom_lo/dom_hi: per-dimension domain limits (model_torch.py:37-46), length ndims.  has_bc/bc_value and has_ic
+ * select the ansatz of model_torch.py:107-128 (ndims_spatial = ndims-1 iff has_ic, :25). */
+int pinn_create(const int* layer_dims, int n_layers, int act, int ndims, int nparams,
+                int has_bc, int has_ic, const float* dom_lo, const float* dom_hi, float bc_value,
+                pinn_t** out);
+int pinn_destroy(pinn_t* net);
+int pinn_layout(const pinn_t* net, pinn_layout_t* out);
+
+/* Bytes of scratch the step/backward entry points need for n_points (per-workgroup partial gradients +
+ * activation slab).  Caller allocates once (torch tensor) and reuses it. */
+size_t pinn_workspace_bytes(const pinn_t* net, int64_t n_points, int nd, int n2);
+
+/* Value + derivative streams of the ansatz-transformed network on given points.
+ * Replaces ConvBlockModel.forward (model_torch.py:170-172) + anzatc (:107-128) and, for nd>0, the nested
+ * autograd sweeps of D (:174-178).  xs [N][d] row-major; ic_streams [S][N] or NULL (then ic_const is the
+ * constant initial condition, :31-35); streams_out [S][N].  nd = n2 = 0 is `Solver.predict` (:482-487). */
+int pinn_jet_forward(pinn_t* net, const float* params, const float* xs, int64_t n_points,
+                     const int* dir_cols, int nd, int n2, const float* ic_streams, float ic_const,
+                     float* streams_out, void* stream);
+
+/* Parameter gradient for given upstream stream gradients: grads[p_core] (+)= d(sum_{s,n} grad_streams*streams)/dparams.
+ * Replaces `loss.backward()` (model_torch.py:460) for equations the host evaluates itself (generic path) and for
+ * constraint terms (:451-457).  The forward jets are recomputed inside the kernel (no state kept between
+ * pinn_jet_forward and this call).  accumulate != 0 adds into grads. */
+int pinn_jet_backward(pinn_t* net, const float* params, const float* xs, int64_t n_points,
+                      const int* dir_cols, int nd, int n2, const float* ic_streams, float ic_const,
+                      const float* grad_streams, float* grads, int accumulate, void* workspace, size_t workspace_bytes,
+                      void* stream);
+
+/* One fused residual + gradient evaluation: forward jets, ansatz, residual program, mean-square loss and the
+ * full reverse sweep, in one launch (+ a reduction launch).  Replaces model_torch.py:437-460
+ * (forward, equation, MSELoss vs zeros, backward).  grads[0..p_core) receives d(loss)/dparams with
+ * loss = inv_n_global * sum r^2 over THIS call's points (data-parallel ranks pass 1/N_global and all-reduce
+ * the buffer); grads[off_loss] receives this call's share of the loss. */
+int pinn_residual_step(pinn_t* net, const pinn_program_t* program, const float* params, const float* xs,
+                       int64_t n_points, const int* dir_cols, int nd, int n2, const float* ic_streams,
+                       float ic_const, float inv_n_global, float* grads, void* workspace, size_t workspace_bytes,
+                       void* stream);
+
+/* torch.optim.Adam.step (model_torch.py:461; defaults beta=(0.9,0.999), eps=1e-8, no weight decay) on the flat
+ * buffer.  mask[i]==0 freezes entry i (padding, frozen layers/variables: model_torch.py:56-105, :420-421).
+ * `step` is the 1-based step count read from device memory (step_ptr[0], int32) so that the call can be
+ * replayed from a hipGraph; the kernel increments it. */
+int pinn_adam_step(float* params, const float* grads, float* exp_avg, float* exp_avg_sq, const uint8_t* mask,
+                   int64_t n, int32_t* step_ptr, float lr, float beta1, float beta2, float eps, void* stream);
+
+/* Measurement hook (bench.py `roofline`): with enable != 0 the step/backward entry points bracket their TILE
+ * kernel launch with hipEvents on the launch stream; pinn_last_tile_ms() waits for the last bracket and returns
+ * its duration in milliseconds (negative if none). Off by default; never used on the training path. */
+int pinn_profile_tile(int enable);
+float pinn_last_tile_ms(void);
+
+const char* pinn_last_error(void);
+const char* pinn_backend(void);   /* "hip-gfx950" for the product library */
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,71 @@
+""" Builds pydens_amd/libpinn_hip.so for gfx950 with hipcc (cross-compiles without a GPU).
+
+One translation unit per padded hidden width (pinn_inst.inc with -DPINN_INST_HP=...) plus the C-ABI unit,
+compiled in parallel, linked into one shared library that sits in-tree next to the Python package so that it
+travels to the GPU box with the source snapshot.
+"""
+import os
+import shutil
+import subprocess
+import sys
+from concurrent.futures import ThreadPoolExecutor
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+PKG = os.path.dirname(HERE)
+OUT = os.path.join(PKG, 'libpinn_hip.so')
+OBJ = os.path.join(HERE, '_obj')
+WIDTHS = (16, 32, 64, 128)
+FLAGS = ['--offload-arch=gfx950', '-O3', '-std=c++17', '-fPIC', '-x', 'hip', '-Wno-unused-result']
+
+
+def _sources():
+    deps = [os.path.join(HERE, f) for f in os.listdir(HERE) if f.endswith(('.h', '.inc', '.cpp'))]
+    deps.append(os.path.join(os.path.dirname(PKG), 'include', 'pinn.h'))
+    return deps
+
+
+def _stale(target, deps):
+    if not os.path.exists(target):
+        return True
+    t = os.path.getmtime(target)
+    return any(os.path.getmtime(d) > t for d in deps)
+
+
+def build(force=False, verbose=False, extra_flags=()):
+    hipcc = shutil.which('hipcc') or '/opt/rocm/bin/hipcc'
+    deps = _sources()
+    if not force and not _stale(OUT, deps):
+        return OUT
+    os.makedirs(OBJ, exist_ok=True)
+    jobs = []
+    for hp in WIDTHS:
+        obj = os.path.join(OBJ, f'inst_hp{hp}.o')
+        jobs.append((obj, [hipcc, *FLAGS, *extra_flags, f'-DPINN_INST_HP={hp}', '-c', os.path.join(HERE, 'pinn_inst.inc'), '-o', obj]))
+    obj = os.path.join(OBJ, 'abi.o')
+    jobs.append((obj, [hipcc, *FLAGS, *extra_flags, '-c', os.path.join(HERE, 'pinn_abi.cpp'), '-o', obj]))
+
+    def run(job):
+        obj, cmd = job
+        if not force and not _stale(obj, deps):
+            return obj
+        if verbose:
+            print(' '.join(cmd), flush=True)
+        res = subprocess.run(cmd, capture_output=True, text=True)
+        if res.returncode != 0:
+            raise RuntimeError(f'hipcc failed for {obj}:\n{res.stdout}\n{res.stderr}')
+        if verbose and res.stderr.strip():
+            print(res.stderr)
+        return obj
+
+    with ThreadPoolExecutor(max_workers=min(len(jobs), os.cpu_count() or 4)) as pool:
+        objs = list(pool.map(run, jobs))
+    cmd = [hipcc, '--offload-arch=gfx950', '-shared', '-fPIC', '-o', OUT + '.tmp', *objs]
+    res = subprocess.run(cmd, capture_output=True, text=True)
+    if res.returncode != 0:
+        raise RuntimeError(f'link failed:\n{res.stdout}\n{res.stderr}')
+    os.replace(OUT + '.tmp', OUT)
+    return OUT
+
+
+if __name__ == '__main__':
+    print(build(force='--force' in sys.argv, verbose=True))

@@ -1,0 +1,338 @@
+// pinn_abi.cpp -- C-ABI of libpinn_hip.so (declared in include/pinn.h): descriptor, layout, launch dispatch.
+// Built with hipcc for gfx950 (product) or, with -DPINN_EMU, as tests/emu/_build/libpinn_emu.so (test only).
+#include "pinn_inst.h"
+#include "pinn_aux_kernels.h"
+
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <new>
+
+namespace {
+thread_local char g_err[512] = "";
+
+int fail(const char* fmt, ...) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof(g_err), fmt, ap);
+    va_end(ap);
+    return 1;
+}
+
+int round16(int v) { return (v + 15) / 16 * 16; }
+
+int g_profile = 0;
+bool g_have_bracket = false;
+#ifndef PINN_EMU
+hipEvent_t g_ev0 = nullptr, g_ev1 = nullptr;
+#endif
+}  // namespace
+
+struct pinn_net {
+    pinn_layout_t lay;
+    int n_layers, act, ndims, nparams, has_bc, has_ic, nsp;
+    int dims[PINN_MAX_LAYERS + 1];
+    float lo[PINN_MAX_INPUTS], hi[PINN_MAX_INPUTS], bc_value;
+    int n_cu;
+};
+
+namespace {
+typedef int (*launch_fn)(int, int, const PinnKArgs*, int, void*, int, long long*);
+
+launch_fn launcher_for(int hp) {
+    switch (hp) {
+        case 16: return pinn_launch_tile_hp16;
+        case 32: return pinn_launch_tile_hp32;
+        case 64: return pinn_launch_tile_hp64;
+        case 128: return pinn_launch_tile_hp128;
+        default: return nullptr;
+    }
+}
+
+// smallest compiled (nd, n2k) with n2k >= n2 (extra second-derivative streams get zero upstream gradient)
+int pick_n2(int nd, int n2) {
+    static const int avail[4][4] = {{1, 0, 0, 0}, {1, 1, 0, 0}, {1, 0, 1, 0}, {0, 0, 1, 1}};
+    if (nd < 0 || nd > 3 || n2 < 0 || n2 > nd) return -1;
+    for (int k = n2; k <= nd; ++k)
+        if (avail[nd][k]) return k;
+    return -1;
+}
+
+struct Plan {
+    launch_fn fn;
+    int n2k, grid, threads;
+    size_t smem, slab_vec4_per_wg;
+};
+
+int make_plan(const pinn_net* net, int64_t n_points, int nd, int n2, Plan* plan) {
+    plan->fn = launcher_for(net->lay.hp);
+    if (!plan->fn) return fail("no kernel for padded hidden width %d (supported: 16, 32, 64, 128)", net->lay.hp);
+    plan->n2k = pick_n2(nd, n2);
+    if (plan->n2k < 0) return fail("unsupported derivative spec nd=%d n2=%d (nd <= 3, n2 <= nd)", nd, n2);
+    PinnKArgs probe;
+    memset(&probe, 0, sizeof(probe));
+    probe.lh = net->lay.lh;
+    long long info[4];
+    if (plan->fn(nd, plan->n2k, &probe, 0, nullptr, 1, info)) return fail("kernel query failed");
+    plan->smem = (size_t)info[0];
+    plan->threads = (int)info[1];
+    plan->slab_vec4_per_wg = (size_t)info[2];
+    const int64_t ntiles = (n_points + 15) / 16;
+    int64_t grid = (int64_t)net->n_cu * info[3];
+    if (grid > ntiles) grid = ntiles;
+    if (grid < 1) grid = 1;
+    plan->grid = (int)grid;
+    return 0;
+}
+
+void fill_args(const pinn_net* net, PinnKArgs* a, const float* params, const float* xs, int64_t n, const int* dir_cols,
+               int nd, int n2, const float* ic_streams, float ic_const) {
+    memset(a, 0, sizeof(*a));
+    const pinn_layout_t& L = net->lay;
+    a->params = params; a->xs = xs; a->ic_streams = ic_streams; a->n_points = n;
+    a->lh = L.lh; a->d = L.d; a->act = net->act;
+    a->off_b1 = L.off_b1; a->off_wh = L.off_wh; a->hidden_stride = L.hidden_stride; a->off_wl = L.off_wl;
+    a->off_bl = L.off_bl; a->off_ls = L.off_log_scale; a->off_loss = L.off_loss; a->p_core = L.p_core;
+    a->ndims = net->ndims; a->nsp = net->nsp; a->has_bc = net->has_bc; a->has_ic = net->has_ic;
+    a->bc_value = net->bc_value; a->t0 = net->lo[net->ndims - 1]; a->ic_const = ic_const;
+    for (int i = 0; i < PINN_MAX_INPUTS; ++i) { a->lo[i] = net->lo[i]; a->hi[i] = net->hi[i]; }
+    for (int k = 0; k < PINN_MAX_DIRS; ++k) a->dir_cols[k] = (k < nd) ? dir_cols[k] : 0;
+    a->s_user = 1 + nd + n2;
+}
+
+int check_dirs(const pinn_net* net, const int* dir_cols, int nd, int n2) {
+    if (nd < 0 || nd > PINN_MAX_DIRS || n2 < 0 || n2 > nd) return fail("bad derivative spec nd=%d n2=%d", nd, n2);
+    for (int k = 0; k < nd; ++k)
+        if (!dir_cols || dir_cols[k] < 0 || dir_cols[k] >= net->lay.d) return fail("dir_cols[%d] out of range", k);
+    return 0;
+}
+
+int launch_reduce(const float* partials, int n_wg, int p_core, float* grads, int accumulate, void* stream) {
+    const int blocks = (p_core + 15) / 16;
+#ifdef PINN_EMU
+    emu::launch(blocks, 256, 256 * sizeof(float), [&] { pinn_reduce_kernel(partials, n_wg, p_core, grads, accumulate); });
+#else
+    hipLaunchKernelGGL(pinn_reduce_kernel, dim3(blocks), dim3(256), 256 * sizeof(float), (hipStream_t)stream, partials,
+                       n_wg, p_core, grads, accumulate);
+    if (hipGetLastError() != hipSuccess) return fail("reduce kernel launch failed");
+#endif
+    return 0;
+}
+
+size_t align256(size_t v) { return (v + 255) / 256 * 256; }
+}  // namespace
+
+extern "C" {
+
+const char* pinn_last_error(void) { return g_err; }
+
+int pinn_profile_tile(int enable) {
+    g_profile = enable ? 1 : 0;
+    g_have_bracket = false;
+    return 0;
+}
+
+float pinn_last_tile_ms(void) {
+#ifndef PINN_EMU
+    if (!g_have_bracket) return -1.0f;
+    float ms = -1.0f;
+    if (hipEventSynchronize(g_ev1) != hipSuccess || hipEventElapsedTime(&ms, g_ev0, g_ev1) != hipSuccess) return -1.0f;
+    return ms;
+#else
+    return -1.0f;
+#endif
+}
+
+const char* pinn_backend(void) {
+#ifdef PINN_EMU
+    return "emu-host";
+#else
+    return "hip-gfx950";
+#endif
+}
+
+int pinn_create(const int* layer_dims, int n_layers, int act, int ndims, int nparams, int has_bc, int has_ic,
+                const float* dom_lo, const float* dom_hi, float bc_value, pinn_t** out) {
+    if (!layer_dims || !out) return fail("null argument");
+    if (n_layers < 2 || n_layers > PINN_MAX_LAYERS) return fail("n_layers=%d outside [2, %d]", n_layers, PINN_MAX_LAYERS);
+    if (act != PINN_ACT_TANH && act != PINN_ACT_SIGMOID) return fail("unknown activation code %d", act);
+    const int d = ndims + nparams;
+    if (ndims < 1 || nparams < 0 || d > PINN_MAX_INPUTS) return fail("ndims+nparams=%d outside [1, %d]", d, PINN_MAX_INPUTS);
+    if (layer_dims[0] != d) return fail("layer_dims[0]=%d must equal ndims+nparams=%d", layer_dims[0], d);
+    if (layer_dims[n_layers] != 1) return fail("the last layer must have one unit (got %d)", layer_dims[n_layers]);
+    int hmax = 0;
+    for (int l = 1; l < n_layers; ++l) {
+        if (layer_dims[l] < 1) return fail("layer %d has width %d", l, layer_dims[l]);
+        if (layer_dims[l] > hmax) hmax = layer_dims[l];
+    }
+    int hp = round16(hmax);
+    if (hp == 48) hp = 64;
+    if (hp > 64 && hp < 128) hp = 128;
+    if (hp > 128) return fail("hidden width %d > 128 is not supported by this build", hmax);
+    const int lh = n_layers - 2;
+    if (lh > PINN_LHMAX) return fail("%d hidden->hidden layers > %d is not supported by this build", lh, PINN_LHMAX);
+    pinn_net* net = new (std::nothrow) pinn_net();
+    if (!net) return fail("out of memory");
+    memset(net, 0, sizeof(*net));
+    net->n_layers = n_layers; net->act = act; net->ndims = ndims; net->nparams = nparams;
+    net->has_bc = has_bc ? 1 : 0; net->has_ic = has_ic ? 1 : 0; net->bc_value = bc_value;
+    net->nsp = has_ic ? ndims - 1 : ndims;
+    for (int l = 0; l <= n_layers; ++l) net->dims[l] = layer_dims[l];
+    for (int i = 0; i < PINN_MAX_INPUTS; ++i) {
+        net->lo[i] = (dom_lo && i < ndims) ? dom_lo[i] : 0.0f;
+        net->hi[i] = (dom_hi && i < ndims) ? dom_hi[i] : 1.0f;
+    }
+    pinn_layout_t& L = net->lay;
+    L.hp = hp; L.lh = lh; L.d = d;
+    L.off_w1 = 0;
+    L.off_b1 = hp * d;
+    L.off_wh = L.off_b1 + hp;
+    L.hidden_stride = hp * hp + hp;
+    L.off_wl = L.off_wh + lh * L.hidden_stride;
+    L.off_bl = L.off_wl + hp;
+    L.off_log_scale = L.off_bl + 1;
+    L.off_loss = L.off_bl + 2;
+    L.p_core = L.off_bl + 4;
+    L.off_extra = L.p_core;
+    L.p_total = L.p_core + PINN_EXTRA_SLOTS;
+    net->n_cu = 256;
+#ifndef PINN_EMU
+    int dev = 0;
+    hipDeviceProp_t prop;
+    if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess && prop.multiProcessorCount > 0)
+        net->n_cu = prop.multiProcessorCount;
+#else
+    net->n_cu = 2;
+#endif
+    *out = net;
+    return 0;
+}
+
+int pinn_destroy(pinn_t* net) {
+    delete net;
+    return 0;
+}
+
+int pinn_layout(const pinn_t* net, pinn_layout_t* out) {
+    if (!net || !out) return fail("null argument");
+    *out = net->lay;
+    return 0;
+}
+
+size_t pinn_workspace_bytes(const pinn_t* net, int64_t n_points, int nd, int n2) {
+    if (!net) return 0;
+    Plan plan;
+    if (make_plan(net, n_points, nd, n2, &plan)) return 0;
+    return align256((size_t)plan.grid * net->lay.p_core * sizeof(float)) +
+           align256((size_t)plan.grid * plan.slab_vec4_per_wg * 16) + 256;
+}
+
+int pinn_jet_forward(pinn_t* net, const float* params, const float* xs, int64_t n_points, const int* dir_cols, int nd,
+                     int n2, const float* ic_streams, float ic_const, float* streams_out, void* stream) {
+    if (!net || !params || !xs || !streams_out) return fail("null argument");
+    if (n_points <= 0) return 0;
+    if (check_dirs(net, dir_cols, nd, n2)) return 1;
+    Plan plan;
+    if (make_plan(net, n_points, nd, n2, &plan)) return 1;
+    PinnKArgs a;
+    fill_args(net, &a, params, xs, n_points, dir_cols, nd, n2, ic_streams, ic_const);
+    a.mode = PINN_MODE_FORWARD;
+    a.out_streams = streams_out;
+    const int rc = plan.fn(nd, plan.n2k, &a, plan.grid, stream, 0, nullptr);
+    return rc ? fail("tile kernel launch failed (%d)", rc) : 0;
+}
+
+static int run_train(pinn_t* net, PinnKArgs* a, const Plan& plan, int nd, float* grads, int accumulate, void* workspace,
+                     size_t workspace_bytes, void* stream) {
+    const size_t part_bytes = align256((size_t)plan.grid * net->lay.p_core * sizeof(float));
+    const size_t slab_bytes = align256((size_t)plan.grid * plan.slab_vec4_per_wg * 16);
+    if (!workspace || workspace_bytes < part_bytes + slab_bytes)
+        return fail("workspace too small: need %zu bytes, got %zu", part_bytes + slab_bytes, workspace_bytes);
+    if (((uintptr_t)workspace & 15) != 0) return fail("workspace must be 16-byte aligned");
+    a->partials = reinterpret_cast<float*>(workspace);
+    a->slab = reinterpret_cast<f32x4*>(reinterpret_cast<char*>(workspace) + part_bytes);
+#ifndef PINN_EMU
+    if (g_profile) {
+        if (!g_ev0 && (hipEventCreate(&g_ev0) != hipSuccess || hipEventCreate(&g_ev1) != hipSuccess))
+            return fail("hipEventCreate failed");
+        hipEventRecord(g_ev0, (hipStream_t)stream);
+    }
+#endif
+    const int rc = plan.fn(nd, plan.n2k, a, plan.grid, stream, 0, nullptr);
+    if (rc) return fail("tile kernel launch failed (%d)", rc);
+#ifndef PINN_EMU
+    if (g_profile) { hipEventRecord(g_ev1, (hipStream_t)stream); g_have_bracket = true; }
+#endif
+    return launch_reduce(a->partials, plan.grid, net->lay.p_core, grads, accumulate, stream);
+}
+
+int pinn_jet_backward(pinn_t* net, const float* params, const float* xs, int64_t n_points, const int* dir_cols, int nd,
+                      int n2, const float* ic_streams, float ic_const, const float* grad_streams, float* grads,
+                      int accumulate, void* workspace, size_t workspace_bytes, void* stream) {
+    if (!net || !params || !xs || !grad_streams || !grads) return fail("null argument");
+    if (n_points <= 0) return 0;
+    if (check_dirs(net, dir_cols, nd, n2)) return 1;
+    Plan plan;
+    if (make_plan(net, n_points, nd, n2, &plan)) return 1;
+    PinnKArgs a;
+    fill_args(net, &a, params, xs, n_points, dir_cols, nd, n2, ic_streams, ic_const);
+    a.mode = PINN_MODE_BACKWARD;
+    a.gin = grad_streams;
+    return run_train(net, &a, plan, nd, grads, accumulate, workspace, workspace_bytes, stream);
+}
+
+int pinn_residual_step(pinn_t* net, const pinn_program_t* program, const float* params, const float* xs,
+                       int64_t n_points, const int* dir_cols, int nd, int n2, const float* ic_streams, float ic_const,
+                       float inv_n_global, float* grads, void* workspace, size_t workspace_bytes, void* stream) {
+    if (!net || !program || !params || !xs || !grads) return fail("null argument");
+    if (n_points <= 0) return fail("n_points must be positive");
+    if (check_dirs(net, dir_cols, nd, n2)) return 1;
+    if (program->n_ops < 1 || program->n_ops > PINN_MAX_OPS || program->n_consts < 0 || program->n_consts > PINN_MAX_CONSTS)
+        return fail("residual program size out of range (ops=%d consts=%d)", program->n_ops, program->n_consts);
+    Plan plan;
+    if (make_plan(net, n_points, nd, n2, &plan)) return 1;
+    // the program addresses registers with the caller's stream count; re-base the input columns and temporaries
+    // onto the instantiation's stream count (extra second-derivative streams sit between them)
+    const int s_user = 1 + nd + n2, s_kernel = 1 + nd + plan.n2k, shift = s_kernel - s_user;
+    PinnKArgs a;
+    fill_args(net, &a, params, xs, n_points, dir_cols, nd, n2, ic_streams, ic_const);
+    a.prog = *program;
+    for (int i = 0; i < program->n_ops; ++i) {
+        const uint32_t w = program->code[i];
+        int op = w & 255, dst = (w >> 8) & 255, ra = (w >> 16) & 255, rb = (w >> 24) & 255;
+        auto fix = [&](int r) { return r >= s_user ? r + shift : r; };
+        const bool a_is_reg = op != PINN_OP_CONST;
+        const bool b_is_reg = op == PINN_OP_ADD || op == PINN_OP_SUB || op == PINN_OP_MUL || op == PINN_OP_DIV;
+        if (dst < s_user + net->lay.d) return fail("program instruction %d overwrites an input register", i);
+        dst = fix(dst);
+        if (a_is_reg) ra = fix(ra);
+        if (b_is_reg) rb = fix(rb);
+        if (dst >= PINN_MAX_REGS || (a_is_reg && ra >= PINN_MAX_REGS) || (b_is_reg && rb >= PINN_MAX_REGS))
+            return fail("program instruction %d uses a register >= %d", i, PINN_MAX_REGS);
+        if (op == PINN_OP_CONST && ra >= program->n_consts) return fail("program instruction %d: bad constant", i);
+        if (op == PINN_OP_POW && rb >= program->n_consts) return fail("program instruction %d: bad exponent", i);
+        a.prog.code[i] = (uint32_t)op | ((uint32_t)dst << 8) | ((uint32_t)ra << 16) | ((uint32_t)rb << 24);
+    }
+    a.mode = PINN_MODE_STEP;
+    a.inv_n = inv_n_global;
+    return run_train(net, &a, plan, nd, grads, 0, workspace, workspace_bytes, stream);
+}
+
+int pinn_adam_step(float* params, const float* grads, float* exp_avg, float* exp_avg_sq, const uint8_t* mask, int64_t n,
+                   int32_t* step_ptr, float lr, float beta1, float beta2, float eps, void* stream) {
+    if (!params || !grads || !exp_avg || !exp_avg_sq || !step_ptr) return fail("null argument");
+    if (n <= 0) return 0;
+    const int blocks = (int)((n + 255) / 256);
+#ifdef PINN_EMU
+    emu::launch(1, 64, 0, [&] { pinn_tick_kernel(step_ptr); });
+    emu::launch(blocks, 256, 0, [&] { pinn_adam_kernel(params, grads, exp_avg, exp_avg_sq, mask, n, step_ptr, lr, beta1, beta2, eps); });
+#else
+    hipLaunchKernelGGL(pinn_tick_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, step_ptr);
+    hipLaunchKernelGGL(pinn_adam_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, params, grads, exp_avg,
+                       exp_avg_sq, mask, (long long)n, (const int*)step_ptr, lr, beta1, beta2, eps);
+    if (hipGetLastError() != hipSuccess) return fail("adam kernel launch failed");
+#endif
+    return 0;
+}
+
+}  // extern "C"

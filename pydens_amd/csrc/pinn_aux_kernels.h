@@ -1,0 +1,51 @@
+// pinn_aux_kernels.h -- small non-template kernels (gradient reduction, Adam); included by pinn_abi.cpp only.
+#pragma once
+#include "pinn_port.h"
+
+// ------------------------------------------------------------------------------------------------------------
+// sum of the per-workgroup partial gradients (fixed order => deterministic), 16 params x 16 chunks per block
+// ------------------------------------------------------------------------------------------------------------
+PINN_GLOBAL void PINN_LAUNCH_BOUNDS(256)
+pinn_reduce_kernel(const float* partials, int n_wg, int p_core, float* grads, int accumulate) {
+    PINN_SMEM(red);
+    const int tid = PINN_TID;
+    const int pl = tid & 15, ch = tid >> 4;
+    const int p = PINN_BID * 16 + pl;
+    float s = 0.0f;
+    if (p < p_core)
+        for (int w = ch; w < n_wg; w += 16) s += partials[(size_t)w * p_core + p];
+    red[ch * 16 + pl] = s;
+    PINN_SYNC();
+    if (tid < 16 && p < p_core) {
+        float t = 0.0f;
+        for (int c = 0; c < 16; ++c) t += red[c * 16 + tid];
+        grads[p] = accumulate ? grads[p] + t : t;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------------------
+// Adam (torch.optim.Adam single-tensor form, model_torch.py:461): exp_avg/exp_avg_sq EMA, bias-corrected step
+// ------------------------------------------------------------------------------------------------------------
+PINN_GLOBAL void PINN_LAUNCH_BOUNDS(64) pinn_tick_kernel(int* step_ptr) {
+    if (PINN_TID == 0 && PINN_BID == 0) step_ptr[0] += 1;
+}
+
+PINN_GLOBAL void PINN_LAUNCH_BOUNDS(256)
+pinn_adam_kernel(float* params, const float* grads, float* m, float* v, const unsigned char* mask, long long n,
+                 const int* step_ptr, float lr, float b1, float b2, float eps) {
+    const long long i = (long long)PINN_BID * 256 + PINN_TID;
+    if (i >= n) return;
+    if (mask && !mask[i]) return;
+    // bias corrections in double like torch's Python-side scalars (1 - beta ** step)
+    const double t = (double)step_ptr[0];
+    const double bc1 = 1.0 - pow((double)b1, t);
+    const double bc2 = 1.0 - pow((double)b2, t);
+    const float step_size = (float)((double)lr / bc1);
+    const float bc2_sqrt = (float)sqrt(bc2);
+    const float gi = grads[i];
+    const float mi = m[i] + (1.0f - b1) * (gi - m[i]);       // exp_avg.lerp_(grad, 1 - beta1)
+    const float vi = fmaf(1.0f - b2, gi * gi, b2 * v[i]);    // exp_avg_sq.mul_(beta2).addcmul_(grad, grad, 1 - beta2)
+    m[i] = mi; v[i] = vi;
+    const float denom = sqrtf(vi) / bc2_sqrt + eps;
+    params[i] -= step_size * (mi / denom);
+}

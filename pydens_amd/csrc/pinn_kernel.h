@@ -1,0 +1,790 @@
+// pinn_kernel.h -- the fused PINN tile kernel (forward Taylor-mode jets -> ansatz -> residual -> reverse sweep).
+//
+// Replaces, for one tile of T collocation points per workgroup pass, the whole per-iteration arithmetic of the
+// reference `Solver.fit` (pydens/model_torch.py:437-460): MLP forward (:170-172), the nested-autograd sweeps of
+// D(...) (:174-178), the ansatz (:107-128), the user equation + MSELoss (:447-448) and loss.backward() (:460).
+//
+// Execution model (gfx950): one workgroup = NW waves; wave w owns output units [16*NTW*w, 16*NTW*(w+1)) of every
+// hidden layer.  The S derivative streams of a tile (value, d/dx_k, d2/dx_k2) are stacked as extra GEMM rows and
+// pushed through each fc layer with v_mfma_f32_16x16x4_f32 (exact fp32): A = activations from LDS
+// (ds_read_b128 along K), B = weight fragment held in VGPRs for all S*MT row tiles.  The activation jets are
+// evaluated on the MFMA accumulators in registers (all S streams of one (point, unit) live in one lane).
+// Weight gradients are accumulated in MFMA accumulators that persist across all tiles of the (persistent)
+// workgroup; per-workgroup partials are summed by pinn_reduce_kernel.  See DESIGN.md sections 3-5.
+#pragma once
+#include "pinn_port.h"
+
+#include "../../include/pinn.h"
+
+#ifndef PINN_EMU
+#define PINN_HOST_DEVICE __host__ __device__
+#else
+#define PINN_HOST_DEVICE
+#endif
+
+enum { PINN_MODE_FORWARD = 0, PINN_MODE_STEP = 1, PINN_MODE_BACKWARD = 2 };
+
+constexpr int PINN_LHMAX = 4;      // hidden->hidden layers whose dW accumulators live in registers
+constexpr int PINN_XS_LD = PINN_MAX_INPUTS;
+
+struct PinnKArgs {
+    const float* params;
+    const float* xs;             // [N][d]
+    const float* ic_streams;     // [S_user][N] or null
+    const float* gin;            // MODE_BACKWARD: [S_user][N]
+    float* out_streams;          // MODE_FORWARD: [S_user][N]
+    float* partials;             // [nWG][p_core]
+    f32x4* slab;                 // saved activations, lane private
+    long long n_points;
+    int lh, d, act, mode;
+    int off_b1, off_wh, hidden_stride, off_wl, off_bl, off_ls, off_loss, p_core;
+    int ndims, nsp, has_bc, has_ic;
+    float bc_value, t0, ic_const, inv_n;
+    float lo[PINN_MAX_INPUTS], hi[PINN_MAX_INPUTS];
+    int dir_cols[PINN_MAX_DIRS];
+    int s_user;                  // streams visible to the caller (<= S of the instantiation)
+    pinn_program_t prog;
+};
+
+template <int HP_, int ND_, int N2_, int MT_>
+struct PinnCfg {
+    static constexpr int HP = HP_, ND = ND_, N2 = N2_, MT = MT_;
+    static constexpr int S = 1 + ND + N2;
+    static constexpr int NT = HP / 16;                       // 16-wide unit tiles
+    static constexpr int NW = (NT <= 4) ? NT : 8;            // waves per workgroup
+    static constexpr int NTW = NT / NW;                      // unit tiles per wave
+    static constexpr int T = 16 * MT;                        // points per tile
+    static constexpr int LDA = HP + 4;                       // row stride of point-major activation buffers
+    static constexpr int NTHREADS = NW * 64;
+    // LDS carve (floats); every offset is a multiple of 4 floats (16 B, ds_read_b128 alignment)
+    static constexpr int O_XS = 0;
+    static constexpr int O_W1 = O_XS + T * PINN_XS_LD;
+    static constexpr int O_B1 = O_W1 + HP * PINN_XS_LD;
+    static constexpr int O_WL = O_B1 + HP;
+    static constexpr int O_BUFA = O_WL + HP;
+    static constexpr int O_BUFB = O_BUFA + S * T * LDA;
+    static constexpr int O_NET = O_BUFB + S * T * LDA;
+    static constexpr int O_GNET = O_NET + S * T;
+    static constexpr int O_ACCB = O_GNET + S * T;
+    static constexpr int O_ACCW1 = O_ACCB + (PINN_LHMAX + 1) * HP;
+    static constexpr int O_SCAL = O_ACCW1 + HP * PINN_XS_LD;
+    static constexpr int O_PREG = O_SCAL + T * 4;
+    static constexpr int O_PADJ = O_PREG + PINN_MAX_REGS * T;
+    static constexpr int SMEM_FLOATS = O_PADJ + PINN_MAX_REGS * T;
+    PINN_HOST_DEVICE static constexpr size_t slab_vec4_per_wg(int lh) {
+        return (size_t)(lh + 1) * S * NTW * MT * NTHREADS;
+    }
+};
+
+// ------------------------------------------------------------------------------------------------------------
+// activation and its derivatives from the activation VALUE (tanh: t, sigmoid: s)
+// ------------------------------------------------------------------------------------------------------------
+PINN_DEVICE float pinn_act(float z, int act) {
+    if (act == PINN_ACT_TANH) return tanhf(z);
+    return 1.0f / (1.0f + expf(-z));
+}
+PINN_DEVICE void pinn_act_d12(float v, int act, float& d1, float& d2) {
+    if (act == PINN_ACT_TANH) { d1 = 1.0f - v * v; d2 = -2.0f * v * d1; }
+    else { d1 = v * (1.0f - v); d2 = d1 * (1.0f - 2.0f * v); }
+}
+PINN_DEVICE float pinn_act_d3(float v, float d1, float d2, int act) {
+    if (act == PINN_ACT_TANH) return d1 * (6.0f * v * v - 2.0f);
+    const float q = 1.0f - 2.0f * v;
+    return d1 * (q * q - 2.0f * d1);
+}
+
+// forward jet of one (point, unit): z[S] pre-activations -> h[S] activations; sv[S] = what the reverse sweep
+// needs (activation value in slot 0, derivative pre-activations unchanged).
+template <int ND, int N2>
+PINN_DEVICE void pinn_jet_fwd(const float (&z)[1 + ND + N2], int act, float (&h)[1 + ND + N2]) {
+    const float v = pinn_act(z[0], act);
+    float d1, d2;
+    pinn_act_d12(v, act, d1, d2);
+    h[0] = v;
+#pragma unroll
+    for (int k = 0; k < ND; ++k) h[1 + k] = d1 * z[1 + k];
+#pragma unroll
+    for (int k = 0; k < N2; ++k) h[1 + ND + k] = d2 * z[1 + k] * z[1 + k] + d1 * z[1 + ND + k];
+}
+
+// activations h[S] recomputed from the saved form (v, z_k, z_kk)
+template <int ND, int N2>
+PINN_DEVICE void pinn_jet_recompute(const float (&sv)[1 + ND + N2], int act, float (&h)[1 + ND + N2]) {
+    float d1, d2;
+    pinn_act_d12(sv[0], act, d1, d2);
+    h[0] = sv[0];
+#pragma unroll
+    for (int k = 0; k < ND; ++k) h[1 + k] = d1 * sv[1 + k];
+#pragma unroll
+    for (int k = 0; k < N2; ++k) h[1 + ND + k] = d2 * sv[1 + k] * sv[1 + k] + d1 * sv[1 + ND + k];
+}
+
+// reverse jet: gh[S] = dL/dh streams -> gz[S] = dL/dz streams
+template <int ND, int N2>
+PINN_DEVICE void pinn_jet_bwd(const float (&gh)[1 + ND + N2], const float (&sv)[1 + ND + N2], int act,
+                              float (&gz)[1 + ND + N2]) {
+    const float v = sv[0];
+    float d1, d2;
+    pinn_act_d12(v, act, d1, d2);
+    const float d3 = pinn_act_d3(v, d1, d2, act);
+    float acc = d1 * gh[0];
+#pragma unroll
+    for (int k = 0; k < ND; ++k) {
+        const float zk = sv[1 + k];
+        float gzk = d1 * gh[1 + k];
+        acc += d2 * zk * gh[1 + k];
+        if (k < N2) {
+            const float zkk = sv[1 + ND + k], ghkk = gh[1 + ND + k];
+            gz[1 + ND + k] = d1 * ghkk;
+            gzk += 2.0f * d2 * zk * ghkk;
+            acc += (d3 * zk * zk + d2 * zkk) * ghkk;
+        }
+        gz[1 + k] = gzk;
+    }
+    gz[0] = acc;
+}
+
+// ------------------------------------------------------------------------------------------------------------
+// residual program interpreter (one thread per point; registers live in LDS: reg r of point p at regs[r*T + p])
+// ------------------------------------------------------------------------------------------------------------
+PINN_DEVICE float pinn_sigmoidf(float x) { return 1.0f / (1.0f + expf(-x)); }
+
+PINN_DEVICE float pinn_prog_forward(const pinn_program_t& pg, float* regs, int T) {
+    int last = 0;
+    for (int i = 0; i < pg.n_ops; ++i) {
+        const unsigned w = pg.code[i];
+        const int op = w & 255, dst = (w >> 8) & 255, a = (w >> 16) & 255, b = (w >> 24) & 255;
+        const float x = (op == PINN_OP_CONST) ? 0.0f : regs[a * T];
+        float y;
+        switch (op) {
+            case PINN_OP_CONST: y = pg.consts[a]; break;
+            case PINN_OP_ADD: y = x + regs[b * T]; break;
+            case PINN_OP_SUB: y = x - regs[b * T]; break;
+            case PINN_OP_MUL: y = x * regs[b * T]; break;
+            case PINN_OP_DIV: y = x / regs[b * T]; break;
+            case PINN_OP_NEG: y = -x; break;
+            case PINN_OP_SIN: y = sinf(x); break;
+            case PINN_OP_COS: y = cosf(x); break;
+            case PINN_OP_EXP: y = expf(x); break;
+            case PINN_OP_LOG: y = logf(x); break;
+            case PINN_OP_TANH: y = tanhf(x); break;
+            case PINN_OP_SQRT: y = sqrtf(x); break;
+            case PINN_OP_POW: y = powf(x, pg.consts[b]); break;
+            case PINN_OP_ABS: y = fabsf(x); break;
+            case PINN_OP_SIGMOID: y = pinn_sigmoidf(x); break;
+            case PINN_OP_RECIP: y = 1.0f / x; break;
+            default: y = x; break;    // COPY
+        }
+        regs[dst * T] = y;
+        last = dst;
+    }
+    return regs[last * T];
+}
+
+// reverse sweep: adj[] must be zero on entry for every register; adj[result] is seeded with 1.
+PINN_DEVICE void pinn_prog_backward(const pinn_program_t& pg, const float* regs, float* adj, int T) {
+    if (pg.n_ops == 0) return;
+    adj[((pg.code[pg.n_ops - 1] >> 8) & 255) * T] = 1.0f;
+    for (int i = pg.n_ops - 1; i >= 0; --i) {
+        const unsigned w = pg.code[i];
+        const int op = w & 255, dst = (w >> 8) & 255, a = (w >> 16) & 255, b = (w >> 24) & 255;
+        const float g = adj[dst * T];
+        adj[dst * T] = 0.0f;                       // registers are single-assignment; clear for the next point
+        if (op == PINN_OP_CONST) continue;
+        const float x = regs[a * T], y = regs[dst * T];
+        switch (op) {
+            case PINN_OP_ADD: adj[a * T] += g; adj[b * T] += g; break;
+            case PINN_OP_SUB: adj[a * T] += g; adj[b * T] -= g; break;
+            case PINN_OP_MUL: { const float xb = regs[b * T]; adj[a * T] += g * xb; adj[b * T] += g * x; } break;
+            case PINN_OP_DIV: { const float xb = regs[b * T]; adj[a * T] += g / xb; adj[b * T] -= g * y / xb; } break;
+            case PINN_OP_NEG: adj[a * T] -= g; break;
+            case PINN_OP_SIN: adj[a * T] += g * cosf(x); break;
+            case PINN_OP_COS: adj[a * T] -= g * sinf(x); break;
+            case PINN_OP_EXP: adj[a * T] += g * y; break;
+            case PINN_OP_LOG: adj[a * T] += g / x; break;
+            case PINN_OP_TANH: adj[a * T] += g * (1.0f - y * y); break;
+            case PINN_OP_SQRT: adj[a * T] += g * 0.5f / y; break;
+            case PINN_OP_POW: { const float e = pg.consts[b]; adj[a * T] += g * e * powf(x, e - 1.0f); } break;
+            case PINN_OP_ABS: adj[a * T] += (x >= 0.0f ? g : -g); break;
+            case PINN_OP_SIGMOID: adj[a * T] += g * y * (1.0f - y); break;
+            case PINN_OP_RECIP: adj[a * T] -= g * y * y; break;
+            default: adj[a * T] += g; break;
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------------------
+// point stage: ansatz forward, residual / upstream gradient, ansatz reverse.  One thread per point of the tile.
+// Formulas: oracle/jet_f64.py (ansatz_forward / ansatz_backward), i.e. model_torch.py:107-128 + product rule.
+// ------------------------------------------------------------------------------------------------------------
+template <int ND, int N2>
+struct PinnPointOut {
+    float gnet[1 + ND + N2];
+    float loss, g_ls;
+};
+
+template <int ND, int N2>
+PINN_DEVICE void pinn_point_stage(const PinnKArgs& A, const float (&net)[1 + ND + N2], const float* x /*[d]*/,
+                                  long long gidx, bool valid, float* pregs, float* padj, int T,
+                                  PinnPointOut<ND, N2>& out) {
+    constexpr int S = 1 + ND + N2;
+    // ---- BC factor P and its direction derivatives --------------------------------------------------------
+    float P = 1.0f, Pk[ND > 0 ? ND : 1], Pkk[ND > 0 ? ND : 1];
+#pragma unroll
+    for (int k = 0; k < ND; ++k) { Pk[k] = 0.0f; Pkk[k] = 0.0f; }
+    if (A.has_bc) {
+        float p[PINN_MAX_INPUTS], p1[PINN_MAX_INPUTS], p2[PINN_MAX_INPUTS];
+#pragma unroll
+        for (int j = 0; j < PINN_MAX_INPUTS; ++j) {
+            p[j] = 1.0f; p1[j] = 0.0f; p2[j] = 0.0f;
+            if (j < A.nsp) {
+                const float lo = A.lo[j], hi = A.hi[j], w = hi - lo, xj = x[j];
+                p[j] = ((xj - lo) / w) * ((hi - xj) / w);
+                p1[j] = (lo + hi - 2.0f * xj) / (w * w);
+                p2[j] = -2.0f / (w * w);
+                P *= p[j];
+            }
+        }
+#pragma unroll
+        for (int k = 0; k < ND; ++k) {
+            const int c = A.dir_cols[k];
+            if (c < A.nsp) {
+                float rest = 1.0f, q1 = 0.0f, q2 = 0.0f;
+#pragma unroll
+                for (int j = 0; j < PINN_MAX_INPUTS; ++j) {
+                    if (j == c) { q1 = p1[j]; q2 = p2[j]; }
+                    else rest *= p[j];
+                }
+                Pk[k] = q1 * rest;
+                Pkk[k] = q2 * rest;
+            }
+        }
+    }
+    // ---- Q = net * P + bc ---------------------------------------------------------------------------------
+    float Q[S];
+#pragma unroll
+    for (int s = 0; s < S; ++s) Q[s] = net[s];
+    if (A.has_bc) {
+        Q[0] = net[0] * P + A.bc_value;
+#pragma unroll
+        for (int k = 0; k < ND; ++k) Q[1 + k] = net[1 + k] * P + net[0] * Pk[k];
+#pragma unroll
+        for (int k = 0; k < N2; ++k) Q[1 + ND + k] = net[1 + ND + k] * P + 2.0f * net[1 + k] * Pk[k] + net[0] * Pkk[k];
+    }
+    // ---- IC gate G = sigmoid(tau) - 1/2, tau = (t - t0) exp(-log_scale) -----------------------------------------
+    float u[S];
+#pragma unroll
+    for (int s = 0; s < S; ++s) u[s] = Q[s];
+    float G = 1.0f, Gk[ND > 0 ? ND : 1], Gkk[ND > 0 ? ND : 1], dG = 0.0f, dGk[ND > 0 ? ND : 1], dGkk[ND > 0 ? ND : 1];
+#pragma unroll
+    for (int k = 0; k < ND; ++k) { Gk[k] = 0.0f; Gkk[k] = 0.0f; dGk[k] = 0.0f; dGkk[k] = 0.0f; }
+    if (A.has_ic) {
+        const int tcol = A.ndims - 1;
+        const float es = expf(-A.params[A.off_ls]);
+        const float tau = (x[tcol] - A.t0) * es;
+        const float sg = pinn_sigmoidf(tau);
+        float d1, d2;
+        pinn_act_d12(sg, PINN_ACT_SIGMOID, d1, d2);
+        const float d3 = pinn_act_d3(sg, d1, d2, PINN_ACT_SIGMOID);
+        G = sg - 0.5f;
+        dG = -tau * d1;
+#pragma unroll
+        for (int k = 0; k < ND; ++k) {
+            if (A.dir_cols[k] == tcol) {
+                Gk[k] = d1 * es; Gkk[k] = d2 * es * es;
+                dGk[k] = es * (-tau * d2 - d1);
+                dGkk[k] = es * es * (-tau * d3 - 2.0f * d2);
+            }
+        }
+        u[0] = G * Q[0];
+#pragma unroll
+        for (int k = 0; k < ND; ++k) u[1 + k] = Gk[k] * Q[0] + G * Q[1 + k];
+#pragma unroll
+        for (int k = 0; k < N2; ++k) u[1 + ND + k] = Gkk[k] * Q[0] + 2.0f * Gk[k] * Q[1 + k] + G * Q[1 + ND + k];
+        if (A.ic_streams) {
+#pragma unroll
+            for (int s = 0; s < S; ++s)
+                if (s < A.s_user && valid) u[s] += A.ic_streams[(long long)s * A.n_points + gidx];
+        } else {
+            u[0] += A.ic_const;
+        }
+    }
+    // ---- output / residual / upstream gradient -----------------------------------------------------------------
+    float gu[S];
+#pragma unroll
+    for (int s = 0; s < S; ++s) gu[s] = 0.0f;
+    out.loss = 0.0f;
+    if (A.mode == PINN_MODE_FORWARD) {
+        if (valid) {
+#pragma unroll
+            for (int s = 0; s < S; ++s)
+                if (s < A.s_user) A.out_streams[(long long)s * A.n_points + gidx] = u[s];
+        }
+#pragma unroll
+        for (int s = 0; s < S; ++s) out.gnet[s] = 0.0f;
+        out.g_ls = 0.0f;
+        return;
+    } else if (A.mode == PINN_MODE_STEP) {
+#pragma unroll
+        for (int s = 0; s < S; ++s) pregs[s * T] = u[s];
+        for (int c = 0; c < A.d; ++c) pregs[(S + c) * T] = x[c];
+        // note: registers S..S+d are addressed with the INSTANTIATION's S; the host emits programs for it
+        const float r = pinn_prog_forward(A.prog, pregs, T);
+        pinn_prog_backward(A.prog, pregs, padj, T);
+        const float w = valid ? 2.0f * r * A.inv_n : 0.0f;
+#pragma unroll
+        for (int s = 0; s < S; ++s) { gu[s] = w * padj[s * T]; padj[s * T] = 0.0f; }
+        for (int c = 0; c < A.d; ++c) padj[(S + c) * T] = 0.0f;
+        out.loss = valid ? r * r * A.inv_n : 0.0f;
+    } else {
+        if (valid) {
+#pragma unroll
+            for (int s = 0; s < S; ++s)
+                if (s < A.s_user) gu[s] = A.gin[(long long)s * A.n_points + gidx];
+        }
+    }
+    // ---- reverse: u -> Q (gate) ---------------------------------------------------------------------------------
+    float gQ[S];
+#pragma unroll
+    for (int s = 0; s < S; ++s) gQ[s] = gu[s];
+    float g_ls = 0.0f;
+    if (A.has_ic) {
+        float gG = gu[0] * Q[0];
+        gQ[0] = gu[0] * G;
+#pragma unroll
+        for (int k = 0; k < ND; ++k) {
+            gG += gu[1 + k] * Q[1 + k];
+            float gGk = gu[1 + k] * Q[0];
+            gQ[0] += gu[1 + k] * Gk[k];
+            gQ[1 + k] = gu[1 + k] * G;
+            if (k < N2) {
+                const float gkk = gu[1 + ND + k];
+                gG += gkk * Q[1 + ND + k];
+                gGk += 2.0f * gkk * Q[1 + k];
+                g_ls += gkk * Q[0] * dGkk[k];
+                gQ[0] += gkk * Gkk[k];
+                gQ[1 + k] += 2.0f * gkk * Gk[k];
+                gQ[1 + ND + k] = gkk * G;
+            }
+            g_ls += gGk * dGk[k];
+        }
+        g_ls += gG * dG;
+    }
+    // ---- reverse: Q -> net (BC factor) -----------------------------------------------------------------------
+#pragma unroll
+    for (int s = 0; s < S; ++s) out.gnet[s] = gQ[s];
+    if (A.has_bc) {
+        float g0 = gQ[0] * P;
+#pragma unroll
+        for (int k = 0; k < ND; ++k) {
+            g0 += gQ[1 + k] * Pk[k];
+            float g1 = gQ[1 + k] * P;
+            if (k < N2) {
+                const float gkk = gQ[1 + ND + k];
+                g0 += gkk * Pkk[k];
+                g1 += 2.0f * gkk * Pk[k];
+                out.gnet[1 + ND + k] = gkk * P;
+            }
+            out.gnet[1 + k] = g1;
+        }
+        out.gnet[0] = g0;
+    }
+    out.g_ls = g_ls;
+}
+
+// ------------------------------------------------------------------------------------------------------------
+// the tile kernel
+// ------------------------------------------------------------------------------------------------------------
+PINN_DEVICE f32x4 pinn_ld4(const float* p) { return *reinterpret_cast<const f32x4*>(p); }
+
+template <int HP, int ND, int N2, int MT>
+PINN_GLOBAL void PINN_LAUNCH_BOUNDS((PinnCfg<HP, ND, N2, MT>::NTHREADS))
+pinn_tile_kernel(const PinnKArgs A) {
+    using C = PinnCfg<HP, ND, N2, MT>;
+    constexpr int S = C::S, NT = C::NT, NTW = C::NTW, T = C::T, LDA = C::LDA, NTHREADS = C::NTHREADS;
+    const int tid = PINN_TID, lane = tid & 63, wave = tid >> 6;
+    const int lr = lane & 15, lq = lane >> 4;
+    const int act = A.act, lh = A.lh, d = A.d;
+    const bool train = A.mode != PINN_MODE_FORWARD;
+
+    PINN_SMEM(smem);
+    float* xs_t = smem + C::O_XS;
+    float* W1s = smem + C::O_W1;
+    float* b1s = smem + C::O_B1;
+    float* WLs = smem + C::O_WL;
+    float* bufA = smem + C::O_BUFA;
+    float* bufB = smem + C::O_BUFB;
+    float* netb = smem + C::O_NET;
+    float* gnetb = smem + C::O_GNET;
+    float* accB = smem + C::O_ACCB;
+    float* accW1 = smem + C::O_ACCW1;
+    float* scal = smem + C::O_SCAL;
+    float* pregs = smem + C::O_PREG;
+    float* padj = smem + C::O_PADJ;
+
+    // ---- one-time staging of the small layers and zeroing of the LDS accumulators -------------------------------
+    for (int i = tid; i < HP * PINN_XS_LD; i += NTHREADS) {
+        const int n = i / PINN_XS_LD, c = i % PINN_XS_LD;
+        W1s[i] = (c < d) ? A.params[n * d + c] : 0.0f;
+        accW1[i] = 0.0f;
+    }
+    for (int i = tid; i < HP; i += NTHREADS) { b1s[i] = A.params[A.off_b1 + i]; WLs[i] = A.params[A.off_wl + i]; }
+    for (int i = tid; i < (PINN_LHMAX + 1) * HP; i += NTHREADS) accB[i] = 0.0f;
+    for (int i = tid; i < PINN_MAX_REGS * T; i += NTHREADS) padj[i] = 0.0f;
+    const float bL = A.params[A.off_bl];
+
+    // persistent per-lane accumulators
+    f32x4 dW[PINN_LHMAX][NT][NTW];
+#pragma unroll
+    for (int l = 0; l < PINN_LHMAX; ++l)
+#pragma unroll
+        for (int o = 0; o < NT; ++o)
+#pragma unroll
+            for (int j = 0; j < NTW; ++j) dW[l][o][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+    float accWL[NTW];
+#pragma unroll
+    for (int j = 0; j < NTW; ++j) accWL[j] = 0.0f;
+    float sum_loss = 0.0f, sum_ls = 0.0f, sum_bl = 0.0f;
+
+    f32x4* slab = A.slab ? A.slab + (size_t)PINN_BID * C::slab_vec4_per_wg(lh) : nullptr;
+    auto slab_at = [&](int a, int s, int j, int mt) -> f32x4* {
+        return slab + ((((size_t)a * S + s) * NTW + j) * MT + mt) * NTHREADS + tid;
+    };
+
+    const long long ntiles = (A.n_points + T - 1) / T;
+    PINN_SYNC();
+
+    for (long long tile = PINN_BID; tile < ntiles; tile += PINN_NBLK) {
+        const long long base = tile * T;
+        // ---- (0) stage the points of this tile ------------------------------------------------------------
+        for (int i = tid; i < T * PINN_XS_LD; i += NTHREADS) {
+            const int pt = i / PINN_XS_LD, c = i % PINN_XS_LD;
+            const long long g = base + pt;
+            xs_t[i] = (c < d && g < A.n_points) ? A.xs[g * d + c] : 0.0f;
+        }
+        PINN_SYNC();
+
+        float* cur = bufA;
+        float* nxt = bufB;
+        // ---- (1) first layer on the VALU: z0 = W1 x + b1, z_k = W1[:, col_k], z_kk = 0 ------------------------
+#pragma unroll
+        for (int j = 0; j < NTW; ++j) {
+            const int n = (wave * NTW + j) * 16 + lr;
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt) {
+                f32x4 sv[S];
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int pt = mt * 16 + lq * 4 + r;
+                    float z[S], h[S];
+                    float z0 = b1s[n];
+                    for (int c = 0; c < d; ++c) z0 = fmaf(W1s[n * PINN_XS_LD + c], xs_t[pt * PINN_XS_LD + c], z0);
+                    z[0] = z0;
+#pragma unroll
+                    for (int k = 0; k < ND; ++k) z[1 + k] = W1s[n * PINN_XS_LD + A.dir_cols[k]];
+#pragma unroll
+                    for (int k = 0; k < N2; ++k) z[1 + ND + k] = 0.0f;
+                    pinn_jet_fwd<ND, N2>(z, act, h);
+#pragma unroll
+                    for (int s = 0; s < S; ++s) {
+                        cur[(s * T + pt) * LDA + n] = h[s];
+                        sv[s][r] = (s == 0) ? h[0] : z[s];
+                    }
+                }
+                if (train) {
+#pragma unroll
+                    for (int s = 0; s < S; ++s) *slab_at(0, s, j, mt) = sv[s];
+                }
+            }
+        }
+        PINN_SYNC();
+
+        // ---- (2) hidden layers: z_s = h_s W^T (MFMA), jets on the accumulators ------------------------------------
+        for (int li = 0; li < lh; ++li) {
+            const float* Wl = A.params + A.off_wh + (size_t)li * A.hidden_stride;
+            const float* bl = Wl + HP * HP;
+            f32x4 acc[NTW][MT][S];
+#pragma unroll
+            for (int j = 0; j < NTW; ++j)
+#pragma unroll
+                for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+                    for (int s = 0; s < S; ++s) acc[j][mt][s] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int q = 0; q < HP / 16; ++q) {
+                f32x4 bf[NTW];
+#pragma unroll
+                for (int j = 0; j < NTW; ++j)
+                    bf[j] = pinn_ld4(Wl + ((wave * NTW + j) * 16 + lr) * HP + 16 * q + 4 * lq);
+#pragma unroll
+                for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+                    for (int s = 0; s < S; ++s) {
+                        const f32x4 af = pinn_ld4(cur + (s * T + mt * 16 + lr) * LDA + 16 * q + 4 * lq);
+#pragma unroll
+                        for (int j = 0; j < NTW; ++j) {
+#pragma unroll
+                            for (int m = 0; m < 4; ++m) acc[j][mt][s] = pinn_mfma16(af[m], bf[j][m], acc[j][mt][s]);
+                        }
+                    }
+            }
+#pragma unroll
+            for (int j = 0; j < NTW; ++j) {
+                const int n = (wave * NTW + j) * 16 + lr;
+                const float bias = bl[n];
+#pragma unroll
+                for (int mt = 0; mt < MT; ++mt) {
+                    f32x4 sv[S];
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const int pt = mt * 16 + lq * 4 + r;
+                        float z[S], h[S];
+#pragma unroll
+                        for (int s = 0; s < S; ++s) z[s] = acc[j][mt][s][r];
+                        z[0] += bias;
+                        pinn_jet_fwd<ND, N2>(z, act, h);
+#pragma unroll
+                        for (int s = 0; s < S; ++s) {
+                            nxt[(s * T + pt) * LDA + n] = h[s];
+                            sv[s][r] = (s == 0) ? h[0] : z[s];
+                        }
+                    }
+                    if (train) {
+#pragma unroll
+                        for (int s = 0; s < S; ++s) *slab_at(li + 1, s, j, mt) = sv[s];
+                    }
+                }
+            }
+            PINN_SYNC();
+            float* tmp = cur; cur = nxt; nxt = tmp;
+        }
+
+        // ---- (3) last layer (out = 1): net_s[pt] = WL . h_s[pt] -----------------------------------------------
+        for (int i = tid; i < S * T; i += NTHREADS) {
+            const float* row = cur + i * LDA;          // i = s*T + pt
+            float sum = (i < T) ? bL : 0.0f;
+#pragma unroll 4
+            for (int n4 = 0; n4 < HP / 4; ++n4) {
+                const f32x4 hv = pinn_ld4(row + 4 * n4), wv = pinn_ld4(WLs + 4 * n4);
+                sum = fmaf(hv[0], wv[0], sum); sum = fmaf(hv[1], wv[1], sum);
+                sum = fmaf(hv[2], wv[2], sum); sum = fmaf(hv[3], wv[3], sum);
+            }
+            netb[i] = sum;
+        }
+        PINN_SYNC();
+
+        // ---- (4) ansatz + residual + their reverse, one thread per point ------------------------------------------
+        if (tid < T) {
+            const int pt = tid;
+            float net[S];
+#pragma unroll
+            for (int s = 0; s < S; ++s) net[s] = netb[s * T + pt];
+            PinnPointOut<ND, N2> po;
+            pinn_point_stage<ND, N2>(A, net, xs_t + pt * PINN_XS_LD, base + pt, base + pt < A.n_points,
+                                     pregs + pt, padj + pt, T, po);
+#pragma unroll
+            for (int s = 0; s < S; ++s) gnetb[s * T + pt] = po.gnet[s];
+            sum_loss += po.loss; sum_ls += po.g_ls; sum_bl += po.gnet[0];
+        }
+        if (!train) { PINN_SYNC(); continue; }
+        PINN_SYNC();
+
+        // ---- (5) reverse through the last layer: gh_s = gnet_s * WL ; dWL += sum gnet_s h_s -------------------------
+        f32x4 g[NTW][MT][S];
+        f32x4 sv[NTW][MT][S];
+#pragma unroll
+        for (int j = 0; j < NTW; ++j) {
+            const int n = (wave * NTW + j) * 16 + lr;
+            const float wl = WLs[n];
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt) {
+#pragma unroll
+                for (int s = 0; s < S; ++s) {
+                    sv[j][mt][s] = *slab_at(lh, s, j, mt);
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const int pt = mt * 16 + lq * 4 + r;
+                        const float gn = gnetb[s * T + pt];
+                        g[j][mt][s][r] = gn * wl;
+                        accWL[j] = fmaf(gn, cur[(s * T + pt) * LDA + n], accWL[j]);
+                    }
+                }
+            }
+        }
+
+        // ---- (6) reverse through the activations / hidden layers -------------------------------------------------
+        for (int a = lh; a >= 0; --a) {
+            f32x4 gz[NTW][MT][S];
+#pragma unroll
+            for (int j = 0; j < NTW; ++j) {
+                float bsum = 0.0f;
+#pragma unroll
+                for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        float gh1[S], sv1[S], gz1[S];
+#pragma unroll
+                        for (int s = 0; s < S; ++s) { gh1[s] = g[j][mt][s][r]; sv1[s] = sv[j][mt][s][r]; }
+                        pinn_jet_bwd<ND, N2>(gh1, sv1, act, gz1);
+#pragma unroll
+                        for (int s = 0; s < S; ++s) gz[j][mt][s][r] = gz1[s];
+                        bsum += gz1[0];
+                    }
+                bsum += pinn_shfl_xor(bsum, 16);
+                bsum += pinn_shfl_xor(bsum, 32);
+                if (lq == 0) accB[a * HP + (wave * NTW + j) * 16 + lr] += bsum;
+            }
+            if (a == 0) {
+                // first layer: dW1[n][c] += sum_pt gz0 x_c  (+ sum_pt gz_k when c == col_k)
+#pragma unroll
+                for (int j = 0; j < NTW; ++j) {
+                    const int n = (wave * NTW + j) * 16 + lr;
+                    for (int c = 0; c < d; ++c) {
+                        float v = 0.0f;
+#pragma unroll
+                        for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+                            for (int r = 0; r < 4; ++r) {
+                                const int pt = mt * 16 + lq * 4 + r;
+                                v = fmaf(gz[j][mt][0][r], xs_t[pt * PINN_XS_LD + c], v);
+#pragma unroll
+                                for (int k = 0; k < ND; ++k)
+                                    if (A.dir_cols[k] == c) v += gz[j][mt][1 + k][r];
+                            }
+                        v += pinn_shfl_xor(v, 16);
+                        v += pinn_shfl_xor(v, 32);
+                        if (lq == 0) accW1[n * PINN_XS_LD + c] += v;
+                    }
+                }
+                break;
+            }
+            // stage gz_a (-> nxt) and the recomputed h_{a-1} (-> cur) for the two GEMMs of linear layer a
+#pragma unroll
+            for (int j = 0; j < NTW; ++j) {
+                const int n = (wave * NTW + j) * 16 + lr;
+#pragma unroll
+                for (int mt = 0; mt < MT; ++mt) {
+#pragma unroll
+                    for (int s = 0; s < S; ++s) sv[j][mt][s] = *slab_at(a - 1, s, j, mt);
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const int pt = mt * 16 + lq * 4 + r;
+                        float sv1[S], h[S];
+#pragma unroll
+                        for (int s = 0; s < S; ++s) sv1[s] = sv[j][mt][s][r];
+                        pinn_jet_recompute<ND, N2>(sv1, act, h);
+#pragma unroll
+                        for (int s = 0; s < S; ++s) {
+                            cur[(s * T + pt) * LDA + n] = h[s];
+                            nxt[(s * T + pt) * LDA + n] = gz[j][mt][s][r];
+                        }
+                    }
+                }
+            }
+            PINN_SYNC();
+            const int li = a - 1;
+            // weight gradient: dW_li[out][in] += sum_{s,pt} gz_s[pt][out] * h_s[pt][in]   (A = gz^T, B = h)
+            auto wgrad = [&](f32x4 (&dw)[NT][NTW]) {
+#pragma unroll
+                for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+                    for (int s = 0; s < S; ++s) {
+                        float bq[NTW][4];
+#pragma unroll
+                        for (int j = 0; j < NTW; ++j)
+#pragma unroll
+                            for (int m = 0; m < 4; ++m)
+                                bq[j][m] = cur[(s * T + mt * 16 + lq * 4 + m) * LDA + (wave * NTW + j) * 16 + lr];
+#pragma unroll
+                        for (int o = 0; o < NT; ++o) {
+                            float aq[4];
+#pragma unroll
+                            for (int m = 0; m < 4; ++m)
+                                aq[m] = nxt[(s * T + mt * 16 + lq * 4 + m) * LDA + o * 16 + lr];
+#pragma unroll
+                            for (int j = 0; j < NTW; ++j)
+#pragma unroll
+                                for (int m = 0; m < 4; ++m) dw[o][j] = pinn_mfma16(aq[m], bq[j][m], dw[o][j]);
+                        }
+                    }
+            };
+            switch (li) {
+                case 0: wgrad(dW[0]); break;
+                case 1: wgrad(dW[1]); break;
+                case 2: wgrad(dW[2]); break;
+                default: wgrad(dW[3]); break;
+            }
+            // data gradient: gh_{a-1}[pt][in] = sum_out gz[pt][out] * W_li[out][in]
+            const float* Wl = A.params + A.off_wh + (size_t)li * A.hidden_stride;
+#pragma unroll
+            for (int j = 0; j < NTW; ++j)
+#pragma unroll
+                for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+                    for (int s = 0; s < S; ++s) g[j][mt][s] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int q = 0; q < HP / 16; ++q) {
+                float bq[NTW][4];
+#pragma unroll
+                for (int j = 0; j < NTW; ++j)
+#pragma unroll
+                    for (int m = 0; m < 4; ++m)
+                        bq[j][m] = Wl[(16 * q + 4 * lq + m) * HP + (wave * NTW + j) * 16 + lr];
+#pragma unroll
+                for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+                    for (int s = 0; s < S; ++s) {
+                        const f32x4 af = pinn_ld4(nxt + (s * T + mt * 16 + lr) * LDA + 16 * q + 4 * lq);
+#pragma unroll
+                        for (int j = 0; j < NTW; ++j)
+#pragma unroll
+                            for (int m = 0; m < 4; ++m) g[j][mt][s] = pinn_mfma16(af[m], bq[j][m], g[j][mt][s]);
+                    }
+            }
+            PINN_SYNC();
+        }
+        PINN_SYNC();      // a == 0 block reads xs_t; the next tile's staging overwrites it
+    }
+
+    if (!train) return;
+    // ---- write this workgroup's partial gradient ---------------------------------------------------------------
+    PINN_SYNC();
+    float* part = A.partials + (size_t)PINN_BID * A.p_core;
+#pragma unroll
+    for (int l = 0; l < PINN_LHMAX; ++l) {
+        if (l < lh) {
+            float* dst = part + A.off_wh + (size_t)l * A.hidden_stride;
+#pragma unroll
+            for (int o = 0; o < NT; ++o)
+#pragma unroll
+                for (int j = 0; j < NTW; ++j)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r)
+                        dst[(o * 16 + lq * 4 + r) * HP + (wave * NTW + j) * 16 + lr] = dW[l][o][j][r];
+        }
+    }
+    for (int i = tid; i < (lh + 1) * HP; i += NTHREADS) {
+        const int a = i / HP, n = i % HP;
+        const int dst = (a == 0) ? A.off_b1 + n : A.off_wh + (a - 1) * A.hidden_stride + HP * HP + n;
+        part[dst] = accB[i];
+    }
+    for (int i = tid; i < HP * d; i += NTHREADS) part[i] = accW1[(i / d) * PINN_XS_LD + (i % d)];
+#pragma unroll
+    for (int j = 0; j < NTW; ++j) {
+        float v = accWL[j];
+        v += pinn_shfl_xor(v, 16);
+        v += pinn_shfl_xor(v, 32);
+        if (lq == 0) part[A.off_wl + (wave * NTW + j) * 16 + lr] = v;
+    }
+    if (tid < T) { scal[tid * 4 + 0] = sum_loss; scal[tid * 4 + 1] = sum_ls; scal[tid * 4 + 2] = sum_bl; }
+    PINN_SYNC();
+    if (tid == 0) {
+        float l0 = 0.0f, l1 = 0.0f, l2 = 0.0f;
+        for (int i = 0; i < T; ++i) { l0 += scal[i * 4]; l1 += scal[i * 4 + 1]; l2 += scal[i * 4 + 2]; }
+        part[A.off_loss] = l0;
+        part[A.off_ls] = l1;
+        part[A.off_bl] = l2;
+        for (int i = A.off_loss + 1; i < A.p_core; ++i) part[i] = 0.0f;
+    }
+}
+

@@ -1,0 +1,228 @@
+""" ctypes binding of the C-ABI in include/pinn.h (libpinn_hip.so, hand-written HIP for gfx950).
+
+This is the only place where Python meets the kernels. There is NO fallback: if the HIP library is missing the
+import of the product fails loudly (`load_library`). Buffers are torch tensors; the library receives raw device
+pointers (`Tensor.data_ptr()`) and torch's current HIP stream, allocates nothing and never synchronises.
+"""
+import ctypes
+import os
+
+import numpy as np
+import torch
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_NAME = 'libpinn_hip.so'
+
+MAX_LAYERS, MAX_INPUTS, MAX_DIRS, EXTRA_SLOTS = 16, 8, 3, 16
+MAX_OPS, MAX_CONSTS, MAX_REGS = 64, 32, 40
+ACT_CODES = {'tanh': 0, 'sigmoid': 1}
+
+OPS = dict(CONST=0, ADD=1, SUB=2, MUL=3, DIV=4, NEG=5, SIN=6, COS=7, EXP=8, LOG=9, TANH=10, SQRT=11, POW=12,
+           ABS=13, SIGMOID=14, RECIP=15, COPY=16)
+
+
+class Layout(ctypes.Structure):
+    _fields_ = [(name, ctypes.c_int) for name in
+                ('hp', 'lh', 'd', 'off_w1', 'off_b1', 'off_wh', 'hidden_stride', 'off_wl', 'off_bl',
+                 'off_log_scale', 'off_loss', 'p_core', 'off_extra', 'p_total')]
+
+
+class Program(ctypes.Structure):
+    _fields_ = [('n_ops', ctypes.c_int), ('n_consts', ctypes.c_int),
+                ('code', ctypes.c_uint32 * MAX_OPS), ('consts', ctypes.c_float * MAX_CONSTS)]
+
+    @classmethod
+    def from_lists(cls, code, consts):
+        if len(code) > MAX_OPS or len(consts) > MAX_CONSTS:
+            raise ValueError(f'residual program too long ({len(code)} ops, {len(consts)} constants)')
+        prog = cls()
+        prog.n_ops, prog.n_consts = len(code), len(consts)
+        for i, (op, dst, a, b) in enumerate(code):
+            prog.code[i] = op | (dst << 8) | (a << 16) | (b << 24)
+        for i, c in enumerate(consts):
+            prog.consts[i] = c
+        return prog
+
+
+def bind(lib):
+    """ declare the signatures of include/pinn.h on a loaded shared library. """
+    vp, i32, i64, f32 = ctypes.c_void_p, ctypes.c_int, ctypes.c_int64, ctypes.c_float
+    ip = ctypes.POINTER(ctypes.c_int)
+    lib.pinn_last_error.restype = ctypes.c_char_p
+    lib.pinn_backend.restype = ctypes.c_char_p
+    lib.pinn_create.argtypes = [ip, i32, i32, i32, i32, i32, i32, ctypes.POINTER(f32), ctypes.POINTER(f32), f32,
+                                ctypes.POINTER(vp)]
+    lib.pinn_destroy.argtypes = [vp]
+    lib.pinn_layout.argtypes = [vp, ctypes.POINTER(Layout)]
+    lib.pinn_workspace_bytes.argtypes = [vp, i64, i32, i32]
+    lib.pinn_workspace_bytes.restype = ctypes.c_size_t
+    lib.pinn_jet_forward.argtypes = [vp, vp, vp, i64, ip, i32, i32, vp, f32, vp, vp]
+    lib.pinn_jet_backward.argtypes = [vp, vp, vp, i64, ip, i32, i32, vp, f32, vp, vp, i32, vp, ctypes.c_size_t, vp]
+    lib.pinn_residual_step.argtypes = [vp, ctypes.POINTER(Program), vp, vp, i64, ip, i32, i32, vp, f32, f32, vp, vp,
+                                       ctypes.c_size_t, vp]
+    lib.pinn_adam_step.argtypes = [vp, vp, vp, vp, vp, i64, vp, f32, f32, f32, f32, vp]
+    lib.pinn_profile_tile.argtypes = [i32]
+    lib.pinn_profile_tile.restype = i32
+    lib.pinn_last_tile_ms.restype = f32
+    for name in ('pinn_create', 'pinn_destroy', 'pinn_layout', 'pinn_jet_forward', 'pinn_jet_backward',
+                 'pinn_residual_step', 'pinn_adam_step'):
+        getattr(lib, name).restype = i32
+    return lib
+
+
+ABI_SYMBOLS = ('pinn_create', 'pinn_destroy', 'pinn_layout', 'pinn_workspace_bytes', 'pinn_jet_forward',
+               'pinn_jet_backward', 'pinn_residual_step', 'pinn_adam_step', 'pinn_profile_tile', 'pinn_last_tile_ms',
+               'pinn_last_error', 'pinn_backend')
+
+_LIB = None
+
+
+def library_path():
+    return os.path.join(_HERE, LIB_NAME)
+
+
+def load_library():
+    """ the product library; raises if it has not been built (no CPU / eager fallback exists). """
+    global _LIB
+    if _LIB is None:
+        path = library_path()
+        if not os.path.exists(path):
+            raise RuntimeError(f'{path} is missing: build it with `python -m pydens_amd.csrc.build` '
+                               '(or __graft_entry__.build()); pydens_amd has no fallback path')
+        lib = bind(ctypes.CDLL(path))
+        if lib.pinn_backend() != b'hip-gfx950':
+            raise RuntimeError(f'{path} is not the HIP build ({lib.pinn_backend()!r})')
+        _LIB = lib
+    return _LIB
+
+
+def _ptr(t):
+    return None if t is None else ctypes.c_void_p(t.data_ptr())
+
+
+def _stream(t):
+    if t.is_cuda:
+        return ctypes.c_void_p(torch.cuda.current_stream(t.device).cuda_stream)
+    return None
+
+
+def _check(t, name, dtype=torch.float32):
+    if t is None:
+        return
+    if t.dtype != dtype or not t.is_contiguous():
+        raise ValueError(f'{name} must be a contiguous {dtype} tensor')
+
+
+class Net:
+    """ pinn_t handle + its flat padded parameter layout. """
+    def __init__(self, layer_dims, activation, ndims, nparams=0, has_bc=False, bc_value=0.0, has_ic=False,
+                 domain=None, lib=None):
+        self.lib = lib if lib is not None else load_library()
+        act = ACT_CODES.get(str(activation).lower())
+        if act is None:
+            raise NotImplementedError(f'activation {activation!r}: the HIP kernels implement Tanh and Sigmoid')
+        domain = list(domain) if domain is not None else [(0.0, 1.0)] * ndims
+        dims = (ctypes.c_int * len(layer_dims))(*layer_dims)
+        lo = (ctypes.c_float * ndims)(*[float(d[0]) for d in domain])
+        hi = (ctypes.c_float * ndims)(*[float(d[1]) for d in domain])
+        handle = ctypes.c_void_p()
+        rc = self.lib.pinn_create(dims, len(layer_dims) - 1, act, ndims, nparams, int(has_bc), int(has_ic), lo, hi,
+                                  float(bc_value), ctypes.byref(handle))
+        self._raise(rc)
+        self.handle = handle
+        lay = Layout()
+        self._raise(self.lib.pinn_layout(self.handle, ctypes.byref(lay)))
+        self.layout = lay
+        self.layer_dims = list(layer_dims)
+        self.ndims, self.nparams = ndims, nparams
+
+    def _raise(self, rc):
+        if rc != 0:
+            raise RuntimeError('libpinn: ' + self.lib.pinn_last_error().decode())
+
+    def __del__(self):
+        if getattr(self, 'handle', None):
+            self.lib.pinn_destroy(self.handle)
+            self.handle = None
+
+    # ---- parameter views ----------------------------------------------------------------------------------------
+    def param_views(self, flat):
+        """ nn.Linear-shaped (weight [out,in], bias [out]) views into the flat padded buffer, layer by layer. """
+        L, dims = self.layout, self.layer_dims
+        n_lin = len(dims) - 1
+        views = []
+        for l in range(n_lin):
+            n_in, n_out = dims[l], dims[l + 1]
+            if l == 0:
+                w = flat.as_strided((n_out, n_in), (L.d, 1), L.off_w1)
+                b = flat.as_strided((n_out,), (1,), L.off_b1)
+            elif l == n_lin - 1:
+                w = flat.as_strided((1, n_in), (L.hp, 1), L.off_wl)
+                b = flat.as_strided((1,), (1,), L.off_bl)
+            else:
+                off = L.off_wh + (l - 1) * L.hidden_stride
+                w = flat.as_strided((n_out, n_in), (L.hp, 1), off)
+                b = flat.as_strided((n_out,), (1,), off + L.hp * L.hp)
+            views.append((w, b))
+        return views
+
+    def real_mask(self, device):
+        """ uint8 [p_total]: 1 where the flat buffer holds a real network parameter (not padding / loss slot). """
+        mask = torch.zeros(self.layout.p_total, dtype=torch.uint8, device=device)
+        for w, b in self.param_views(mask):
+            w.fill_(1)
+            b.fill_(1)
+        mask[self.layout.off_log_scale] = 1
+        return mask
+
+    # ---- kernels ----------------------------------------------------------------------------------------------------
+    def _dirs(self, dir_cols):
+        dir_cols = list(dir_cols)
+        return (ctypes.c_int * max(len(dir_cols), 1))(*dir_cols), len(dir_cols)
+
+    def workspace_bytes(self, n_points, nd, n2):
+        return int(self.lib.pinn_workspace_bytes(self.handle, n_points, nd, n2))
+
+    def jet_forward(self, params, xs, dir_cols=(), n2=0, ic_streams=None, ic_const=0.0, out=None):
+        _check(params, 'params'); _check(xs, 'xs'); _check(ic_streams, 'ic_streams')
+        n = xs.shape[0]
+        dirs, nd = self._dirs(dir_cols)
+        s = 1 + nd + n2
+        if out is None:
+            out = torch.empty((s, n), dtype=torch.float32, device=xs.device)
+        _check(out, 'out')
+        self._raise(self.lib.pinn_jet_forward(self.handle, _ptr(params), _ptr(xs), n, dirs, nd, n2, _ptr(ic_streams),
+                                              float(ic_const), _ptr(out), _stream(xs)))
+        return out
+
+    def jet_backward(self, params, xs, grad_streams, grads, workspace, dir_cols=(), n2=0, ic_streams=None,
+                     ic_const=0.0, accumulate=False):
+        for t, name in ((params, 'params'), (xs, 'xs'), (grad_streams, 'grad_streams'), (grads, 'grads'),
+                        (ic_streams, 'ic_streams')):
+            _check(t, name)
+        dirs, nd = self._dirs(dir_cols)
+        self._raise(self.lib.pinn_jet_backward(self.handle, _ptr(params), _ptr(xs), xs.shape[0], dirs, nd, n2,
+                                               _ptr(ic_streams), float(ic_const), _ptr(grad_streams), _ptr(grads),
+                                               int(accumulate), _ptr(workspace), workspace.numel() * workspace.element_size(),
+                                               _stream(xs)))
+
+    def residual_step(self, program, params, xs, grads, workspace, dir_cols=(), n2=0, ic_streams=None, ic_const=0.0,
+                      inv_n_global=None):
+        for t, name in ((params, 'params'), (xs, 'xs'), (grads, 'grads'), (ic_streams, 'ic_streams')):
+            _check(t, name)
+        dirs, nd = self._dirs(dir_cols)
+        n = xs.shape[0]
+        inv_n = 1.0 / n if inv_n_global is None else inv_n_global
+        self._raise(self.lib.pinn_residual_step(self.handle, ctypes.byref(program), _ptr(params), _ptr(xs), n, dirs, nd,
+                                                n2, _ptr(ic_streams), float(ic_const), float(inv_n), _ptr(grads),
+                                                _ptr(workspace), workspace.numel() * workspace.element_size(),
+                                                _stream(xs)))
+
+    def adam_step(self, params, grads, exp_avg, exp_avg_sq, mask, step, lr, betas=(0.9, 0.999), eps=1e-8):
+        for t, name in ((params, 'params'), (grads, 'grads'), (exp_avg, 'exp_avg'), (exp_avg_sq, 'exp_avg_sq')):
+            _check(t, name)
+        _check(mask, 'mask', torch.uint8)
+        _check(step, 'step', torch.int32)
+        self._raise(self.lib.pinn_adam_step(_ptr(params), _ptr(grads), _ptr(exp_avg), _ptr(exp_avg_sq), _ptr(mask),
+                                            params.numel(), _ptr(step), float(lr), float(betas[0]), float(betas[1]),
+                                            float(eps), _stream(params)))

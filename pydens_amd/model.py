@@ -1,0 +1,220 @@
+""" Problem/model description on the host: same classes, constructor arguments and attributes as the reference's
+`TorchModel` / `ConvBlockModel` (pydens/model_torch.py:17-172), but the network lives in ONE flat fp32 device
+buffer laid out for the HIP kernels (include/pinn.h); `nn.Parameter`s are views into it, so `parameters()`,
+`state_dict()`, `freeze_trainable` and user code that pokes weights keep working. """
+from abc import ABC, abstractmethod
+
+import numpy as np
+import torch
+from torch import nn
+
+from . import engine
+
+
+def default_device():
+    if not torch.cuda.is_available():
+        raise RuntimeError('pydens_amd needs a HIP device (torch.cuda.is_available() is False); '
+                           'there is no CPU fallback')
+    return torch.device('cuda', torch.cuda.current_device())
+
+
+class TorchModel(ABC, nn.Module):
+    """ reference model_torch.py:17-128. """
+    def __init__(self, ndims, initial_condition=None, boundary_condition=None, domain=(0, 1), nparams=0, **kwargs):
+        _ = kwargs
+        super().__init__()
+        self.ndims = ndims
+        self.ndims_spatial = ndims if initial_condition is None else ndims - 1          # :25
+        self.nparams = nparams
+        self.total = ndims + nparams
+        self.variables = {}
+        if initial_condition is None:
+            self.initial_condition = None
+            self.ic_constant = None
+        elif callable(initial_condition):
+            self.initial_condition = initial_condition
+            self.ic_constant = None
+        else:                                                                             # :31-35
+            self.ic_constant = float(initial_condition)
+            self.initial_condition = lambda *args: torch.tensor(self.ic_constant, dtype=torch.float32)
+        self.boundary_condition = boundary_condition
+        if isinstance(domain, (tuple, list)):                                             # :37-46
+            if isinstance(domain[0], (float, int)):
+                domain = [domain] * ndims
+            elif isinstance(domain[0], (tuple, list)):
+                pass
+            else:
+                raise ValueError('Should be either 1d or 2d-sequence of float/ints.')
+        else:
+            raise ValueError('Should be either 1d or 2d-sequence of float/ints.')
+        self.domain = domain
+
+    @abstractmethod
+    def forward(self, xs):
+        """ Forward of the model-network. """
+
+    def freeze_trainable(self, layers=None, variables=None):
+        """ reference model_torch.py:56-80: flips requires_grad; `Solver.fit` turns it into the Adam mask. """
+        for layer in (layers or []):
+            for param in getattr(self, layer).parameters():
+                param.requires_grad = False
+        for variable in (variables or []):
+            getattr(self, variable).requires_grad = False
+
+    def unfreeze_trainable(self, layers=None, variables=None):
+        """ reference model_torch.py:82-105 """
+        for layer in (layers or []):
+            for param in getattr(self, layer).parameters():
+                param.requires_grad = True
+        for variable in (variables or []):
+            getattr(self, variable).requires_grad = True
+
+
+class FlatLinear(nn.Module):
+    """ fc layer whose weight [out,in] / bias [out] are views into the model's flat kernel buffer. """
+    def __init__(self, weight, bias):
+        super().__init__()
+        self.weight = nn.Parameter(weight)
+        self.bias = nn.Parameter(bias)
+        self.in_features, self.out_features = weight.shape[1], weight.shape[0]
+
+    def forward(self, x):
+        return nn.functional.linear(x, self.weight, self.bias)
+
+
+def parse_fc_layout(layout, features, activation):
+    """ 'fa fa f' -> widths; only alternating dense/activation layouts ending in a 1-unit dense layer run on the
+    kernels (reference documents more letters at model_torch.py:142-156; DESIGN.md lists them as out of scope). """
+    letters = layout.replace(' ', '')
+    features = list(features)
+    n_f = letters.count('f')
+    if set(letters) - set('fa'):
+        raise NotImplementedError(f"layout {layout!r}: only 'f' (dense) and 'a' (activation) letters are supported")
+    if letters != 'fa' * (n_f - 1) + 'f' or n_f < 2:
+        raise NotImplementedError(f"layout {layout!r}: expected 'fa' repeated and a final 'f' (at least two dense layers)")
+    if len(features) < n_f:
+        raise ValueError(f'layout {layout!r} needs {n_f} entries in `features`, got {features}')
+    features = features[:n_f]
+    if features[-1] != 1:
+        raise NotImplementedError('the last dense layer must have one unit (the scalar solution approximation)')
+    if isinstance(activation, (list, tuple)):
+        if len(set(map(str, activation))) != 1:
+            raise NotImplementedError('per-layer activation lists with different activations are not supported')
+        activation = activation[0]
+    if isinstance(activation, type):
+        activation = activation.__name__
+    elif isinstance(activation, nn.Module):
+        activation = type(activation).__name__
+    return features, str(activation)
+
+
+class _ModelForward(torch.autograd.Function):
+    """ value-only network+ansatz on arbitrary points with gradients to the parameters (constraint terms,
+    reference model_torch.py:451-457). Forward = pinn_jet_forward(nd=0); backward = pinn_jet_backward(nd=0),
+    accumulated straight into the solver's flat gradient buffer (`model.grad_sink`): the nn.Parameters are views
+    of the flat kernel buffer, so the parameter gradient is delivered there and not through autograd leaves. """
+    @staticmethod
+    def forward(ctx, anchor, xs, model):
+        ctx.model, ctx.xs = model, xs
+        return model.net.jet_forward(model.flat, xs, ic_const=model.kernel_ic_const()).view(-1, 1)
+
+    @staticmethod
+    def backward(ctx, grad_out):
+        model, xs = ctx.model, ctx.xs
+        if model.grad_sink is None:
+            raise RuntimeError('gradients through model(xs) are only available inside Solver.fit')
+        ws = model.workspace(xs.shape[0], 0, 0)
+        model.net.jet_backward(model.flat, xs, grad_out.contiguous().view(1, -1), model.grad_sink, ws,
+                               ic_const=model.kernel_ic_const(), accumulate=True)
+        return None, None, None
+
+
+class ConvBlockModel(TorchModel):
+    """ reference model_torch.py:130-172 for fully connected layouts. """
+    def __init__(self, ndims, initial_condition=None, boundary_condition=None, domain=(0, 1), nparams=0,
+                 layout='fafaf', features=(20, 30, 1), activation='Sigmoid', device=None, lib=None, **kwargs):
+        features = kwargs.pop('units', features)                  # README.md:41-42 spells it `units`
+        super().__init__(ndims=ndims, initial_condition=initial_condition, boundary_condition=boundary_condition,
+                         domain=domain, nparams=nparams, **kwargs)
+        widths, act_name = parse_fc_layout(layout, features, activation)
+        self.activation_name = act_name
+        self.device = torch.device(device) if device is not None else default_device()
+        self.layer_dims = [self.total] + widths
+        self.net = engine.Net(self.layer_dims, act_name, ndims, nparams,
+                              has_bc=boundary_condition is not None, bc_value=boundary_condition or 0.0,
+                              has_ic=initial_condition is not None, domain=self.domain, lib=lib)
+        lay = self.net.layout
+        # flat kernel buffer; PyTorch-default nn.Linear init drawn in the reference's order
+        # (fake inputs first, model_torch.py:167, then the layers of Block, :168)
+        host = torch.zeros(lay.p_total, dtype=torch.float32)
+        _ = torch.rand((2, self.total), dtype=torch.float32)
+        for (w, b), (n_in, n_out) in zip(self.net.param_views(host), zip(self.layer_dims[:-1], self.layer_dims[1:])):
+            lin = nn.Linear(n_in, n_out, bias=True)
+            w.copy_(lin.weight.detach()); b.copy_(lin.bias.detach())
+        self.register_buffer('flat', host.to(self.device), persistent=False)
+        self.log_scale = nn.Parameter(self.flat.as_strided((), (), lay.off_log_scale))   # :50, value 0.0
+        self.conv_block = nn.Sequential()
+        for i, (w, b) in enumerate(self.net.param_views(self.flat)):
+            self.conv_block.add_module(f'fc{i + 1}', FlatLinear(w, b))
+        self._next_extra = lay.off_extra
+        self._workspaces = {}
+        self._anchor = torch.zeros((), device=self.device, requires_grad=True)
+        self.grad_sink = None
+
+    # ---- trainable V(...) variables live in the tail of the flat buffer ---------------------------------------
+    def register_variable(self, name, param):
+        lay = self.net.layout
+        n = param.numel()
+        if self._next_extra + n > lay.p_total:
+            raise RuntimeError(f'V({name!r}): no room left for {n} more trainable scalars '
+                               f'({engine.EXTRA_SLOTS} slots per model)')
+        off = self._next_extra
+        self._next_extra += n
+        with torch.no_grad():
+            self.flat[off:off + n] = param.detach().to(self.flat).reshape(-1)
+        view = self.flat.as_strided(tuple(param.shape), tuple(param.stride()) if param.dim() else (), off)
+        self.variables[name] = (off, n)
+        return nn.Parameter(view, requires_grad=param.requires_grad)
+
+    # ---- helpers for the solver --------------------------------------------------------------------------------
+    def kernel_ic_const(self):
+        """ constant initial condition handled inside the kernels (0 when the IC is a callable added by the host) """
+        return self.ic_constant if self.ic_constant is not None else 0.0
+
+    def workspace(self, n_points, nd, n2):
+        key = (nd, n2)
+        need = self.net.workspace_bytes(n_points, nd, n2)
+        ws = self._workspaces.get(key)
+        if ws is None or ws.numel() * 4 < need:
+            ws = torch.empty((need + 3) // 4, dtype=torch.float32, device=self.flat.device)
+            self._workspaces[key] = ws
+        return ws
+
+    def trainable_mask(self):
+        """ uint8 [p_total]: 1 for entries Adam may touch = real (non-padding) parameters with requires_grad. """
+        mask = torch.zeros_like(self.flat, dtype=torch.uint8)
+        lay = self.net.layout
+        lins = [m for m in self.conv_block if isinstance(m, FlatLinear)]
+        for (w, b), lin in zip(self.net.param_views(mask), lins):
+            w.fill_(1 if lin.weight.requires_grad else 0)
+            b.fill_(1 if lin.bias.requires_grad else 0)
+        mask[lay.off_log_scale] = 1 if self.log_scale.requires_grad else 0
+        for name, (off, n) in self.variables.items():
+            mask[off:off + n] = 1 if getattr(self, name).requires_grad else 0
+        return mask
+
+    def ic_values(self, xs):
+        """ IC(x_spatial) as [N,1] on the device (callable ICs only; differentiable w.r.t. V-variables). """
+        cols = [xs[:, i] for i in range(self.ndims_spatial)]              # 1-D [N] columns, model_torch.py:125
+        val = self.initial_condition(*cols)
+        if not isinstance(val, torch.Tensor):
+            val = torch.tensor(float(val), dtype=torch.float32)
+        return val.to(device=xs.device, dtype=torch.float32).view(-1, 1)
+
+    def forward(self, xs):
+        """ u_hat [N,1] = anzatc(conv_block(xs), xs) (reference model_torch.py:170-172) on the HIP kernels. """
+        xs = xs.to(device=self.flat.device, dtype=torch.float32).contiguous()
+        u = _ModelForward.apply(self._anchor, xs, self)
+        if self.initial_condition is not None and self.ic_constant is None:
+            u = u + self.ic_values(xs).expand_as(u)
+        return u

@@ -1,0 +1,84 @@
+""" Point samplers with the `batchflow.sampler` surface pydens re-exports (reference pydens/__init__.py:5):
+`NumpySampler(name, **kwargs)`, `a & b` = column concatenation, `.sample(size) -> ndarray [size, dim]`
+(call site reference model_torch.py:433; README.md:82 `NumpySampler('uniform') & NumpySampler('uniform', low=1, high=5)`).
+
+`batchflow` itself is third-party and not vendored by the reference; only the numpy-distribution samplers and
+`&` are restated. On top of the numpy surface every sampler offers `sample_device(size, device)`, which draws the
+batch directly in HBM (uniform / normal), so that `Solver.fit` keeps the host out of the step path.
+"""
+import numpy as np
+import torch
+
+__all__ = ['Sampler', 'NumpySampler', 'ConstantSampler', 'NS']
+
+_ALIASES = {'u': 'uniform', 'n': 'normal', 'e': 'exponential', 'g': 'gamma'}
+
+
+class Sampler:
+    dim = 1
+
+    def sample(self, size):
+        raise NotImplementedError
+
+    def sample_device(self, size, device, generator=None):
+        """ default: numpy draw + one host-to-device copy. """
+        return torch.from_numpy(np.asarray(self.sample(size), dtype=np.float32)).to(device)
+
+    def __and__(self, other):
+        if isinstance(other, (int, float)):
+            other = ConstantSampler(other)
+        return _ConcatSampler(self, other)
+
+
+class _ConcatSampler(Sampler):
+    def __init__(self, left, right):
+        self.left, self.right = left, right
+        self.dim = left.dim + right.dim
+
+    def sample(self, size):
+        return np.concatenate([self.left.sample(size), self.right.sample(size)], axis=1)
+
+    def sample_device(self, size, device, generator=None):
+        return torch.cat([self.left.sample_device(size, device, generator),
+                          self.right.sample_device(size, device, generator)], dim=1)
+
+
+class ConstantSampler(Sampler):
+    def __init__(self, value, dim=1):
+        self.value, self.dim = float(value), dim
+
+    def sample(self, size):
+        return np.full((size, self.dim), self.value, dtype=np.float64)
+
+    def sample_device(self, size, device, generator=None):
+        return torch.full((size, self.dim), self.value, dtype=torch.float32, device=device)
+
+
+class NumpySampler(Sampler):
+    """ sampler named after a `numpy.random` distribution ('uniform'/'u', 'normal'/'n', ...). """
+    def __init__(self, name, dim=1, seed=None, **kwargs):
+        self.name = _ALIASES.get(name, name)
+        self.dim = dim
+        self.kwargs = kwargs
+        self.rng = np.random.RandomState(seed)
+        if not hasattr(self.rng, self.name):
+            raise ValueError(f'unknown numpy distribution {name!r}')
+
+    def sample(self, size):
+        draw = getattr(self.rng, self.name)
+        return np.asarray(draw(size=(size, self.dim), **self.kwargs), dtype=np.float64)
+
+    def sample_device(self, size, device, generator=None):
+        if self.name == 'uniform' and not (set(self.kwargs) - {'low', 'high'}):
+            low, high = float(self.kwargs.get('low', 0.0)), float(self.kwargs.get('high', 1.0))
+            out = torch.rand((size, self.dim), dtype=torch.float32, device=device, generator=generator)
+            if low != 0.0 or high != 1.0:
+                out = out * (high - low) + low
+            return out
+        if self.name == 'normal' and not (set(self.kwargs) - {'loc', 'scale'}):
+            out = torch.randn((size, self.dim), dtype=torch.float32, device=device, generator=generator)
+            return out * float(self.kwargs.get('scale', 1.0)) + float(self.kwargs.get('loc', 0.0))
+        return super().sample_device(size, device, generator)
+
+
+NS = NumpySampler

@@ -1,0 +1,343 @@
+""" `Solver`: same constructor, `fit`, `predict`, `losses` as the reference (pydens/model_torch.py:191-487); the
+per-iteration arithmetic runs in the HIP kernels behind include/pinn.h.
+
+Two step paths share every kernel:
+  * fused   -- the equation was lowered to a residual program (trace.py): ONE call of pinn_residual_step does
+               forward jets, ansatz, residual, MSE and the whole reverse sweep; then pinn_adam_step. No torch
+               arithmetic and no host synchronisation inside the loop (losses stay on the device).
+  * generic -- anything else the reference API allows (trainable `V` variables, callable ICs holding variables,
+               constraint terms, user criteria): pinn_jet_forward hands the derivative streams to the user's own
+               torch code, torch differentiates those few pointwise ops, pinn_jet_backward turns the upstream
+               stream gradients into parameter gradients.
+Data parallelism: if torch.distributed is initialised, every rank steps on its own `batch_size` points and the flat
+gradient buffer (loss slot included) is summed with one all-reduce (RCCL) per iteration.
+"""
+from contextvars import copy_context
+
+import numpy as np
+import torch
+from torch import nn
+from tqdm import tqdm
+
+from . import engine, trace
+from .model import ConvBlockModel, TorchModel
+from .tokens import current_model
+
+
+class FlatAdam:
+    """ torch.optim.Adam semantics (reference model_torch.py:419-422, :461) on the flat kernel buffer. """
+    def __init__(self, model, lr=0.005, betas=(0.9, 0.999), eps=1e-8, weight_decay=0, amsgrad=False, **kwargs):
+        if weight_decay != 0 or amsgrad or kwargs:
+            raise NotImplementedError('the HIP Adam kernel implements plain Adam (lr, betas, eps); got '
+                                      f'weight_decay={weight_decay}, amsgrad={amsgrad}, {kwargs}')
+        self.model, self.lr, self.betas, self.eps = model, lr, betas, eps
+        self.exp_avg = torch.zeros_like(model.flat)
+        self.exp_avg_sq = torch.zeros_like(model.flat)
+        self.step_count = torch.zeros(1, dtype=torch.int32, device=model.flat.device)
+        self.mask = None
+
+    def refresh(self):
+        self.mask = self.model.trainable_mask()
+
+    def step(self, grads):
+        self.model.net.adam_step(self.model.flat, grads, self.exp_avg, self.exp_avg_sq, self.mask, self.step_count,
+                                 self.lr, self.betas, self.eps)
+
+
+class TorchOptimizerAdapter:
+    """ any other `torch.optim` optimizer the reference accepts by name (model_torch.py:420): torch updates the
+    parameter views in place; their .grad are views of the flat gradient buffer the kernels fill. """
+    def __init__(self, model, name, lr, **kwargs):
+        self.model = model
+        self.params = [p for p in model.parameters() if p.requires_grad]
+        self.opt = getattr(torch.optim, name)(self.params, lr=lr, **kwargs)
+
+    def refresh(self):
+        pass
+
+    def step(self, grads):
+        for p in self.params:
+            p.grad = grads.as_strided(tuple(p.shape), tuple(p.stride()), p.storage_offset())
+        self.opt.step()
+        for p in self.params:
+            p.grad = None
+
+
+class Solver:
+    """ reference model_torch.py:191-487. Extra keyword `device` selects the HIP device (default: current). """
+    def __init__(self, equation, ndims, initial_condition=None, boundary_condition=None, domain=(0, 1),
+                 nparams=0, model=ConvBlockModel, constraints=None, **kwargs):
+        self.equation = equation
+        if constraints is None:
+            self.constraints = ()
+        elif isinstance(constraints, (tuple, list)):
+            self.constraints = constraints
+        else:
+            self.constraints = (constraints, )
+        self._losses = []
+        self._pending = []
+        self.optimizer = None
+
+        self.model = model(**kwargs, ndims=ndims, initial_condition=initial_condition,
+                           boundary_condition=boundary_condition, domain=domain, nparams=nparams)
+        if not isinstance(self.model, ConvBlockModel):
+            raise NotImplementedError('custom TorchModel subclasses run arbitrary torch code in forward(); only '
+                                      'ConvBlockModel (fully connected layouts) is backed by the HIP kernels')
+        current_model.set(self.model)                                     # :316-317
+        self.ctx = copy_context()
+        self.device = self.model.flat.device
+        lay = self.model.net.layout
+        self.grads = torch.zeros(lay.p_total, dtype=torch.float32, device=self.device)
+        self._generator = None
+        self._broadcast_done = False
+
+        # "fake run" (:319-325): materialises V-variables and, here, tells which derivative streams D(...) needs
+        if self.model.initial_condition is not None and self.model.ic_constant is None:
+            fake = torch.rand((3, self.model.total), device=self.device)
+            self.ctx.run(self.model.ic_values, fake)
+        self.spec, self.needs_x_grad = trace.discover(self.equation, self.ctx.run, self.model.total, self.device)
+        self.ic_trainable = self._ic_depends_on_variables()
+        self.program, self.program_error = self._try_compile()
+
+    # ---- tracing ---------------------------------------------------------------------------------------------------
+    def _ic_depends_on_variables(self):
+        m = self.model
+        if m.initial_condition is None or m.ic_constant is not None:
+            return False
+        fake = torch.rand((3, m.total), device=self.device)
+        return bool(self.ctx.run(m.ic_values, fake).requires_grad)
+
+    def _try_compile(self):
+        """ lower the equation to a residual program and cross-check it numerically against the callable. """
+        total = self.model.total
+        try:
+            root = trace.symbolic(self.equation, self.ctx.run, total)
+            code, consts = trace.compile_program(root, self.spec, total)
+            # validation on random data: program (fp64 host interpreter) vs the user's callable on tagged tensors
+            n = 17
+            streams = torch.rand((self.spec.n_streams, n), device=self.device) * 2 - 1
+            pts = torch.rand((n, total), device=self.device) + 0.25
+            want = self._eval_equation(streams, pts, requires_grad=False).reshape(-1).double().cpu().numpy()
+            got = trace.run_program_numpy(code, consts, streams.cpu().numpy(), pts.cpu().numpy())
+            if not np.allclose(got, want, rtol=1e-4, atol=1e-5):
+                raise trace.TraceUnsupported('traced program disagrees with the callable (data-dependent control flow?)')
+            return engine.Program.from_lists(code, consts), None
+        except trace.TraceUnsupported as err:
+            return None, str(err)
+
+    def _eval_equation(self, streams, xs, ic_streams=None, requires_grad=True):
+        """ run the user's callable on stream tensors [S,N] (+ optional IC streams), D resolves to streams. """
+        total = self.model.total
+        sc = trace.StreamContext(total)
+        for alpha, idx in self.spec.index.items():
+            t = streams[idx].view(-1, 1)
+            if ic_streams is not None and ic_streams[idx] is not None:
+                t = t + ic_streams[idx]
+            sc.tag(t, alpha)
+        cols = []
+        for c in range(total):
+            col = xs[:, c:c + 1]
+            if self.needs_x_grad and requires_grad:
+                col = col.clone().requires_grad_()
+            col._pinn_col = c
+            cols.append(col)
+        token = trace.active_streams.set(sc)
+        try:
+            return self.ctx.run(self.equation, sc.tensors[()], *cols)
+        finally:
+            trace.active_streams.reset(token)
+
+    def _ic_streams(self, xs, create_graph):
+        """ IC(x_spatial) and its derivative streams as a list over stream indices ([N,1] tensors or None). """
+        m, spec = self.model, self.spec
+        cols = [xs[:, i].clone().requires_grad_() for i in range(m.ndims_spatial)]
+        val = self.ctx.run(m.initial_condition, *cols)
+        if not isinstance(val, torch.Tensor):
+            val = torch.tensor(float(val), dtype=torch.float32, device=xs.device)
+        val = val.to(xs.device).float()
+        out = [None] * spec.n_streams
+        out[0] = val.view(-1, 1) if val.numel() > 1 else val.reshape(1, 1).expand(xs.shape[0], 1)
+        if val.numel() > 1 and val.requires_grad:
+            for k, c in enumerate(spec.dir_cols):
+                if c >= m.ndims_spatial:
+                    continue
+                (g1,) = torch.autograd.grad(val.sum(), cols[c], create_graph=True, retain_graph=True, allow_unused=True)
+                if g1 is None:
+                    continue
+                out[1 + k] = g1.view(-1, 1)
+                if k < spec.n2 and g1.requires_grad:
+                    (g2,) = torch.autograd.grad(g1.sum(), cols[c], create_graph=create_graph, retain_graph=True,
+                                                    allow_unused=True)
+                    if g2 is not None:
+                        out[1 + spec.nd + k] = g2.view(-1, 1)
+        if not create_graph:
+            out = [None if t is None else t.detach() for t in out]
+        return out
+
+    # ---- reference API -----------------------------------------------------------------------------------------------
+    @property
+    def losses(self):
+        """ list of 0-d numpy arrays, one per iteration (reference model_torch.py:308, :464); device-side history is
+        fetched lazily so that `fit` itself never synchronises. """
+        if self._pending:
+            for chunk in self._pending:
+                self._losses.extend(np.float32(v) for v in chunk.detach().cpu().numpy().reshape(-1))
+            self._pending = []
+            self._losses = [np.asarray(v) for v in self._losses]
+        return self._losses
+
+    @losses.setter
+    def losses(self, value):
+        self._pending, self._losses = [], list(value)
+
+    @classmethod
+    def reshape_and_concat(cls, tensors, device=None):
+        """ Input casting of reference model_torch.py:327-362 -> float32 [N, D] (on `device` if given). """
+        items = list(tensors)
+        lengths = [int(np.prod(np.shape(t))) for t in items
+                   if isinstance(t, (np.ndarray, torch.Tensor, tuple, list))]
+        n = max(lengths) if lengths else 1
+        cols = []
+        for x in items:
+            if isinstance(x, torch.Tensor):
+                col = x.reshape(-1, 1).float()
+            elif isinstance(x, np.ndarray):
+                arr = x if x.size == n else np.tile(x.squeeze()[0], (n, 1))            # :355-356
+                col = torch.from_numpy(np.ascontiguousarray(arr, dtype=np.float32).reshape(n, 1))
+            elif isinstance(x, (list, tuple)):
+                col = torch.tensor(x, dtype=torch.float32).view(-1, 1)
+            else:
+                col = torch.full((n, 1), float(x), dtype=torch.float32)
+            if device is not None:
+                col = col.to(device)
+            cols.append(col)
+        return torch.cat(cols, dim=1)
+
+    def _world(self):
+        dist = torch.distributed
+        if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
+            return dist.get_rank(), dist.get_world_size()
+        return 0, 1
+
+    def _sample(self, batch_size, sampler):
+        """ reference model_torch.py:430-434: default U[0,1) columns (domain is ignored, trap 3 of SURVEY 8a),
+        or `sampler.sample(batch_size)`. Drawn in HBM whenever the sampler can (`sample_device`). """
+        if self._generator is None:
+            rank, _ = self._world()
+            self._generator = torch.Generator(device=self.device)
+            self._generator.manual_seed(torch.initial_seed() + 7919 * rank)
+        if sampler is None:
+            return torch.rand((batch_size, self.model.total), dtype=torch.float32, device=self.device,
+                              generator=self._generator)
+        if hasattr(sampler, 'sample_device'):
+            xs = sampler.sample_device(batch_size, self.device, self._generator)
+        else:
+            xs = torch.from_numpy(np.asarray(sampler.sample(batch_size)).astype(np.float32)).to(self.device)
+        if xs.shape[1] != self.model.total:
+            raise ValueError(f'sampler produced {xs.shape[1]} columns, the problem has {self.model.total}')
+        return xs.contiguous()
+
+    def fit(self, niters, batch_size, sampler=None, loss_terms='equation', optimizer='Adam',
+            criterion=nn.MSELoss(), lr=0.005, **kwargs):
+        """ reference model_torch.py:364-464. `batch_size` is per rank under torch.distributed. """
+        model = self.model
+        if optimizer is not None:                                                          # :419-422
+            self.optimizer = (FlatAdam(model, lr=lr, **kwargs) if optimizer == 'Adam'
+                              else TorchOptimizerAdapter(model, optimizer, lr, **kwargs))
+        elif self.optimizer is None:
+            raise ValueError('optimizer=None reuses the optimizer of a previous fit call; there is none yet')
+        self.optimizer.refresh()
+        model.train()
+        loss_terms = loss_terms if isinstance(loss_terms, (tuple, list)) else (loss_terms, )
+        nums_constraints = [int(term.replace('constraint', '').replace('_', ''))
+                            for term in loss_terms if 'constraint' in term]
+        mse_mean = isinstance(criterion, nn.MSELoss) and criterion.reduction == 'mean'
+        fused = (self.program is not None and tuple(loss_terms) == ('equation',) and mse_mean
+                 and not self.ic_trainable)
+        rank, world = self._world()
+        if world > 1 and not self._broadcast_done:
+            torch.distributed.broadcast(model.flat, src=0)
+            self._broadcast_done = True
+        lay = model.net.layout
+        history = torch.zeros(niters, dtype=torch.float32, device=self.device)
+        self.last_fit_path = 'fused' if fused else 'generic'
+        for it in tqdm(range(niters), disable=None):
+            xs = self._sample(batch_size, sampler)
+            if fused:
+                self._fused_step(xs, world)
+            else:
+                self._generic_step(xs, loss_terms, nums_constraints, criterion, world)
+            if world > 1:
+                torch.distributed.all_reduce(self.grads)      # flat [p_total]: network, log_scale, loss slot, V slots
+            self.optimizer.step(self.grads)
+            history[it:it + 1].copy_(self.grads[lay.off_loss:lay.off_loss + 1])
+        self._pending.append(history)
+
+    def _fused_step(self, xs, world):
+        model, spec = self.model, self.spec
+        ic_streams = None
+        if model.initial_condition is not None and model.ic_constant is None:
+            parts = self._ic_streams(xs, create_graph=False)
+            ic_streams = torch.zeros((spec.n_streams, xs.shape[0]), dtype=torch.float32, device=self.device)
+            for i, t in enumerate(parts):
+                if t is not None:
+                    ic_streams[i] = t.reshape(-1)
+        ws = model.workspace(xs.shape[0], spec.nd, spec.n2)
+        model.net.residual_step(self.program, model.flat, xs, self.grads, ws, spec.dir_cols, spec.n2,
+                                ic_streams=ic_streams, ic_const=model.kernel_ic_const(),
+                                inv_n_global=1.0 / (xs.shape[0] * world))
+
+    def _generic_step(self, xs, loss_terms, nums_constraints, criterion, world):
+        model, spec = self.model, self.spec
+        lay = model.net.layout
+        self.grads.zero_()
+        model.grad_sink = self.grads
+        for name in model.variables:
+            getattr(model, name).grad = None
+        try:
+            loss = 0
+            leaf = None
+            if 'equation' in loss_terms:
+                leaf = model.net.jet_forward(model.flat, xs, spec.dir_cols, spec.n2,
+                                             ic_const=model.kernel_ic_const()).requires_grad_()
+                ic_streams = None
+                if model.initial_condition is not None and model.ic_constant is None:
+                    ic_streams = self._ic_streams(xs, create_graph=True)
+                r = self._eval_equation(leaf, xs, ic_streams)
+                loss = loss + criterion(r, torch.zeros_like(xs[:, :1]))                 # :448
+
+            def _forward(*pts):                                                          # :451-454
+                return model(self.reshape_and_concat(pts, device=self.device))
+
+            cols = [xs[:, c:c + 1] for c in range(model.total)]
+            for num in nums_constraints:                                                  # :456-457
+                loss = loss + criterion(self.ctx.run(self.constraints[num], _forward, *cols),
+                                        torch.zeros(1, device=self.device))
+            loss.backward()
+            if leaf is not None and leaf.grad is not None:
+                ws = model.workspace(xs.shape[0], spec.nd, spec.n2)
+                model.net.jet_backward(model.flat, xs, leaf.grad.contiguous(), self.grads, ws, spec.dir_cols, spec.n2,
+                                       ic_const=model.kernel_ic_const(), accumulate=True)
+            for name, (off, n) in model.variables.items():
+                p = getattr(model, name)
+                if p.grad is not None:
+                    self.grads[off:off + n] += p.grad.reshape(-1)
+                    p.grad = None
+            if world > 1:
+                self.grads[:lay.p_core] /= world
+                self.grads[lay.off_extra:] /= world
+                loss = loss / world
+            self.grads[lay.off_loss] = loss.detach()
+        finally:
+            model.grad_sink = None
+
+    def predict(self, *xs):
+        """ reference model_torch.py:466-487 -> ndarray [N,1]. """
+        model = self.model
+        pts = self.reshape_and_concat(xs, device=self.device).contiguous()
+        model.eval()
+        with torch.no_grad():
+            u = model.net.jet_forward(model.flat, pts, ic_const=model.kernel_ic_const()).view(-1, 1)
+            if model.initial_condition is not None and model.ic_constant is None:
+                u = u + self.ctx.run(model.ic_values, pts).expand_as(u)
+        return u.detach().cpu().numpy()

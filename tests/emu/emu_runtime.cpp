@@ -1,0 +1,120 @@
+// TEST INFRASTRUCTURE ONLY -- see emu_runtime.h.
+#include "emu_runtime.h"
+
+#include <ucontext.h>
+
+#include <cstdio>
+#include <cstdlib>
+#include <vector>
+
+namespace emu {
+namespace {
+constexpr size_t kStack = 512 * 1024;
+
+struct Fiber {
+    ucontext_t ctx;
+    char* stack = nullptr;
+    bool done = false;
+};
+
+struct Wave {
+    float a[64], b[64];
+    int arrived = 0;
+    unsigned gen = 0;
+};
+
+ucontext_t g_sched;
+std::vector<Fiber> g_fibers;
+std::vector<Wave> g_waves;
+const std::function<void()>* g_body = nullptr;
+int g_cur = 0, g_block = 0, g_bid = 0, g_grid = 0;
+int g_barrier_count = 0;
+unsigned g_barrier_gen = 0;
+float* g_smem = nullptr;
+
+void yield() { swapcontext(&g_fibers[g_cur].ctx, &g_sched); }
+
+void trampoline() {
+    (*g_body)();
+    g_fibers[g_cur].done = true;
+    swapcontext(&g_fibers[g_cur].ctx, &g_sched);
+}
+
+// rendezvous of the 64 lanes of the calling wave; returns after every lane has arrived.
+void wave_sync(Wave& w) {
+    unsigned my = w.gen;
+    if (++w.arrived == 64) { w.arrived = 0; ++w.gen; return; }
+    while (w.gen == my) yield();
+}
+}  // namespace
+
+int tid() { return g_cur; }
+int bid() { return g_bid; }
+int nblk() { return g_grid; }
+float* smem() { return g_smem; }
+
+void sync_block() {
+    unsigned my = g_barrier_gen;
+    if (++g_barrier_count == g_block) { g_barrier_count = 0; ++g_barrier_gen; return; }
+    while (g_barrier_gen == my) yield();
+}
+
+f32x4 mfma16(float a, float b, f32x4 c) {
+    Wave& w = g_waves[g_cur >> 6];
+    const int l = g_cur & 63;
+    w.a[l] = a; w.b[l] = b;
+    wave_sync(w);
+    const int col = l & 15, rq = l >> 4;
+    f32x4 d = c;
+    for (int r = 0; r < 4; ++r) {
+        const int row = rq * 4 + r;
+        float acc = c[r];
+        for (int k = 0; k < 4; ++k) acc = fmaf(w.a[k * 16 + row], w.b[k * 16 + col], acc);
+        d[r] = acc;
+    }
+    wave_sync(w);      // nobody overwrites a/b before everyone has read them
+    return d;
+}
+
+float shfl_xor(float v, int mask) {
+    Wave& w = g_waves[g_cur >> 6];
+    const int l = g_cur & 63;
+    w.a[l] = v;
+    wave_sync(w);
+    float r = w.a[(l ^ mask) & 63];
+    wave_sync(w);
+    return r;
+}
+
+void launch(int grid, int block, size_t smem_bytes, const std::function<void()>& body) {
+    if (block % 64) { fprintf(stderr, "emu: block size must be a multiple of 64\n"); abort(); }
+    g_body = &body; g_block = block; g_grid = grid;
+    g_fibers.assign(block, Fiber());
+    for (auto& f : g_fibers) f.stack = (char*)malloc(kStack);
+    std::vector<float> lds(smem_bytes / 4 + 4);
+    g_smem = lds.data();
+    for (int b = 0; b < grid; ++b) {
+        g_bid = b; g_barrier_count = 0;
+        g_waves.assign(block / 64, Wave());
+        for (int i = 0; i < block; ++i) {
+            Fiber& f = g_fibers[i];
+            f.done = false;
+            getcontext(&f.ctx);
+            f.ctx.uc_stack.ss_sp = f.stack; f.ctx.uc_stack.ss_size = kStack; f.ctx.uc_link = &g_sched;
+            makecontext(&f.ctx, trampoline, 0);
+        }
+        int remaining = block;
+        while (remaining > 0) {
+            remaining = 0;
+            for (int i = 0; i < block; ++i) {
+                if (g_fibers[i].done) continue;
+                g_cur = i;
+                swapcontext(&g_sched, &g_fibers[i].ctx);
+                if (!g_fibers[i].done) ++remaining;
+            }
+        }
+    }
+    for (auto& f : g_fibers) free(f.stack);
+    g_fibers.clear();
+}
+}  // namespace emu

@@ -1,0 +1,37 @@
+// emu_runtime.h -- TEST INFRASTRUCTURE ONLY.  Host-side SIMT emulator for the port layer of
+// pydens_amd/csrc/pinn_port.h: every workgroup thread is a ucontext fiber, scheduled round-robin on one OS
+// thread; __syncthreads() and the wave-collective primitives (MFMA, shuffles) are rendezvous points.
+// The emulated v_mfma_f32_16x16x4_f32 follows the lane maps documented for gfx950
+// (/opt/skills/guides/cdna_hip_programming.md section 3): A[i=l&15][k=l>>4], B[k=l>>4][j=l&15],
+// D row = (l>>4)*4 + reg, col = l&15, accumulated as a k-ordered fmaf chain.
+#pragma once
+#include <cmath>
+#include <cstdint>
+#include <cstring>
+#include <functional>
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+struct float4 { float x, y, z, w; };
+
+namespace emu {
+int tid();
+int bid();
+int nblk();
+float* smem();
+void sync_block();
+f32x4 mfma16(float a, float b, f32x4 c);
+float shfl_xor(float v, int mask);
+void launch(int grid, int block, size_t smem_bytes, const std::function<void()>& body);
+}
+
+#define PINN_GLOBAL
+#define PINN_DEVICE static inline
+#define PINN_TID (emu::tid())
+#define PINN_BID (emu::bid())
+#define PINN_NBLK (emu::nblk())
+#define PINN_SYNC() emu::sync_block()
+#define PINN_SMEM(name) float* name = emu::smem()
+#define PINN_LAUNCH_BOUNDS(n)
+
+static inline f32x4 pinn_mfma16(float a, float b, f32x4 c) { return emu::mfma16(a, b, c); }
+static inline float pinn_shfl_xor(float v, int mask) { return emu::shfl_xor(v, mask); }

@@ -1,0 +1,53 @@
+""" shared test helpers: build a pydens_amd Solver for a golden fixture and load the fixture's parameters. """
+import numpy as np
+import torch
+
+import pinn_configs as pc
+
+
+class FixedBatches:
+    """ sampler plug-in that replays pre-drawn batches (reference model_torch.py:433 call convention). """
+    def __init__(self, batches):
+        self.batches, self.i = batches, 0
+
+    def sample(self, size):
+        out = self.batches[self.i]
+        assert out.shape[0] == size
+        self.i += 1
+        return out.astype(np.float64)
+
+
+def linear_modules(solver):
+    return [m for m in solver.model.conv_block]
+
+
+def load_params(solver, params):
+    with torch.no_grad():
+        it = iter(params)
+        for lin in linear_modules(solver):
+            lin.weight.copy_(torch.as_tensor(next(it)))
+            lin.bias.copy_(torch.as_tensor(next(it)))
+        solver.model.log_scale.copy_(torch.as_tensor(float(next(it))))
+
+
+def export_params(solver):
+    out = []
+    for lin in linear_modules(solver):
+        out += [lin.weight.detach().cpu().numpy().copy(), lin.bias.detach().cpu().numpy().copy()]
+    out.append(solver.model.log_scale.detach().cpu().numpy().copy())
+    return out
+
+
+def export_grads(solver):
+    """ the flat gradient buffer seen through the parameter views (same order as export_params). """
+    net, lay = solver.model.net, solver.model.net.layout
+    out = []
+    for w, b in net.param_views(solver.grads):
+        out += [w.detach().cpu().numpy().copy(), b.detach().cpu().numpy().copy()]
+    out.append(solver.grads[lay.off_log_scale].detach().cpu().numpy().copy())
+    return out
+
+
+def make_solver(name, pa, **kwargs):
+    cfg = pc.make_config(name, pa.D, torch)
+    return cfg, pa.Solver(cfg['equation'], **cfg['solver_kwargs'], **kwargs)

@@ -1,0 +1,155 @@
+""" GPU parity tests (run with -m gpu on the MI355X box): the HIP path, called through the C-ABI by the Python
+host, against (a) the golden fixtures the UNMODIFIED reference produced and (b) the oracle restatement run on the
+box's CPU, on identical parameters and points. Tolerances: 1e-5 relative on loss and predicted field
+(BASELINE.json north_star), fp32; gradients 1e-4 relative L2 per tensor (fp32 summation order differs). """
+import numpy as np
+import pytest
+import torch
+
+import pinn_configs as pc
+from conftest import Golden, rel_l2
+from helpers import FixedBatches, export_grads, export_params, load_params, make_solver
+
+pytestmark = pytest.mark.gpu
+
+SUPPORTED = ('cfg1', 'cfg2', 'cfg3', 'cfg4', 'ode_sigmoid')
+
+
+@pytest.fixture(scope='module')
+def pa():
+    assert torch.cuda.is_available(), 'GPU tests need a HIP device'
+    import pydens_amd
+    from pydens_amd import engine
+    assert engine.load_library().pinn_backend() == b'hip-gfx950'
+    return pydens_amd
+
+
+@pytest.mark.parametrize('name', SUPPORTED)
+def test_predict_and_step_match_reference_golden(pa, name):
+    g = Golden(name)
+    _, solver = make_solver(name, pa)
+    load_params(solver, g.params)
+    pts = g.points
+    pred = solver.predict(*[pts[1][:, i] for i in range(pts.shape[2])])
+    assert pred.shape == (pts.shape[1], 1) and pred.dtype == np.float32
+    assert np.abs(pred[:, 0] - g.predict).max() <= 1e-5 * max(1.0, np.abs(g.predict).max())
+
+    # one fused residual+grad evaluation on batch 0 (no optimizer step): loss and every parameter gradient
+    assert solver.program is not None, solver.program_error
+    xs = torch.from_numpy(pts[0].copy()).cuda()
+    solver._fused_step(xs, 1)
+    lay = solver.model.net.layout
+    loss = float(solver.grads[lay.off_loss])
+    assert abs(loss - g.loss0) <= 1e-5 * g.loss0
+    for got, want in zip(export_grads(solver), g.grads):
+        if want is None:
+            assert float(np.abs(got).max()) == 0.0
+        else:
+            assert rel_l2(got, want) < 1e-4
+
+
+@pytest.mark.parametrize('name', SUPPORTED)
+@pytest.mark.parametrize('path', ['fused', 'generic'])
+def test_fit_matches_reference_golden(pa, name, path):
+    g = Golden(name)
+    _, solver = make_solver(name, pa)
+    load_params(solver, g.params)
+    if path == 'generic':
+        solver.program = None
+    solver.fit(niters=len(g.losses), batch_size=g.points.shape[1], sampler=FixedBatches(g.points), lr=g.lr)
+    assert solver.last_fit_path == path
+    losses = np.array([float(v) for v in solver.losses])
+    np.testing.assert_allclose(losses, g.losses, rtol=2e-5)
+    for got, want in zip(export_params(solver), g.finals):
+        assert rel_l2(got, want) < 2e-5
+
+
+def test_streams_match_fp64_jets(pa):
+    """ the derivative streams D(...) resolves to, against the fp64 jet formulas, heat config (IC + BC, 6 streams) """
+    from oracle import jet_f64 as jf, problems
+    from test_oracle_vs_golden import make_spec
+    g = Golden('cfg3')
+    _, solver = make_solver('cfg3', pa)
+    load_params(solver, g.params)
+    sf, spec = make_spec(g)
+    pts = g.points[0]
+    out = jf.step(spec, pts, sf['residual'], problems.ic_streams_f64('cfg3', pts, sf['dir_cols'], sf['n2']))
+    xs = torch.from_numpy(pts.copy()).cuda()
+    ic = torch.from_numpy(problems.ic_streams_f64('cfg3', pts, sf['dir_cols'], sf['n2']).astype(np.float32)).cuda()
+    streams = solver.model.net.jet_forward(solver.model.flat, xs, sf['dir_cols'], sf['n2'], ic_streams=ic.contiguous())
+    for s in range(spec.S):
+        assert rel_l2(streams[s].cpu().numpy(), out['u_streams'][s]) < 2e-5, s
+
+
+@pytest.mark.parametrize('n', [1, 15, 17, 1000, 4099])
+def test_ragged_batch_sizes(pa, n):
+    """ tiles of 16 points: every tail length must give the same per-point answer and a correctly normalised loss """
+    g = Golden('cfg2')
+    cfg, solver = make_solver('cfg2', pa)
+    load_params(solver, g.params)
+    pts = pc.sample_points(cfg, 4112, seed=11)
+    full = solver.predict(pts[:, 0], pts[:, 1])
+    part = solver.predict(pts[:n, 0], pts[:n, 1])
+    assert np.array_equal(full[:n], part)
+    lay = solver.model.net.layout
+    xs = torch.from_numpy(pts[:n].copy()).cuda()
+    solver._fused_step(xs, 1)
+    loss_fused = float(solver.grads[lay.off_loss])
+    streams = solver.model.net.jet_forward(solver.model.flat, xs, [0, 1], 2)
+    r = streams[3] + streams[4] - 5 * torch.sin(np.pi * (xs[:, 0] + xs[:, 1]))
+    assert abs(loss_fused - float((r * r).mean())) <= 2e-6 * loss_fused
+
+
+def test_full_size_step_against_chunked_oracle(pa):
+    """ BASELINE config 2 at its full batch (65 536 points): loss and gradients vs the oracle evaluated in chunks """
+    from oracle import pinn_oracle as po
+    torch.manual_seed(5)
+    cfg, solver = make_solver('cfg2', pa)
+    ocfg = pc.make_config('cfg2', po.D, torch)
+    oracle = po.OracleSolver(ocfg['equation'], **ocfg['solver_kwargs'])
+    oracle.import_params(export_params(solver))
+    pts = pc.sample_points(cfg, cfg['n_points'], seed=2)
+    ev = oracle.evaluate(pts, chunk=16384)
+    solver._fused_step(torch.from_numpy(pts).cuda(), 1)
+    lay = solver.model.net.layout
+    assert abs(float(solver.grads[lay.off_loss]) - ev['loss']) <= 1e-5 * ev['loss']
+    for got, want in zip(export_grads(solver), oracle.export_grads()):
+        if want is not None:
+            assert rel_l2(got, want) < 1e-4
+
+
+def test_sharded_sum_equals_whole(pa):
+    """ data-parallel property: gradients of shards, each scaled by 1/N_global, add up to the whole """
+    g = Golden('cfg4')
+    cfg, solver = make_solver('cfg4', pa)
+    load_params(solver, g.params)
+    pts = torch.from_numpy(pc.sample_points(cfg, 4096, seed=4)).cuda()
+    solver._fused_step(pts, 1)
+    whole = solver.grads.clone()
+    acc = torch.zeros_like(whole)
+    for shard in pts.chunk(4):
+        solver._fused_step(shard.contiguous(), 4)
+        acc += solver.grads
+    assert rel_l2(acc.cpu().numpy(), whole.cpu().numpy()) < 1e-5
+
+
+def test_adam_matches_torch(pa):
+    from pydens_amd import engine
+    torch.manual_seed(0)
+    n = 5000
+    p = torch.randn(n, device='cuda'); ref = p.clone().requires_grad_()
+    opt = torch.optim.Adam([ref], lr=0.01)
+    m, v = torch.zeros_like(p), torch.zeros_like(p)
+    step = torch.zeros(1, dtype=torch.int32, device='cuda')
+    mask = torch.ones(n, dtype=torch.uint8, device='cuda'); mask[::7] = 0
+    keep = p.clone()
+    net = engine.Net([2, 16, 1], 'tanh', 2)
+    for _ in range(20):
+        grad = torch.randn(n, device='cuda')
+        ref.grad = grad.clone()
+        opt.step()
+        net.adam_step(p, grad, m, v, mask, step, 0.01)
+    live = mask.bool()
+    assert torch.equal(p[~live], keep[~live])
+    assert rel_l2(p[live].cpu().numpy(), ref.detach()[live].cpu().numpy()) < 1e-6
+    assert int(step) == 20
