@@ -40,20 +40,28 @@ def flops_per_point(layer_dims, n_streams):
     return 6 * n_streams * inner + 4 * d * h1
 
 
-def cpu_baseline(n_points, steps):
-    """ oracle (port of the reference step) on the host cores; bounded sample of the same workload. """
+def cpu_baseline(budget_s=15.0, n_points=16384):
+    """ oracle (port of the reference step) on the host cores; bounded sample of the same workload:
+    batches of `n_points` points (reference throughput is flat in the batch size),
+    as many Solver.fit iterations as fit in ~budget_s seconds. """
     from oracle import pinn_oracle as po
-    torch.set_num_threads(os.cpu_count() or 1)
+    threads = min(os.cpu_count() or 1, 32)        # ATen CPU ops stop scaling (and oversubscribe) beyond this
+    torch.set_num_threads(threads)
     cfg = pc.make_config(WORKLOAD, po.D, torch)
     solver = po.OracleSolver(cfg['equation'], **cfg['solver_kwargs'])
-    pts = pc.sample_points(cfg, n_points, seed=0, steps=steps + 1)
-    solver.fit(niters=1, batch_size=n_points, points=pts[:1])
+    pts = pc.sample_points(cfg, n_points, seed=0, steps=1)
     t0 = time.perf_counter()
-    solver.fit(niters=steps, batch_size=n_points, points=pts[1:])
+    solver.fit(niters=1, batch_size=n_points, points=pts)              # warm-up, also sizes the sample
+    warm = time.perf_counter() - t0
+    steps = int(max(2, min(200, budget_s / max(warm, 1e-3))))
+    print(f'[bench] cpu baseline: {threads} threads, warm-up step {warm:.2f} s, timing {steps} steps', file=sys.stderr)
+    t0 = time.perf_counter()
+    solver.fit(niters=steps, batch_size=n_points, points=np.repeat(pts, steps, axis=0))
     dt = time.perf_counter() - t0
-    return dict(value=n_points * steps / dt, unit='points/s', cores=torch.get_num_threads(), kind='port',
+    return dict(value=n_points * steps / dt, unit='points/s', cores=threads, kind='port',
                 sample=f'{steps} Solver.fit iterations of {WORKLOAD} at batch {n_points} '
-                       f'(oracle/pinn_oracle.py, torch {torch.__version__} CPU ops, fp32), {dt:.1f} s')
+                       f'(oracle/pinn_oracle.py, torch {torch.__version__} CPU ops, fp32, '
+                       f'{os.cpu_count()} logical CPUs on the host), {dt:.1f} s')
 
 
 def main():
@@ -135,6 +143,7 @@ def main():
         dist.barrier()
 
     if rank == 0:
+        print(f'[bench] gpu: {dt / args.steps * 1e3:.3f} ms/step, tile kernel {tile_ms:.3f} ms', file=sys.stderr)
         f_pt = flops_per_point(model.layer_dims, spec.n_streams)
         achieved = f_pt * n / (tile_ms * 1e-3) / 1e12
         out = {
@@ -155,12 +164,12 @@ def main():
                        'points_per_gpu': n, 'global_points': n * world, 'streams': spec.n_streams,
                        'parallelism': f'dp{world}', 'step_path': 'fused'},
             'final_loss': loss,
-            'roofline': {'bound': 'mfma', 'kernel': 'pinn_tile_kernel<64,2,2,1>', 'achieved': achieved,
+            'roofline': {'bound': 'mfma', 'kernel': 'pinn_tile_kernel<64,2,2,1,3,0>', 'achieved': achieved,
                          'peak': PEAK_FP32_MFMA_TFLOPS, 'unit': 'TFLOP/s', 'frac': achieved / PEAK_FP32_MFMA_TFLOPS,
                          'flops_per_point': f_pt, 'kernel_ms': tile_ms, 'traffic': None},
         }
         if not args.no_cpu_baseline:
-            out['cpu_baseline'] = cpu_baseline(65536, 15)
+            out['cpu_baseline'] = cpu_baseline()
         print(json.dumps(out))
     if world > 1:
         dist.destroy_process_group()

@@ -31,7 +31,18 @@ def _stale(target, deps):
     return any(os.path.getmtime(d) > t for d in deps)
 
 
-def build(force=False, verbose=False, extra_flags=()):
+def build(force=False, verbose=False, extra_flags=(), out=None, obj_dir=None, widths=WIDTHS):
+    global OUT, OBJ
+    OUT_, OBJ_ = OUT, OBJ
+    if out is not None:
+        OUT, OBJ = out, obj_dir or (out + '.obj')
+    try:
+        return _build(force, verbose, extra_flags, widths)
+    finally:
+        OUT, OBJ = OUT_, OBJ_
+
+
+def _build(force, verbose, extra_flags, widths):
     hipcc = shutil.which('hipcc') or '/opt/rocm/bin/hipcc'
     deps = _sources()
     if not force and not _stale(OUT, deps):
@@ -40,7 +51,11 @@ def build(force=False, verbose=False, extra_flags=()):
     jobs = []
     for hp in WIDTHS:
         obj = os.path.join(OBJ, f'inst_hp{hp}.o')
-        jobs.append((obj, [hipcc, *FLAGS, *extra_flags, f'-DPINN_INST_HP={hp}', '-c', os.path.join(HERE, 'pinn_inst.inc'), '-o', obj]))
+        if hp not in widths:
+            extra = ['-DPINN_INST_STUB']
+        else:
+            extra = []
+        jobs.append((obj, [hipcc, *FLAGS, *extra_flags, *extra, f'-DPINN_INST_HP={hp}', '-c', os.path.join(HERE, 'pinn_inst.inc'), '-o', obj]))
     obj = os.path.join(OBJ, 'abi.o')
     jobs.append((obj, [hipcc, *FLAGS, *extra_flags, '-c', os.path.join(HERE, 'pinn_abi.cpp'), '-o', obj]))
 

@@ -72,6 +72,7 @@ int make_plan(const pinn_net* net, int64_t n_points, int nd, int n2, Plan* plan)
     PinnKArgs probe;
     memset(&probe, 0, sizeof(probe));
     probe.lh = net->lay.lh;
+    probe.act = net->act;
     long long info[4];
     if (plan->fn(nd, plan->n2k, &probe, 0, nullptr, 1, info)) return fail("kernel query failed");
     plan->smem = (size_t)info[0];

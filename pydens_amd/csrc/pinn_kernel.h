@@ -46,7 +46,7 @@ struct PinnKArgs {
     pinn_program_t prog;
 };
 
-template <int HP_, int ND_, int N2_, int MT_>
+template <int HP_, int ND_, int N2_, int MT_ = 1>
 struct PinnCfg {
     static constexpr int HP = HP_, ND = ND_, N2 = N2_, MT = MT_;
     static constexpr int S = 1 + ND + N2;
@@ -54,7 +54,7 @@ struct PinnCfg {
     static constexpr int NW = (NT <= 4) ? NT : 8;            // waves per workgroup
     static constexpr int NTW = NT / NW;                      // unit tiles per wave
     static constexpr int T = 16 * MT;                        // points per tile
-    static constexpr int LDA = HP + 4;                       // row stride of point-major activation buffers
+    static constexpr int LDA = HP + 8;                       // row stride of point-major activation buffers (bank spread)
     static constexpr int NTHREADS = NW * 64;
     // LDS carve (floats); every offset is a multiple of 4 floats (16 B, ds_read_b128 alignment)
     static constexpr int O_XS = 0;
@@ -63,8 +63,8 @@ struct PinnCfg {
     static constexpr int O_WL = O_B1 + HP;
     static constexpr int O_BUFA = O_WL + HP;
     static constexpr int O_BUFB = O_BUFA + S * T * LDA;
-    static constexpr int O_NET = O_BUFB + S * T * LDA;
-    static constexpr int O_GNET = O_NET + S * T;
+    static constexpr int O_NET = O_BUFB + S * T * LDA;          // [NW][S][T] per-wave partial dot products
+    static constexpr int O_GNET = O_NET + NW * S * T;
     static constexpr int O_ACCB = O_GNET + S * T;
     static constexpr int O_ACCW1 = O_ACCB + (PINN_LHMAX + 1) * HP;
     static constexpr int O_SCAL = O_ACCW1 + HP * PINN_XS_LD;
@@ -79,9 +79,14 @@ struct PinnCfg {
 // ------------------------------------------------------------------------------------------------------------
 // activation and its derivatives from the activation VALUE (tanh: t, sigmoid: s)
 // ------------------------------------------------------------------------------------------------------------
+// tanh(z) = 1 - 2/(1 + e^{2z}), sigmoid(z) = 1/(1 + e^{-z}) on v_exp_f32 / v_rcp_f32 (about 1 ulp each):
+// absolute error <= ~1.5e-7 over the whole range, saturates cleanly (e -> inf gives rcp 0), no branches.
 PINN_DEVICE float pinn_act(float z, int act) {
-    if (act == PINN_ACT_TANH) return tanhf(z);
-    return 1.0f / (1.0f + expf(-z));
+    if (act == PINN_ACT_TANH) {
+        const float e = pinn_exp2(z * 2.8853900817779268f);       // 2 log2(e)
+        return 1.0f - 2.0f * pinn_rcp(1.0f + e);
+    }
+    return pinn_rcp(1.0f + pinn_exp2(z * -1.4426950408889634f));
 }
 PINN_DEVICE void pinn_act_d12(float v, int act, float& d1, float& d2) {
     if (act == PINN_ACT_TANH) { d1 = 1.0f - v * v; d2 = -2.0f * v * d1; }
@@ -394,17 +399,31 @@ PINN_DEVICE void pinn_point_stage(const PinnKArgs& A, const float (&net)[1 + ND 
 
 // ------------------------------------------------------------------------------------------------------------
 // the tile kernel
+//
+// Lane map (all MFMA accumulators, "swapped" form D = W . H^T so that one lane owns 4 CONSECUTIVE units of ONE
+// point and every LDS activation write is a ds_write_b128):
+//     lr = lane & 15  -> point  pt = 16*mt + lr            lq = lane >> 4 -> unit quad
+//     wave w, unit tile j  -> units  n = (w*NTW + j)*16 + 4*lq + r,  r = accumulator component 0..3
+// LHC / ACTC >= 0 fix the number of hidden->hidden layers / the activation at compile time (fast instantiations
+// for the BASELINE configs); -1 keeps them run-time (generic instantiations).
 // ------------------------------------------------------------------------------------------------------------
 PINN_DEVICE f32x4 pinn_ld4(const float* p) { return *reinterpret_cast<const f32x4*>(p); }
+PINN_DEVICE void pinn_st4(float* p, f32x4 v) { *reinterpret_cast<f32x4*>(p) = v; }
 
-template <int HP, int ND, int N2, int MT>
-PINN_GLOBAL void PINN_LAUNCH_BOUNDS((PinnCfg<HP, ND, N2, MT>::NTHREADS))
+template <int HP, int ND, int N2, int MT, int LHC, int ACTC>
+#ifndef PINN_WAVES_PER_SIMD
+#define PINN_WAVES_PER_SIMD 2
+#endif
+PINN_GLOBAL void PINN_LAUNCH_BOUNDS2((PinnCfg<HP, ND, N2, MT>::NTHREADS),
+                                    (PinnCfg<HP, ND, N2, MT>::NW <= 4 ? PINN_WAVES_PER_SIMD : 1))
 pinn_tile_kernel(const PinnKArgs A) {
     using C = PinnCfg<HP, ND, N2, MT>;
-    constexpr int S = C::S, NT = C::NT, NTW = C::NTW, T = C::T, LDA = C::LDA, NTHREADS = C::NTHREADS;
+    constexpr int S = C::S, NT = C::NT, NTW = C::NTW, NW = C::NW, T = C::T, LDA = C::LDA, NTHREADS = C::NTHREADS;
     const int tid = PINN_TID, lane = tid & 63, wave = tid >> 6;
     const int lr = lane & 15, lq = lane >> 4;
-    const int act = A.act, lh = A.lh, d = A.d;
+    const int act = (ACTC >= 0) ? ACTC : A.act;
+    const int lh = (LHC >= 0) ? LHC : A.lh;
+    const int d = A.d;
     const bool train = A.mode != PINN_MODE_FORWARD;
 
     PINN_SMEM(smem);
@@ -414,7 +433,7 @@ pinn_tile_kernel(const PinnKArgs A) {
     float* WLs = smem + C::O_WL;
     float* bufA = smem + C::O_BUFA;
     float* bufB = smem + C::O_BUFB;
-    float* netb = smem + C::O_NET;
+    float* netp = smem + C::O_NET;
     float* gnetb = smem + C::O_GNET;
     float* accB = smem + C::O_ACCB;
     float* accW1 = smem + C::O_ACCW1;
@@ -441,15 +460,16 @@ pinn_tile_kernel(const PinnKArgs A) {
         for (int o = 0; o < NT; ++o)
 #pragma unroll
             for (int j = 0; j < NTW; ++j) dW[l][o][j] = f32x4{0.f, 0.f, 0.f, 0.f};
-    float accWL[NTW];
+    f32x4 accWL[NTW];
 #pragma unroll
-    for (int j = 0; j < NTW; ++j) accWL[j] = 0.0f;
+    for (int j = 0; j < NTW; ++j) accWL[j] = f32x4{0.f, 0.f, 0.f, 0.f};
     float sum_loss = 0.0f, sum_ls = 0.0f, sum_bl = 0.0f;
 
     f32x4* slab = A.slab ? A.slab + (size_t)PINN_BID * C::slab_vec4_per_wg(lh) : nullptr;
     auto slab_at = [&](int a, int s, int j, int mt) -> f32x4* {
         return slab + ((((size_t)a * S + s) * NTW + j) * MT + mt) * NTHREADS + tid;
     };
+    auto unit0 = [&](int j) { return (wave * NTW + j) * 16 + 4 * lq; };     // first of this lane's 4 units
 
     const long long ntiles = (A.n_points + T - 1) / T;
     PINN_SYNC();
@@ -469,13 +489,14 @@ pinn_tile_kernel(const PinnKArgs A) {
         // ---- (1) first layer on the VALU: z0 = W1 x + b1, z_k = W1[:, col_k], z_kk = 0 ------------------------
 #pragma unroll
         for (int j = 0; j < NTW; ++j) {
-            const int n = (wave * NTW + j) * 16 + lr;
+            const int n0 = unit0(j);
 #pragma unroll
             for (int mt = 0; mt < MT; ++mt) {
-                f32x4 sv[S];
+                const int pt = mt * 16 + lr;
+                f32x4 hv[S], sv[S];
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
-                    const int pt = mt * 16 + lq * 4 + r;
+                    const int n = n0 + r;
                     float z[S], h[S];
                     float z0 = b1s[n];
                     for (int c = 0; c < d; ++c) z0 = fmaf(W1s[n * PINN_XS_LD + c], xs_t[pt * PINN_XS_LD + c], z0);
@@ -486,11 +507,10 @@ pinn_tile_kernel(const PinnKArgs A) {
                     for (int k = 0; k < N2; ++k) z[1 + ND + k] = 0.0f;
                     pinn_jet_fwd<ND, N2>(z, act, h);
 #pragma unroll
-                    for (int s = 0; s < S; ++s) {
-                        cur[(s * T + pt) * LDA + n] = h[s];
-                        sv[s][r] = (s == 0) ? h[0] : z[s];
-                    }
+                    for (int s = 0; s < S; ++s) { hv[s][r] = h[s]; sv[s][r] = (s == 0) ? h[0] : z[s]; }
                 }
+#pragma unroll
+                for (int s = 0; s < S; ++s) pinn_st4(cur + (s * T + pt) * LDA + n0, hv[s]);
                 if (train) {
 #pragma unroll
                     for (int s = 0; s < S; ++s) *slab_at(0, s, j, mt) = sv[s];
@@ -499,7 +519,7 @@ pinn_tile_kernel(const PinnKArgs A) {
         }
         PINN_SYNC();
 
-        // ---- (2) hidden layers: z_s = h_s W^T (MFMA), jets on the accumulators ------------------------------------
+        // ---- (2) hidden layers: Z^T = W H^T (MFMA: A = weight fragment, B = activations), jets on accumulators --------
         for (int li = 0; li < lh; ++li) {
             const float* Wl = A.params + A.off_wh + (size_t)li * A.hidden_stride;
             const float* bl = Wl + HP * HP;
@@ -512,43 +532,42 @@ pinn_tile_kernel(const PinnKArgs A) {
                     for (int s = 0; s < S; ++s) acc[j][mt][s] = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
             for (int q = 0; q < HP / 16; ++q) {
-                f32x4 bf[NTW];
+                f32x4 wf[NTW];
 #pragma unroll
                 for (int j = 0; j < NTW; ++j)
-                    bf[j] = pinn_ld4(Wl + ((wave * NTW + j) * 16 + lr) * HP + 16 * q + 4 * lq);
+                    wf[j] = pinn_ld4(Wl + ((wave * NTW + j) * 16 + lr) * HP + 16 * q + 4 * lq);
 #pragma unroll
                 for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
                     for (int s = 0; s < S; ++s) {
-                        const f32x4 af = pinn_ld4(cur + (s * T + mt * 16 + lr) * LDA + 16 * q + 4 * lq);
+                        const f32x4 hf = pinn_ld4(cur + (s * T + mt * 16 + lr) * LDA + 16 * q + 4 * lq);
 #pragma unroll
                         for (int j = 0; j < NTW; ++j) {
 #pragma unroll
-                            for (int m = 0; m < 4; ++m) acc[j][mt][s] = pinn_mfma16(af[m], bf[j][m], acc[j][mt][s]);
+                            for (int m = 0; m < 4; ++m) acc[j][mt][s] = pinn_mfma16(wf[j][m], hf[m], acc[j][mt][s]);
                         }
                     }
             }
 #pragma unroll
             for (int j = 0; j < NTW; ++j) {
-                const int n = (wave * NTW + j) * 16 + lr;
-                const float bias = bl[n];
+                const int n0 = unit0(j);
+                const f32x4 bias = pinn_ld4(bl + n0);
 #pragma unroll
                 for (int mt = 0; mt < MT; ++mt) {
-                    f32x4 sv[S];
+                    const int pt = mt * 16 + lr;
+                    f32x4 hv[S], sv[S];
 #pragma unroll
                     for (int r = 0; r < 4; ++r) {
-                        const int pt = mt * 16 + lq * 4 + r;
                         float z[S], h[S];
 #pragma unroll
                         for (int s = 0; s < S; ++s) z[s] = acc[j][mt][s][r];
-                        z[0] += bias;
+                        z[0] += bias[r];
                         pinn_jet_fwd<ND, N2>(z, act, h);
 #pragma unroll
-                        for (int s = 0; s < S; ++s) {
-                            nxt[(s * T + pt) * LDA + n] = h[s];
-                            sv[s][r] = (s == 0) ? h[0] : z[s];
-                        }
+                        for (int s = 0; s < S; ++s) { hv[s][r] = h[s]; sv[s][r] = (s == 0) ? h[0] : z[s]; }
                     }
+#pragma unroll
+                    for (int s = 0; s < S; ++s) pinn_st4(nxt + (s * T + pt) * LDA + n0, hv[s]);
                     if (train) {
 #pragma unroll
                         for (int s = 0; s < S; ++s) *slab_at(li + 1, s, j, mt) = sv[s];
@@ -559,17 +578,24 @@ pinn_tile_kernel(const PinnKArgs A) {
             float* tmp = cur; cur = nxt; nxt = tmp;
         }
 
-        // ---- (3) last layer (out = 1): net_s[pt] = WL . h_s[pt] -----------------------------------------------
-        for (int i = tid; i < S * T; i += NTHREADS) {
-            const float* row = cur + i * LDA;          // i = s*T + pt
-            float sum = (i < T) ? bL : 0.0f;
-#pragma unroll 4
-            for (int n4 = 0; n4 < HP / 4; ++n4) {
-                const f32x4 hv = pinn_ld4(row + 4 * n4), wv = pinn_ld4(WLs + 4 * n4);
-                sum = fmaf(hv[0], wv[0], sum); sum = fmaf(hv[1], wv[1], sum);
-                sum = fmaf(hv[2], wv[2], sum); sum = fmaf(hv[3], wv[3], sum);
+        // ---- (3) last layer (out = 1): net_s[pt] = WL . h_s[pt]; per-wave partials, summed by the point stage ------
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt) {
+            const int pt = mt * 16 + lr;
+#pragma unroll
+            for (int s = 0; s < S; ++s) {
+                float part = 0.0f;
+#pragma unroll
+                for (int j = 0; j < NTW; ++j) {
+                    const int n0 = unit0(j);
+                    const f32x4 hv = pinn_ld4(cur + (s * T + pt) * LDA + n0), wv = pinn_ld4(WLs + n0);
+                    part = fmaf(hv[0], wv[0], part); part = fmaf(hv[1], wv[1], part);
+                    part = fmaf(hv[2], wv[2], part); part = fmaf(hv[3], wv[3], part);
+                }
+                part += pinn_shfl_xor(part, 16);
+                part += pinn_shfl_xor(part, 32);
+                if (lq == 0) netp[(wave * S + s) * T + pt] = part;
             }
-            netb[i] = sum;
         }
         PINN_SYNC();
 
@@ -578,7 +604,12 @@ pinn_tile_kernel(const PinnKArgs A) {
             const int pt = tid;
             float net[S];
 #pragma unroll
-            for (int s = 0; s < S; ++s) net[s] = netb[s * T + pt];
+            for (int s = 0; s < S; ++s) {
+                float v = (s == 0) ? bL : 0.0f;
+#pragma unroll
+                for (int w = 0; w < NW; ++w) v += netp[(w * S + s) * T + pt];
+                net[s] = v;
+            }
             PinnPointOut<ND, N2> po;
             pinn_point_stage<ND, N2>(A, net, xs_t + pt * PINN_XS_LD, base + pt, base + pt < A.n_points,
                                      pregs + pt, padj + pt, T, po);
@@ -586,38 +617,37 @@ pinn_tile_kernel(const PinnKArgs A) {
             for (int s = 0; s < S; ++s) gnetb[s * T + pt] = po.gnet[s];
             sum_loss += po.loss; sum_ls += po.g_ls; sum_bl += po.gnet[0];
         }
-        if (!train) { PINN_SYNC(); continue; }
         PINN_SYNC();
+        if (!train) continue;
 
         // ---- (5) reverse through the last layer: gh_s = gnet_s * WL ; dWL += sum gnet_s h_s -------------------------
         f32x4 g[NTW][MT][S];
         f32x4 sv[NTW][MT][S];
 #pragma unroll
         for (int j = 0; j < NTW; ++j) {
-            const int n = (wave * NTW + j) * 16 + lr;
-            const float wl = WLs[n];
+            const int n0 = unit0(j);
+            const f32x4 wl = pinn_ld4(WLs + n0);
 #pragma unroll
             for (int mt = 0; mt < MT; ++mt) {
+                const int pt = mt * 16 + lr;
 #pragma unroll
                 for (int s = 0; s < S; ++s) {
                     sv[j][mt][s] = *slab_at(lh, s, j, mt);
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) {
-                        const int pt = mt * 16 + lq * 4 + r;
-                        const float gn = gnetb[s * T + pt];
-                        g[j][mt][s][r] = gn * wl;
-                        accWL[j] = fmaf(gn, cur[(s * T + pt) * LDA + n], accWL[j]);
-                    }
+                    const float gn = gnetb[s * T + pt];
+                    const f32x4 hv = pinn_ld4(cur + (s * T + pt) * LDA + n0);
+                    g[j][mt][s] = wl * gn;
+                    accWL[j] += hv * gn;
                 }
             }
         }
 
-        // ---- (6) reverse through the activations / hidden layers -------------------------------------------------
-        for (int a = lh; a >= 0; --a) {
-            f32x4 gz[NTW][MT][S];
+        // ---- (6) reverse through the activations / hidden layers; the layer index is unrolled so that the dW
+        //          accumulators are addressed statically (they must stay in registers) ----------------------------
+        auto act_reverse = [&](int a, f32x4 (&gz)[NTW][MT][S]) {
+            // gz_a = jet-reverse(gh, saved_a);  db_a += sum_pt gz_a,0 (DPP row sum over the 16 points of the lane row)
 #pragma unroll
             for (int j = 0; j < NTW; ++j) {
-                float bsum = 0.0f;
+                f32x4 bsum = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
                 for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
@@ -628,93 +658,71 @@ pinn_tile_kernel(const PinnKArgs A) {
                         pinn_jet_bwd<ND, N2>(gh1, sv1, act, gz1);
 #pragma unroll
                         for (int s = 0; s < S; ++s) gz[j][mt][s][r] = gz1[s];
-                        bsum += gz1[0];
+                        bsum[r] += gz1[0];
                     }
-                bsum += pinn_shfl_xor(bsum, 16);
-                bsum += pinn_shfl_xor(bsum, 32);
-                if (lq == 0) accB[a * HP + (wave * NTW + j) * 16 + lr] += bsum;
-            }
-            if (a == 0) {
-                // first layer: dW1[n][c] += sum_pt gz0 x_c  (+ sum_pt gz_k when c == col_k)
 #pragma unroll
-                for (int j = 0; j < NTW; ++j) {
-                    const int n = (wave * NTW + j) * 16 + lr;
-                    for (int c = 0; c < d; ++c) {
-                        float v = 0.0f;
-#pragma unroll
-                        for (int mt = 0; mt < MT; ++mt)
-#pragma unroll
-                            for (int r = 0; r < 4; ++r) {
-                                const int pt = mt * 16 + lq * 4 + r;
-                                v = fmaf(gz[j][mt][0][r], xs_t[pt * PINN_XS_LD + c], v);
-#pragma unroll
-                                for (int k = 0; k < ND; ++k)
-                                    if (A.dir_cols[k] == c) v += gz[j][mt][1 + k][r];
-                            }
-                        v += pinn_shfl_xor(v, 16);
-                        v += pinn_shfl_xor(v, 32);
-                        if (lq == 0) accW1[n * PINN_XS_LD + c] += v;
-                    }
+                for (int r = 0; r < 4; ++r) bsum[r] = pinn_row_sum16(bsum[r]);
+                if (lr == 0) {
+                    float* dst = accB + a * HP + unit0(j);
+                    pinn_st4(dst, pinn_ld4(dst) + bsum);
                 }
-                break;
             }
+        };
+        auto hidden_reverse = [&](int a, f32x4 (&dw)[NT][NTW]) {
+            f32x4 gz[NTW][MT][S];
+            act_reverse(a, gz);
             // stage gz_a (-> nxt) and the recomputed h_{a-1} (-> cur) for the two GEMMs of linear layer a
 #pragma unroll
             for (int j = 0; j < NTW; ++j) {
-                const int n = (wave * NTW + j) * 16 + lr;
+                const int n0 = unit0(j);
 #pragma unroll
                 for (int mt = 0; mt < MT; ++mt) {
+                    const int pt = mt * 16 + lr;
+                    f32x4 hv[S];
 #pragma unroll
                     for (int s = 0; s < S; ++s) sv[j][mt][s] = *slab_at(a - 1, s, j, mt);
 #pragma unroll
                     for (int r = 0; r < 4; ++r) {
-                        const int pt = mt * 16 + lq * 4 + r;
                         float sv1[S], h[S];
 #pragma unroll
                         for (int s = 0; s < S; ++s) sv1[s] = sv[j][mt][s][r];
                         pinn_jet_recompute<ND, N2>(sv1, act, h);
 #pragma unroll
-                        for (int s = 0; s < S; ++s) {
-                            cur[(s * T + pt) * LDA + n] = h[s];
-                            nxt[(s * T + pt) * LDA + n] = gz[j][mt][s][r];
-                        }
+                        for (int s = 0; s < S; ++s) hv[s][r] = h[s];
+                    }
+#pragma unroll
+                    for (int s = 0; s < S; ++s) {
+                        pinn_st4(cur + (s * T + pt) * LDA + n0, hv[s]);
+                        pinn_st4(nxt + (s * T + pt) * LDA + n0, gz[j][mt][s]);
                     }
                 }
             }
             PINN_SYNC();
             const int li = a - 1;
             // weight gradient: dW_li[out][in] += sum_{s,pt} gz_s[pt][out] * h_s[pt][in]   (A = gz^T, B = h)
-            auto wgrad = [&](f32x4 (&dw)[NT][NTW]) {
 #pragma unroll
-                for (int mt = 0; mt < MT; ++mt)
+            for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
-                    for (int s = 0; s < S; ++s) {
-                        float bq[NTW][4];
+                for (int s = 0; s < S; ++s) {
+                    float bq[NTW][4];
+#pragma unroll
+                    for (int j = 0; j < NTW; ++j)
+#pragma unroll
+                        for (int m = 0; m < 4; ++m)
+                            bq[j][m] = cur[(s * T + mt * 16 + lq * 4 + m) * LDA + (wave * NTW + j) * 16 + lr];
+#pragma unroll
+                    for (int o = 0; o < NT; ++o) {
+                        float aq[4];
+#pragma unroll
+                        for (int m = 0; m < 4; ++m)
+                            aq[m] = nxt[(s * T + mt * 16 + lq * 4 + m) * LDA + o * 16 + lr];
 #pragma unroll
                         for (int j = 0; j < NTW; ++j)
 #pragma unroll
-                            for (int m = 0; m < 4; ++m)
-                                bq[j][m] = cur[(s * T + mt * 16 + lq * 4 + m) * LDA + (wave * NTW + j) * 16 + lr];
-#pragma unroll
-                        for (int o = 0; o < NT; ++o) {
-                            float aq[4];
-#pragma unroll
-                            for (int m = 0; m < 4; ++m)
-                                aq[m] = nxt[(s * T + mt * 16 + lq * 4 + m) * LDA + o * 16 + lr];
-#pragma unroll
-                            for (int j = 0; j < NTW; ++j)
-#pragma unroll
-                                for (int m = 0; m < 4; ++m) dw[o][j] = pinn_mfma16(aq[m], bq[j][m], dw[o][j]);
-                        }
+                            for (int m = 0; m < 4; ++m) dw[o][j] = pinn_mfma16(aq[m], bq[j][m], dw[o][j]);
                     }
-            };
-            switch (li) {
-                case 0: wgrad(dW[0]); break;
-                case 1: wgrad(dW[1]); break;
-                case 2: wgrad(dW[2]); break;
-                default: wgrad(dW[3]); break;
-            }
-            // data gradient: gh_{a-1}[pt][in] = sum_out gz[pt][out] * W_li[out][in]
+                }
+            // data gradient: GH^T[in][pt] = sum_out W_li[out][in] * gz[pt][out]   (A = W^T fragment, B = gz)
             const float* Wl = A.params + A.off_wh + (size_t)li * A.hidden_stride;
 #pragma unroll
             for (int j = 0; j < NTW; ++j)
@@ -724,26 +732,53 @@ pinn_tile_kernel(const PinnKArgs A) {
                     for (int s = 0; s < S; ++s) g[j][mt][s] = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
             for (int q = 0; q < HP / 16; ++q) {
-                float bq[NTW][4];
+                float wq[NTW][4];
 #pragma unroll
                 for (int j = 0; j < NTW; ++j)
 #pragma unroll
                     for (int m = 0; m < 4; ++m)
-                        bq[j][m] = Wl[(16 * q + 4 * lq + m) * HP + (wave * NTW + j) * 16 + lr];
+                        wq[j][m] = Wl[(16 * q + 4 * lq + m) * HP + (wave * NTW + j) * 16 + lr];
 #pragma unroll
                 for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
                     for (int s = 0; s < S; ++s) {
-                        const f32x4 af = pinn_ld4(nxt + (s * T + mt * 16 + lr) * LDA + 16 * q + 4 * lq);
+                        const f32x4 gf = pinn_ld4(nxt + (s * T + mt * 16 + lr) * LDA + 16 * q + 4 * lq);
 #pragma unroll
                         for (int j = 0; j < NTW; ++j)
 #pragma unroll
-                            for (int m = 0; m < 4; ++m) g[j][mt][s] = pinn_mfma16(af[m], bq[j][m], g[j][mt][s]);
+                            for (int m = 0; m < 4; ++m) g[j][mt][s] = pinn_mfma16(wq[j][m], gf[m], g[j][mt][s]);
                     }
             }
             PINN_SYNC();
+        };
+#pragma unroll
+        for (int a = PINN_LHMAX; a >= 1; --a) {
+            if (a <= lh) hidden_reverse(a, dW[a - 1]);
         }
-        PINN_SYNC();      // a == 0 block reads xs_t; the next tile's staging overwrites it
+        {
+            // first layer: db_0, dW1[n][c] += sum_pt gz0 x_c  (+ sum_pt gz_k when c == col_k)
+            f32x4 gz[NTW][MT][S];
+            act_reverse(0, gz);
+#pragma unroll
+            for (int j = 0; j < NTW; ++j) {
+                for (int c = 0; c < d; ++c) {
+                    f32x4 v = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                    for (int mt = 0; mt < MT; ++mt) {
+                        v += gz[j][mt][0] * xs_t[(mt * 16 + lr) * PINN_XS_LD + c];
+#pragma unroll
+                        for (int k = 0; k < ND; ++k)
+                            if (A.dir_cols[k] == c) v += gz[j][mt][1 + k];
+                    }
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const float t = pinn_row_sum16(v[r]);
+                        if (lr == 0) accW1[(unit0(j) + r) * PINN_XS_LD + c] += t;
+                    }
+                }
+            }
+        }
+        PINN_SYNC();      // the first-layer block reads xs_t; the next tile's staging overwrites it
     }
 
     if (!train) return;
@@ -771,10 +806,11 @@ pinn_tile_kernel(const PinnKArgs A) {
     for (int i = tid; i < HP * d; i += NTHREADS) part[i] = accW1[(i / d) * PINN_XS_LD + (i % d)];
 #pragma unroll
     for (int j = 0; j < NTW; ++j) {
-        float v = accWL[j];
-        v += pinn_shfl_xor(v, 16);
-        v += pinn_shfl_xor(v, 32);
-        if (lq == 0) part[A.off_wl + (wave * NTW + j) * 16 + lr] = v;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const float v = pinn_row_sum16(accWL[j][r]);
+            if (lr == 0) part[A.off_wl + unit0(j) + r] = v;
+        }
     }
     if (tid < T) { scal[tid * 4 + 0] = sum_loss; scal[tid * 4 + 1] = sum_ls; scal[tid * 4 + 2] = sum_bl; }
     PINN_SYNC();
@@ -787,4 +823,3 @@ pinn_tile_kernel(const PinnKArgs A) {
         for (int i = A.off_loss + 1; i < A.p_core; ++i) part[i] = 0.0f;
     }
 }
-

@@ -27,4 +27,18 @@ PINN_DEVICE f32x4 pinn_mfma16(float a, float b, f32x4 c) {
     return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0);
 }
 PINN_DEVICE float pinn_shfl_xor(float v, int mask) { return __shfl_xor(v, mask, 64); }
+
+// sum over the 16 lanes of a DPP row (lanes sharing lane>>4); every lane of the row gets the sum.
+// quad_perm [1,0,3,2], quad_perm [2,3,0,1], row_half_mirror, row_mirror: four full-rate VALU adds, no LDS.
+PINN_DEVICE float pinn_row_sum16(float v) {
+    v += __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, v), 0xB1, 0xF, 0xF, true));
+    v += __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, v), 0x4E, 0xF, 0xF, true));
+    v += __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, v), 0x141, 0xF, 0xF, true));
+    v += __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, v), 0x140, 0xF, 0xF, true));
+    return v;
+}
+// 2^x and 1/x at hardware precision (v_exp_f32 / v_rcp_f32, ~1 ulp)
+PINN_DEVICE float pinn_exp2(float x) { return __builtin_amdgcn_exp2f(x); }
+PINN_DEVICE float pinn_rcp(float x) { return __builtin_amdgcn_rcpf(x); }
+#define PINN_LAUNCH_BOUNDS2(n, w) __launch_bounds__(n, w)
 #endif

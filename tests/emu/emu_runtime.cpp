@@ -86,6 +86,21 @@ float shfl_xor(float v, int mask) {
     return r;
 }
 
+float row_sum16(float v) {
+    // same butterfly as the DPP sequence in pinn_port.h: xor 1, xor 2, half-mirror (i <-> 7-i), mirror (i <-> 15-i)
+    Wave& w = g_waves[g_cur >> 6];
+    const int l = g_cur & 63, row = l & ~15, i = l & 15;
+    const int partner[4] = {i ^ 1, i ^ 2, (i & 8) | (7 - (i & 7)), 15 - i};
+    for (int step = 0; step < 4; ++step) {
+        w.a[l] = v;
+        wave_sync(w);
+        const float o = w.a[row + partner[step]];
+        wave_sync(w);
+        v += o;
+    }
+    return v;
+}
+
 void launch(int grid, int block, size_t smem_bytes, const std::function<void()>& body) {
     if (block % 64) { fprintf(stderr, "emu: block size must be a multiple of 64\n"); abort(); }
     g_body = &body; g_block = block; g_grid = grid;

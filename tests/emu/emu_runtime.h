@@ -21,6 +21,7 @@ float* smem();
 void sync_block();
 f32x4 mfma16(float a, float b, f32x4 c);
 float shfl_xor(float v, int mask);
+float row_sum16(float v);
 void launch(int grid, int block, size_t smem_bytes, const std::function<void()>& body);
 }
 
@@ -35,3 +36,7 @@ void launch(int grid, int block, size_t smem_bytes, const std::function<void()>&
 
 static inline f32x4 pinn_mfma16(float a, float b, f32x4 c) { return emu::mfma16(a, b, c); }
 static inline float pinn_shfl_xor(float v, int mask) { return emu::shfl_xor(v, mask); }
+static inline float pinn_row_sum16(float v) { return emu::row_sum16(v); }
+static inline float pinn_exp2(float x) { return exp2f(x); }
+static inline float pinn_rcp(float x) { return 1.0f / x; }
+#define PINN_LAUNCH_BOUNDS2(n, w)
