@@ -30,7 +30,7 @@ def D(y, x):
         return y._pinn_ctx.derivative(alpha, col)
     if sc is not None and col is not None and y.requires_grad:
         sc.used_autograd_fallback = True
-        items = sc.stream_tensors()
+        items = [(a, t) for a, t in sc.stream_tensors() if t.requires_grad]
         wrt = [x] + [t for _, t in items]
         grads = torch.autograd.grad(y.sum(), wrt, retain_graph=True, create_graph=True, allow_unused=True)
         total = grads[0] if grads[0] is not None else torch.zeros_like(x)

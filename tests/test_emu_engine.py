@@ -1,0 +1,249 @@
+""" CPU-side checks of the PRODUCT kernel sources through the real C-ABI, executed by the fiber SIMT emulator
+(tests/emu): same pinn_kernel.h / pinn_abi.cpp as libpinn_hip.so, compiled for the host with an emulated
+v_mfma_f32_16x16x4_f32, barriers and DPP row sums. What they pin here, without a GPU: tile indexing, lane maps,
+the reverse sweep, the residual interpreter, Adam, the Python host (Solver/D/V/tracer) and the data-parallel path.
+The product never loads this library (it is injected with `lib=`); the GPU parity tests are in test_gpu_parity.py. """
+import ctypes
+import os
+import sys
+
+import numpy as np
+import pytest
+import torch
+
+import pinn_configs as pc
+from conftest import Golden, rel_l2
+from helpers import FixedBatches, export_grads, export_params, load_params, make_solver
+
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), 'emu'))
+
+
+@pytest.fixture(scope='session')
+def emu_lib():
+    import build_emu
+    from pydens_amd import engine
+    lib = engine.bind(ctypes.CDLL(build_emu.build()))
+    assert lib.pinn_backend() == b'emu-host'
+    return lib
+
+
+@pytest.fixture(scope='session')
+def pa():
+    import pydens_amd
+    return pydens_amd
+
+
+def emu_kwargs(lib):
+    return dict(lib=lib, device='cpu')
+
+
+@pytest.mark.parametrize('name', ['cfg1', 'cfg2', 'cfg3', 'cfg4', 'ode_sigmoid'])
+def test_fused_fit_matches_reference_golden(pa, emu_lib, name):
+    g = Golden(name)
+    _, solver = make_solver(name, pa, **emu_kwargs(emu_lib))
+    load_params(solver, g.params)
+    pts = g.points
+    pred = solver.predict(*[pts[1][:, i] for i in range(pts.shape[2])])
+    assert np.abs(pred[:, 0] - g.predict).max() <= 1e-5 * max(1.0, np.abs(g.predict).max())
+    assert solver.program is not None, solver.program_error
+    niters = 2 if name == 'cfg3' else len(g.losses)        # 8-wave / 128-wide emulation is slow: two steps suffice
+    solver.fit(niters=niters, batch_size=pts.shape[1], sampler=FixedBatches(pts), lr=g.lr)
+    assert solver.last_fit_path == 'fused'
+    np.testing.assert_allclose(np.array([float(v) for v in solver.losses]), g.losses[:niters], rtol=2e-5)
+    if niters == len(g.losses):
+        for got, want in zip(export_params(solver), g.finals):
+            assert rel_l2(got, want) < 2e-5
+
+
+@pytest.mark.parametrize('name', ['cfg1', 'ode_sigmoid'])
+def test_generic_fit_matches_reference_golden(pa, emu_lib, name):
+    g = Golden(name)
+    _, solver = make_solver(name, pa, **emu_kwargs(emu_lib))
+    load_params(solver, g.params)
+    solver.program = None                           # force: kernel streams -> user's torch code -> kernel backward
+    solver.fit(niters=len(g.losses), batch_size=g.points.shape[1], sampler=FixedBatches(g.points), lr=g.lr)
+    assert solver.last_fit_path == 'generic'
+    np.testing.assert_allclose(np.array([float(v) for v in solver.losses]), g.losses, rtol=2e-5)
+    for got, want in zip(export_params(solver), g.finals):
+        assert rel_l2(got, want) < 2e-5
+
+
+@pytest.mark.parametrize('name', ['cfg1', 'cfg4'])
+def test_gradients_match_reference_golden(pa, emu_lib, name):
+    g = Golden(name)
+    _, solver = make_solver(name, pa, **emu_kwargs(emu_lib))
+    load_params(solver, g.params)
+    solver._fused_step(torch.from_numpy(g.points[0].copy()), 1)
+    lay = solver.model.net.layout
+    assert abs(float(solver.grads[lay.off_loss]) - g.loss0) <= 1e-5 * g.loss0
+    for got, want in zip(export_grads(solver), g.grads):
+        if want is None:
+            assert float(np.abs(got).max()) == 0.0
+        else:
+            assert rel_l2(got, want) < 1e-4
+
+
+@pytest.mark.parametrize('n', [1, 15, 17, 50])
+def test_ragged_tiles(pa, emu_lib, n):
+    g = Golden('cfg1')
+    cfg, solver = make_solver('cfg1', pa, **emu_kwargs(emu_lib))
+    load_params(solver, g.params)
+    pts = pc.sample_points(cfg, 64, seed=9)
+    full = solver.predict(pts[:, 0], pts[:, 1])
+    part = solver.predict(pts[:n, 0], pts[:n, 1])
+    assert np.array_equal(full[:n], part)
+    xs = torch.from_numpy(pts[:n].copy())
+    solver._fused_step(xs, 1)
+    lay = solver.model.net.layout
+    streams = solver.model.net.jet_forward(solver.model.flat, xs, [0, 1], 2)
+    r = streams[3] + streams[4] - 5 * torch.sin(np.pi * (xs[:, 0] + xs[:, 1]))
+    assert abs(float(solver.grads[lay.off_loss]) - float((r * r).mean())) <= 2e-6 * float((r * r).mean())
+
+
+def test_streams_match_fp64_jets(pa, emu_lib):
+    from oracle import jet_f64 as jf, problems
+    from test_oracle_vs_golden import make_spec
+    g = Golden('cfg3')
+    _, solver = make_solver('cfg3', pa, **emu_kwargs(emu_lib))
+    load_params(solver, g.params)
+    sf, spec = make_spec(g)
+    pts = g.points[0][:48]
+    ic64 = problems.ic_streams_f64('cfg3', pts, sf['dir_cols'], sf['n2'])
+    out = jf.step(spec, pts, sf['residual'], ic64)
+    streams = solver.model.net.jet_forward(solver.model.flat, torch.from_numpy(pts.copy()), sf['dir_cols'], sf['n2'],
+                                           ic_streams=torch.from_numpy(ic64.astype(np.float32)).contiguous())
+    for s in range(spec.S):
+        assert rel_l2(streams[s].numpy(), out['u_streams'][s]) < 2e-5, s
+
+
+def test_sharded_sum_equals_whole(pa, emu_lib):
+    g = Golden('cfg4')
+    cfg, solver = make_solver('cfg4', pa, **emu_kwargs(emu_lib))
+    load_params(solver, g.params)
+    pts = torch.from_numpy(pc.sample_points(cfg, 96, seed=4))
+    solver._fused_step(pts, 1)
+    whole = solver.grads.clone()
+    acc = torch.zeros_like(whole)
+    for shard in pts.chunk(3):
+        solver._fused_step(shard.contiguous(), 3)
+        acc += solver.grads
+    assert rel_l2(acc.numpy(), whole.numpy()) < 1e-5
+
+
+def test_adam_matches_torch(emu_lib):
+    from pydens_amd import engine
+    torch.manual_seed(0)
+    n = 700
+    p = torch.randn(n); ref = p.clone().requires_grad_()
+    opt = torch.optim.Adam([ref], lr=0.01)
+    m, v = torch.zeros_like(p), torch.zeros_like(p)
+    step = torch.zeros(1, dtype=torch.int32)
+    mask = torch.ones(n, dtype=torch.uint8); mask[::7] = 0
+    keep = p.clone()
+    net = engine.Net([2, 16, 1], 'tanh', 2, lib=emu_lib)
+    for _ in range(12):
+        grad = torch.randn(n)
+        ref.grad = grad.clone()
+        opt.step()
+        net.adam_step(p, grad, m, v, mask, step, 0.01)
+    live = mask.bool()
+    assert torch.equal(p[~live], keep[~live])
+    assert rel_l2(p[live].numpy(), ref.detach()[live].numpy()) < 1e-6
+    assert int(step) == 12
+
+
+# ---- reference API beyond the plain equation: trainable V, constraints, freezing, other optimizers -----------------------
+def _variable_problem(D, V, torch):
+    def odevar(f, x):                               # tutorial cell 50
+        return D(f, x) - 2 * np.pi * torch.cos(2 * np.pi * x) + V('new_var', data=torch.Tensor([1.0]))
+    return odevar, (lambda f, x: f(torch.tensor([0.5])))
+
+
+def _paired(pa, emu_lib, **fit_kwargs):
+    from oracle import pinn_oracle as po
+    kw = dict(ndims=1, initial_condition=1, layout='fafaf', features=[12, 10, 1], activation='Tanh')
+    eq_o, con_o = _variable_problem(po.D, po.V, torch)
+    oracle = po.OracleSolver(eq_o, constraints=con_o, **kw)
+    eq_p, con_p = _variable_problem(pa.D, pa.V, torch)
+    solver = pa.Solver(eq_p, constraints=con_p, **kw, **emu_kwargs(emu_lib))
+    load_params(solver, oracle.export_params())
+    return oracle, solver
+
+
+def test_trainable_variable_and_constraint_follow_the_reference(pa, emu_lib):
+    oracle, solver = _paired(pa, emu_lib)
+    assert solver.program is None and 'trainable' in solver.program_error
+    pts = np.random.RandomState(3).rand(6, 40, 1).astype(np.float32)
+    terms = ['equation', 'constraint_0']
+    oracle.fit(niters=6, batch_size=40, points=pts, lr=0.05, loss_terms=terms)
+    solver.fit(niters=6, batch_size=40, sampler=FixedBatches(pts), lr=0.05, loss_terms=terms)
+    assert solver.last_fit_path == 'generic'
+    np.testing.assert_allclose([float(v) for v in solver.losses], [float(v) for v in oracle.losses], rtol=5e-5)
+    assert abs(float(solver.model.new_var) - float(oracle.model.new_var)) < 1e-5
+    for got, want in zip(export_params(solver), oracle.export_params()):
+        assert rel_l2(got, want) < 5e-5
+
+
+def test_freeze_and_unfreeze(pa, emu_lib):
+    oracle, solver = _paired(pa, emu_lib)
+    pts = np.random.RandomState(4).rand(4, 32, 1).astype(np.float32)
+    oracle.model.new_var.requires_grad = False                           # reference freeze_trainable(variables=...)
+    solver.model.freeze_trainable(variables=('new_var',))
+    oracle.fit(niters=2, batch_size=32, points=pts[:2], lr=0.1)
+    solver.fit(niters=2, batch_size=32, sampler=FixedBatches(pts[:2]), lr=0.1)
+    assert float(solver.model.new_var) == 1.0
+    np.testing.assert_allclose([float(v) for v in solver.losses], [float(v) for v in oracle.losses], rtol=5e-5)
+    oracle.model.new_var.requires_grad = True
+    solver.model.unfreeze_trainable(variables=['new_var'])
+    oracle.fit(niters=2, batch_size=32, points=pts[2:], lr=0.1)
+    solver.fit(niters=2, batch_size=32, sampler=FixedBatches(pts[2:]), lr=0.1)
+    assert float(solver.model.new_var) != 1.0
+    assert abs(float(solver.model.new_var) - float(oracle.model.new_var)) < 2e-5
+    solver.model.freeze_trainable(layers=['conv_block'])
+    before = [p.copy() for p in export_params(solver)]
+    solver.fit(niters=1, batch_size=32, sampler=FixedBatches(pts[:1]), lr=0.1)
+    for a, b in zip(before[:-1], export_params(solver)[:-1]):
+        assert np.array_equal(a, b)
+
+
+def test_other_torch_optimizer_by_name(pa, emu_lib):
+    from oracle import pinn_oracle as po
+    g = Golden('cfg1')
+    cfg, solver = make_solver('cfg1', pa, **emu_kwargs(emu_lib))
+    load_params(solver, g.params)
+    ocfg = pc.make_config('cfg1', po.D, torch)
+    oracle = po.OracleSolver(ocfg['equation'], **ocfg['solver_kwargs'])
+    oracle.import_params(g.params)
+    oracle.fit(niters=3, batch_size=100, points=g.points[:3], optimizer='SGD', lr=1e-3, momentum=0.9)
+    solver.fit(niters=3, batch_size=100, sampler=FixedBatches(g.points[:3]), optimizer='SGD', lr=1e-3, momentum=0.9)
+    for got, want in zip(export_params(solver), oracle.export_params()):
+        assert rel_l2(got, want) < 2e-5
+    # optimizer=None keeps the existing optimizer (reference model_torch.py:392-393)
+    solver.fit(niters=1, batch_size=100, sampler=FixedBatches(g.points[3:4]), optimizer=None)
+    oracle.fit(niters=1, batch_size=100, points=g.points[3:4], optimizer=None)
+    for got, want in zip(export_params(solver), oracle.export_params()):
+        assert rel_l2(got, want) < 2e-5
+
+
+def test_callable_ic_with_variable(pa, emu_lib):
+    """ README.md:111-118: the initial condition itself is a trainable V(...) """
+    from oracle import pinn_oracle as po
+
+    def problem(D, V):
+        return (lambda u, t: D(u, t) - 2 * np.pi * torch.cos(2 * np.pi * t)), (lambda *a: V('init', data=torch.Tensor([3.0])))
+    kw = dict(ndims=1, layout='fafaf', features=[8, 8, 1], activation='Tanh')
+    eq_o, ic_o = problem(po.D, po.V)
+    oracle = po.OracleSolver(eq_o, initial_condition=ic_o, constraints=lambda u, t: u(torch.tensor([0.5])), **kw)
+    eq_p, ic_p = problem(pa.D, pa.V)
+    solver = pa.Solver(eq_p, initial_condition=ic_p, constraints=lambda u, t: u(torch.tensor([0.5])), **kw,
+                       **emu_kwargs(emu_lib))
+    load_params(solver, oracle.export_params())
+    assert solver.ic_trainable
+    pts = np.random.RandomState(5).rand(5, 24, 1).astype(np.float32)
+    terms = ('equation', 'constraint_0')
+    oracle.fit(niters=5, batch_size=24, points=pts, lr=0.05, loss_terms=terms)
+    solver.fit(niters=5, batch_size=24, sampler=FixedBatches(pts), lr=0.05, loss_terms=terms)
+    np.testing.assert_allclose([float(v) for v in solver.losses], [float(v) for v in oracle.losses], rtol=5e-5)
+    assert abs(float(solver.model.init) - float(oracle.model.init)) < 2e-5
+    xs = np.linspace(0, 1, 7).astype(np.float32)
+    assert np.abs(solver.predict(xs) - oracle.predict(xs)).max() < 2e-5

@@ -1,0 +1,105 @@
+""" Equation tracing (pydens_amd/trace.py): which derivative streams an equation asks for, and its lowering to a
+residual program; no kernel library needed. """
+import numpy as np
+import pytest
+import torch
+
+from pydens_amd import trace
+from pydens_amd.tokens import D
+
+
+def run(fn, *args):
+    return fn(*args)
+
+
+def test_discover_poisson_heat_wave():
+    spec, fallback = trace.discover(lambda f, x, y: D(D(f, x), x) + D(D(f, y), y) - 5 * torch.sin(np.pi * (x + y)), run, 2)
+    assert (spec.dir_cols, spec.n2, spec.n_streams, fallback) == ([0, 1], 2, 5, False)
+    spec, _ = trace.discover(lambda f, x, y, t: D(D(f, x), x) + D(D(f, y), y) - D(f, t), run, 3)
+    assert (spec.dir_cols, spec.n2) == ([0, 1, 2], 2)
+    assert spec.index[(2,)] == 3 and spec.index[(0, 0)] == 4 and spec.index[(1, 1)] == 5
+    spec, _ = trace.discover(lambda f, x, t: D(D(f, t), t) - D(D(f, x), x), run, 2)
+    assert (spec.dir_cols, spec.n2) == ([0, 1], 2)
+    spec, _ = trace.discover(lambda f, t, x: D(f, t) - D(D(f, x), x), run, 2)        # second-order direction first
+    assert (spec.dir_cols, spec.n2) == ([1, 0], 1)
+    spec, _ = trace.discover(lambda f, x, e: D(f, x) - e * np.pi * torch.cos(e * np.pi * x), run, 2)
+    assert (spec.dir_cols, spec.n2, spec.n_streams) == ([0], 0, 2)
+
+
+def test_mixed_partials_are_rejected_loudly():
+    with pytest.raises(NotImplementedError, match='mixed'):
+        trace.discover(lambda f, x, y: D(D(f, x), y), run, 2)
+    with pytest.raises(NotImplementedError):
+        trace.discover(lambda f, x: D(D(D(f, x), x), x), run, 1)
+
+
+def test_non_field_D_uses_autograd_fallback():
+    spec, fallback = trace.discover(lambda f, x: D(f, x) + D(torch.sin(x), x), run, 1)
+    assert fallback and spec.n_streams == 2
+
+
+def compile_eq(eq, n_inputs):
+    spec, _ = trace.discover(eq, run, n_inputs)
+    root = trace.symbolic(eq, run, n_inputs)
+    return spec, trace.compile_program(root, spec, n_inputs)
+
+
+@pytest.mark.parametrize('eq,n_inputs', [
+    (lambda f, x, y: D(D(f, x), x) + D(D(f, y), y) - 5 * torch.sin(np.pi * (x + y)), 2),
+    (lambda f, x, e: D(f, x) - e * np.pi * torch.cos(e * np.pi * x), 2),
+    (lambda f, x: D(f, x) + torch.log(x) * f ** 2 - torch.exp(-x) / (1 + x ** 2), 1),
+    (lambda f, x, t: D(f, t) - 0.1 * D(D(f, x), x) + f * D(f, x) - torch.tanh(x) + np.float64(2.5) * t, 2),
+    (lambda f, x: torch.sqrt(torch.abs(D(f, x))) + x.sin() * torch.sigmoid(f) + 2 ** x - (-f) + 1 / (x + 3), 1),
+])
+def test_program_reproduces_the_callable(eq, n_inputs):
+    spec, (code, consts) = compile_eq(eq, n_inputs)
+    rng = np.random.RandomState(0)
+    streams = rng.rand(spec.n_streams, 33) * 2 - 1
+    xs = rng.rand(33, n_inputs) + 0.5
+    got = trace.run_program_numpy(code, consts, streams, xs)
+    sc = trace.StreamContext(n_inputs)
+    for alpha, idx in spec.index.items():
+        sc.tag(torch.tensor(streams[idx]).view(-1, 1), alpha)
+    cols = []
+    for c in range(n_inputs):
+        col = torch.tensor(xs[:, c:c + 1])
+        col._pinn_col = c
+        cols.append(col)
+    token = trace.active_streams.set(sc)
+    try:
+        want = eq(sc.tensors[()], *cols).numpy()[:, 0]
+    finally:
+        trace.active_streams.reset(token)
+    np.testing.assert_allclose(got, want, rtol=1e-6, atol=1e-6)   # constants are rounded to fp32 in the program
+    assert code[-1][1] == max(op[1] for op in code)               # the residual is the last instruction
+
+
+def test_untraceable_equations_fall_back():
+    par = torch.nn.Parameter(torch.tensor([1.0]))
+    for eq in (lambda f, x: D(f, x) + par,                                     # trainable variable
+               lambda f, x: D(x * D(f, x), x),                                 # D of a composite expression
+               lambda f, x: D(f, x) + torch.cumsum(x, 0),                      # op outside the program ISA
+               lambda f, x: D(f, x) * torch.arange(3.0)):                      # tensor constant
+        with pytest.raises(trace.TraceUnsupported):
+            trace.symbolic(eq, run, 1)
+
+
+def test_chain_rule_D_of_composite_expression():
+    """ D(k(x) * D(f, x), x) = k'(x) f_x + k(x) f_xx through the stream chain rule of tokens.D """
+    eq = lambda f, x: D((1 + x ** 2) * D(f, x), x)
+    spec, fallback = trace.discover(eq, run, 1)
+    assert fallback and (spec.dir_cols, spec.n2) == ([0], 1)
+    n = 9
+    x = torch.rand(n, 1, dtype=torch.float64).requires_grad_()
+    x._pinn_col = 0
+    fx, fxx = torch.rand(n, 1, dtype=torch.float64).requires_grad_(), torch.rand(n, 1, dtype=torch.float64)
+    sc = trace.StreamContext(1)
+    f = sc.tag(torch.rand(n, 1, dtype=torch.float64).requires_grad_(), ())
+    sc.tag(fx, (0,)); sc.tag(fxx, (0, 0))
+    token = trace.active_streams.set(sc)
+    try:
+        got = eq(f, x)
+    finally:
+        trace.active_streams.reset(token)
+    want = 2 * x * fx + (1 + x ** 2) * fxx
+    assert torch.allclose(got, want, rtol=1e-12)
