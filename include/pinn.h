@@ -42,6 +42,8 @@ extern "C" {
 #define PINN_MAX_OPS      64   /* residual program length */
 #define PINN_MAX_CONSTS   32
 #define PINN_MAX_REGS     40   /* residual program registers (inputs included) */
+#define PINN_MAX_STREAMS  7    /* 1 + nd + n2 */
+#define PINN_MAX_AUX      8    /* per-point rows produced by the x-only pre-pass */
 
 #define PINN_ACT_TANH     0
 #define PINN_ACT_SIGMOID  1
@@ -70,7 +72,8 @@ enum pinn_op {
     PINN_OP_CONST = 0, PINN_OP_ADD, PINN_OP_SUB, PINN_OP_MUL, PINN_OP_DIV, PINN_OP_NEG,
     PINN_OP_SIN, PINN_OP_COS, PINN_OP_EXP, PINN_OP_LOG, PINN_OP_TANH, PINN_OP_SQRT,
     PINN_OP_POW,      /* a ** consts[b] */
-    PINN_OP_ABS, PINN_OP_SIGMOID, PINN_OP_RECIP, PINN_OP_COPY
+    PINN_OP_ABS, PINN_OP_SIGMOID, PINN_OP_RECIP, PINN_OP_COPY,
+    PINN_OP_STORE     /* pre-pass only: aux row b <- register a */
 };
 
 typedef struct pinn_program {
@@ -79,6 +82,28 @@ typedef struct pinn_program {
     uint32_t code[PINN_MAX_OPS];
     float consts[PINN_MAX_CONSTS];
 } pinn_program_t;
+
+/* Residual = what `equation(u_hat, *xs)` computes per point (model_torch.py:447), in the form the host tracer
+ * (pydens_amd/trace.py) reduced it to:
+ *   pre     x-only sub-expressions (source terms, variable coefficients): evaluated for ALL points by a tiny
+ *           pre-pass kernel; registers 0..d-1 = input columns, PINN_OP_STORE writes a register to aux row b.
+ *   kind PINN_RES_AFFINE   r = sum_s C_s * u_s + F with C_s = coef[s] or aux row coef_row[s] (if >= 0) and
+ *                          F = src_const or aux row src_row (if >= 0): every linear PDE; no interpreter in the step.
+ *   kind PINN_RES_PROGRAM  general pointwise program over streams, inputs and aux rows (registers
+ *                          S+d .. S+d+n_aux-1), interpreted per point with its reverse sweep inside the tile kernel. */
+#define PINN_RES_PROGRAM 0
+#define PINN_RES_AFFINE  1
+
+typedef struct pinn_residual {
+    int kind;
+    int n_aux;
+    pinn_program_t pre;
+    pinn_program_t program;
+    float coef[PINN_MAX_STREAMS];
+    int coef_row[PINN_MAX_STREAMS];
+    float src_const;
+    int src_row;
+} pinn_residual_t;
 
 /* Descriptor of network + ansatz.  Replaces ConvBlockModel.__init__/TorchModel.__init__ bookkeeping
  * (model_torch.py:19-50, :158-168).  layer_dims[0] = ndims+nparams, layer_dims[n_layers] = 1.
@@ -91,7 +116,7 @@ int pinn_destroy(pinn_t* net);
 int pinn_layout(const pinn_t* net, pinn_layout_t* out);
 
 /* Bytes of scratch the step/backward entry points need for n_points (per-workgroup partial gradients +
- * activation slab).  Caller allocates once (torch tensor) and reuses it. */
+ * activation slab + PINN_MAX_AUX pre-pass rows).  Caller allocates once (torch tensor) and reuses it. */
 size_t pinn_workspace_bytes(const pinn_t* net, int64_t n_points, int nd, int n2);
 
 /* Value + derivative streams of the ansatz-transformed network on given points.
@@ -112,11 +137,11 @@ int pinn_jet_backward(pinn_t* net, const float* params, const float* xs, int64_t
                       void* stream);
 
 /* One fused residual + gradient evaluation: forward jets, ansatz, residual program, mean-square loss and the
- * full reverse sweep, in one launch (+ a reduction launch).  Replaces model_torch.py:437-460
+ * full reverse sweep, in one launch (+ the x-only pre-pass and a reduction launch).  Replaces model_torch.py:437-460
  * (forward, equation, MSELoss vs zeros, backward).  grads[0..p_core) receives d(loss)/dparams with
  * loss = inv_n_global * sum r^2 over THIS call's points (data-parallel ranks pass 1/N_global and all-reduce
  * the buffer); grads[off_loss] receives this call's share of the loss. */
-int pinn_residual_step(pinn_t* net, const pinn_program_t* program, const float* params, const float* xs,
+int pinn_residual_step(pinn_t* net, const pinn_residual_t* residual, const float* params, const float* xs,
                        int64_t n_points, const int* dir_cols, int nd, int n2, const float* ic_streams,
                        float ic_const, float inv_n_global, float* grads, void* workspace, size_t workspace_bytes,
                        void* stream);

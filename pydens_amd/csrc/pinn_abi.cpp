@@ -22,6 +22,7 @@ int fail(const char* fmt, ...) {
 int round16(int v) { return (v + 15) / 16 * 16; }
 
 int g_profile = 0;
+long long* g_phase_prof = nullptr;
 bool g_have_bracket = false;
 #ifndef PINN_EMU
 hipEvent_t g_ev0 = nullptr, g_ev1 = nullptr;
@@ -96,7 +97,10 @@ void fill_args(const pinn_net* net, PinnKArgs* a, const float* params, const flo
     a->off_bl = L.off_bl; a->off_ls = L.off_log_scale; a->off_loss = L.off_loss; a->p_core = L.p_core;
     a->ndims = net->ndims; a->nsp = net->nsp; a->has_bc = net->has_bc; a->has_ic = net->has_ic;
     a->bc_value = net->bc_value; a->t0 = net->lo[net->ndims - 1]; a->ic_const = ic_const;
-    for (int i = 0; i < PINN_MAX_INPUTS; ++i) { a->lo[i] = net->lo[i]; a->hi[i] = net->hi[i]; }
+    for (int i = 0; i < PINN_MAX_INPUTS; ++i) {
+        a->lo[i] = net->lo[i]; a->hi[i] = net->hi[i];
+        a->inv_w[i] = 1.0f / (net->hi[i] - net->lo[i]);
+    }
     for (int k = 0; k < PINN_MAX_DIRS; ++k) a->dir_cols[k] = (k < nd) ? dir_cols[k] : 0;
     a->s_user = 1 + nd + n2;
 }
@@ -126,6 +130,11 @@ size_t align256(size_t v) { return (v + 255) / 256 * 256; }
 extern "C" {
 
 const char* pinn_last_error(void) { return g_err; }
+
+int pinn_debug_phase_buffer(void* buf) {
+    g_phase_prof = reinterpret_cast<long long*>(buf);
+    return 0;
+}
 
 int pinn_profile_tile(int enable) {
     g_profile = enable ? 1 : 0;
@@ -225,7 +234,8 @@ size_t pinn_workspace_bytes(const pinn_t* net, int64_t n_points, int nd, int n2)
     Plan plan;
     if (make_plan(net, n_points, nd, n2, &plan)) return 0;
     return align256((size_t)plan.grid * net->lay.p_core * sizeof(float)) +
-           align256((size_t)plan.grid * plan.slab_vec4_per_wg * 16) + 256;
+           align256((size_t)plan.grid * plan.slab_vec4_per_wg * 16) +
+           align256((size_t)PINN_MAX_AUX * (size_t)n_points * sizeof(float)) + 256;
 }
 
 int pinn_jet_forward(pinn_t* net, const float* params, const float* xs, int64_t n_points, const int* dir_cols, int nd,
@@ -244,14 +254,28 @@ int pinn_jet_forward(pinn_t* net, const float* params, const float* xs, int64_t 
 }
 
 static int run_train(pinn_t* net, PinnKArgs* a, const Plan& plan, int nd, float* grads, int accumulate, void* workspace,
-                     size_t workspace_bytes, void* stream) {
+                     size_t workspace_bytes, void* stream, const pinn_program_t* pre = nullptr) {
     const size_t part_bytes = align256((size_t)plan.grid * net->lay.p_core * sizeof(float));
     const size_t slab_bytes = align256((size_t)plan.grid * plan.slab_vec4_per_wg * 16);
-    if (!workspace || workspace_bytes < part_bytes + slab_bytes)
-        return fail("workspace too small: need %zu bytes, got %zu", part_bytes + slab_bytes, workspace_bytes);
+    const size_t aux_bytes = (pre && a->n_aux > 0) ? align256((size_t)a->n_aux * (size_t)a->n_points * sizeof(float)) : 0;
+    if (!workspace || workspace_bytes < part_bytes + slab_bytes + aux_bytes)
+        return fail("workspace too small: need %zu bytes, got %zu", part_bytes + slab_bytes + aux_bytes, workspace_bytes);
     if (((uintptr_t)workspace & 15) != 0) return fail("workspace must be 16-byte aligned");
+    a->prof = g_phase_prof;
     a->partials = reinterpret_cast<float*>(workspace);
     a->slab = reinterpret_cast<f32x4*>(reinterpret_cast<char*>(workspace) + part_bytes);
+    if (aux_bytes) {
+        float* aux = reinterpret_cast<float*>(reinterpret_cast<char*>(workspace) + part_bytes + slab_bytes);
+        a->aux = aux;
+        const int blocks = (int)((a->n_points + 255) / 256);
+#ifdef PINN_EMU
+        emu::launch(blocks, 256, 0, [&] { pinn_aux_kernel(a->xs, a->n_points, a->d, *pre, aux); });
+#else
+        hipLaunchKernelGGL(pinn_aux_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, a->xs, a->n_points, a->d,
+                           *pre, aux);
+        if (hipGetLastError() != hipSuccess) return fail("pre-pass kernel launch failed");
+#endif
+    }
 #ifndef PINN_EMU
     if (g_profile) {
         if (!g_ev0 && (hipEventCreate(&g_ev0) != hipSuccess || hipEventCreate(&g_ev1) != hipSuccess))
@@ -282,41 +306,77 @@ int pinn_jet_backward(pinn_t* net, const float* params, const float* xs, int64_t
     return run_train(net, &a, plan, nd, grads, accumulate, workspace, workspace_bytes, stream);
 }
 
-int pinn_residual_step(pinn_t* net, const pinn_program_t* program, const float* params, const float* xs,
+static int check_program(const pinn_program_t& pg, int first_temp, int n_consts_max, bool pre, int n_aux, const char* what) {
+    if (pg.n_ops < 0 || pg.n_ops > PINN_MAX_OPS || pg.n_consts < 0 || pg.n_consts > n_consts_max)
+        return fail("%s program size out of range (ops=%d consts=%d)", what, pg.n_ops, pg.n_consts);
+    for (int i = 0; i < pg.n_ops; ++i) {
+        const uint32_t w = pg.code[i];
+        const int op = w & 255, dst = (w >> 8) & 255, ra = (w >> 16) & 255, rb = (w >> 24) & 255;
+        if (op > PINN_OP_STORE) return fail("%s program instruction %d: unknown opcode %d", what, i, op);
+        if (op == PINN_OP_STORE) {
+            if (!pre) return fail("%s program instruction %d: STORE is a pre-pass instruction", what, i);
+            if (rb >= n_aux || ra >= PINN_MAX_REGS) return fail("%s program instruction %d: bad STORE", what, i);
+            continue;
+        }
+        const bool b_is_reg = op == PINN_OP_ADD || op == PINN_OP_SUB || op == PINN_OP_MUL || op == PINN_OP_DIV;
+        if (dst < first_temp) return fail("%s program instruction %d overwrites an input register", what, i);
+        if (dst >= PINN_MAX_REGS || (op != PINN_OP_CONST && ra >= PINN_MAX_REGS) || (b_is_reg && rb >= PINN_MAX_REGS))
+            return fail("%s program instruction %d uses a register >= %d", what, i, PINN_MAX_REGS);
+        if (op == PINN_OP_CONST && ra >= pg.n_consts) return fail("%s program instruction %d: bad constant", what, i);
+        if (op == PINN_OP_POW && rb >= pg.n_consts) return fail("%s program instruction %d: bad exponent", what, i);
+    }
+    return 0;
+}
+
+int pinn_residual_step(pinn_t* net, const pinn_residual_t* residual, const float* params, const float* xs,
                        int64_t n_points, const int* dir_cols, int nd, int n2, const float* ic_streams, float ic_const,
                        float inv_n_global, float* grads, void* workspace, size_t workspace_bytes, void* stream) {
-    if (!net || !program || !params || !xs || !grads) return fail("null argument");
+    if (!net || !residual || !params || !xs || !grads) return fail("null argument");
     if (n_points <= 0) return fail("n_points must be positive");
     if (check_dirs(net, dir_cols, nd, n2)) return 1;
-    if (program->n_ops < 1 || program->n_ops > PINN_MAX_OPS || program->n_consts < 0 || program->n_consts > PINN_MAX_CONSTS)
-        return fail("residual program size out of range (ops=%d consts=%d)", program->n_ops, program->n_consts);
+    if (residual->n_aux < 0 || residual->n_aux > PINN_MAX_AUX) return fail("n_aux=%d outside [0, %d]", residual->n_aux, PINN_MAX_AUX);
+    if (residual->kind != PINN_RES_AFFINE && residual->kind != PINN_RES_PROGRAM) return fail("unknown residual kind %d", residual->kind);
     Plan plan;
     if (make_plan(net, n_points, nd, n2, &plan)) return 1;
-    // the program addresses registers with the caller's stream count; re-base the input columns and temporaries
-    // onto the instantiation's stream count (extra second-derivative streams sit between them)
+    const int d = net->lay.d;
     const int s_user = 1 + nd + n2, s_kernel = 1 + nd + plan.n2k, shift = s_kernel - s_user;
     PinnKArgs a;
     fill_args(net, &a, params, xs, n_points, dir_cols, nd, n2, ic_streams, ic_const);
-    a.prog = *program;
-    for (int i = 0; i < program->n_ops; ++i) {
-        const uint32_t w = program->code[i];
-        int op = w & 255, dst = (w >> 8) & 255, ra = (w >> 16) & 255, rb = (w >> 24) & 255;
-        auto fix = [&](int r) { return r >= s_user ? r + shift : r; };
-        const bool a_is_reg = op != PINN_OP_CONST;
-        const bool b_is_reg = op == PINN_OP_ADD || op == PINN_OP_SUB || op == PINN_OP_MUL || op == PINN_OP_DIV;
-        if (dst < s_user + net->lay.d) return fail("program instruction %d overwrites an input register", i);
-        dst = fix(dst);
-        if (a_is_reg) ra = fix(ra);
-        if (b_is_reg) rb = fix(rb);
-        if (dst >= PINN_MAX_REGS || (a_is_reg && ra >= PINN_MAX_REGS) || (b_is_reg && rb >= PINN_MAX_REGS))
-            return fail("program instruction %d uses a register >= %d", i, PINN_MAX_REGS);
-        if (op == PINN_OP_CONST && ra >= program->n_consts) return fail("program instruction %d: bad constant", i);
-        if (op == PINN_OP_POW && rb >= program->n_consts) return fail("program instruction %d: bad exponent", i);
-        a.prog.code[i] = (uint32_t)op | ((uint32_t)dst << 8) | ((uint32_t)ra << 16) | ((uint32_t)rb << 24);
+    a.res_kind = residual->kind;
+    a.n_aux = residual->n_aux;
+    if (residual->n_aux > 0 && check_program(residual->pre, d, PINN_MAX_CONSTS, true, residual->n_aux, "pre-pass")) return 1;
+    if (residual->kind == PINN_RES_AFFINE) {
+        for (int s = 0; s < PINN_MAX_STREAMS; ++s) {
+            a.coef[s] = (s < s_user) ? residual->coef[s] : 0.0f;
+            a.coef_row[s] = (s < s_user) ? residual->coef_row[s] : -1;
+            if (a.coef_row[s] >= residual->n_aux) return fail("coef_row[%d] refers to a missing pre-pass row", s);
+        }
+        a.src_const = residual->src_const;
+        a.src_row = residual->src_row;
+        if (a.src_row >= residual->n_aux) return fail("src_row refers to a missing pre-pass row");
+    } else {
+        const pinn_program_t* program = &residual->program;
+        if (program->n_ops < 1) return fail("empty residual program");
+        if (check_program(*program, s_user + d + residual->n_aux, PINN_MAX_CONSTS, false, 0, "residual")) return 1;
+        // the program addresses registers with the caller's stream count; re-base everything behind the streams
+        // onto the instantiation's stream count (extra second-derivative streams sit in between)
+        a.prog = *program;
+        for (int i = 0; i < program->n_ops; ++i) {
+            const uint32_t w = program->code[i];
+            int op = w & 255, dst = (w >> 8) & 255, ra = (w >> 16) & 255, rb = (w >> 24) & 255;
+            auto fix = [&](int r) { return r >= s_user ? r + shift : r; };
+            const bool b_is_reg = op == PINN_OP_ADD || op == PINN_OP_SUB || op == PINN_OP_MUL || op == PINN_OP_DIV;
+            dst = fix(dst);
+            if (op != PINN_OP_CONST) ra = fix(ra);
+            if (b_is_reg) rb = fix(rb);
+            if (dst >= PINN_MAX_REGS || ra >= PINN_MAX_REGS || (b_is_reg && rb >= PINN_MAX_REGS))
+                return fail("program instruction %d uses a register >= %d after re-basing", i, PINN_MAX_REGS);
+            a.prog.code[i] = (uint32_t)op | ((uint32_t)dst << 8) | ((uint32_t)ra << 16) | ((uint32_t)rb << 24);
+        }
     }
     a.mode = PINN_MODE_STEP;
     a.inv_n = inv_n_global;
-    return run_train(net, &a, plan, nd, grads, 0, workspace, workspace_bytes, stream);
+    return run_train(net, &a, plan, nd, grads, 0, workspace, workspace_bytes, stream, &residual->pre);
 }
 
 int pinn_adam_step(float* params, const float* grads, float* exp_avg, float* exp_avg_sq, const uint8_t* mask, int64_t n,

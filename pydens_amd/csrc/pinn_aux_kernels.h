@@ -1,6 +1,46 @@
 // pinn_aux_kernels.h -- small non-template kernels (gradient reduction, Adam); included by pinn_abi.cpp only.
 #pragma once
 #include "pinn_port.h"
+#include "pinn_kernel.h"
+
+// ------------------------------------------------------------------------------------------------------------
+// x-only pre-pass: evaluates the source terms / variable coefficients of the residual for every point once,
+// outside the tile kernel (one thread per point, registers in private memory; N * a-few-ops, microseconds).
+// ------------------------------------------------------------------------------------------------------------
+PINN_GLOBAL void PINN_LAUNCH_BOUNDS(256)
+pinn_aux_kernel(const float* xs, long long n, int d, pinn_program_t pg, float* aux) {
+    const long long i = (long long)PINN_BID * 256 + PINN_TID;
+    if (i >= n) return;
+    float regs[PINN_MAX_REGS];
+    for (int c = 0; c < d; ++c) regs[c] = xs[i * d + c];
+    for (int k = 0; k < pg.n_ops; ++k) {
+        const unsigned w = pg.code[k];
+        const int op = w & 255, dst = (w >> 8) & 255, a = (w >> 16) & 255, b = (w >> 24) & 255;
+        if (op == PINN_OP_STORE) { aux[(long long)b * n + i] = regs[a]; continue; }
+        const float x = (op == PINN_OP_CONST) ? 0.0f : regs[a];
+        float y;
+        switch (op) {
+            case PINN_OP_CONST: y = pg.consts[a]; break;
+            case PINN_OP_ADD: y = x + regs[b]; break;
+            case PINN_OP_SUB: y = x - regs[b]; break;
+            case PINN_OP_MUL: y = x * regs[b]; break;
+            case PINN_OP_DIV: y = x / regs[b]; break;
+            case PINN_OP_NEG: y = -x; break;
+            case PINN_OP_SIN: y = sinf(x); break;
+            case PINN_OP_COS: y = cosf(x); break;
+            case PINN_OP_EXP: y = expf(x); break;
+            case PINN_OP_LOG: y = logf(x); break;
+            case PINN_OP_TANH: y = tanhf(x); break;
+            case PINN_OP_SQRT: y = sqrtf(x); break;
+            case PINN_OP_POW: y = powf(x, pg.consts[b]); break;
+            case PINN_OP_ABS: y = fabsf(x); break;
+            case PINN_OP_SIGMOID: y = 1.0f / (1.0f + expf(-x)); break;
+            case PINN_OP_RECIP: y = 1.0f / x; break;
+            default: y = x; break;
+        }
+        regs[dst] = y;
+    }
+}
 
 // ------------------------------------------------------------------------------------------------------------
 // sum of the per-workgroup partial gradients (fixed order => deterministic), 16 params x 16 chunks per block

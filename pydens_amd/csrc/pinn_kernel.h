@@ -35,6 +35,7 @@ struct PinnKArgs {
     float* out_streams;          // MODE_FORWARD: [S_user][N]
     float* partials;             // [nWG][p_core]
     f32x4* slab;                 // saved activations, lane private
+    long long* prof;             // optional per-phase cycle counters (PINN_PROFILE_PHASES builds only)
     long long n_points;
     int lh, d, act, mode;
     int off_b1, off_wh, hidden_stride, off_wl, off_bl, off_ls, off_loss, p_core;
@@ -43,6 +44,13 @@ struct PinnKArgs {
     float lo[PINN_MAX_INPUTS], hi[PINN_MAX_INPUTS];
     int dir_cols[PINN_MAX_DIRS];
     int s_user;                  // streams visible to the caller (<= S of the instantiation)
+    float inv_w[PINN_MAX_INPUTS];    // 1 / (hi - lo)
+    // residual (MODE_STEP)
+    int res_kind, n_aux, src_row;
+    float src_const;
+    float coef[PINN_MAX_STREAMS];
+    int coef_row[PINN_MAX_STREAMS];
+    const float* aux;            // [n_aux][N] rows of the x-only pre-pass
     pinn_program_t prog;
 };
 
@@ -228,10 +236,48 @@ struct PinnPointOut {
     float loss, g_ls;
 };
 
+// per-point values that come from global memory (pre-pass rows, IC streams): fetched at the START of the tile by the
+// point's thread, so that their latency is not paid inside the serial point stage
+template <int ND, int N2>
+struct PinnPointPre {
+    float src;                       // affine source term F
+    float cs[1 + ND + N2];           // affine coefficients C_s
+    float ic[1 + ND + N2];           // IC streams
+};
+
+template <int ND, int N2>
+PINN_DEVICE void pinn_point_prefetch(const PinnKArgs& A, long long gidx, bool valid, float* pregs, int T,
+                                     PinnPointPre<ND, N2>& pre) {
+    constexpr int S = 1 + ND + N2;
+    const long long gi = valid ? gidx : 0;
+    pre.src = A.src_const;
+#pragma unroll
+    for (int s = 0; s < S; ++s) { pre.cs[s] = 0.0f; pre.ic[s] = 0.0f; }
+    if (A.mode == PINN_MODE_STEP) {
+        if (A.res_kind == PINN_RES_AFFINE) {
+            if (A.src_row >= 0) pre.src = A.aux[(long long)A.src_row * A.n_points + gi];
+#pragma unroll
+            for (int s = 0; s < S; ++s)
+                if (s < A.s_user) pre.cs[s] = (A.coef_row[s] >= 0) ? A.aux[(long long)A.coef_row[s] * A.n_points + gi] : A.coef[s];
+        } else {
+            for (int m = 0; m < A.n_aux; ++m) pregs[(S + A.d + m) * T] = A.aux[(long long)m * A.n_points + gi];
+        }
+    }
+    if (A.has_ic) {
+        if (A.ic_streams) {
+#pragma unroll
+            for (int s = 0; s < S; ++s)
+                if (s < A.s_user && valid) pre.ic[s] = A.ic_streams[(long long)s * A.n_points + gidx];
+        } else {
+            pre.ic[0] = A.ic_const;
+        }
+    }
+}
+
 template <int ND, int N2>
 PINN_DEVICE void pinn_point_stage(const PinnKArgs& A, const float (&net)[1 + ND + N2], const float* x /*[d]*/,
                                   long long gidx, bool valid, float* pregs, float* padj, int T,
-                                  PinnPointOut<ND, N2>& out) {
+                                  const PinnPointPre<ND, N2>& pre, PinnPointOut<ND, N2>& out) {
     constexpr int S = 1 + ND + N2;
     // ---- BC factor P and its direction derivatives --------------------------------------------------------
     float P = 1.0f, Pk[ND > 0 ? ND : 1], Pkk[ND > 0 ? ND : 1];
@@ -243,10 +289,10 @@ PINN_DEVICE void pinn_point_stage(const PinnKArgs& A, const float (&net)[1 + ND 
         for (int j = 0; j < PINN_MAX_INPUTS; ++j) {
             p[j] = 1.0f; p1[j] = 0.0f; p2[j] = 0.0f;
             if (j < A.nsp) {
-                const float lo = A.lo[j], hi = A.hi[j], w = hi - lo, xj = x[j];
-                p[j] = ((xj - lo) / w) * ((hi - xj) / w);
-                p1[j] = (lo + hi - 2.0f * xj) / (w * w);
-                p2[j] = -2.0f / (w * w);
+                const float lo = A.lo[j], hi = A.hi[j], iw = A.inv_w[j], xj = x[j];
+                p[j] = ((xj - lo) * iw) * ((hi - xj) * iw);
+                p1[j] = (lo + hi - 2.0f * xj) * (iw * iw);
+                p2[j] = -2.0f * (iw * iw);
                 P *= p[j];
             }
         }
@@ -306,13 +352,8 @@ PINN_DEVICE void pinn_point_stage(const PinnKArgs& A, const float (&net)[1 + ND 
         for (int k = 0; k < ND; ++k) u[1 + k] = Gk[k] * Q[0] + G * Q[1 + k];
 #pragma unroll
         for (int k = 0; k < N2; ++k) u[1 + ND + k] = Gkk[k] * Q[0] + 2.0f * Gk[k] * Q[1 + k] + G * Q[1 + ND + k];
-        if (A.ic_streams) {
 #pragma unroll
-            for (int s = 0; s < S; ++s)
-                if (s < A.s_user && valid) u[s] += A.ic_streams[(long long)s * A.n_points + gidx];
-        } else {
-            u[0] += A.ic_const;
-        }
+        for (int s = 0; s < S; ++s) u[s] += pre.ic[s];
     }
     // ---- output / residual / upstream gradient -----------------------------------------------------------------
     float gu[S];
@@ -329,17 +370,27 @@ PINN_DEVICE void pinn_point_stage(const PinnKArgs& A, const float (&net)[1 + ND 
         for (int s = 0; s < S; ++s) out.gnet[s] = 0.0f;
         out.g_ls = 0.0f;
         return;
+    } else if (A.mode == PINN_MODE_STEP && A.res_kind == PINN_RES_AFFINE) {
+        // r = sum_s C_s u_s + F, coefficients constant or per-point rows of the x-only pre-pass
+        float r = pre.src;
+#pragma unroll
+        for (int s = 0; s < S; ++s) r = fmaf(pre.cs[s], u[s], r);
+        const float w = valid ? 2.0f * r * A.inv_n : 0.0f;
+#pragma unroll
+        for (int s = 0; s < S; ++s) gu[s] = w * pre.cs[s];
+        out.loss = valid ? r * r * A.inv_n : 0.0f;
     } else if (A.mode == PINN_MODE_STEP) {
+        // registers: S streams (the INSTANTIATION's S), d input columns, n_aux pre-pass rows (already staged by
+        // pinn_point_prefetch), then temporaries
 #pragma unroll
         for (int s = 0; s < S; ++s) pregs[s * T] = u[s];
         for (int c = 0; c < A.d; ++c) pregs[(S + c) * T] = x[c];
-        // note: registers S..S+d are addressed with the INSTANTIATION's S; the host emits programs for it
         const float r = pinn_prog_forward(A.prog, pregs, T);
         pinn_prog_backward(A.prog, pregs, padj, T);
         const float w = valid ? 2.0f * r * A.inv_n : 0.0f;
 #pragma unroll
         for (int s = 0; s < S; ++s) { gu[s] = w * padj[s * T]; padj[s * T] = 0.0f; }
-        for (int c = 0; c < A.d; ++c) padj[(S + c) * T] = 0.0f;
+        for (int c = 0; c < A.d + A.n_aux; ++c) padj[(S + c) * T] = 0.0f;
         out.loss = valid ? r * r * A.inv_n : 0.0f;
     } else {
         if (valid) {
@@ -407,15 +458,27 @@ PINN_DEVICE void pinn_point_stage(const PinnKArgs& A, const float (&net)[1 + ND 
 // LHC / ACTC >= 0 fix the number of hidden->hidden layers / the activation at compile time (fast instantiations
 // for the BASELINE configs); -1 keeps them run-time (generic instantiations).
 // ------------------------------------------------------------------------------------------------------------
+#if defined(PINN_PROFILE_PHASES) && !defined(PINN_EMU)
+#define PH_DECL long long ph_acc[16] = {0}; long long ph_last = __builtin_readcyclecounter();
+#define PH(i) { const long long ph_now = __builtin_readcyclecounter(); ph_acc[i] += ph_now - ph_last; ph_last = ph_now; }
+#define PH_FLUSH if (A.prof && lane == 0) { for (int i = 0; i < 16; ++i) A.prof[((size_t)PINN_BID * NW + wave) * 16 + i] = ph_acc[i]; }
+#else
+#define PH_DECL
+#define PH(i)
+#define PH_FLUSH
+#endif
+
 PINN_DEVICE f32x4 pinn_ld4(const float* p) { return *reinterpret_cast<const f32x4*>(p); }
 PINN_DEVICE void pinn_st4(float* p, f32x4 v) { *reinterpret_cast<f32x4*>(p) = v; }
 
 template <int HP, int ND, int N2, int MT, int LHC, int ACTC>
+// occupancy hint: the fused kernel of a 64/128-wide net wants the whole register file of a SIMD (one wave per SIMD,
+// no spills); narrower nets (1-2 waves per workgroup) run several workgroups per CU
 #ifndef PINN_WAVES_PER_SIMD
-#define PINN_WAVES_PER_SIMD 2
+#define PINN_WAVES_PER_SIMD 1
 #endif
 PINN_GLOBAL void PINN_LAUNCH_BOUNDS2((PinnCfg<HP, ND, N2, MT>::NTHREADS),
-                                    (PinnCfg<HP, ND, N2, MT>::NW <= 4 ? PINN_WAVES_PER_SIMD : 1))
+                                    (PinnCfg<HP, ND, N2, MT>::NW < 4 ? 2 : PINN_WAVES_PER_SIMD))
 pinn_tile_kernel(const PinnKArgs A) {
     using C = PinnCfg<HP, ND, N2, MT>;
     constexpr int S = C::S, NT = C::NT, NTW = C::NTW, NW = C::NW, T = C::T, LDA = C::LDA, NTHREADS = C::NTHREADS;
@@ -470,22 +533,57 @@ pinn_tile_kernel(const PinnKArgs A) {
         return slab + ((((size_t)a * S + s) * NTW + j) * MT + mt) * NTHREADS + tid;
     };
     auto unit0 = [&](int j) { return (wave * NTW + j) * 16 + 4 * lq; };     // first of this lane's 4 units
+    // weight-gradient GEMM: MFMA k-slot (lq, m) -> point of the tile. Any bijection works (K is a sum index); this one
+    // puts lanes lq and lq+1 two rows (2*LDA = 16 mod 32 banks) apart, so the ds_read_b32 column reads are conflict-free.
+    auto wg_pt = [&](int m) { return 2 * lq + (m & 1) + 8 * (m >> 1); };
 
     const long long ntiles = (A.n_points + T - 1) / T;
+    // the points of a tile are fetched one tile ahead into registers (HBM latency hidden behind a whole tile)
+    constexpr int NPRE = (T * PINN_XS_LD + NTHREADS - 1) / NTHREADS;
+    float xpre[NPRE];
+    auto fetch_points = [&](long long tile) {
+#pragma unroll
+        for (int e = 0; e < NPRE; ++e) {
+            const int i = tid + e * NTHREADS;
+            const int pt = i / PINN_XS_LD, c = i % PINN_XS_LD;
+            const long long g = tile * T + pt;
+            xpre[e] = (i < T * PINN_XS_LD && c < d && tile < ntiles && g < A.n_points) ? A.xs[g * d + c] : 0.0f;
+        }
+    };
+    fetch_points(PINN_BID);
     PINN_SYNC();
+    PH_DECL
 
     for (long long tile = PINN_BID; tile < ntiles; tile += PINN_NBLK) {
         const long long base = tile * T;
-        // ---- (0) stage the points of this tile ------------------------------------------------------------
-        for (int i = tid; i < T * PINN_XS_LD; i += NTHREADS) {
-            const int pt = i / PINN_XS_LD, c = i % PINN_XS_LD;
-            const long long g = base + pt;
-            xs_t[i] = (c < d && g < A.n_points) ? A.xs[g * d + c] : 0.0f;
+        // ---- (0) stage the points of this tile, start fetching the next tile's ---------------------------------------
+#pragma unroll
+        for (int e = 0; e < NPRE; ++e) {
+            const int i = tid + e * NTHREADS;
+            if (i < T * PINN_XS_LD) xs_t[i] = xpre[e];
         }
         PINN_SYNC();
+        fetch_points(tile + PINN_NBLK);
+        PinnPointPre<ND, N2> ppre;
+        if (tid < T) pinn_point_prefetch<ND, N2>(A, base + tid, base + tid < A.n_points, pregs + tid, T, ppre);
+        PH(0)
 
         float* cur = bufA;
         float* nxt = bufB;
+        f32x4 svtop[NTW][MT][S];       // saved jets of the LAST hidden activation: they never leave the registers
+        f32x4 htop[NTW][MT][S];        // ... and its activations (last-layer dot and dWL need them again)
+        // whole-layer weight fragments are fetched one phase ahead (L2 latency hidden behind the previous epilogue)
+        constexpr bool WPF = (NW <= 4);
+        constexpr int NQ = HP / 16;
+        f32x4 wall[WPF ? NQ : 1][NTW];
+        auto load_wall = [&](const float* Wl) {
+#pragma unroll
+            for (int q = 0; q < (WPF ? NQ : 1); ++q)
+#pragma unroll
+                for (int j = 0; j < NTW; ++j)
+                    wall[q][j] = pinn_ld4(Wl + ((wave * NTW + j) * 16 + lr) * HP + 16 * q + 4 * lq);
+        };
+        if (WPF && lh > 0) load_wall(A.params + A.off_wh);
         // ---- (1) first layer on the VALU: z0 = W1 x + b1, z_k = W1[:, col_k], z_kk = 0 ------------------------
 #pragma unroll
         for (int j = 0; j < NTW; ++j) {
@@ -511,13 +609,23 @@ pinn_tile_kernel(const PinnKArgs A) {
                 }
 #pragma unroll
                 for (int s = 0; s < S; ++s) pinn_st4(cur + (s * T + pt) * LDA + n0, hv[s]);
-                if (train) {
+                if (lh == 0) {
 #pragma unroll
-                    for (int s = 0; s < S; ++s) *slab_at(0, s, j, mt) = sv[s];
+                    for (int s = 0; s < S; ++s) htop[j][mt][s] = hv[s];
+                }
+                if (train) {
+                    if (lh == 0) {
+#pragma unroll
+                        for (int s = 0; s < S; ++s) svtop[j][mt][s] = sv[s];
+                    } else {
+                        *slab_at(0, 0, j, mt) = sv[0];     // z_k = W1[:, col_k] and z_kk = 0 are rebuilt in the reverse half
+                    }
                 }
             }
         }
+        PH(1)
         PINN_SYNC();
+        PH(2)
 
         // ---- (2) hidden layers: Z^T = W H^T (MFMA: A = weight fragment, B = activations), jets on accumulators --------
         for (int li = 0; li < lh; ++li) {
@@ -530,28 +638,50 @@ pinn_tile_kernel(const PinnKArgs A) {
                 for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
                     for (int s = 0; s < S; ++s) acc[j][mt][s] = f32x4{0.f, 0.f, 0.f, 0.f};
+            {
+                // software pipeline over the K quads: the operands of quad q+1 are in flight while the S*MT*NTW*4 MFMAs
+                // of quad q issue, accumulators interleaved (an accumulator is re-used every S*MT*NTW issues, far
+                // beyond the 40-cycle dependent latency). sched_barrier pins that order (the register-pressured
+                // scheduler otherwise sinks every load next to its first use).
+                f32x4 wf[2][NTW], hf[2][MT][S];
+                auto load_q = [&](int q, f32x4 (&w)[NTW], f32x4 (&h)[MT][S]) {
 #pragma unroll
-            for (int q = 0; q < HP / 16; ++q) {
-                f32x4 wf[NTW];
+                    for (int j = 0; j < NTW; ++j)
+                        w[j] = WPF ? wall[WPF ? q : 0][j]
+                                   : pinn_ld4(Wl + ((wave * NTW + j) * 16 + lr) * HP + 16 * q + 4 * lq);
 #pragma unroll
-                for (int j = 0; j < NTW; ++j)
-                    wf[j] = pinn_ld4(Wl + ((wave * NTW + j) * 16 + lr) * HP + 16 * q + 4 * lq);
+                    for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
-                for (int mt = 0; mt < MT; ++mt)
+                        for (int s = 0; s < S; ++s)
+                            h[mt][s] = pinn_ld4(cur + (s * T + mt * 16 + lr) * LDA + 16 * q + 4 * lq);
+                };
+                load_q(0, wf[0], hf[0]);
 #pragma unroll
-                    for (int s = 0; s < S; ++s) {
-                        const f32x4 hf = pinn_ld4(cur + (s * T + mt * 16 + lr) * LDA + 16 * q + 4 * lq);
+                for (int q = 0; q < HP / 16; ++q) {
+                    if (q + 1 < HP / 16) load_q(q + 1, wf[(q + 1) & 1], hf[(q + 1) & 1]);
+                    PINN_SCHED_BARRIER();
 #pragma unroll
-                        for (int j = 0; j < NTW; ++j) {
+                    for (int m = 0; m < 4; ++m)
 #pragma unroll
-                            for (int m = 0; m < 4; ++m) acc[j][mt][s] = pinn_mfma16(wf[j][m], hf[m], acc[j][mt][s]);
-                        }
-                    }
+                        for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+                            for (int s = 0; s < S; ++s)
+#pragma unroll
+                                for (int j = 0; j < NTW; ++j)
+                                    acc[j][mt][s] = pinn_mfma16(wf[q & 1][j][m], hf[q & 1][mt][s][m], acc[j][mt][s]);
+                    PINN_SCHED_BARRIER();
+                }
             }
+            PH(3)
+            f32x4 biasv[NTW];
+#pragma unroll
+            for (int j = 0; j < NTW; ++j) biasv[j] = pinn_ld4(bl + unit0(j));    // before the prefetch: vmcnt retires in order
+            PINN_SCHED_BARRIER();
+            if (WPF && li + 1 < lh) load_wall(Wl + A.hidden_stride);
 #pragma unroll
             for (int j = 0; j < NTW; ++j) {
                 const int n0 = unit0(j);
-                const f32x4 bias = pinn_ld4(bl + n0);
+                const f32x4 bias = biasv[j];
 #pragma unroll
                 for (int mt = 0; mt < MT; ++mt) {
                     const int pt = mt * 16 + lr;
@@ -566,15 +696,27 @@ pinn_tile_kernel(const PinnKArgs A) {
 #pragma unroll
                         for (int s = 0; s < S; ++s) { hv[s][r] = h[s]; sv[s][r] = (s == 0) ? h[0] : z[s]; }
                     }
+                    if (li + 1 == lh) {
 #pragma unroll
-                    for (int s = 0; s < S; ++s) pinn_st4(nxt + (s * T + pt) * LDA + n0, hv[s]);
+                        for (int s = 0; s < S; ++s) htop[j][mt][s] = hv[s];
+                    } else {
+#pragma unroll
+                        for (int s = 0; s < S; ++s) pinn_st4(nxt + (s * T + pt) * LDA + n0, hv[s]);
+                    }
                     if (train) {
+                        if (li + 1 == lh) {
 #pragma unroll
-                        for (int s = 0; s < S; ++s) *slab_at(li + 1, s, j, mt) = sv[s];
+                            for (int s = 0; s < S; ++s) svtop[j][mt][s] = sv[s];
+                        } else {
+#pragma unroll
+                            for (int s = 0; s < S; ++s) *slab_at(li + 1, s, j, mt) = sv[s];
+                        }
                     }
                 }
             }
+            PH(4)
             PINN_SYNC();
+            PH(5)
             float* tmp = cur; cur = nxt; nxt = tmp;
         }
 
@@ -587,8 +729,7 @@ pinn_tile_kernel(const PinnKArgs A) {
                 float part = 0.0f;
 #pragma unroll
                 for (int j = 0; j < NTW; ++j) {
-                    const int n0 = unit0(j);
-                    const f32x4 hv = pinn_ld4(cur + (s * T + pt) * LDA + n0), wv = pinn_ld4(WLs + n0);
+                    const f32x4 hv = htop[j][mt][s], wv = pinn_ld4(WLs + unit0(j));
                     part = fmaf(hv[0], wv[0], part); part = fmaf(hv[1], wv[1], part);
                     part = fmaf(hv[2], wv[2], part); part = fmaf(hv[3], wv[3], part);
                 }
@@ -597,7 +738,9 @@ pinn_tile_kernel(const PinnKArgs A) {
                 if (lq == 0) netp[(wave * S + s) * T + pt] = part;
             }
         }
+        PH(6)
         PINN_SYNC();
+        PH(7)
 
         // ---- (4) ansatz + residual + their reverse, one thread per point ------------------------------------------
         if (tid < T) {
@@ -612,12 +755,14 @@ pinn_tile_kernel(const PinnKArgs A) {
             }
             PinnPointOut<ND, N2> po;
             pinn_point_stage<ND, N2>(A, net, xs_t + pt * PINN_XS_LD, base + pt, base + pt < A.n_points,
-                                     pregs + pt, padj + pt, T, po);
+                                     pregs + pt, padj + pt, T, ppre, po);
 #pragma unroll
             for (int s = 0; s < S; ++s) gnetb[s * T + pt] = po.gnet[s];
             sum_loss += po.loss; sum_ls += po.g_ls; sum_bl += po.gnet[0];
         }
+        PH(8)
         PINN_SYNC();
+        PH(9)
         if (!train) continue;
 
         // ---- (5) reverse through the last layer: gh_s = gnet_s * WL ; dWL += sum gnet_s h_s -------------------------
@@ -632,11 +777,10 @@ pinn_tile_kernel(const PinnKArgs A) {
                 const int pt = mt * 16 + lr;
 #pragma unroll
                 for (int s = 0; s < S; ++s) {
-                    sv[j][mt][s] = *slab_at(lh, s, j, mt);
+                    sv[j][mt][s] = svtop[j][mt][s];
                     const float gn = gnetb[s * T + pt];
-                    const f32x4 hv = pinn_ld4(cur + (s * T + pt) * LDA + n0);
                     g[j][mt][s] = wl * gn;
-                    accWL[j] += hv * gn;
+                    accWL[j] += htop[j][mt][s] * gn;
                 }
             }
         }
@@ -668,9 +812,13 @@ pinn_tile_kernel(const PinnKArgs A) {
                 }
             }
         };
+        // after the forward half `nxt` still holds h_{lh-1} (the input of the last hidden layer): the top reverse step
+        // uses it in place and stages only gz
         auto hidden_reverse = [&](int a, f32x4 (&dw)[NT][NTW]) {
             f32x4 gz[NTW][MT][S];
             act_reverse(a, gz);
+            const bool top = (a == lh);
+            if (top) { float* tmp = cur; cur = nxt; nxt = tmp; }     // cur = h_{a-1}, nxt = free (receives gz)
             // stage gz_a (-> nxt) and the recomputed h_{a-1} (-> cur) for the two GEMMs of linear layer a
 #pragma unroll
             for (int j = 0; j < NTW; ++j) {
@@ -679,8 +827,19 @@ pinn_tile_kernel(const PinnKArgs A) {
                 for (int mt = 0; mt < MT; ++mt) {
                     const int pt = mt * 16 + lr;
                     f32x4 hv[S];
+                    if (a == 1) {
+                        sv[j][mt][0] = *slab_at(0, 0, j, mt);
 #pragma unroll
-                    for (int s = 0; s < S; ++s) sv[j][mt][s] = *slab_at(a - 1, s, j, mt);
+                        for (int r = 0; r < 4; ++r) {
+#pragma unroll
+                            for (int k = 0; k < ND; ++k) sv[j][mt][1 + k][r] = W1s[(n0 + r) * PINN_XS_LD + A.dir_cols[k]];
+#pragma unroll
+                            for (int k = 0; k < N2; ++k) sv[j][mt][1 + ND + k][r] = 0.0f;
+                        }
+                    } else {
+#pragma unroll
+                        for (int s = 0; s < S; ++s) sv[j][mt][s] = *slab_at(a - 1, s, j, mt);
+                    }
 #pragma unroll
                     for (int r = 0; r < 4; ++r) {
                         float sv1[S], h[S];
@@ -692,64 +851,100 @@ pinn_tile_kernel(const PinnKArgs A) {
                     }
 #pragma unroll
                     for (int s = 0; s < S; ++s) {
-                        pinn_st4(cur + (s * T + pt) * LDA + n0, hv[s]);
+                        if (!top) pinn_st4(cur + (s * T + pt) * LDA + n0, hv[s]);
                         pinn_st4(nxt + (s * T + pt) * LDA + n0, gz[j][mt][s]);
                     }
                 }
             }
+            PH(10)
             PINN_SYNC();
+            PH(11)
             const int li = a - 1;
-            // weight gradient: dW_li[out][in] += sum_{s,pt} gz_s[pt][out] * h_s[pt][in]   (A = gz^T, B = h)
+            // weight gradient: dW_li[out][in] += sum_{s,pt} gz_s[pt][out] * h_s[pt][in]   (A = gz^T, B = h);
+            // software pipeline over the (mt, s) row tiles, NT*NTW accumulators interleaved
+            const float* Wl = A.params + A.off_wh + (size_t)li * A.hidden_stride;
+            float wqall[WPF ? NQ : 1][NTW][4];
+            if (WPF) {
 #pragma unroll
-            for (int mt = 0; mt < MT; ++mt)
-#pragma unroll
-                for (int s = 0; s < S; ++s) {
-                    float bq[NTW][4];
+                for (int q = 0; q < NQ; ++q)
 #pragma unroll
                     for (int j = 0; j < NTW; ++j)
 #pragma unroll
                         for (int m = 0; m < 4; ++m)
-                            bq[j][m] = cur[(s * T + mt * 16 + lq * 4 + m) * LDA + (wave * NTW + j) * 16 + lr];
+                            wqall[WPF ? q : 0][j][m] = Wl[(16 * q + 4 * lq + m) * HP + (wave * NTW + j) * 16 + lr];
+            }
+            {
+                float bq[2][NTW][4], aq[2][NT][4];
+                auto load_ms = [&](int ms, float (&b)[NTW][4], float (&a_)[NT][4]) {
+                    const int mt = ms / S, s = ms % S;
 #pragma unroll
-                    for (int o = 0; o < NT; ++o) {
-                        float aq[4];
+                    for (int m = 0; m < 4; ++m) {
+                        const int row = (s * T + mt * 16 + wg_pt(m)) * LDA;
 #pragma unroll
-                        for (int m = 0; m < 4; ++m)
-                            aq[m] = nxt[(s * T + mt * 16 + lq * 4 + m) * LDA + o * 16 + lr];
+                        for (int j = 0; j < NTW; ++j) b[j][m] = cur[row + (wave * NTW + j) * 16 + lr];
 #pragma unroll
-                        for (int j = 0; j < NTW; ++j)
-#pragma unroll
-                            for (int m = 0; m < 4; ++m) dw[o][j] = pinn_mfma16(aq[m], bq[j][m], dw[o][j]);
+                        for (int o = 0; o < NT; ++o) a_[o][m] = nxt[row + o * 16 + lr];
                     }
+                };
+                load_ms(0, bq[0], aq[0]);
+#pragma unroll
+                for (int ms = 0; ms < MT * S; ++ms) {
+                    if (ms + 1 < MT * S) load_ms(ms + 1, bq[(ms + 1) & 1], aq[(ms + 1) & 1]);
+                    PINN_SCHED_BARRIER();
+#pragma unroll
+                    for (int m = 0; m < 4; ++m)
+#pragma unroll
+                        for (int o = 0; o < NT; ++o)
+#pragma unroll
+                            for (int j = 0; j < NTW; ++j)
+                                dw[o][j] = pinn_mfma16(aq[ms & 1][o][m], bq[ms & 1][j][m], dw[o][j]);
+                    PINN_SCHED_BARRIER();
                 }
+            }
+            PH(12)
             // data gradient: GH^T[in][pt] = sum_out W_li[out][in] * gz[pt][out]   (A = W^T fragment, B = gz)
-            const float* Wl = A.params + A.off_wh + (size_t)li * A.hidden_stride;
 #pragma unroll
             for (int j = 0; j < NTW; ++j)
 #pragma unroll
                 for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
                     for (int s = 0; s < S; ++s) g[j][mt][s] = f32x4{0.f, 0.f, 0.f, 0.f};
+            {
+                float wq[2][NTW][4];
+                f32x4 gf[2][MT][S];
+                auto load_q = [&](int q, float (&w)[NTW][4], f32x4 (&gfr)[MT][S]) {
 #pragma unroll
-            for (int q = 0; q < HP / 16; ++q) {
-                float wq[NTW][4];
+                    for (int j = 0; j < NTW; ++j)
 #pragma unroll
-                for (int j = 0; j < NTW; ++j)
+                        for (int m = 0; m < 4; ++m)
+                            w[j][m] = WPF ? wqall[WPF ? q : 0][j][m]
+                                          : Wl[(16 * q + 4 * lq + m) * HP + (wave * NTW + j) * 16 + lr];
+#pragma unroll
+                    for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+                        for (int s = 0; s < S; ++s)
+                            gfr[mt][s] = pinn_ld4(nxt + (s * T + mt * 16 + lr) * LDA + 16 * q + 4 * lq);
+                };
+                load_q(0, wq[0], gf[0]);
+#pragma unroll
+                for (int q = 0; q < HP / 16; ++q) {
+                    if (q + 1 < HP / 16) load_q(q + 1, wq[(q + 1) & 1], gf[(q + 1) & 1]);
+                    PINN_SCHED_BARRIER();
 #pragma unroll
                     for (int m = 0; m < 4; ++m)
-                        wq[j][m] = Wl[(16 * q + 4 * lq + m) * HP + (wave * NTW + j) * 16 + lr];
 #pragma unroll
-                for (int mt = 0; mt < MT; ++mt)
+                        for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
-                    for (int s = 0; s < S; ++s) {
-                        const f32x4 gf = pinn_ld4(nxt + (s * T + mt * 16 + lr) * LDA + 16 * q + 4 * lq);
+                            for (int s = 0; s < S; ++s)
 #pragma unroll
-                        for (int j = 0; j < NTW; ++j)
-#pragma unroll
-                            for (int m = 0; m < 4; ++m) g[j][mt][s] = pinn_mfma16(wq[j][m], gf[m], g[j][mt][s]);
-                    }
+                                for (int j = 0; j < NTW; ++j)
+                                    g[j][mt][s] = pinn_mfma16(wq[q & 1][j][m], gf[q & 1][mt][s][m], g[j][mt][s]);
+                    PINN_SCHED_BARRIER();
+                }
             }
+            PH(13)
             PINN_SYNC();
+            PH(14)
         };
 #pragma unroll
         for (int a = PINN_LHMAX; a >= 1; --a) {
@@ -778,8 +973,10 @@ pinn_tile_kernel(const PinnKArgs A) {
                 }
             }
         }
+        PH(15)
         PINN_SYNC();      // the first-layer block reads xs_t; the next tile's staging overwrites it
     }
+    PH_FLUSH
 
     if (!train) return;
     // ---- write this workgroup's partial gradient ---------------------------------------------------------------

@@ -41,4 +41,5 @@ PINN_DEVICE float pinn_row_sum16(float v) {
 PINN_DEVICE float pinn_exp2(float x) { return __builtin_amdgcn_exp2f(x); }
 PINN_DEVICE float pinn_rcp(float x) { return __builtin_amdgcn_rcpf(x); }
 #define PINN_LAUNCH_BOUNDS2(n, w) __launch_bounds__(n, w)
+#define PINN_SCHED_BARRIER() __builtin_amdgcn_sched_barrier(0)
 #endif

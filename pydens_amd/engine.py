@@ -15,10 +15,12 @@ LIB_NAME = 'libpinn_hip.so'
 
 MAX_LAYERS, MAX_INPUTS, MAX_DIRS, EXTRA_SLOTS = 16, 8, 3, 16
 MAX_OPS, MAX_CONSTS, MAX_REGS = 64, 32, 40
+MAX_STREAMS, MAX_AUX = 7, 8
+RES_PROGRAM, RES_AFFINE = 0, 1
 ACT_CODES = {'tanh': 0, 'sigmoid': 1}
 
 OPS = dict(CONST=0, ADD=1, SUB=2, MUL=3, DIV=4, NEG=5, SIN=6, COS=7, EXP=8, LOG=9, TANH=10, SQRT=11, POW=12,
-           ABS=13, SIGMOID=14, RECIP=15, COPY=16)
+           ABS=13, SIGMOID=14, RECIP=15, COPY=16, STORE=17)
 
 
 class Layout(ctypes.Structure):
@@ -44,6 +46,25 @@ class Program(ctypes.Structure):
         return prog
 
 
+class Residual(ctypes.Structure):
+    """ pinn_residual_t """
+    _fields_ = [('kind', ctypes.c_int), ('n_aux', ctypes.c_int), ('pre', Program), ('program', Program),
+                ('coef', ctypes.c_float * MAX_STREAMS), ('coef_row', ctypes.c_int * MAX_STREAMS),
+                ('src_const', ctypes.c_float), ('src_row', ctypes.c_int)]
+
+    @classmethod
+    def build(cls, kind, n_aux, pre, program=None, coef=(), coef_row=(), src_const=0.0, src_row=-1):
+        res = cls()
+        res.kind, res.n_aux = kind, n_aux
+        res.pre = Program.from_lists(*pre) if pre is not None else Program()
+        res.program = Program.from_lists(*program) if program is not None else Program()
+        for i in range(MAX_STREAMS):
+            res.coef[i] = coef[i] if i < len(coef) else 0.0
+            res.coef_row[i] = coef_row[i] if i < len(coef_row) else -1
+        res.src_const, res.src_row = src_const, src_row
+        return res
+
+
 def bind(lib):
     """ declare the signatures of include/pinn.h on a loaded shared library. """
     vp, i32, i64, f32 = ctypes.c_void_p, ctypes.c_int, ctypes.c_int64, ctypes.c_float
@@ -58,7 +79,7 @@ def bind(lib):
     lib.pinn_workspace_bytes.restype = ctypes.c_size_t
     lib.pinn_jet_forward.argtypes = [vp, vp, vp, i64, ip, i32, i32, vp, f32, vp, vp]
     lib.pinn_jet_backward.argtypes = [vp, vp, vp, i64, ip, i32, i32, vp, f32, vp, vp, i32, vp, ctypes.c_size_t, vp]
-    lib.pinn_residual_step.argtypes = [vp, ctypes.POINTER(Program), vp, vp, i64, ip, i32, i32, vp, f32, f32, vp, vp,
+    lib.pinn_residual_step.argtypes = [vp, ctypes.POINTER(Residual), vp, vp, i64, ip, i32, i32, vp, f32, f32, vp, vp,
                                        ctypes.c_size_t, vp]
     lib.pinn_adam_step.argtypes = [vp, vp, vp, vp, vp, i64, vp, f32, f32, f32, f32, vp]
     lib.pinn_profile_tile.argtypes = [i32]
@@ -206,14 +227,14 @@ class Net:
                                                int(accumulate), _ptr(workspace), workspace.numel() * workspace.element_size(),
                                                _stream(xs)))
 
-    def residual_step(self, program, params, xs, grads, workspace, dir_cols=(), n2=0, ic_streams=None, ic_const=0.0,
+    def residual_step(self, residual, params, xs, grads, workspace, dir_cols=(), n2=0, ic_streams=None, ic_const=0.0,
                       inv_n_global=None):
         for t, name in ((params, 'params'), (xs, 'xs'), (grads, 'grads'), (ic_streams, 'ic_streams')):
             _check(t, name)
         dirs, nd = self._dirs(dir_cols)
         n = xs.shape[0]
         inv_n = 1.0 / n if inv_n_global is None else inv_n_global
-        self._raise(self.lib.pinn_residual_step(self.handle, ctypes.byref(program), _ptr(params), _ptr(xs), n, dirs, nd,
+        self._raise(self.lib.pinn_residual_step(self.handle, ctypes.byref(residual), _ptr(params), _ptr(xs), n, dirs, nd,
                                                 n2, _ptr(ic_streams), float(ic_const), float(inv_n), _ptr(grads),
                                                 _ptr(workspace), workspace.numel() * workspace.element_size(),
                                                 _stream(xs)))

@@ -97,6 +97,7 @@ class Solver:
             self.ctx.run(self.model.ic_values, fake)
         self.spec, self.needs_x_grad = trace.discover(self.equation, self.ctx.run, self.model.total, self.device)
         self.ic_trainable = self._ic_depends_on_variables()
+        self.residual_plan = None
         self.program, self.program_error = self._try_compile()
 
     # ---- tracing ---------------------------------------------------------------------------------------------------
@@ -112,16 +113,17 @@ class Solver:
         total = self.model.total
         try:
             root = trace.symbolic(self.equation, self.ctx.run, total)
-            code, consts = trace.compile_program(root, self.spec, total)
+            plan = trace.lower_residual(root, self.spec, total)
             # validation on random data: program (fp64 host interpreter) vs the user's callable on tagged tensors
             n = 17
             streams = torch.rand((self.spec.n_streams, n), device=self.device) * 2 - 1
             pts = torch.rand((n, total), device=self.device) + 0.25
             want = self._eval_equation(streams, pts, requires_grad=False).reshape(-1).double().cpu().numpy()
-            got = trace.run_program_numpy(code, consts, streams.cpu().numpy(), pts.cpu().numpy())
+            got = trace.run_residual_numpy(plan, streams.cpu().numpy(), pts.cpu().numpy())
             if not np.allclose(got, want, rtol=1e-4, atol=1e-5):
                 raise trace.TraceUnsupported('traced program disagrees with the callable (data-dependent control flow?)')
-            return engine.Program.from_lists(code, consts), None
+            self.residual_plan = plan
+            return plan.to_struct(), None
         except trace.TraceUnsupported as err:
             return None, str(err)
 

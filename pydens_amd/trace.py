@@ -21,7 +21,7 @@ from contextvars import ContextVar
 import numpy as np
 import torch
 
-from .engine import OPS, MAX_OPS, MAX_CONSTS, MAX_REGS, MAX_DIRS
+from .engine import OPS, MAX_OPS, MAX_CONSTS, MAX_REGS, MAX_DIRS, MAX_AUX, RES_AFFINE, RES_PROGRAM
 
 active_streams = ContextVar('pinn_active_streams', default=None)
 
@@ -235,70 +235,199 @@ def symbolic(equation, ctx_run, n_inputs):
     return Sym.wrap(root)
 
 
-def compile_program(root, spec, n_inputs):
-    """ DAG -> (code [(op, dst, a, b)], consts [float]) in the register convention of include/pinn.h:
-    registers 0..S-1 = streams, S..S+d-1 = inputs, then one fresh register per instruction. """
-    S = spec.n_streams
-    code, consts, memo = [], [], {}
-    const_index = {}
+class _Emitter:
+    """ register-code emitter shared by the pre-pass and the main program. """
+    def __init__(self, first_temp):
+        self.first_temp, self.code, self.consts, self.memo, self._cidx = first_temp, [], [], {}, {}
 
-    def const_slot(v):
+    def const_slot(self, v):
         key = float(np.float32(v))
-        if key not in const_index:
-            const_index[key] = len(consts)
-            consts.append(key)
-        return const_index[key]
+        if key not in self._cidx:
+            if len(self.consts) >= MAX_CONSTS:
+                raise TraceUnsupported('too many constants')
+            self._cidx[key] = len(self.consts)
+            self.consts.append(key)
+        return self._cidx[key]
 
-    def emit(op, a=0, b=0):
-        dst = S + n_inputs + len(code)
-        if dst >= MAX_REGS or len(code) >= MAX_OPS:
+    def emit(self, op, a=0, b=0):
+        dst = self.first_temp + sum(1 for c in self.code if c[0] != OPS['STORE'])
+        if dst >= MAX_REGS or len(self.code) >= MAX_OPS:
             raise TraceUnsupported('residual program too long')
-        code.append((OPS[op], dst, a, b))
+        self.code.append((OPS[op], dst, a, b))
         return dst
 
-    def visit(node):
+    def visit(self, node, leaf):
         key = id(node)
-        if key in memo:
-            return memo[key]
+        if key in self.memo:
+            return self.memo[key]
+        reg = leaf(node)
+        if reg is None:
+            if node.kind == 'const':
+                reg = self.emit('CONST', self.const_slot(node.value))
+            elif node.op == 'POW':
+                reg = self.emit('POW', self.visit(node.args[0], leaf), self.const_slot(node.value))
+            elif len(node.args) == 1:
+                reg = self.emit(node.op, self.visit(node.args[0], leaf))
+            else:
+                ra = self.visit(node.args[0], leaf)
+                rb = self.visit(node.args[1], leaf)
+                reg = self.emit(node.op, ra, rb)
+        self.memo[key] = reg
+        return reg
+
+
+def _uses_streams(node, memo):
+    key = id(node)
+    if key not in memo:
+        memo[key] = node.kind == 'stream' or any(_uses_streams(a, memo) for a in node.args)
+    return memo[key]
+
+
+def _affine(node, spec, memo):
+    """ node as sum_s C_s(x) * stream_s + F(x): returns ({stream index: x-only Sym}, x-only Sym) or None. """
+    key = id(node)
+    if key in memo:
+        return memo[key]
+    out = None
+    if node.kind == 'stream':
+        if node.alpha not in spec.index:
+            raise TraceUnsupported(f'stream {node.alpha} not in {spec}')
+        out = ({spec.index[node.alpha]: Sym('const', value=1.0)}, Sym('const', value=0.0))
+    elif node.kind in ('input', 'const'):
+        out = ({}, node)
+    else:
+        parts = [_affine(a, spec, memo) for a in node.args]
+        if all(p is not None for p in parts):
+            if all(not p[0] for p in parts):
+                out = ({}, node)                                   # x-only sub-expression: opaque source term
+            elif node.op in ('ADD', 'SUB'):
+                (ca, fa), (cb, fb) = parts
+                sign = (lambda v: v) if node.op == 'ADD' else (lambda v: -v)
+                coefs = dict(ca)
+                for k, v in cb.items():
+                    coefs[k] = coefs[k] + sign(v) if k in coefs else sign(v)
+                out = (coefs, fa + sign(fb))
+            elif node.op == 'NEG':
+                out = ({k: -v for k, v in parts[0][0].items()}, -parts[0][1])
+            elif node.op == 'MUL' and (not parts[0][0] or not parts[1][0]):
+                (lin, scale) = (parts[1], parts[0][1]) if not parts[0][0] else (parts[0], parts[1][1])
+                out = ({k: v * scale for k, v in lin[0].items()}, lin[1] * scale)
+            elif node.op == 'DIV' and not parts[1][0]:
+                out = ({k: v / parts[1][1] for k, v in parts[0][0].items()}, parts[0][1] / parts[1][1])
+    memo[key] = out
+    return out
+
+
+class ResidualPlan:
+    """ host-side description of a lowered residual (see pinn_residual_t in include/pinn.h). """
+    def __init__(self, kind, n_inputs, n_streams, pre, n_aux, program=None, coef=None, coef_row=None, src_const=0.0,
+                 src_row=-1):
+        self.kind, self.n_inputs, self.n_streams = kind, n_inputs, n_streams
+        self.pre, self.n_aux, self.program = pre, n_aux, program
+        self.coef = coef or [0.0] * n_streams
+        self.coef_row = coef_row or [-1] * n_streams
+        self.src_const, self.src_row = src_const, src_row
+
+    def to_struct(self):
+        from .engine import Residual
+        return Residual.build(self.kind, self.n_aux, self.pre if self.n_aux else None, self.program, self.coef,
+                              self.coef_row, self.src_const, self.src_row)
+
+
+def lower_residual(root, spec, n_inputs):
+    """ DAG -> ResidualPlan. x-only sub-expressions go to the pre-pass; if the rest is affine in the streams the
+    step needs no interpreter at all (every linear PDE), otherwise a register program is emitted. """
+    S = spec.n_streams
+    pre = _Emitter(first_temp=n_inputs)
+    rows = []
+
+    def pre_leaf(node):
+        if node.kind == 'stream':
+            raise TraceUnsupported('internal: stream inside an x-only expression')
+        return node.col if node.kind == 'input' else None
+
+    def aux_row(expr):
+        reg = pre.visit(expr, pre_leaf)
+        if reg not in rows:
+            if len(rows) >= MAX_AUX:
+                raise TraceUnsupported(f'more than {MAX_AUX} x-only sub-expressions')
+            rows.append(reg)
+            pre.code.append((OPS['STORE'], 0, reg, len(rows) - 1))
+            if len(pre.code) > MAX_OPS:
+                raise TraceUnsupported('pre-pass program too long')
+        return rows.index(reg)
+
+    aff = _affine(root, spec, {})
+    if aff is not None:
+        coefs, src = aff
+        coef, coef_row = [0.0] * S, [-1] * S
+        for idx, expr in coefs.items():
+            if expr.kind == 'const':
+                coef[idx] = expr.value
+            else:
+                coef_row[idx] = aux_row(expr)
+        src_const, src_row = (src.value, -1) if src.kind == 'const' else (0.0, aux_row(src))
+        return ResidualPlan(RES_AFFINE, n_inputs, S, (pre.code, pre.consts), len(rows), coef=coef, coef_row=coef_row,
+                            src_const=src_const, src_row=src_row)
+
+    # general program: maximal x-only sub-expressions (with at least one op) become pre-pass rows
+    uses = {}
+    aux_of = {}
+
+    def collect(node):
+        if not _uses_streams(node, uses):
+            if node.kind == 'op' and id(node) not in aux_of:
+                aux_of[id(node)] = aux_row(node)
+            return
+        for a in node.args:
+            collect(a)
+    collect(root)
+    n_aux = len(rows)
+    main = _Emitter(first_temp=S + n_inputs + n_aux)
+
+    def main_leaf(node):
+        if id(node) in aux_of:
+            return S + n_inputs + aux_of[id(node)]
         if node.kind == 'stream':
             if node.alpha not in spec.index:
                 raise TraceUnsupported(f'stream {node.alpha} not in {spec}')
-            reg = spec.index[node.alpha]
-        elif node.kind == 'input':
-            reg = S + node.col
-        elif node.kind == 'const':
-            reg = emit('CONST', const_slot(node.value))
-        elif node.op == 'POW':
-            reg = emit('POW', visit(node.args[0]), const_slot(node.value))
-        elif len(node.args) == 1:
-            reg = emit(node.op, visit(node.args[0]))
-        else:
-            ra = visit(node.args[0])
-            rb = visit(node.args[1])
-            reg = emit(node.op, ra, rb)
-        memo[key] = reg
-        return reg
+            return spec.index[node.alpha]
+        return S + node.col if node.kind == 'input' else None
 
-    res = visit(root)
-    if not code or code[-1][1] != res:
-        emit('COPY', res)                       # the residual must be the value of the last instruction
-    if len(consts) > MAX_CONSTS:
-        raise TraceUnsupported('too many constants')
-    return code, consts
+    res = main.visit(root, main_leaf)
+    if not main.code or main.code[-1][1] != res:
+        main.emit('COPY', res)                      # the residual must be the value of the last instruction
+    return ResidualPlan(RES_PROGRAM, n_inputs, S, (pre.code, pre.consts), n_aux, program=(main.code, main.consts))
 
 
-def run_program_numpy(code, consts, streams, xs):
-    """ fp64 host interpreter of a residual program (validation of the trace; never on the step path). """
+def compile_program(root, spec, n_inputs):
+    """ plain single program over streams and inputs (no pre-pass); kept for tests of the register convention. """
+    S = spec.n_streams
+    em = _Emitter(first_temp=S + n_inputs)
+
+    def leaf(node):
+        if node.kind == 'stream':
+            if node.alpha not in spec.index:
+                raise TraceUnsupported(f'stream {node.alpha} not in {spec}')
+            return spec.index[node.alpha]
+        return S + node.col if node.kind == 'input' else None
+
+    res = em.visit(root, leaf)
+    if not em.code or em.code[-1][1] != res:
+        em.emit('COPY', res)
+    return em.code, em.consts
+
+
+def _run_code_numpy(code, consts, regs, n, aux=None):
     inv = {v: k for k, v in OPS.items()}
-    S, d = streams.shape[0], xs.shape[1]
-    regs = {s: streams[s].astype(np.float64) for s in range(S)}
-    for c in range(d):
-        regs[S + c] = xs[:, c].astype(np.float64)
     out = None
     for op, dst, a, b in code:
         name = inv[op]
+        if name == 'STORE':
+            aux[b] = regs[a]
+            continue
         if name == 'CONST':
-            out = np.full(xs.shape[0], consts[a], dtype=np.float64)
+            out = np.full(n, consts[a], dtype=np.float64)
         elif name in ('ADD', 'SUB', 'MUL', 'DIV'):
             out = {'ADD': np.add, 'SUB': np.subtract, 'MUL': np.multiply, 'DIV': np.divide}[name](regs[a], regs[b])
         elif name == 'POW':
@@ -312,3 +441,33 @@ def run_program_numpy(code, consts, streams, xs):
             out = fn(regs[a])
         regs[dst] = out
     return out
+
+
+def run_residual_numpy(plan, streams, xs):
+    """ fp64 host interpreter of a ResidualPlan (validation of the trace; never on the step path). """
+    n, d, S = xs.shape[0], xs.shape[1], streams.shape[0]
+    aux = {}
+    if plan.n_aux:
+        regs = {c: xs[:, c].astype(np.float64) for c in range(d)}
+        _run_code_numpy(plan.pre[0], plan.pre[1], regs, n, aux)
+    if plan.kind == RES_AFFINE:
+        r = aux[plan.src_row].copy() if plan.src_row >= 0 else np.full(n, plan.src_const, dtype=np.float64)
+        for s in range(S):
+            c = aux[plan.coef_row[s]] if plan.coef_row[s] >= 0 else plan.coef[s]
+            r = r + c * streams[s]
+        return r
+    regs = {s: streams[s].astype(np.float64) for s in range(S)}
+    for c in range(d):
+        regs[S + c] = xs[:, c].astype(np.float64)
+    for m in range(plan.n_aux):
+        regs[S + d + m] = aux[m]
+    return _run_code_numpy(plan.program[0], plan.program[1], regs, n)
+
+
+def run_program_numpy(code, consts, streams, xs):
+    """ fp64 host interpreter of a plain program from `compile_program`. """
+    S, d = streams.shape[0], xs.shape[1]
+    regs = {s: streams[s].astype(np.float64) for s in range(S)}
+    for c in range(d):
+        regs[S + c] = xs[:, c].astype(np.float64)
+    return _run_code_numpy(code, consts, regs, xs.shape[0])

@@ -40,3 +40,4 @@ static inline float pinn_row_sum16(float v) { return emu::row_sum16(v); }
 static inline float pinn_exp2(float x) { return exp2f(x); }
 static inline float pinn_rcp(float x) { return 1.0f / x; }
 #define PINN_LAUNCH_BOUNDS2(n, w)
+#define PINN_SCHED_BARRIER()

@@ -247,3 +247,34 @@ def test_callable_ic_with_variable(pa, emu_lib):
     assert abs(float(solver.model.init) - float(oracle.model.init)) < 2e-5
     xs = np.linspace(0, 1, 7).astype(np.float32)
     assert np.abs(solver.predict(xs) - oracle.predict(xs)).max() < 2e-5
+
+
+def _nonlinear_problem(D, torch):
+    def burgers(f, x, t):                            # nonlinear in the field: lowered to a residual PROGRAM
+        return D(f, t) + f * D(f, x) - 0.05 * D(D(f, x), x) - torch.sin(np.pi * x) * torch.exp(-t)
+    return burgers, dict(ndims=2, boundary_condition=0, initial_condition=lambda x: torch.sin(np.pi * x),
+                         layout='fafaf', features=[16, 16, 1], activation='Tanh')
+
+
+def _variable_coefficient_problem(D, torch):
+    def eq(f, x, y):                                 # affine with x-dependent coefficients: pre-pass rows
+        return (1 + x * y) * D(D(f, x), x) + torch.exp(-x) * D(D(f, y), y) + torch.cos(y) * D(f, x) - 3 * f - x * torch.sin(y)
+    return eq, dict(ndims=2, boundary_condition=0.5, layout='fafaf', features=[16, 16, 1], activation='Sigmoid')
+
+
+@pytest.mark.parametrize('problem,kind', [(_nonlinear_problem, 0), (_variable_coefficient_problem, 1)])
+def test_residual_kinds_match_the_oracle(pa, emu_lib, problem, kind):
+    from oracle import pinn_oracle as po
+    eq_o, kw = problem(po.D, torch)
+    oracle = po.OracleSolver(eq_o, **kw)
+    eq_p, kw = problem(pa.D, torch)
+    solver = pa.Solver(eq_p, **kw, **emu_kwargs(emu_lib))
+    assert solver.program is not None and solver.residual_plan.kind == kind, solver.program_error
+    load_params(solver, oracle.export_params())
+    pts = np.random.RandomState(8).rand(4, 50, 2).astype(np.float32)
+    oracle.fit(niters=4, batch_size=50, points=pts, lr=0.01)
+    solver.fit(niters=4, batch_size=50, sampler=FixedBatches(pts), lr=0.01)
+    assert solver.last_fit_path == 'fused'
+    np.testing.assert_allclose([float(v) for v in solver.losses], [float(v) for v in oracle.losses], rtol=3e-5)
+    for got, want in zip(export_params(solver), oracle.export_params()):
+        assert rel_l2(got, want) < 3e-5

@@ -153,3 +153,25 @@ def test_adam_matches_torch(pa):
     assert torch.equal(p[~live], keep[~live])
     assert rel_l2(p[live].cpu().numpy(), ref.detach()[live].cpu().numpy()) < 1e-6
     assert int(step) == 20
+
+
+@pytest.mark.parametrize('which', ['nonlinear', 'variable_coefficient'])
+def test_residual_kinds_match_the_oracle(pa, which):
+    """ residual PROGRAM (nonlinear Burgers-type, interpreter inside the tile kernel) and AFFINE residual with
+    x-dependent coefficients (pre-pass rows) against the oracle's nested autograd on the same points """
+    from oracle import pinn_oracle as po
+    from test_emu_engine import _nonlinear_problem, _variable_coefficient_problem
+    problem, kind = (_nonlinear_problem, 0) if which == 'nonlinear' else (_variable_coefficient_problem, 1)
+    eq_o, kw = problem(po.D, torch)
+    oracle = po.OracleSolver(eq_o, **kw)
+    eq_p, kw = problem(pa.D, torch)
+    solver = pa.Solver(eq_p, **kw)
+    assert solver.program is not None and solver.residual_plan.kind == kind, solver.program_error
+    load_params(solver, oracle.export_params())
+    pts = np.random.RandomState(8).rand(4, 1000, 2).astype(np.float32)
+    oracle.fit(niters=4, batch_size=1000, points=pts, lr=0.01)
+    solver.fit(niters=4, batch_size=1000, sampler=FixedBatches(pts), lr=0.01)
+    assert solver.last_fit_path == 'fused'
+    np.testing.assert_allclose([float(v) for v in solver.losses], [float(v) for v in oracle.losses], rtol=3e-5)
+    for got, want in zip(export_params(solver), oracle.export_params()):
+        assert rel_l2(got, want) < 3e-5

@@ -103,3 +103,53 @@ def test_chain_rule_D_of_composite_expression():
         trace.active_streams.reset(token)
     want = 2 * x * fx + (1 + x ** 2) * fxx
     assert torch.allclose(got, want, rtol=1e-12)
+
+
+def lower(eq, n_inputs):
+    spec, _ = trace.discover(eq, run, n_inputs)
+    return spec, trace.lower_residual(trace.symbolic(eq, run, n_inputs), spec, n_inputs)
+
+
+def test_linear_pdes_lower_to_affine_form_with_prepass():
+    from pydens_amd.engine import RES_AFFINE, RES_PROGRAM
+    spec, plan = lower(lambda f, x, y: D(D(f, x), x) + D(D(f, y), y) - 5 * torch.sin(np.pi * (x + y)), 2)
+    assert plan.kind == RES_AFFINE and plan.n_aux == 1 and plan.src_row == 0
+    assert plan.coef == [0.0, 0.0, 0.0, 1.0, 1.0] and plan.coef_row == [-1] * 5
+    spec, plan = lower(lambda f, x, y, t: D(D(f, x), x) + D(D(f, y), y) - D(f, t), 3)      # constant coefficients only
+    assert plan.kind == RES_AFFINE and plan.n_aux == 0 and plan.src_const == 0.0
+    assert plan.coef[spec.index[(2,)]] == -1.0
+    # variable coefficient k(x) u_xx and a reaction term: still affine, two pre-pass rows + the source
+    spec, plan = lower(lambda f, x: (1 + x ** 2) * D(D(f, x), x) / 2 - torch.exp(x) * f + torch.cos(x), 1)
+    assert plan.kind == RES_AFFINE and plan.n_aux == 3
+    assert plan.coef_row[spec.index[(0, 0)]] >= 0 and plan.coef_row[0] >= 0 and plan.src_row >= 0
+    # nonlinear in the field: general program, x-only part still hoisted
+    spec, plan = lower(lambda f, x, t: D(f, t) + f * D(f, x) - 0.01 * D(D(f, x), x) - torch.sin(np.pi * x), 2)
+    assert plan.kind == RES_PROGRAM and plan.n_aux == 1
+
+
+@pytest.mark.parametrize('eq,n_inputs', [
+    (lambda f, x, y: D(D(f, x), x) + D(D(f, y), y) - 5 * torch.sin(np.pi * (x + y)), 2),
+    (lambda f, x: (1 + x ** 2) * D(D(f, x), x) / 2 - torch.exp(x) * f + torch.cos(x), 1),
+    (lambda f, x, t: D(f, t) + f * D(f, x) - 0.01 * D(D(f, x), x) - torch.sin(np.pi * x), 2),
+    (lambda f, x: torch.tanh(f) * D(f, x) + (x + 1) * torch.log(x + 2) - f / (x + 3), 1),
+])
+def test_lowered_residual_reproduces_the_callable(eq, n_inputs):
+    spec, plan = lower(eq, n_inputs)
+    rng = np.random.RandomState(1)
+    streams = rng.rand(spec.n_streams, 21) * 2 - 1
+    xs = rng.rand(21, n_inputs) + 0.5
+    got = trace.run_residual_numpy(plan, streams, xs)
+    sc = trace.StreamContext(n_inputs)
+    for alpha, idx in spec.index.items():
+        sc.tag(torch.tensor(streams[idx]).view(-1, 1), alpha)
+    cols = []
+    for c in range(n_inputs):
+        col = torch.tensor(xs[:, c:c + 1])
+        col._pinn_col = c
+        cols.append(col)
+    token = trace.active_streams.set(sc)
+    try:
+        want = eq(sc.tensors[()], *cols).numpy()[:, 0]
+    finally:
+        trace.active_streams.reset(token)
+    np.testing.assert_allclose(got, want, rtol=1e-6, atol=1e-6)

@@ -1,0 +1,35 @@
+""" Per-phase cycle breakdown of the tile kernel (needs a -DPINN_PROFILE_PHASES build of the library). """
+import ctypes, os, sys
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import numpy as np, torch
+import pinn_configs as pc
+import pydens_amd as pa
+from pydens_amd import engine
+
+NAMES = ['0 stage xs+barrier', '1 first layer', '2 barrier', '3 fwd MFMA', '4 fwd epilogue', '5 fwd barrier',
+         '6 head dot', '7 barrier', '8 point stage', '9 barrier', '10 bwd act+stage', '11 barrier', '12 wgrad MFMA',
+         '13 dgrad MFMA', '14 barrier', '15 layer0 bwd+(5)']
+lib_path, cfg_name = sys.argv[1], (sys.argv[2] if len(sys.argv) > 2 else 'cfg2')
+lib = engine.bind(ctypes.CDLL(lib_path))
+lib.pinn_debug_phase_buffer.argtypes = [ctypes.c_void_p]
+torch.manual_seed(0)
+cfg = pc.make_config(cfg_name, pa.D, torch)
+solver = pa.Solver(cfg['equation'], **cfg['solver_kwargs'], lib=lib)
+n = min(cfg['n_points'], 131072)
+xs = torch.from_numpy(pc.sample_points(cfg, n, seed=1)).cuda()
+buf = torch.zeros(1024 * 8 * 16, dtype=torch.int64, device='cuda')
+for _ in range(3):
+    solver._fused_step(xs, 1)
+lib.pinn_debug_phase_buffer(ctypes.c_void_p(buf.data_ptr()))
+buf.zero_()
+solver._fused_step(xs, 1)
+torch.cuda.synchronize()
+lib.pinn_debug_phase_buffer(None)
+b = buf.cpu().numpy().reshape(-1, 16)
+b = b[b.sum(axis=1) > 0]
+nw = b.shape[0]
+tot = b.sum(axis=1).mean()
+print(f'{cfg_name}: {nw} waves reported, mean total cycles/wave {tot:.0f}')
+for i, name in enumerate(NAMES):
+    print(f'  {name:22s} {b[:, i].mean():10.0f} cycles/wave  {100 * b[:, i].mean() / tot:5.1f} %   (wave0-of-WG mean {b[0::4, i].mean():9.0f})')
