@@ -29,6 +29,10 @@ hipEvent_t g_ev0 = nullptr, g_ev1 = nullptr;
 #endif
 }  // namespace
 
+int g_pinn_disable_duo = 1;      // the two-team kernel is an experiment; off by default
+int g_pinn_last_kernel = -1;
+int g_pinn_debug_flags = 0;
+
 struct pinn_net {
     pinn_layout_t lay;
     int n_layers, act, ndims, nparams, has_bc, has_ic, nsp;
@@ -65,7 +69,8 @@ struct Plan {
     size_t smem, slab_vec4_per_wg;
 };
 
-int make_plan(const pinn_net* net, int64_t n_points, int nd, int n2, Plan* plan) {
+int make_plan(const pinn_net* net, int64_t n_points, int nd, int n2, Plan* plan, int mode = PINN_MODE_FORWARD,
+              int res_kind = PINN_RES_PROGRAM) {
     plan->fn = launcher_for(net->lay.hp);
     if (!plan->fn) return fail("no kernel for padded hidden width %d (supported: 16, 32, 64, 128)", net->lay.hp);
     plan->n2k = pick_n2(nd, n2);
@@ -74,14 +79,17 @@ int make_plan(const pinn_net* net, int64_t n_points, int nd, int n2, Plan* plan)
     memset(&probe, 0, sizeof(probe));
     probe.lh = net->lay.lh;
     probe.act = net->act;
-    long long info[4];
+    probe.mode = mode;
+    probe.res_kind = res_kind;
+    long long info[5] = {0, 0, 0, 1, 1};
     if (plan->fn(nd, plan->n2k, &probe, 0, nullptr, 1, info)) return fail("kernel query failed");
     plan->smem = (size_t)info[0];
     plan->threads = (int)info[1];
     plan->slab_vec4_per_wg = (size_t)info[2];
     const int64_t ntiles = (n_points + 15) / 16;
+    const int64_t wg_tiles = (ntiles + info[4] - 1) / info[4];       // a two-team workgroup streams two tiles at a time
     int64_t grid = (int64_t)net->n_cu * info[3];
-    if (grid > ntiles) grid = ntiles;
+    if (grid > wg_tiles) grid = wg_tiles;
     if (grid < 1) grid = 1;
     plan->grid = (int)grid;
     return 0;
@@ -130,6 +138,15 @@ size_t align256(size_t v) { return (v + 255) / 256 * 256; }
 extern "C" {
 
 const char* pinn_last_error(void) { return g_err; }
+
+int pinn_debug_set_flags(int flags) { g_pinn_debug_flags = flags; return 0; }
+
+int pinn_debug_last_kernel(void) { return g_pinn_last_kernel; }
+
+int pinn_debug_disable_duo(int disable) {
+    g_pinn_disable_duo = disable ? 1 : 0;
+    return 0;
+}
 
 int pinn_debug_phase_buffer(void* buf) {
     g_phase_prof = reinterpret_cast<long long*>(buf);
@@ -231,11 +248,16 @@ int pinn_layout(const pinn_t* net, pinn_layout_t* out) {
 
 size_t pinn_workspace_bytes(const pinn_t* net, int64_t n_points, int nd, int n2) {
     if (!net) return 0;
-    Plan plan;
-    if (make_plan(net, n_points, nd, n2, &plan)) return 0;
-    return align256((size_t)plan.grid * net->lay.p_core * sizeof(float)) +
-           align256((size_t)plan.grid * plan.slab_vec4_per_wg * 16) +
-           align256((size_t)PINN_MAX_AUX * (size_t)n_points * sizeof(float)) + 256;
+    size_t need = 0;
+    const int modes[3][2] = {{PINN_MODE_STEP, PINN_RES_AFFINE}, {PINN_MODE_STEP, PINN_RES_PROGRAM}, {PINN_MODE_BACKWARD, 0}};
+    for (int i = 0; i < 3; ++i) {
+        Plan plan;
+        if (make_plan(net, n_points, nd, n2, &plan, modes[i][0], modes[i][1])) return 0;
+        const size_t v = align256((size_t)plan.grid * net->lay.p_core * sizeof(float)) +
+                         align256((size_t)plan.grid * plan.slab_vec4_per_wg * 16);
+        if (v > need) need = v;
+    }
+    return need + align256((size_t)PINN_MAX_AUX * (size_t)n_points * sizeof(float)) + 256;
 }
 
 int pinn_jet_forward(pinn_t* net, const float* params, const float* xs, int64_t n_points, const int* dir_cols, int nd,
@@ -262,6 +284,7 @@ static int run_train(pinn_t* net, PinnKArgs* a, const Plan& plan, int nd, float*
         return fail("workspace too small: need %zu bytes, got %zu", part_bytes + slab_bytes + aux_bytes, workspace_bytes);
     if (((uintptr_t)workspace & 15) != 0) return fail("workspace must be 16-byte aligned");
     a->prof = g_phase_prof;
+    a->debug_flags = g_pinn_debug_flags;
     a->partials = reinterpret_cast<float*>(workspace);
     a->slab = reinterpret_cast<f32x4*>(reinterpret_cast<char*>(workspace) + part_bytes);
     if (aux_bytes) {
@@ -298,7 +321,7 @@ int pinn_jet_backward(pinn_t* net, const float* params, const float* xs, int64_t
     if (n_points <= 0) return 0;
     if (check_dirs(net, dir_cols, nd, n2)) return 1;
     Plan plan;
-    if (make_plan(net, n_points, nd, n2, &plan)) return 1;
+    if (make_plan(net, n_points, nd, n2, &plan, PINN_MODE_BACKWARD, 0)) return 1;
     PinnKArgs a;
     fill_args(net, &a, params, xs, n_points, dir_cols, nd, n2, ic_streams, ic_const);
     a.mode = PINN_MODE_BACKWARD;
@@ -337,7 +360,7 @@ int pinn_residual_step(pinn_t* net, const pinn_residual_t* residual, const float
     if (residual->n_aux < 0 || residual->n_aux > PINN_MAX_AUX) return fail("n_aux=%d outside [0, %d]", residual->n_aux, PINN_MAX_AUX);
     if (residual->kind != PINN_RES_AFFINE && residual->kind != PINN_RES_PROGRAM) return fail("unknown residual kind %d", residual->kind);
     Plan plan;
-    if (make_plan(net, n_points, nd, n2, &plan)) return 1;
+    if (make_plan(net, n_points, nd, n2, &plan, PINN_MODE_STEP, residual->kind)) return 1;
     const int d = net->lay.d;
     const int s_user = 1 + nd + n2, s_kernel = 1 + nd + plan.n2k, shift = s_kernel - s_user;
     PinnKArgs a;

@@ -36,6 +36,7 @@ struct PinnKArgs {
     float* partials;             // [nWG][p_core]
     f32x4* slab;                 // saved activations, lane private
     long long* prof;             // optional per-phase cycle counters (PINN_PROFILE_PHASES builds only)
+    int debug_flags;             // bit 0: two-team kernel runs team 0 only (experiments)
     long long n_points;
     int lh, d, act, mode;
     int off_b1, off_wh, hidden_stride, off_wl, off_bl, off_ls, off_loss, p_core;
@@ -274,7 +275,7 @@ PINN_DEVICE void pinn_point_prefetch(const PinnKArgs& A, long long gidx, bool va
     }
 }
 
-template <int ND, int N2>
+template <int ND, int N2, bool WITH_PROGRAMS = true>
 PINN_DEVICE void pinn_point_stage(const PinnKArgs& A, const float (&net)[1 + ND + N2], const float* x /*[d]*/,
                                   long long gidx, bool valid, float* pregs, float* padj, int T,
                                   const PinnPointPre<ND, N2>& pre, PinnPointOut<ND, N2>& out) {
@@ -379,7 +380,7 @@ PINN_DEVICE void pinn_point_stage(const PinnKArgs& A, const float (&net)[1 + ND 
 #pragma unroll
         for (int s = 0; s < S; ++s) gu[s] = w * pre.cs[s];
         out.loss = valid ? r * r * A.inv_n : 0.0f;
-    } else if (A.mode == PINN_MODE_STEP) {
+    } else if (WITH_PROGRAMS && A.mode == PINN_MODE_STEP) {
         // registers: S streams (the INSTANTIATION's S), d input columns, n_aux pre-pass rows (already staged by
         // pinn_point_prefetch), then temporaries
 #pragma unroll

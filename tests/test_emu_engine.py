@@ -278,3 +278,24 @@ def test_residual_kinds_match_the_oracle(pa, emu_lib, problem, kind):
     np.testing.assert_allclose([float(v) for v in solver.losses], [float(v) for v in oracle.losses], rtol=3e-5)
     for got, want in zip(export_params(solver), oracle.export_params()):
         assert rel_l2(got, want) < 3e-5
+
+
+@pytest.mark.parametrize('name', ['cfg1', 'cfg4'])
+def test_two_team_kernel_agrees_with_solo_kernel(pa, emu_lib, name):
+    """ the experimental two-team form of the tile kernel (pinn_duo_kernel.h, off by default) must produce the same
+    gradients as the default kernel on the same points """
+    g = Golden(name)
+    grads = {}
+    try:
+        for disable in (1, 0):
+            emu_lib.pinn_debug_disable_duo(disable)
+            _, solver = make_solver(name, pa, **emu_kwargs(emu_lib))
+            load_params(solver, g.params)
+            solver._fused_step(torch.from_numpy(g.points[0].copy()), 1)
+            assert emu_lib.pinn_debug_last_kernel() == (0 if disable else 1)
+            grads[disable] = solver.grads.clone().numpy()
+    finally:
+        emu_lib.pinn_debug_disable_duo(1)
+    assert rel_l2(grads[0], grads[1]) < 1e-6
+    lay = solver.model.net.layout
+    assert abs(grads[0][lay.off_loss] - g.loss0) <= 1e-5 * g.loss0

@@ -11,6 +11,9 @@ NAMES = ['0 stage xs+barrier', '1 first layer', '2 barrier', '3 fwd MFMA', '4 fw
          '6 head dot', '7 barrier', '8 point stage', '9 barrier', '10 bwd act+stage', '11 barrier', '12 wgrad MFMA',
          '13 dgrad MFMA', '14 barrier', '15 layer0 bwd+(5)']
 lib_path, cfg_name = sys.argv[1], (sys.argv[2] if len(sys.argv) > 2 else 'cfg2')
+DUO = len(sys.argv) > 3 and sys.argv[3] == 'duo'
+if DUO:
+    NAMES = [f'phase {i}' for i in range(14)] + ['idle slot', 'barrier wait']
 lib = engine.bind(ctypes.CDLL(lib_path))
 lib.pinn_debug_phase_buffer.argtypes = [ctypes.c_void_p]
 torch.manual_seed(0)
@@ -21,6 +24,8 @@ xs = torch.from_numpy(pc.sample_points(cfg, n, seed=1)).cuda()
 buf = torch.zeros(1024 * 8 * 16, dtype=torch.int64, device='cuda')
 for _ in range(3):
     solver._fused_step(xs, 1)
+if len(sys.argv) > 4:
+    lib.pinn_debug_set_flags(int(sys.argv[4]))
 lib.pinn_debug_phase_buffer(ctypes.c_void_p(buf.data_ptr()))
 buf.zero_()
 solver._fused_step(xs, 1)
@@ -32,4 +37,4 @@ nw = b.shape[0]
 tot = b.sum(axis=1).mean()
 print(f'{cfg_name}: {nw} waves reported, mean total cycles/wave {tot:.0f}')
 for i, name in enumerate(NAMES):
-    print(f'  {name:22s} {b[:, i].mean():10.0f} cycles/wave  {100 * b[:, i].mean() / tot:5.1f} %   (wave0-of-WG mean {b[0::4, i].mean():9.0f})')
+    print(f'  {name:22s} {b[:, i].mean():10.0f} cycles/wave  {100 * b[:, i].mean() / tot:5.1f} %   (wave0-of-WG mean {b[0::(8 if DUO else 4), i].mean():9.0f})')
