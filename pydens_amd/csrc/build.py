@@ -14,7 +14,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 PKG = os.path.dirname(HERE)
 OUT = os.path.join(PKG, 'libpinn_hip.so')
 OBJ = os.path.join(HERE, '_obj')
-WIDTHS = (16, 32, 64, 128)
+WIDTHS = (16, 32, 64, 128, 256)
 FLAGS = ['--offload-arch=gfx950', '-O3', '-std=c++17', '-fPIC', '-x', 'hip', '-Wno-unused-result']
 
 

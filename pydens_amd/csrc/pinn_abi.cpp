@@ -50,6 +50,7 @@ launch_fn launcher_for(int hp) {
         case 32: return pinn_launch_tile_hp32;
         case 64: return pinn_launch_tile_hp64;
         case 128: return pinn_launch_tile_hp128;
+        case 256: return pinn_launch_tile_hp256;
         default: return nullptr;
     }
 }
@@ -72,7 +73,7 @@ struct Plan {
 int make_plan(const pinn_net* net, int64_t n_points, int nd, int n2, Plan* plan, int mode = PINN_MODE_FORWARD,
               int res_kind = PINN_RES_PROGRAM) {
     plan->fn = launcher_for(net->lay.hp);
-    if (!plan->fn) return fail("no kernel for padded hidden width %d (supported: 16, 32, 64, 128)", net->lay.hp);
+    if (!plan->fn) return fail("no kernel for padded hidden width %d (supported: 16, 32, 64, 128, 256)", net->lay.hp);
     plan->n2k = pick_n2(nd, n2);
     if (plan->n2k < 0) return fail("unsupported derivative spec nd=%d n2=%d (nd <= 3, n2 <= nd)", nd, n2);
     PinnKArgs probe;
@@ -195,9 +196,9 @@ int pinn_create(const int* layer_dims, int n_layers, int act, int ndims, int npa
     int hp = round16(hmax);
     if (hp == 48) hp = 64;
     if (hp > 64 && hp < 128) hp = 128;
-    if (hp > 128) return fail("hidden width %d > 128 is not supported by this build", hmax);
+    if (hp > 128 && hp <= 256) hp = 256;
+    if (hp > 256) return fail("hidden width %d > 256 is not supported by this build", hmax);
     const int lh = n_layers - 2;
-    if (lh > PINN_LHMAX) return fail("%d hidden->hidden layers > %d is not supported by this build", lh, PINN_LHMAX);
     pinn_net* net = new (std::nothrow) pinn_net();
     if (!net) return fail("out of memory");
     memset(net, 0, sizeof(*net));

@@ -8,3 +8,4 @@ int pinn_launch_tile_hp16(int nd, int n2, const PinnKArgs* a, int grid, void* st
 int pinn_launch_tile_hp32(int nd, int n2, const PinnKArgs* a, int grid, void* stream, int query, long long* info);
 int pinn_launch_tile_hp64(int nd, int n2, const PinnKArgs* a, int grid, void* stream, int query, long long* info);
 int pinn_launch_tile_hp128(int nd, int n2, const PinnKArgs* a, int grid, void* stream, int query, long long* info);
+int pinn_launch_tile_hp256(int nd, int n2, const PinnKArgs* a, int grid, void* stream, int query, long long* info);

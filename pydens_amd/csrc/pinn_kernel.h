@@ -65,17 +65,20 @@ struct PinnCfg {
     static constexpr int T = 16 * MT;                        // points per tile
     static constexpr int LDA = HP + 8;                       // row stride of point-major activation buffers (bank spread)
     static constexpr int NTHREADS = NW * 64;
+    // widths above 128: ONE activation buffer (two would not fit the 160 KB of LDS): the forward pass works in place and
+    // the reverse pass keeps the weight-gradient B fragments of h_{a-1} in registers while gz_a replaces it in LDS
+    static constexpr bool ONEBUF = HP > 128;
     // LDS carve (floats); every offset is a multiple of 4 floats (16 B, ds_read_b128 alignment)
     static constexpr int O_XS = 0;
     static constexpr int O_W1 = O_XS + T * PINN_XS_LD;
     static constexpr int O_B1 = O_W1 + HP * PINN_XS_LD;
     static constexpr int O_WL = O_B1 + HP;
     static constexpr int O_BUFA = O_WL + HP;
-    static constexpr int O_BUFB = O_BUFA + S * T * LDA;
+    static constexpr int O_BUFB = ONEBUF ? O_BUFA : O_BUFA + S * T * LDA;
     static constexpr int O_NET = O_BUFB + S * T * LDA;          // [NW][S][T] per-wave partial dot products
     static constexpr int O_GNET = O_NET + NW * S * T;
     static constexpr int O_ACCB = O_GNET + S * T;
-    static constexpr int O_ACCW1 = O_ACCB + (PINN_LHMAX + 1) * HP;
+    static constexpr int O_ACCW1 = O_ACCB + PINN_MAX_LAYERS * HP;   // bias-gradient rows for any depth
     static constexpr int O_SCAL = O_ACCW1 + HP * PINN_XS_LD;
     static constexpr int O_PREG = O_SCAL + T * 4;
     static constexpr int O_PADJ = O_PREG + PINN_MAX_REGS * T;
@@ -483,6 +486,8 @@ PINN_GLOBAL void PINN_LAUNCH_BOUNDS2((PinnCfg<HP, ND, N2, MT>::NTHREADS),
 pinn_tile_kernel(const PinnKArgs A) {
     using C = PinnCfg<HP, ND, N2, MT>;
     constexpr int S = C::S, NT = C::NT, NTW = C::NTW, NW = C::NW, T = C::T, LDA = C::LDA, NTHREADS = C::NTHREADS;
+    constexpr bool DWG = (LHC < 0), ONEBUF = C::ONEBUF;
+    constexpr int LHREG = DWG ? 1 : PINN_LHMAX;            // layers with register-resident dW accumulators
     const int tid = PINN_TID, lane = tid & 63, wave = tid >> 6;
     const int lr = lane & 15, lq = lane >> 4;
     const int act = (ACTC >= 0) ? ACTC : A.act;
@@ -512,18 +517,31 @@ pinn_tile_kernel(const PinnKArgs A) {
         accW1[i] = 0.0f;
     }
     for (int i = tid; i < HP; i += NTHREADS) { b1s[i] = A.params[A.off_b1 + i]; WLs[i] = A.params[A.off_wl + i]; }
-    for (int i = tid; i < (PINN_LHMAX + 1) * HP; i += NTHREADS) accB[i] = 0.0f;
+    for (int i = tid; i < PINN_MAX_LAYERS * HP; i += NTHREADS) accB[i] = 0.0f;
     for (int i = tid; i < PINN_MAX_REGS * T; i += NTHREADS) padj[i] = 0.0f;
     const float bL = A.params[A.off_bl];
 
     // persistent per-lane accumulators
-    f32x4 dW[PINN_LHMAX][NT][NTW];
+    f32x4 dW[LHREG][DWG ? 1 : NT][NTW];
 #pragma unroll
-    for (int l = 0; l < PINN_LHMAX; ++l)
+    for (int l = 0; l < LHREG; ++l)
 #pragma unroll
-        for (int o = 0; o < NT; ++o)
+        for (int o = 0; o < (DWG ? 1 : NT); ++o)
 #pragma unroll
             for (int j = 0; j < NTW; ++j) dW[l][o][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+    // this lane's element of weight-gradient tile (o, j) of hidden layer li inside the workgroup's partial buffer
+    auto dwg_ptr = [&](int li, int o, int j, int r) -> float* {
+        return A.partials + (size_t)PINN_BID * A.p_core + A.off_wh + (size_t)li * A.hidden_stride +
+               (o * 16 + lq * 4 + r) * HP + (wave * NTW + j) * 16 + lr;
+    };
+    if (DWG && train) {
+        for (int li = 0; li < lh; ++li)
+            for (int o = 0; o < NT; ++o)
+#pragma unroll
+                for (int j = 0; j < NTW; ++j)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) *dwg_ptr(li, o, j, r) = 0.0f;
+    }
     f32x4 accWL[NTW];
 #pragma unroll
     for (int j = 0; j < NTW; ++j) accWL[j] = f32x4{0.f, 0.f, 0.f, 0.f};
@@ -674,6 +692,7 @@ pinn_tile_kernel(const PinnKArgs A) {
                 }
             }
             PH(3)
+            if (ONEBUF) PINN_SYNC();                       // in place: every wave must be done reading h_{l-1}
             f32x4 biasv[NTW];
 #pragma unroll
             for (int j = 0; j < NTW; ++j) biasv[j] = pinn_ld4(bl + unit0(j));    // before the prefetch: vmcnt retires in order
@@ -815,19 +834,18 @@ pinn_tile_kernel(const PinnKArgs A) {
         };
         // after the forward half `nxt` still holds h_{lh-1} (the input of the last hidden layer): the top reverse step
         // uses it in place and stages only gz
-        auto hidden_reverse = [&](int a, f32x4 (&dw)[NT][NTW]) {
+        auto hidden_reverse = [&](int a, f32x4 (&dw)[DWG ? 1 : NT][NTW]) {
             f32x4 gz[NTW][MT][S];
             act_reverse(a, gz);
             const bool top = (a == lh);
-            if (top) { float* tmp = cur; cur = nxt; nxt = tmp; }     // cur = h_{a-1}, nxt = free (receives gz)
-            // stage gz_a (-> nxt) and the recomputed h_{a-1} (-> cur) for the two GEMMs of linear layer a
+            if (top && !ONEBUF) { float* tmp = cur; cur = nxt; nxt = tmp; }   // cur = h_{a-1}, nxt = free (receives gz)
+            // recompute h_{a-1} from its saved jets (kept in sv for the next step); stage h_{a-1} and gz_a for the GEMMs
+            f32x4 hv[NTW][MT][S];
 #pragma unroll
             for (int j = 0; j < NTW; ++j) {
                 const int n0 = unit0(j);
 #pragma unroll
                 for (int mt = 0; mt < MT; ++mt) {
-                    const int pt = mt * 16 + lr;
-                    f32x4 hv[S];
                     if (a == 1) {
                         sv[j][mt][0] = *slab_at(0, 0, j, mt);
 #pragma unroll
@@ -848,21 +866,41 @@ pinn_tile_kernel(const PinnKArgs A) {
                         for (int s = 0; s < S; ++s) sv1[s] = sv[j][mt][s][r];
                         pinn_jet_recompute<ND, N2>(sv1, act, h);
 #pragma unroll
-                        for (int s = 0; s < S; ++s) hv[s][r] = h[s];
-                    }
-#pragma unroll
-                    for (int s = 0; s < S; ++s) {
-                        if (!top) pinn_st4(cur + (s * T + pt) * LDA + n0, hv[s]);
-                        pinn_st4(nxt + (s * T + pt) * LDA + n0, gz[j][mt][s]);
+                        for (int s = 0; s < S; ++s) hv[j][mt][s][r] = h[s];
                     }
                 }
+            }
+            auto stage = [&](float* buf, f32x4 (&v)[NTW][MT][S]) {
+#pragma unroll
+                for (int j = 0; j < NTW; ++j)
+#pragma unroll
+                    for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+                        for (int s = 0; s < S; ++s) pinn_st4(buf + (s * T + mt * 16 + lr) * LDA + unit0(j), v[j][mt][s]);
+            };
+            // B fragments of the weight-gradient GEMM (h_{a-1}): lane (lr, lq) needs h[pt = wg_pt(m)][its unit column]
+            float hfrag[ONEBUF ? MT * S : 1][NTW][4];
+            if (ONEBUF) {
+                // one LDS buffer: h_{a-1} -> LDS -> fragments in registers, then gz_a takes its place
+                if (!top) { stage(cur, hv); PINN_SYNC(); }
+#pragma unroll
+                for (int ms = 0; ms < MT * S; ++ms)
+#pragma unroll
+                    for (int j = 0; j < NTW; ++j)
+#pragma unroll
+                        for (int m = 0; m < 4; ++m)
+                            hfrag[ONEBUF ? ms : 0][j][m] =
+                                cur[((ms % S) * T + (ms / S) * 16 + wg_pt(m)) * LDA + (wave * NTW + j) * 16 + lr];
+                PINN_SYNC();
+                stage(nxt, gz);
+            } else {
+                if (!top) stage(cur, hv);
+                stage(nxt, gz);
             }
             PH(10)
             PINN_SYNC();
             PH(11)
             const int li = a - 1;
-            // weight gradient: dW_li[out][in] += sum_{s,pt} gz_s[pt][out] * h_s[pt][in]   (A = gz^T, B = h);
-            // software pipeline over the (mt, s) row tiles, NT*NTW accumulators interleaved
             const float* Wl = A.params + A.off_wh + (size_t)li * A.hidden_stride;
             float wqall[WPF ? NQ : 1][NTW][4];
             if (WPF) {
@@ -874,7 +912,9 @@ pinn_tile_kernel(const PinnKArgs A) {
                         for (int m = 0; m < 4; ++m)
                             wqall[WPF ? q : 0][j][m] = Wl[(16 * q + 4 * lq + m) * HP + (wave * NTW + j) * 16 + lr];
             }
-            {
+            // weight gradient: dW_li[out][in] += sum_{s,pt} gz_s[pt][out] * h_s[pt][in]   (A = gz^T, B = h)
+            if constexpr (!DWG) {
+                // register accumulators, software pipeline over the (mt, s) row tiles, NT*NTW accumulators interleaved
                 float bq[2][NTW][4], aq[2][NT][4];
                 auto load_ms = [&](int ms, float (&b)[NTW][4], float (&a_)[NT][4]) {
                     const int mt = ms / S, s = ms % S;
@@ -900,6 +940,36 @@ pinn_tile_kernel(const PinnKArgs A) {
                             for (int j = 0; j < NTW; ++j)
                                 dw[o][j] = pinn_mfma16(aq[ms & 1][o][m], bq[ms & 1][j][m], dw[o][j]);
                     PINN_SCHED_BARRIER();
+                }
+            } else {
+                // accumulators in the workgroup's partial buffer: one output tile row at a time (any depth, any width)
+                for (int o = 0; o < NT; ++o) {
+                    f32x4 dwt[NTW];
+#pragma unroll
+                    for (int j = 0; j < NTW; ++j)
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) dwt[j][r] = *dwg_ptr(li, o, j, r);
+#pragma unroll
+                    for (int ms = 0; ms < MT * S; ++ms) {
+                        const int mt = ms / S, s = ms % S;
+                        float aq[4], bq[NTW][4];
+#pragma unroll
+                        for (int m = 0; m < 4; ++m) {
+                            const int row = (s * T + mt * 16 + wg_pt(m)) * LDA;
+                            aq[m] = nxt[row + o * 16 + lr];
+#pragma unroll
+                            for (int j = 0; j < NTW; ++j)
+                                bq[j][m] = ONEBUF ? hfrag[ONEBUF ? ms : 0][j][m] : cur[row + (wave * NTW + j) * 16 + lr];
+                        }
+#pragma unroll
+                        for (int m = 0; m < 4; ++m)
+#pragma unroll
+                            for (int j = 0; j < NTW; ++j) dwt[j] = pinn_mfma16(aq[m], bq[j][m], dwt[j]);
+                    }
+#pragma unroll
+                    for (int j = 0; j < NTW; ++j)
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) *dwg_ptr(li, o, j, r) = dwt[j][r];
                 }
             }
             PH(12)
@@ -947,9 +1017,13 @@ pinn_tile_kernel(const PinnKArgs A) {
             PINN_SYNC();
             PH(14)
         };
+        if constexpr (DWG) {
+            for (int a = lh; a >= 1; --a) hidden_reverse(a, dW[0]);
+        } else {
 #pragma unroll
-        for (int a = PINN_LHMAX; a >= 1; --a) {
-            if (a <= lh) hidden_reverse(a, dW[a - 1]);
+            for (int a = PINN_LHMAX; a >= 1; --a) {
+                if (a <= lh) hidden_reverse(a, dW[a - 1]);
+            }
         }
         {
             // first layer: db_0, dW1[n][c] += sum_pt gz0 x_c  (+ sum_pt gz_k when c == col_k)
@@ -984,7 +1058,7 @@ pinn_tile_kernel(const PinnKArgs A) {
     PINN_SYNC();
     float* part = A.partials + (size_t)PINN_BID * A.p_core;
 #pragma unroll
-    for (int l = 0; l < PINN_LHMAX; ++l) {
+    for (int l = 0; l < (DWG ? 0 : PINN_LHMAX); ++l) {
         if (l < lh) {
             float* dst = part + A.off_wh + (size_t)l * A.hidden_stride;
 #pragma unroll

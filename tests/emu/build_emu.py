@@ -13,7 +13,7 @@ OUT = os.path.join(BUILD, 'libpinn_emu.so')
 CXX = '/opt/rocm/lib/llvm/bin/clang++'
 FLAGS = ['-x', 'c++', '-DPINN_EMU', '-O1', '-std=c++17', '-fPIC', '-I', HERE, '-I', CSRC, '-Wno-unknown-pragmas',
          '-Wno-pass-failed']
-WIDTHS = (16, 32, 64, 128)
+WIDTHS = (16, 32, 64, 128, 256)
 
 
 def build(force=False):

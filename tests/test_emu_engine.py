@@ -299,3 +299,44 @@ def test_two_team_kernel_agrees_with_solo_kernel(pa, emu_lib, name):
     assert rel_l2(grads[0], grads[1]) < 1e-6
     lay = solver.model.net.layout
     assert abs(grads[0][lay.off_loss] - g.loss0) <= 1e-5 * g.loss0
+
+
+def test_deep_network_any_number_of_hidden_layers(pa, emu_lib):
+    """ more hidden->hidden layers than the register-resident weight-gradient accumulators hold: generic kernel with
+    read-modify-write accumulation in the workgroup's partial buffer """
+    from oracle import pinn_oracle as po
+    kw = dict(ndims=2, boundary_condition=0.5, layout='fa' * 8 + 'f', features=[20] * 8 + [1], activation='Tanh')
+
+    def eq(D):
+        return lambda f, x, y: D(D(f, x), x) + D(D(f, y), y) - 5 * torch.sin(np.pi * (x + y))
+    oracle = po.OracleSolver(eq(po.D), **kw)
+    solver = pa.Solver(eq(pa.D), **kw, **emu_kwargs(emu_lib))
+    assert solver.model.net.layout.lh == 7
+    load_params(solver, oracle.export_params())
+    pts = np.random.RandomState(12).rand(3, 40, 2).astype(np.float32)
+    oracle.fit(niters=3, batch_size=40, points=pts, lr=0.01)
+    solver.fit(niters=3, batch_size=40, sampler=FixedBatches(pts), lr=0.01)
+    np.testing.assert_allclose([float(v) for v in solver.losses], [float(v) for v in oracle.losses], rtol=3e-5)
+    for got, want in zip(export_params(solver), oracle.export_params()):
+        assert rel_l2(got, want) < 3e-5
+
+
+def test_width_256_one_buffer_kernel(pa, emu_lib):
+    """ BASELINE config 5 (wave equation, 6x256): single-LDS-buffer form of the tile kernel; one fused evaluation on 32
+    points of the golden batch against the oracle (emulating 8 waves x 256 units is slow, so one step only) """
+    from oracle import pinn_oracle as po
+    g = Golden('cfg5')
+    cfg, solver = make_solver('cfg5', pa, **emu_kwargs(emu_lib))
+    load_params(solver, g.params)
+    ocfg = pc.make_config('cfg5', po.D, torch)
+    oracle = po.OracleSolver(ocfg['equation'], **ocfg['solver_kwargs'])
+    oracle.import_params(g.params)
+    pts = g.points[0][:32]
+    ev = oracle.evaluate(pts)
+    pred = solver.predict(pts[:, 0], pts[:, 1])
+    assert np.abs(pred[:, 0] - ev['u'][:, 0]).max() < 1e-5
+    solver._fused_step(torch.from_numpy(pts.copy()), 1)
+    lay = solver.model.net.layout
+    assert abs(float(solver.grads[lay.off_loss]) - ev['loss']) <= 1e-5 * ev['loss']
+    for got, want in zip(export_grads(solver), oracle.export_grads()):
+        assert rel_l2(got, want) < 1e-4

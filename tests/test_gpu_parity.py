@@ -12,7 +12,7 @@ from helpers import FixedBatches, export_grads, export_params, load_params, make
 
 pytestmark = pytest.mark.gpu
 
-SUPPORTED = ('cfg1', 'cfg2', 'cfg3', 'cfg4', 'ode_sigmoid')
+SUPPORTED = ('cfg1', 'cfg2', 'cfg3', 'cfg4', 'cfg5', 'ode_sigmoid')
 
 
 @pytest.fixture(scope='module')
@@ -175,3 +175,33 @@ def test_residual_kinds_match_the_oracle(pa, which):
     np.testing.assert_allclose([float(v) for v in solver.losses], [float(v) for v in oracle.losses], rtol=3e-5)
     for got, want in zip(export_params(solver), oracle.export_params()):
         assert rel_l2(got, want) < 3e-5
+
+
+def test_deep_network_and_full_size_cfg5(pa):
+    """ depth beyond the register-resident accumulators (8 hidden layers) and BASELINE config 5 (6x256) at a larger batch:
+    loss and gradients against the oracle evaluated in chunks """
+    from oracle import pinn_oracle as po
+    kw = dict(ndims=2, boundary_condition=0.5, layout='fa' * 8 + 'f', features=[20] * 8 + [1], activation='Tanh')
+
+    def eq(D):
+        return lambda f, x, y: D(D(f, x), x) + D(D(f, y), y) - 5 * torch.sin(np.pi * (x + y))
+    oracle = po.OracleSolver(eq(po.D), **kw)
+    solver = pa.Solver(eq(pa.D), **kw)
+    load_params(solver, oracle.export_params())
+    pts = np.random.RandomState(12).rand(3, 500, 2).astype(np.float32)
+    oracle.fit(niters=3, batch_size=500, points=pts, lr=0.01)
+    solver.fit(niters=3, batch_size=500, sampler=FixedBatches(pts), lr=0.01)
+    np.testing.assert_allclose([float(v) for v in solver.losses], [float(v) for v in oracle.losses], rtol=3e-5)
+
+    torch.manual_seed(7)
+    cfg, solver = make_solver('cfg5', pa)
+    ocfg = pc.make_config('cfg5', po.D, torch)
+    oracle = po.OracleSolver(ocfg['equation'], **ocfg['solver_kwargs'])
+    oracle.import_params(export_params(solver))
+    pts = pc.sample_points(cfg, 8192, seed=3)
+    ev = oracle.evaluate(pts, chunk=2048)
+    solver._fused_step(torch.from_numpy(pts).cuda(), 1)
+    lay = solver.model.net.layout
+    assert abs(float(solver.grads[lay.off_loss]) - ev['loss']) <= 1e-5 * ev['loss']
+    for got, want in zip(export_grads(solver), oracle.export_grads()):
+        assert rel_l2(got, want) < 1e-4
