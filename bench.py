@@ -116,10 +116,12 @@ def main():
         dist.broadcast(model.flat, src=0)
 
     def step(i):
-        solver._fused_step(pool[i % POOL], world)
-        if world > 1:
+        if world == 1:
+            solver._fused_step(pool[i % POOL], 1, adam=solver.optimizer)    # Adam fused into the reduction launch
+        else:
+            solver._fused_step(pool[i % POOL], world)
             dist.all_reduce(solver.grads)
-        solver.optimizer.step(solver.grads)
+            solver.optimizer.step(solver.grads)
 
     for i in range(args.warmup):
         step(i)

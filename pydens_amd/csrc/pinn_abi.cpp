@@ -121,13 +121,27 @@ int check_dirs(const pinn_net* net, const int* dir_cols, int nd, int n2) {
     return 0;
 }
 
-int launch_reduce(const float* partials, int n_wg, int p_core, float* grads, int accumulate, void* stream) {
-    const int blocks = (p_core + 15) / 16;
+struct AdamArgs {
+    float* params; float* m; float* v; const unsigned char* mask; int* step_ptr;
+    int step_value; float lr, b1, b2, eps;
+};
+
+int launch_reduce(const float* partials, int n_wg, int p_core, float* grads, int accumulate, void* stream,
+                  const AdamArgs* adam = nullptr) {
+    const int blocks = (p_core + 63) / 64;
+    const size_t smem = 1024 * sizeof(float);
+    AdamArgs z = {nullptr, nullptr, nullptr, nullptr, nullptr, 0, 0.f, 0.f, 0.f, 0.f};
+    const AdamArgs& a = adam ? *adam : z;
+    const int do_adam = adam ? 1 : 0;
 #ifdef PINN_EMU
-    emu::launch(blocks, 256, 256 * sizeof(float), [&] { pinn_reduce_kernel(partials, n_wg, p_core, grads, accumulate); });
+    emu::launch(blocks, 1024, smem, [&] {
+        pinn_reduce_kernel(partials, n_wg, p_core, grads, accumulate, do_adam, a.params, a.m, a.v, a.mask, a.step_value,
+                           a.lr, a.b1, a.b2, a.eps, a.step_ptr);
+    });
 #else
-    hipLaunchKernelGGL(pinn_reduce_kernel, dim3(blocks), dim3(256), 256 * sizeof(float), (hipStream_t)stream, partials,
-                       n_wg, p_core, grads, accumulate);
+    hipLaunchKernelGGL(pinn_reduce_kernel, dim3(blocks), dim3(1024), smem, (hipStream_t)stream, partials, n_wg, p_core,
+                       grads, accumulate, do_adam, a.params, a.m, a.v, a.mask, a.step_value, a.lr, a.b1, a.b2, a.eps,
+                       a.step_ptr);
     if (hipGetLastError() != hipSuccess) return fail("reduce kernel launch failed");
 #endif
     return 0;
@@ -277,7 +291,8 @@ int pinn_jet_forward(pinn_t* net, const float* params, const float* xs, int64_t 
 }
 
 static int run_train(pinn_t* net, PinnKArgs* a, const Plan& plan, int nd, float* grads, int accumulate, void* workspace,
-                     size_t workspace_bytes, void* stream, const pinn_program_t* pre = nullptr) {
+                     size_t workspace_bytes, void* stream, const pinn_program_t* pre = nullptr,
+                     const AdamArgs* adam = nullptr) {
     const size_t part_bytes = align256((size_t)plan.grid * net->lay.p_core * sizeof(float));
     const size_t slab_bytes = align256((size_t)plan.grid * plan.slab_vec4_per_wg * 16);
     const size_t aux_bytes = (pre && a->n_aux > 0) ? align256((size_t)a->n_aux * (size_t)a->n_points * sizeof(float)) : 0;
@@ -312,7 +327,7 @@ static int run_train(pinn_t* net, PinnKArgs* a, const Plan& plan, int nd, float*
 #ifndef PINN_EMU
     if (g_profile) { hipEventRecord(g_ev1, (hipStream_t)stream); g_have_bracket = true; }
 #endif
-    return launch_reduce(a->partials, plan.grid, net->lay.p_core, grads, accumulate, stream);
+    return launch_reduce(a->partials, plan.grid, net->lay.p_core, grads, accumulate, stream, adam);
 }
 
 int pinn_jet_backward(pinn_t* net, const float* params, const float* xs, int64_t n_points, const int* dir_cols, int nd,
@@ -352,9 +367,10 @@ static int check_program(const pinn_program_t& pg, int first_temp, int n_consts_
     return 0;
 }
 
-int pinn_residual_step(pinn_t* net, const pinn_residual_t* residual, const float* params, const float* xs,
-                       int64_t n_points, const int* dir_cols, int nd, int n2, const float* ic_streams, float ic_const,
-                       float inv_n_global, float* grads, void* workspace, size_t workspace_bytes, void* stream) {
+static int residual_step_impl(pinn_t* net, const pinn_residual_t* residual, const float* params, const float* xs,
+                              int64_t n_points, const int* dir_cols, int nd, int n2, const float* ic_streams,
+                              float ic_const, float inv_n_global, float* grads, void* workspace, size_t workspace_bytes,
+                              void* stream, const AdamArgs* adam) {
     if (!net || !residual || !params || !xs || !grads) return fail("null argument");
     if (n_points <= 0) return fail("n_points must be positive");
     if (check_dirs(net, dir_cols, nd, n2)) return 1;
@@ -400,7 +416,26 @@ int pinn_residual_step(pinn_t* net, const pinn_residual_t* residual, const float
     }
     a.mode = PINN_MODE_STEP;
     a.inv_n = inv_n_global;
-    return run_train(net, &a, plan, nd, grads, 0, workspace, workspace_bytes, stream, &residual->pre);
+    return run_train(net, &a, plan, nd, grads, 0, workspace, workspace_bytes, stream, &residual->pre, adam);
+}
+
+int pinn_residual_step(pinn_t* net, const pinn_residual_t* residual, const float* params, const float* xs,
+                       int64_t n_points, const int* dir_cols, int nd, int n2, const float* ic_streams, float ic_const,
+                       float inv_n_global, float* grads, void* workspace, size_t workspace_bytes, void* stream) {
+    return residual_step_impl(net, residual, params, xs, n_points, dir_cols, nd, n2, ic_streams, ic_const, inv_n_global,
+                              grads, workspace, workspace_bytes, stream, nullptr);
+}
+
+int pinn_residual_adam_step(pinn_t* net, const pinn_residual_t* residual, float* params, const float* xs,
+                            int64_t n_points, const int* dir_cols, int nd, int n2, const float* ic_streams,
+                            float ic_const, float* grads, float* exp_avg, float* exp_avg_sq, const uint8_t* mask,
+                            int32_t* step_ptr, int32_t step, float lr, float beta1, float beta2, float eps,
+                            void* workspace, size_t workspace_bytes, void* stream) {
+    if (!exp_avg || !exp_avg_sq || !step_ptr) return fail("null argument");
+    if (step < 1) return fail("step must be >= 1");
+    AdamArgs adam = {params, exp_avg, exp_avg_sq, mask, step_ptr, step, lr, beta1, beta2, eps};
+    return residual_step_impl(net, residual, params, xs, n_points, dir_cols, nd, n2, ic_streams, ic_const,
+                              1.0f / (float)n_points, grads, workspace, workspace_bytes, stream, &adam);
 }
 
 int pinn_adam_step(float* params, const float* grads, float* exp_avg, float* exp_avg_sq, const uint8_t* mask, int64_t n,

@@ -43,24 +43,45 @@ pinn_aux_kernel(const float* xs, long long n, int d, pinn_program_t pg, float* a
 }
 
 // ------------------------------------------------------------------------------------------------------------
-// sum of the per-workgroup partial gradients (fixed order => deterministic), 16 params x 16 chunks per block
+// sum of the per-workgroup partial gradients (fixed order => deterministic): block = 64 parameters x 16 chunks of
+// workgroups (every wave reads whole 256-B rows), LDS tree over the chunks; optionally the Adam update of those 64
+// parameters right behind it (single-rank steps: no all-reduce in between, two launches less).
 // ------------------------------------------------------------------------------------------------------------
-PINN_GLOBAL void PINN_LAUNCH_BOUNDS(256)
-pinn_reduce_kernel(const float* partials, int n_wg, int p_core, float* grads, int accumulate) {
+PINN_DEVICE void pinn_adam_update(float* params, float gi, float* m, float* v, long long i, double t, float lr, float b1,
+                                  float b2, float eps) {
+    // bias corrections in double like torch's Python-side scalars (1 - beta ** step)
+    const double bc1 = 1.0 - pow((double)b1, t);
+    const double bc2 = 1.0 - pow((double)b2, t);
+    const float step_size = (float)((double)lr / bc1);
+    const float bc2_sqrt = (float)sqrt(bc2);
+    const float mi = m[i] + (1.0f - b1) * (gi - m[i]);       // exp_avg.lerp_(grad, 1 - beta1)
+    const float vi = fmaf(1.0f - b2, gi * gi, b2 * v[i]);    // exp_avg_sq.mul_(beta2).addcmul_(grad, grad, 1 - beta2)
+    m[i] = mi; v[i] = vi;
+    const float denom = sqrtf(vi) / bc2_sqrt + eps;
+    params[i] -= step_size * (mi / denom);
+}
+
+PINN_GLOBAL void PINN_LAUNCH_BOUNDS(1024)
+pinn_reduce_kernel(const float* partials, int n_wg, int p_core, float* grads, int accumulate, int do_adam, float* params,
+                   float* m, float* v, const unsigned char* mask, int step_value, float lr, float b1, float b2, float eps,
+                   int* step_ptr) {
     PINN_SMEM(red);
     const int tid = PINN_TID;
-    const int pl = tid & 15, ch = tid >> 4;
-    const int p = PINN_BID * 16 + pl;
+    const int pl = tid & 63, ch = tid >> 6;                   // 64 parameters x 16 chunks
+    const int p = PINN_BID * 64 + pl;
     float s = 0.0f;
     if (p < p_core)
         for (int w = ch; w < n_wg; w += 16) s += partials[(size_t)w * p_core + p];
-    red[ch * 16 + pl] = s;
+    red[ch * 64 + pl] = s;
     PINN_SYNC();
-    if (tid < 16 && p < p_core) {
+    if (tid < 64 && p < p_core) {
         float t = 0.0f;
-        for (int c = 0; c < 16; ++c) t += red[c * 16 + tid];
-        grads[p] = accumulate ? grads[p] + t : t;
+        for (int c = 0; c < 16; ++c) t += red[c * 64 + tid];
+        if (accumulate) t += grads[p];
+        grads[p] = t;
+        if (do_adam && (!mask || mask[p])) pinn_adam_update(params, t, m, v, p, (double)step_value, lr, b1, b2, eps);
     }
+    if (do_adam && PINN_BID == 0 && tid == 0) step_ptr[0] = step_value;
 }
 
 // ------------------------------------------------------------------------------------------------------------
@@ -76,16 +97,5 @@ pinn_adam_kernel(float* params, const float* grads, float* m, float* v, const un
     const long long i = (long long)PINN_BID * 256 + PINN_TID;
     if (i >= n) return;
     if (mask && !mask[i]) return;
-    // bias corrections in double like torch's Python-side scalars (1 - beta ** step)
-    const double t = (double)step_ptr[0];
-    const double bc1 = 1.0 - pow((double)b1, t);
-    const double bc2 = 1.0 - pow((double)b2, t);
-    const float step_size = (float)((double)lr / bc1);
-    const float bc2_sqrt = (float)sqrt(bc2);
-    const float gi = grads[i];
-    const float mi = m[i] + (1.0f - b1) * (gi - m[i]);       // exp_avg.lerp_(grad, 1 - beta1)
-    const float vi = fmaf(1.0f - b2, gi * gi, b2 * v[i]);    // exp_avg_sq.mul_(beta2).addcmul_(grad, grad, 1 - beta2)
-    m[i] = mi; v[i] = vi;
-    const float denom = sqrtf(vi) / bc2_sqrt + eps;
-    params[i] -= step_size * (mi / denom);
+    pinn_adam_update(params, grads[i], m, v, i, (double)step_ptr[0], lr, b1, b2, eps);
 }

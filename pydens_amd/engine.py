@@ -82,17 +82,19 @@ def bind(lib):
     lib.pinn_residual_step.argtypes = [vp, ctypes.POINTER(Residual), vp, vp, i64, ip, i32, i32, vp, f32, f32, vp, vp,
                                        ctypes.c_size_t, vp]
     lib.pinn_adam_step.argtypes = [vp, vp, vp, vp, vp, i64, vp, f32, f32, f32, f32, vp]
+    lib.pinn_residual_adam_step.argtypes = [vp, ctypes.POINTER(Residual), vp, vp, i64, ip, i32, i32, vp, f32, vp, vp, vp, vp,
+                                            vp, i32, f32, f32, f32, f32, vp, ctypes.c_size_t, vp]
     lib.pinn_profile_tile.argtypes = [i32]
     lib.pinn_profile_tile.restype = i32
     lib.pinn_last_tile_ms.restype = f32
     for name in ('pinn_create', 'pinn_destroy', 'pinn_layout', 'pinn_jet_forward', 'pinn_jet_backward',
-                 'pinn_residual_step', 'pinn_adam_step'):
+                 'pinn_residual_step', 'pinn_residual_adam_step', 'pinn_adam_step'):
         getattr(lib, name).restype = i32
     return lib
 
 
 ABI_SYMBOLS = ('pinn_create', 'pinn_destroy', 'pinn_layout', 'pinn_workspace_bytes', 'pinn_jet_forward',
-               'pinn_jet_backward', 'pinn_residual_step', 'pinn_adam_step', 'pinn_profile_tile', 'pinn_last_tile_ms',
+               'pinn_jet_backward', 'pinn_residual_step', 'pinn_residual_adam_step', 'pinn_adam_step', 'pinn_profile_tile', 'pinn_last_tile_ms',
                'pinn_last_error', 'pinn_backend')
 
 _LIB = None
@@ -238,6 +240,20 @@ class Net:
                                                 n2, _ptr(ic_streams), float(ic_const), float(inv_n), _ptr(grads),
                                                 _ptr(workspace), workspace.numel() * workspace.element_size(),
                                                 _stream(xs)))
+
+    def residual_adam_step(self, residual, params, xs, grads, workspace, exp_avg, exp_avg_sq, mask, step_tensor, step,
+                           lr, betas=(0.9, 0.999), eps=1e-8, dir_cols=(), n2=0, ic_streams=None, ic_const=0.0):
+        for t, name in ((params, 'params'), (xs, 'xs'), (grads, 'grads'), (ic_streams, 'ic_streams'),
+                        (exp_avg, 'exp_avg'), (exp_avg_sq, 'exp_avg_sq')):
+            _check(t, name)
+        _check(mask, 'mask', torch.uint8)
+        _check(step_tensor, 'step', torch.int32)
+        dirs, nd = self._dirs(dir_cols)
+        self._raise(self.lib.pinn_residual_adam_step(
+            self.handle, ctypes.byref(residual), _ptr(params), _ptr(xs), xs.shape[0], dirs, nd, n2, _ptr(ic_streams),
+            float(ic_const), _ptr(grads), _ptr(exp_avg), _ptr(exp_avg_sq), _ptr(mask), _ptr(step_tensor), int(step),
+            float(lr), float(betas[0]), float(betas[1]), float(eps), _ptr(workspace),
+            workspace.numel() * workspace.element_size(), _stream(xs)))
 
     def adam_step(self, params, grads, exp_avg, exp_avg_sq, mask, step, lr, betas=(0.9, 0.999), eps=1e-8):
         for t, name in ((params, 'params'), (grads, 'grads'), (exp_avg, 'exp_avg'), (exp_avg_sq, 'exp_avg_sq')):

@@ -34,12 +34,14 @@ class FlatAdam:
         self.exp_avg = torch.zeros_like(model.flat)
         self.exp_avg_sq = torch.zeros_like(model.flat)
         self.step_count = torch.zeros(1, dtype=torch.int32, device=model.flat.device)
+        self.t = 0                  # host copy of the step counter (the fused single-rank step passes it by value)
         self.mask = None
 
     def refresh(self):
         self.mask = self.model.trainable_mask()
 
     def step(self, grads):
+        self.t += 1
         self.model.net.adam_step(self.model.flat, grads, self.exp_avg, self.exp_avg_sq, self.mask, self.step_count,
                                  self.lr, self.betas, self.eps)
 
@@ -265,17 +267,20 @@ class Solver:
         self.last_fit_path = 'fused' if fused else 'generic'
         for it in tqdm(range(niters), disable=None):
             xs = self._sample(batch_size, sampler)
-            if fused:
-                self._fused_step(xs, world)
+            if fused and world == 1 and isinstance(self.optimizer, FlatAdam):
+                self._fused_step(xs, 1, adam=self.optimizer)  # Adam rides in the gradient-reduction launch
             else:
-                self._generic_step(xs, loss_terms, nums_constraints, criterion, world)
-            if world > 1:
-                torch.distributed.all_reduce(self.grads)      # flat [p_total]: network, log_scale, loss slot, V slots
-            self.optimizer.step(self.grads)
+                if fused:
+                    self._fused_step(xs, world)
+                else:
+                    self._generic_step(xs, loss_terms, nums_constraints, criterion, world)
+                if world > 1:
+                    torch.distributed.all_reduce(self.grads)  # flat [p_total]: network, log_scale, loss slot, V slots
+                self.optimizer.step(self.grads)
             history[it:it + 1].copy_(self.grads[lay.off_loss:lay.off_loss + 1])
         self._pending.append(history)
 
-    def _fused_step(self, xs, world):
+    def _fused_step(self, xs, world, adam=None):
         model, spec = self.model, self.spec
         ic_streams = None
         if model.initial_condition is not None and model.ic_constant is None:
@@ -285,6 +290,13 @@ class Solver:
                 if t is not None:
                     ic_streams[i] = t.reshape(-1)
         ws = model.workspace(xs.shape[0], spec.nd, spec.n2)
+        if adam is not None:
+            adam.t += 1
+            model.net.residual_adam_step(self.program, model.flat, xs, self.grads, ws, adam.exp_avg, adam.exp_avg_sq,
+                                         adam.mask, adam.step_count, adam.t, adam.lr, adam.betas, adam.eps,
+                                         dir_cols=spec.dir_cols, n2=spec.n2, ic_streams=ic_streams,
+                                         ic_const=model.kernel_ic_const())
+            return
         model.net.residual_step(self.program, model.flat, xs, self.grads, ws, spec.dir_cols, spec.n2,
                                 ic_streams=ic_streams, ic_const=model.kernel_ic_const(),
                                 inv_n_global=1.0 / (xs.shape[0] * world))
