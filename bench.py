@@ -32,6 +32,7 @@ PEAK_FP32_MFMA_TFLOPS = 157.3   # /opt/skills/guides/MI355X_MICROARCH.md "Peak F
 WORKLOAD = 'cfg2'
 BATCH_PER_GPU = 65536
 POOL = 8                        # distinct pre-generated point batches cycled through
+KERNEL = 'pinn_tile_kernel<64,2,2,1,3,0>'
 
 
 def flops_per_point(layer_dims, n_streams):
@@ -73,6 +74,21 @@ def cpu_baseline(budget_s=15.0, n_points=16384):
                 sample=f'{steps} Solver.fit iterations of {WORKLOAD} at batch {n_points} '
                        f'(oracle/pinn_oracle.py = reference step restated, torch {torch.__version__} CPU ops, fp32; '
                        f'best of 4/8/16/32 intra-op threads on {ncpu} logical CPUs), {dt:.1f} s')
+
+
+def hbm_traffic(kernel_name):
+    """ HBM bytes per launch of the dominant kernel from the committed rocprofv3 PMC passes (FETCH_SIZE / WRITE_SIZE,
+    separate --pmc runs, gfx950 correction applied: profiles/r01_cfg2_pmc.json says how). None if the committed
+    counters are of another kernel. """
+    path = os.path.join(ROOT, 'profiles', 'r01_cfg2_pmc.json')
+    try:
+        with open(path) as f:
+            pmc = json.load(f)
+    except OSError:
+        return None
+    if pmc.get('kernel') != kernel_name or pmc.get('points_per_launch') != BATCH_PER_GPU:
+        return None
+    return pmc['hbm_bytes_per_launch']
 
 
 def main():
@@ -177,9 +193,11 @@ def main():
                        'points_per_gpu': n, 'global_points': n * world, 'streams': spec.n_streams,
                        'parallelism': f'dp{world}', 'step_path': 'fused'},
             'final_loss': loss,
-            'roofline': {'bound': 'mfma', 'kernel': 'pinn_tile_kernel<64,2,2,1,3,0>', 'achieved': achieved,
+            'roofline': {'bound': 'mfma', 'kernel': KERNEL, 'achieved': achieved,
                          'peak': PEAK_FP32_MFMA_TFLOPS, 'unit': 'TFLOP/s', 'frac': achieved / PEAK_FP32_MFMA_TFLOPS,
-                         'flops_per_point': f_pt, 'kernel_ms': tile_ms, 'traffic': None},
+                         'flops_per_point': f_pt, 'kernel_ms': tile_ms,
+                         'traffic': hbm_traffic(KERNEL) if n == BATCH_PER_GPU else None,
+                         'traffic_source': 'profiles/r01_cfg2_pmc.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes)'},
         }
         if not args.no_cpu_baseline:
             out['cpu_baseline'] = cpu_baseline()

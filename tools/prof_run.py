@@ -18,7 +18,6 @@ xs = torch.from_numpy(pc.sample_points(cfg, n, seed=1)).cuda()
 solver.optimizer = FlatAdam(solver.model, lr=0.005)
 solver.optimizer.refresh()
 for _ in range(steps):
-    solver._fused_step(xs, 1)
-    solver.optimizer.step(solver.grads)
+    solver._fused_step(xs, 1, adam=solver.optimizer)
 torch.cuda.synchronize()
 print('done', float(solver.grads[solver.model.net.layout.off_loss]))
