@@ -103,6 +103,10 @@ typedef struct pinn_residual {
     int coef_row[PINN_MAX_STREAMS];
     float src_const;
     int src_row;
+    /* combined != 0 (with n2 == 1 in the call): the ONE second-order stream (index 1+nd) is sum_k comb_w[k] d2u/dx_k2 over
+     * the nd directions -- what a Laplacian / wave / heat operator needs -- instead of one stream per direction. */
+    int combined;
+    float comb_w[PINN_MAX_DIRS];
 } pinn_residual_t;
 
 /* Descriptor of network + ansatz.  Replaces ConvBlockModel.__init__/TorchModel.__init__ bookkeeping

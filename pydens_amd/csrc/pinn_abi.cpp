@@ -71,10 +71,11 @@ struct Plan {
 };
 
 int make_plan(const pinn_net* net, int64_t n_points, int nd, int n2, Plan* plan, int mode = PINN_MODE_FORWARD,
-              int res_kind = PINN_RES_PROGRAM) {
+              int res_kind = PINN_RES_PROGRAM, int comb = 0) {
     plan->fn = launcher_for(net->lay.hp);
     if (!plan->fn) return fail("no kernel for padded hidden width %d (supported: 16, 32, 64, 128, 256)", net->lay.hp);
-    plan->n2k = pick_n2(nd, n2);
+    plan->n2k = comb ? 1 : pick_n2(nd, n2);
+    if (comb && (n2 != 1 || nd < 2 || nd > 3)) return fail("combined second-order stream needs n2 == 1 and nd in {2, 3}");
     if (plan->n2k < 0) return fail("unsupported derivative spec nd=%d n2=%d (nd <= 3, n2 <= nd)", nd, n2);
     PinnKArgs probe;
     memset(&probe, 0, sizeof(probe));
@@ -82,8 +83,10 @@ int make_plan(const pinn_net* net, int64_t n_points, int nd, int n2, Plan* plan,
     probe.act = net->act;
     probe.mode = mode;
     probe.res_kind = res_kind;
+    probe.comb = comb;
     long long info[5] = {0, 0, 0, 1, 1};
-    if (plan->fn(nd, plan->n2k, &probe, 0, nullptr, 1, info)) return fail("kernel query failed");
+    if (plan->fn(nd, plan->n2k, &probe, 0, nullptr, 1, info))
+        return fail("no kernel instantiation for width %d with nd=%d n2=%d%s", net->lay.hp, nd, plan->n2k, comb ? " (combined)" : "");
     plan->smem = (size_t)info[0];
     plan->threads = (int)info[1];
     plan->slab_vec4_per_wg = (size_t)info[2];
@@ -265,9 +268,16 @@ size_t pinn_workspace_bytes(const pinn_t* net, int64_t n_points, int nd, int n2)
     if (!net) return 0;
     size_t need = 0;
     const int modes[3][2] = {{PINN_MODE_STEP, PINN_RES_AFFINE}, {PINN_MODE_STEP, PINN_RES_PROGRAM}, {PINN_MODE_BACKWARD, 0}};
-    for (int i = 0; i < 3; ++i) {
+    for (int i = 0; i < 4; ++i) {
         Plan plan;
-        if (make_plan(net, n_points, nd, n2, &plan, modes[i][0], modes[i][1])) return 0;
+        // i == 3: the combined-second-order form of an affine step (n2 folded to 1), only where it exists
+        const bool comb = (i == 3);
+        if (comb && (n2 < 2 || nd < 2 || nd > 3)) continue;
+        if (make_plan(net, n_points, nd, comb ? 1 : n2, &plan, comb ? PINN_MODE_STEP : modes[i][0],
+                      comb ? PINN_RES_AFFINE : modes[i][1], comb ? 1 : 0)) {
+            if (comb) continue;
+            return 0;
+        }
         const size_t v = align256((size_t)plan.grid * net->lay.p_core * sizeof(float)) +
                          align256((size_t)plan.grid * plan.slab_vec4_per_wg * 16);
         if (v > need) need = v;
@@ -377,13 +387,16 @@ static int residual_step_impl(pinn_t* net, const pinn_residual_t* residual, cons
     if (residual->n_aux < 0 || residual->n_aux > PINN_MAX_AUX) return fail("n_aux=%d outside [0, %d]", residual->n_aux, PINN_MAX_AUX);
     if (residual->kind != PINN_RES_AFFINE && residual->kind != PINN_RES_PROGRAM) return fail("unknown residual kind %d", residual->kind);
     Plan plan;
-    if (make_plan(net, n_points, nd, n2, &plan, PINN_MODE_STEP, residual->kind)) return 1;
+    const int comb = residual->combined ? 1 : 0;
+    if (make_plan(net, n_points, nd, n2, &plan, PINN_MODE_STEP, residual->kind, comb)) return 1;
     const int d = net->lay.d;
     const int s_user = 1 + nd + n2, s_kernel = 1 + nd + plan.n2k, shift = s_kernel - s_user;
     PinnKArgs a;
     fill_args(net, &a, params, xs, n_points, dir_cols, nd, n2, ic_streams, ic_const);
     a.res_kind = residual->kind;
     a.n_aux = residual->n_aux;
+    a.comb = comb;
+    for (int k = 0; k < PINN_MAX_DIRS; ++k) a.comb_w[k] = (comb && k < nd) ? residual->comb_w[k] : 0.0f;
     if (residual->n_aux > 0 && check_program(residual->pre, d, PINN_MAX_CONSTS, true, residual->n_aux, "pre-pass")) return 1;
     if (residual->kind == PINN_RES_AFFINE) {
         for (int s = 0; s < PINN_MAX_STREAMS; ++s) {

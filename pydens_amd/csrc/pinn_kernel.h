@@ -45,7 +45,9 @@ struct PinnKArgs {
     float lo[PINN_MAX_INPUTS], hi[PINN_MAX_INPUTS];
     int dir_cols[PINN_MAX_DIRS];
     int s_user;                  // streams visible to the caller (<= S of the instantiation)
+    int comb;                    // 1: the single second-order stream is the combination sum_k comb_w[k] d2/dx_k2
     float inv_w[PINN_MAX_INPUTS];    // 1 / (hi - lo)
+    float comb_w[PINN_MAX_DIRS];     // COMB instantiations: weights c_k of the combined second-order stream sum_k c_k d2/dx_k2
     // residual (MODE_STEP)
     int res_kind, n_aux, src_row;
     float src_const;
@@ -110,10 +112,22 @@ PINN_DEVICE float pinn_act_d3(float v, float d1, float d2, int act) {
     return d1 * (q * q - 2.0f * d1);
 }
 
-// forward jet of one (point, unit): z[S] pre-activations -> h[S] activations; sv[S] = what the reverse sweep
-// needs (activation value in slot 0, derivative pre-activations unchanged).
-template <int ND, int N2>
-PINN_DEVICE void pinn_jet_fwd(const float (&z)[1 + ND + N2], int act, float (&h)[1 + ND + N2]) {
+// Second-order streams. Standard form: stream 1+ND+k is d2/dx_k2 for k < N2. COMB form (N2 == 1): ONE stream
+// sum_k c_k d2/dx_k2 over all ND directions with run-time weights c_k (a Laplacian / wave / heat operator needs only
+// that combination, which saves N2-1 streams through every GEMM). Both are instances of "second stream j collects
+// direction k with weight w": the helpers below give the stream index and weight of direction k.
+template <int ND, int N2, bool COMB>
+struct PinnJet {
+    static constexpr int S = 1 + ND + N2;
+    static PINN_DEVICE bool has2(int k) { return COMB ? true : k < N2; }
+    static PINN_DEVICE int idx2(int k) { return COMB ? 1 + ND : 1 + ND + k; }
+    static PINN_DEVICE float w(int k, const float* cw) { return COMB ? cw[k] : 1.0f; }
+};
+
+// forward jet of one (point, unit): z[S] pre-activations -> h[S] activations
+template <int ND, int N2, bool COMB = false>
+PINN_DEVICE void pinn_jet_fwd(const float (&z)[1 + ND + N2], int act, float (&h)[1 + ND + N2], const float* cw = nullptr) {
+    using J = PinnJet<ND, N2, COMB>;
     const float v = pinn_act(z[0], act);
     float d1, d2;
     pinn_act_d12(v, act, d1, d2);
@@ -121,40 +135,53 @@ PINN_DEVICE void pinn_jet_fwd(const float (&z)[1 + ND + N2], int act, float (&h)
 #pragma unroll
     for (int k = 0; k < ND; ++k) h[1 + k] = d1 * z[1 + k];
 #pragma unroll
-    for (int k = 0; k < N2; ++k) h[1 + ND + k] = d2 * z[1 + k] * z[1 + k] + d1 * z[1 + ND + k];
+    for (int j = 0; j < N2; ++j) h[1 + ND + j] = d1 * z[1 + ND + j];
+#pragma unroll
+    for (int k = 0; k < ND; ++k)
+        if (J::has2(k)) h[J::idx2(k)] += d2 * J::w(k, cw) * z[1 + k] * z[1 + k];
 }
 
 // activations h[S] recomputed from the saved form (v, z_k, z_kk)
-template <int ND, int N2>
-PINN_DEVICE void pinn_jet_recompute(const float (&sv)[1 + ND + N2], int act, float (&h)[1 + ND + N2]) {
+template <int ND, int N2, bool COMB = false>
+PINN_DEVICE void pinn_jet_recompute(const float (&sv)[1 + ND + N2], int act, float (&h)[1 + ND + N2],
+                                    const float* cw = nullptr) {
+    using J = PinnJet<ND, N2, COMB>;
     float d1, d2;
     pinn_act_d12(sv[0], act, d1, d2);
     h[0] = sv[0];
 #pragma unroll
     for (int k = 0; k < ND; ++k) h[1 + k] = d1 * sv[1 + k];
 #pragma unroll
-    for (int k = 0; k < N2; ++k) h[1 + ND + k] = d2 * sv[1 + k] * sv[1 + k] + d1 * sv[1 + ND + k];
+    for (int j = 0; j < N2; ++j) h[1 + ND + j] = d1 * sv[1 + ND + j];
+#pragma unroll
+    for (int k = 0; k < ND; ++k)
+        if (J::has2(k)) h[J::idx2(k)] += d2 * J::w(k, cw) * sv[1 + k] * sv[1 + k];
 }
 
 // reverse jet: gh[S] = dL/dh streams -> gz[S] = dL/dz streams
-template <int ND, int N2>
+template <int ND, int N2, bool COMB = false>
 PINN_DEVICE void pinn_jet_bwd(const float (&gh)[1 + ND + N2], const float (&sv)[1 + ND + N2], int act,
-                              float (&gz)[1 + ND + N2]) {
+                              float (&gz)[1 + ND + N2], const float* cw = nullptr) {
+    using J = PinnJet<ND, N2, COMB>;
     const float v = sv[0];
     float d1, d2;
     pinn_act_d12(v, act, d1, d2);
     const float d3 = pinn_act_d3(v, d1, d2, act);
     float acc = d1 * gh[0];
 #pragma unroll
+    for (int j = 0; j < N2; ++j) {
+        gz[1 + ND + j] = d1 * gh[1 + ND + j];
+        acc += d2 * sv[1 + ND + j] * gh[1 + ND + j];
+    }
+#pragma unroll
     for (int k = 0; k < ND; ++k) {
         const float zk = sv[1 + k];
         float gzk = d1 * gh[1 + k];
         acc += d2 * zk * gh[1 + k];
-        if (k < N2) {
-            const float zkk = sv[1 + ND + k], ghkk = gh[1 + ND + k];
-            gz[1 + ND + k] = d1 * ghkk;
+        if (J::has2(k)) {
+            const float ghkk = gh[J::idx2(k)] * J::w(k, cw);
             gzk += 2.0f * d2 * zk * ghkk;
-            acc += (d3 * zk * zk + d2 * zkk) * ghkk;
+            acc += d3 * zk * zk * ghkk;
         }
         gz[1 + k] = gzk;
     }
@@ -278,11 +305,13 @@ PINN_DEVICE void pinn_point_prefetch(const PinnKArgs& A, long long gidx, bool va
     }
 }
 
-template <int ND, int N2, bool WITH_PROGRAMS = true>
+template <int ND, int N2, bool WITH_PROGRAMS = true, bool COMB = false>
 PINN_DEVICE void pinn_point_stage(const PinnKArgs& A, const float (&net)[1 + ND + N2], const float* x /*[d]*/,
                                   long long gidx, bool valid, float* pregs, float* padj, int T,
                                   const PinnPointPre<ND, N2>& pre, PinnPointOut<ND, N2>& out) {
     constexpr int S = 1 + ND + N2;
+    using J = PinnJet<ND, N2, COMB>;
+    const float* cw = A.comb_w;
     // ---- BC factor P and its direction derivatives --------------------------------------------------------
     float P = 1.0f, Pk[ND > 0 ? ND : 1], Pkk[ND > 0 ? ND : 1];
 #pragma unroll
@@ -324,7 +353,10 @@ PINN_DEVICE void pinn_point_stage(const PinnKArgs& A, const float (&net)[1 + ND 
 #pragma unroll
         for (int k = 0; k < ND; ++k) Q[1 + k] = net[1 + k] * P + net[0] * Pk[k];
 #pragma unroll
-        for (int k = 0; k < N2; ++k) Q[1 + ND + k] = net[1 + ND + k] * P + 2.0f * net[1 + k] * Pk[k] + net[0] * Pkk[k];
+        for (int j = 0; j < N2; ++j) Q[1 + ND + j] = net[1 + ND + j] * P;
+#pragma unroll
+        for (int k = 0; k < ND; ++k)
+            if (J::has2(k)) Q[J::idx2(k)] += J::w(k, cw) * (2.0f * net[1 + k] * Pk[k] + net[0] * Pkk[k]);
     }
     // ---- IC gate G = sigmoid(tau) - 1/2, tau = (t - t0) exp(-log_scale) -----------------------------------------
     float u[S];
@@ -355,7 +387,10 @@ PINN_DEVICE void pinn_point_stage(const PinnKArgs& A, const float (&net)[1 + ND 
 #pragma unroll
         for (int k = 0; k < ND; ++k) u[1 + k] = Gk[k] * Q[0] + G * Q[1 + k];
 #pragma unroll
-        for (int k = 0; k < N2; ++k) u[1 + ND + k] = Gkk[k] * Q[0] + 2.0f * Gk[k] * Q[1 + k] + G * Q[1 + ND + k];
+        for (int j = 0; j < N2; ++j) u[1 + ND + j] = G * Q[1 + ND + j];
+#pragma unroll
+        for (int k = 0; k < ND; ++k)
+            if (J::has2(k)) u[J::idx2(k)] += J::w(k, cw) * (Gkk[k] * Q[0] + 2.0f * Gk[k] * Q[1 + k]);
 #pragma unroll
         for (int s = 0; s < S; ++s) u[s] += pre.ic[s];
     }
@@ -412,19 +447,22 @@ PINN_DEVICE void pinn_point_stage(const PinnKArgs& A, const float (&net)[1 + ND 
         float gG = gu[0] * Q[0];
         gQ[0] = gu[0] * G;
 #pragma unroll
+        for (int j = 0; j < N2; ++j) {
+            gG += gu[1 + ND + j] * Q[1 + ND + j];
+            gQ[1 + ND + j] = gu[1 + ND + j] * G;
+        }
+#pragma unroll
         for (int k = 0; k < ND; ++k) {
             gG += gu[1 + k] * Q[1 + k];
             float gGk = gu[1 + k] * Q[0];
             gQ[0] += gu[1 + k] * Gk[k];
             gQ[1 + k] = gu[1 + k] * G;
-            if (k < N2) {
-                const float gkk = gu[1 + ND + k];
-                gG += gkk * Q[1 + ND + k];
+            if (J::has2(k)) {
+                const float gkk = gu[J::idx2(k)] * J::w(k, cw);
                 gGk += 2.0f * gkk * Q[1 + k];
                 g_ls += gkk * Q[0] * dGkk[k];
                 gQ[0] += gkk * Gkk[k];
                 gQ[1 + k] += 2.0f * gkk * Gk[k];
-                gQ[1 + ND + k] = gkk * G;
             }
             g_ls += gGk * dGk[k];
         }
@@ -436,14 +474,15 @@ PINN_DEVICE void pinn_point_stage(const PinnKArgs& A, const float (&net)[1 + ND 
     if (A.has_bc) {
         float g0 = gQ[0] * P;
 #pragma unroll
+        for (int j = 0; j < N2; ++j) out.gnet[1 + ND + j] = gQ[1 + ND + j] * P;
+#pragma unroll
         for (int k = 0; k < ND; ++k) {
             g0 += gQ[1 + k] * Pk[k];
             float g1 = gQ[1 + k] * P;
-            if (k < N2) {
-                const float gkk = gQ[1 + ND + k];
+            if (J::has2(k)) {
+                const float gkk = gQ[J::idx2(k)] * J::w(k, cw);
                 g0 += gkk * Pkk[k];
                 g1 += 2.0f * gkk * Pk[k];
-                out.gnet[1 + ND + k] = gkk * P;
             }
             out.gnet[1 + k] = g1;
         }
@@ -475,7 +514,7 @@ PINN_DEVICE void pinn_point_stage(const PinnKArgs& A, const float (&net)[1 + ND 
 PINN_DEVICE f32x4 pinn_ld4(const float* p) { return *reinterpret_cast<const f32x4*>(p); }
 PINN_DEVICE void pinn_st4(float* p, f32x4 v) { *reinterpret_cast<f32x4*>(p) = v; }
 
-template <int HP, int ND, int N2, int MT, int LHC, int ACTC>
+template <int HP, int ND, int N2, int MT, int LHC, int ACTC, bool COMB = false>
 // occupancy hint: the fused kernel of a 64/128-wide net wants the whole register file of a SIMD (one wave per SIMD,
 // no spills); narrower nets (1-2 waves per workgroup) run several workgroups per CU
 #ifndef PINN_WAVES_PER_SIMD
@@ -492,6 +531,7 @@ pinn_tile_kernel(const PinnKArgs A) {
     const int lr = lane & 15, lq = lane >> 4;
     const int act = (ACTC >= 0) ? ACTC : A.act;
     const int lh = (LHC >= 0) ? LHC : A.lh;
+    const float* cw = A.comb_w;
     const int d = A.d;
     const bool train = A.mode != PINN_MODE_FORWARD;
 
@@ -622,7 +662,7 @@ pinn_tile_kernel(const PinnKArgs A) {
                     for (int k = 0; k < ND; ++k) z[1 + k] = W1s[n * PINN_XS_LD + A.dir_cols[k]];
 #pragma unroll
                     for (int k = 0; k < N2; ++k) z[1 + ND + k] = 0.0f;
-                    pinn_jet_fwd<ND, N2>(z, act, h);
+                    pinn_jet_fwd<ND, N2, COMB>(z, act, h, cw);
 #pragma unroll
                     for (int s = 0; s < S; ++s) { hv[s][r] = h[s]; sv[s][r] = (s == 0) ? h[0] : z[s]; }
                 }
@@ -712,7 +752,7 @@ pinn_tile_kernel(const PinnKArgs A) {
 #pragma unroll
                         for (int s = 0; s < S; ++s) z[s] = acc[j][mt][s][r];
                         z[0] += bias[r];
-                        pinn_jet_fwd<ND, N2>(z, act, h);
+                        pinn_jet_fwd<ND, N2, COMB>(z, act, h, cw);
 #pragma unroll
                         for (int s = 0; s < S; ++s) { hv[s][r] = h[s]; sv[s][r] = (s == 0) ? h[0] : z[s]; }
                     }
@@ -774,7 +814,7 @@ pinn_tile_kernel(const PinnKArgs A) {
                 net[s] = v;
             }
             PinnPointOut<ND, N2> po;
-            pinn_point_stage<ND, N2>(A, net, xs_t + pt * PINN_XS_LD, base + pt, base + pt < A.n_points,
+            pinn_point_stage<ND, N2, true, COMB>(A, net, xs_t + pt * PINN_XS_LD, base + pt, base + pt < A.n_points,
                                      pregs + pt, padj + pt, T, ppre, po);
 #pragma unroll
             for (int s = 0; s < S; ++s) gnetb[s * T + pt] = po.gnet[s];
@@ -819,7 +859,7 @@ pinn_tile_kernel(const PinnKArgs A) {
                         float gh1[S], sv1[S], gz1[S];
 #pragma unroll
                         for (int s = 0; s < S; ++s) { gh1[s] = g[j][mt][s][r]; sv1[s] = sv[j][mt][s][r]; }
-                        pinn_jet_bwd<ND, N2>(gh1, sv1, act, gz1);
+                        pinn_jet_bwd<ND, N2, COMB>(gh1, sv1, act, gz1, cw);
 #pragma unroll
                         for (int s = 0; s < S; ++s) gz[j][mt][s][r] = gz1[s];
                         bsum[r] += gz1[0];
@@ -864,7 +904,7 @@ pinn_tile_kernel(const PinnKArgs A) {
                         float sv1[S], h[S];
 #pragma unroll
                         for (int s = 0; s < S; ++s) sv1[s] = sv[j][mt][s][r];
-                        pinn_jet_recompute<ND, N2>(sv1, act, h);
+                        pinn_jet_recompute<ND, N2, COMB>(sv1, act, h, cw);
 #pragma unroll
                         for (int s = 0; s < S; ++s) hv[j][mt][s][r] = h[s];
                     }

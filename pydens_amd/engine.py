@@ -50,10 +50,11 @@ class Residual(ctypes.Structure):
     """ pinn_residual_t """
     _fields_ = [('kind', ctypes.c_int), ('n_aux', ctypes.c_int), ('pre', Program), ('program', Program),
                 ('coef', ctypes.c_float * MAX_STREAMS), ('coef_row', ctypes.c_int * MAX_STREAMS),
-                ('src_const', ctypes.c_float), ('src_row', ctypes.c_int)]
+                ('src_const', ctypes.c_float), ('src_row', ctypes.c_int),
+                ('combined', ctypes.c_int), ('comb_w', ctypes.c_float * MAX_DIRS)]
 
     @classmethod
-    def build(cls, kind, n_aux, pre, program=None, coef=(), coef_row=(), src_const=0.0, src_row=-1):
+    def build(cls, kind, n_aux, pre, program=None, coef=(), coef_row=(), src_const=0.0, src_row=-1, comb_w=None):
         res = cls()
         res.kind, res.n_aux = kind, n_aux
         res.pre = Program.from_lists(*pre) if pre is not None else Program()
@@ -62,6 +63,9 @@ class Residual(ctypes.Structure):
             res.coef[i] = coef[i] if i < len(coef) else 0.0
             res.coef_row[i] = coef_row[i] if i < len(coef_row) else -1
         res.src_const, res.src_row = src_const, src_row
+        res.combined = 1 if comb_w is not None else 0
+        for i in range(MAX_DIRS):
+            res.comb_w[i] = comb_w[i] if comb_w is not None and i < len(comb_w) else 0.0
         return res
 
 

@@ -116,6 +116,7 @@ class Solver:
         try:
             root = trace.symbolic(self.equation, self.ctx.run, total)
             plan = trace.lower_residual(root, self.spec, total)
+            trace.combine_second_order(plan, self.spec)
             # validation on random data: program (fp64 host interpreter) vs the user's callable on tagged tensors
             n = 17
             streams = torch.rand((self.spec.n_streams, n), device=self.device) * 2 - 1
@@ -282,22 +283,28 @@ class Solver:
 
     def _fused_step(self, xs, world, adam=None):
         model, spec = self.model, self.spec
+        comb_w = self.residual_plan.comb_w if self.residual_plan is not None else None
+        n2 = spec.n2 if comb_w is None else 1               # combined second-order stream: [u, firsts, sum_k c_k u_kk]
         ic_streams = None
         if model.initial_condition is not None and model.ic_constant is None:
             parts = self._ic_streams(xs, create_graph=False)
-            ic_streams = torch.zeros((spec.n_streams, xs.shape[0]), dtype=torch.float32, device=self.device)
+            ic_streams = torch.zeros((1 + spec.nd + n2, xs.shape[0]), dtype=torch.float32, device=self.device)
             for i, t in enumerate(parts):
-                if t is not None:
+                if t is None:
+                    continue
+                if comb_w is not None and i > spec.nd:
+                    ic_streams[1 + spec.nd] += comb_w[i - 1 - spec.nd] * t.reshape(-1)
+                else:
                     ic_streams[i] = t.reshape(-1)
         ws = model.workspace(xs.shape[0], spec.nd, spec.n2)
         if adam is not None:
             adam.t += 1
             model.net.residual_adam_step(self.program, model.flat, xs, self.grads, ws, adam.exp_avg, adam.exp_avg_sq,
                                          adam.mask, adam.step_count, adam.t, adam.lr, adam.betas, adam.eps,
-                                         dir_cols=spec.dir_cols, n2=spec.n2, ic_streams=ic_streams,
+                                         dir_cols=spec.dir_cols, n2=n2, ic_streams=ic_streams,
                                          ic_const=model.kernel_ic_const())
             return
-        model.net.residual_step(self.program, model.flat, xs, self.grads, ws, spec.dir_cols, spec.n2,
+        model.net.residual_step(self.program, model.flat, xs, self.grads, ws, spec.dir_cols, n2,
                                 ic_streams=ic_streams, ic_const=model.kernel_ic_const(),
                                 inv_n_global=1.0 / (xs.shape[0] * world))
 

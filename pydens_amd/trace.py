@@ -327,11 +327,37 @@ class ResidualPlan:
         self.coef = coef or [0.0] * n_streams
         self.coef_row = coef_row or [-1] * n_streams
         self.src_const, self.src_row = src_const, src_row
+        self.comb_w = None          # set by `combine_second_order`: weights of the single combined second-order stream
+
+    @property
+    def kernel_n2(self):
+        """ number of second-order streams the kernel propagates for this residual """
+        return 1 if self.comb_w is not None else None
 
     def to_struct(self):
         from .engine import Residual
         return Residual.build(self.kind, self.n_aux, self.pre if self.n_aux else None, self.program, self.coef,
-                              self.coef_row, self.src_const, self.src_row)
+                              self.coef_row, self.src_const, self.src_row, self.comb_w)
+
+
+def combine_second_order(plan, spec):
+    """ Affine residual whose second derivatives enter only as  sum_k c_k u_kk  with CONSTANT c_k (Laplacian, wave,
+    heat operators): propagate that one combination instead of n2 separate streams. Rewrites the plan in place to the
+    stream layout [u, firsts (nd), combined] and returns True; otherwise leaves it alone. """
+    if plan.kind != RES_AFFINE or spec.n2 < 2 or spec.nd > MAX_DIRS or plan.comb_w is not None:
+        return False
+    first2 = 1 + spec.nd
+    if any(plan.coef_row[first2 + k] >= 0 for k in range(spec.n2)):
+        return False                                   # x-dependent coefficient on a second derivative
+    weights = [plan.coef[first2 + k] if k < spec.n2 else 0.0 for k in range(spec.nd)]
+    if sum(1 for w in weights if w != 0.0) < 2:
+        return False
+    plan.coef = plan.coef[:first2] + [1.0]
+    plan.coef_row = plan.coef_row[:first2] + [-1]
+    plan.n_streams = first2 + 1
+    plan.comb_w = weights
+    return True
+
 
 
 def lower_residual(root, spec, n_inputs):
@@ -450,6 +476,12 @@ def run_residual_numpy(plan, streams, xs):
     if plan.n_aux:
         regs = {c: xs[:, c].astype(np.float64) for c in range(d)}
         _run_code_numpy(plan.pre[0], plan.pre[1], regs, n, aux)
+    if plan.comb_w is not None:
+        # streams arrive in the caller's layout [u, firsts, seconds...]: fold the seconds into the combined stream
+        nd = len(plan.coef) - 2
+        comb = sum(plan.comb_w[k] * streams[1 + nd + k] for k in range(S - 1 - nd))
+        streams = np.concatenate([streams[:1 + nd], comb[None, :]], axis=0)
+        S = streams.shape[0]
     if plan.kind == RES_AFFINE:
         r = aux[plan.src_row].copy() if plan.src_row >= 0 else np.full(n, plan.src_const, dtype=np.float64)
         for s in range(S):

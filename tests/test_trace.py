@@ -153,3 +153,30 @@ def test_lowered_residual_reproduces_the_callable(eq, n_inputs):
     finally:
         trace.active_streams.reset(token)
     np.testing.assert_allclose(got, want, rtol=1e-6, atol=1e-6)
+
+
+def test_second_derivatives_are_combined_into_one_stream_when_possible():
+    spec, plan = lower(lambda f, x, y: D(D(f, x), x) + D(D(f, y), y) - 5 * torch.sin(np.pi * (x + y)), 2)
+    assert trace.combine_second_order(plan, spec) and plan.comb_w == [1.0, 1.0]
+    assert plan.coef == [0.0, 0.0, 0.0, 1.0] and plan.n_streams == 4
+    spec, plan = lower(lambda f, x, t: D(D(f, t), t) - 4 * D(D(f, x), x), 2)              # wave operator, c^2 = 4
+    assert trace.combine_second_order(plan, spec) and plan.comb_w == [-4.0, 1.0]
+    spec, plan = lower(lambda f, x, y, t: D(D(f, x), x) + D(D(f, y), y) - D(f, t), 3)      # heat: t has no second derivative
+    assert trace.combine_second_order(plan, spec) and plan.comb_w == [1.0, 1.0, 0.0]
+    assert plan.coef == [0.0, 0.0, 0.0, -1.0, 1.0]
+    # not combinable: x-dependent coefficient on a second derivative, a single second derivative, nonlinear residuals
+    spec, plan = lower(lambda f, x, y: (1 + x) * D(D(f, x), x) + D(D(f, y), y), 2)
+    assert not trace.combine_second_order(plan, spec)
+    spec, plan = lower(lambda f, x, t: D(f, t) - D(D(f, x), x), 2)
+    assert not trace.combine_second_order(plan, spec)
+    spec, plan = lower(lambda f, x, y: D(D(f, x), x) * D(D(f, y), y) - 1, 2)
+    assert not trace.combine_second_order(plan, spec)
+    # the combined plan still reproduces the callable from the caller's (uncombined) streams
+    eq = lambda f, x, t: D(D(f, t), t) - 4 * D(D(f, x), x) + 3 * D(f, x) - torch.cos(x * t)
+    spec, plan = lower(eq, 2)
+    assert trace.combine_second_order(plan, spec)
+    rng = np.random.RandomState(2)
+    streams, xs = rng.rand(spec.n_streams, 11), rng.rand(11, 2)
+    want = (streams[spec.index[(1, 1)]] - 4 * streams[spec.index[(0, 0)]] + 3 * streams[spec.index[(0,)]]
+            - np.cos(xs[:, 0] * xs[:, 1]))
+    np.testing.assert_allclose(trace.run_residual_numpy(plan, streams, xs), want, rtol=1e-6)
