@@ -514,18 +514,20 @@ PINN_DEVICE void pinn_point_stage(const PinnKArgs& A, const float (&net)[1 + ND 
 PINN_DEVICE f32x4 pinn_ld4(const float* p) { return *reinterpret_cast<const f32x4*>(p); }
 PINN_DEVICE void pinn_st4(float* p, f32x4 v) { *reinterpret_cast<f32x4*>(p) = v; }
 
-template <int HP, int ND, int N2, int MT, int LHC, int ACTC, bool COMB = false>
+// VAR (experiment bits): 1 = accumulate dW in the partial buffer although the layer count is static, 2 = two waves per
+// SIMD (two workgroups per CU), 4 = no whole-layer weight prefetch.
+template <int HP, int ND, int N2, int MT, int LHC, int ACTC, bool COMB = false, int VAR = 0>
 // occupancy hint: the fused kernel of a 64/128-wide net wants the whole register file of a SIMD (one wave per SIMD,
 // no spills); narrower nets (1-2 waves per workgroup) run several workgroups per CU
 #ifndef PINN_WAVES_PER_SIMD
 #define PINN_WAVES_PER_SIMD 1
 #endif
 PINN_GLOBAL void PINN_LAUNCH_BOUNDS2((PinnCfg<HP, ND, N2, MT>::NTHREADS),
-                                    (PinnCfg<HP, ND, N2, MT>::NW < 4 ? 2 : PINN_WAVES_PER_SIMD))
+                                    (PinnCfg<HP, ND, N2, MT>::NW < 4 || (VAR & 2) ? 2 : PINN_WAVES_PER_SIMD))
 pinn_tile_kernel(const PinnKArgs A) {
     using C = PinnCfg<HP, ND, N2, MT>;
     constexpr int S = C::S, NT = C::NT, NTW = C::NTW, NW = C::NW, T = C::T, LDA = C::LDA, NTHREADS = C::NTHREADS;
-    constexpr bool DWG = (LHC < 0), ONEBUF = C::ONEBUF;
+    constexpr bool DWG = (LHC < 0) || (VAR & 1), ONEBUF = C::ONEBUF;
     constexpr int LHREG = DWG ? 1 : PINN_LHMAX;            // layers with register-resident dW accumulators
     const int tid = PINN_TID, lane = tid & 63, wave = tid >> 6;
     const int lr = lane & 15, lq = lane >> 4;
@@ -632,7 +634,7 @@ pinn_tile_kernel(const PinnKArgs A) {
         f32x4 svtop[NTW][MT][S];       // saved jets of the LAST hidden activation: they never leave the registers
         f32x4 htop[NTW][MT][S];        // ... and its activations (last-layer dot and dWL need them again)
         // whole-layer weight fragments are fetched one phase ahead (L2 latency hidden behind the previous epilogue)
-        constexpr bool WPF = (NW <= 4);
+        constexpr bool WPF = (NW <= 4) && !(VAR & 4);
         constexpr int NQ = HP / 16;
         f32x4 wall[WPF ? NQ : 1][NTW];
         auto load_wall = [&](const float* Wl) {

@@ -160,12 +160,13 @@ def _variable_problem(D, V, torch):
 
 
 def _paired(pa, emu_lib, **fit_kwargs):
+    """ oracle + product solver for the tutorial's trainable-variable problem; emu_lib=None -> the HIP library """
     from oracle import pinn_oracle as po
     kw = dict(ndims=1, initial_condition=1, layout='fafaf', features=[12, 10, 1], activation='Tanh')
     eq_o, con_o = _variable_problem(po.D, po.V, torch)
     oracle = po.OracleSolver(eq_o, constraints=con_o, **kw)
     eq_p, con_p = _variable_problem(pa.D, pa.V, torch)
-    solver = pa.Solver(eq_p, constraints=con_p, **kw, **emu_kwargs(emu_lib))
+    solver = pa.Solver(eq_p, constraints=con_p, **kw, **(emu_kwargs(emu_lib) if emu_lib is not None else {}))
     load_params(solver, oracle.export_params())
     return oracle, solver
 

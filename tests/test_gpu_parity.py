@@ -205,3 +205,40 @@ def test_deep_network_and_full_size_cfg5(pa):
     assert abs(float(solver.grads[lay.off_loss]) - ev['loss']) <= 1e-5 * ev['loss']
     for got, want in zip(export_grads(solver), oracle.export_grads()):
         assert rel_l2(got, want) < 1e-4
+
+
+def test_trainable_variable_constraint_and_freezing_on_the_gpu(pa):
+    """ generic step path on the GPU (kernel streams -> the user's torch code with a trainable V -> kernel reverse sweep,
+    constraint term through model(xs), freeze/unfreeze through the Adam mask): tutorial cells 50-60 vs the oracle """
+    from test_emu_engine import _paired
+    oracle, solver = _paired(pa, None)
+    assert solver.program is None and 'trainable' in solver.program_error
+    pts = np.random.RandomState(3).rand(8, 256, 1).astype(np.float32)
+    terms = ['equation', 'constraint_0']
+    oracle.fit(niters=4, batch_size=256, points=pts[:4], lr=0.05, loss_terms=terms)
+    solver.fit(niters=4, batch_size=256, sampler=FixedBatches(pts[:4]), lr=0.05, loss_terms=terms)
+    assert solver.last_fit_path == 'generic'
+    np.testing.assert_allclose([float(v) for v in solver.losses], [float(v) for v in oracle.losses], rtol=5e-5)
+    assert abs(float(solver.model.new_var) - float(oracle.model.new_var.detach())) < 2e-5
+    oracle.model.new_var.requires_grad = False
+    solver.model.freeze_trainable(variables=('new_var',))
+    frozen = float(solver.model.new_var)
+    oracle.fit(niters=2, batch_size=256, points=pts[4:6], lr=0.05)
+    solver.fit(niters=2, batch_size=256, sampler=FixedBatches(pts[4:6]), lr=0.05)
+    assert float(solver.model.new_var) == frozen
+    for got, want in zip(export_params(solver), oracle.export_params()):
+        assert rel_l2(got, want) < 1e-4
+    xs = np.linspace(0, 1, 9).astype(np.float32)
+    assert np.abs(solver.predict(xs) - oracle.predict(xs)).max() < 2e-5
+
+
+def test_default_sampler_trains_on_device(pa):
+    """ the default sampler draws U[0,1)^d in HBM (reference model_torch.py:431 draws on the host); a short run of the
+    README Poisson problem must bring the loss down and keep the hard boundary condition exact """
+    torch.manual_seed(0)
+    cfg, solver = make_solver('cfg1', pa)
+    solver.fit(niters=600, batch_size=100, lr=0.005)
+    losses = np.array([float(v) for v in solver.losses])
+    assert len(losses) == 600 and losses[-50:].mean() < 0.05 * losses[:10].mean()
+    edge = np.linspace(0, 1, 11).astype(np.float32)
+    assert np.abs(solver.predict(edge, 0.0) - 1.0).max() < 1e-6 and np.abs(solver.predict(1.0, edge) - 1.0).max() < 1e-6
