@@ -341,3 +341,44 @@ def test_width_256_one_buffer_kernel(pa, emu_lib):
     assert abs(float(solver.grads[lay.off_loss]) - ev['loss']) <= 1e-5 * ev['loss']
     for got, want in zip(export_grads(solver), oracle.export_grads()):
         assert rel_l2(got, want) < 1e-4
+
+
+def test_parametric_heat_equation_with_domain(pa, emu_lib):
+    """ tutorial cells 37-40: heat equation in (x, y, t) with an uncertain diffusivity parameter `a` (4 input columns,
+    3 differentiated), callable IC, BC, Sigmoid net -- on a non-default domain with t0 != 0 (model_torch.py:37-46, :115) """
+    from oracle import pinn_oracle as po
+
+    def problem(D):
+        def pde(f, x, y, t, a):
+            return D(D(f, x), x) + D(D(f, y), y) - a * D(f, t)
+        kw = dict(ndims=3, nparams=1, initial_condition=lambda x, y: 10 * x * y * (2 - x) * (1 - y),
+                  boundary_condition=0.25, domain=[(0, 2), (0, 1), (0.5, 1.5)],
+                  layout='fafaf', features=[30, 40, 1], activation='Sigmoid')
+        return pde, kw
+    eq_o, kw = problem(po.D)
+    oracle = po.OracleSolver(eq_o, **kw)
+    eq_p, kw = problem(pa.D)
+    solver = pa.Solver(eq_p, **kw, **emu_kwargs(emu_lib))
+    # x-dependent coefficient on u_t -> affine with a pre-pass row; second derivatives still combine into one stream
+    assert solver.residual_plan.kind == 1 and solver.residual_plan.comb_w == [1.0, 1.0, 0.0]
+    load_params(solver, oracle.export_params())
+    with torch.no_grad():
+        oracle.model.log_scale.fill_(0.3); solver.model.log_scale.fill_(0.3)
+    rng = np.random.RandomState(21)
+    lo, hi = np.array([0, 0, 0.5, 0.1]), np.array([2, 1, 1.5, 4.0])
+    pts = (lo + (hi - lo) * rng.rand(4, 48, 4)).astype(np.float32)
+    grid = pts[0]
+    assert np.abs(solver.predict(*[grid[:, i] for i in range(4)]) - oracle.predict(*[grid[:, i] for i in range(4)])).max() < 1e-5
+    oracle.fit(niters=4, batch_size=48, points=pts, lr=0.005)
+    solver.fit(niters=4, batch_size=48, sampler=FixedBatches(pts), lr=0.005)
+    assert solver.last_fit_path == 'fused'
+    np.testing.assert_allclose([float(v) for v in solver.losses], [float(v) for v in oracle.losses], rtol=3e-5)
+    for got, want in zip(export_params(solver), oracle.export_params()):
+        assert rel_l2(got, want) < 3e-5
+    # hard constraints of the ansatz (reference order, SURVEY 8a trap 5: BC transform first, IC second):
+    # on the spatial boundary u = (sigmoid(tau) - 1/2) * bc + IC, at t = t0 u = IC exactly
+    edge = np.linspace(0, 1, 5).astype(np.float32)
+    gate = 1.0 / (1.0 + np.exp(-(1.0 - 0.5) / np.exp(float(solver.model.log_scale)))) - 0.5
+    assert np.abs(solver.predict(0.0, edge, 1.0, 2.0) - gate * 0.25).max() < 1e-6
+    ic = 10 * 0.7 * edge * (2 - 0.7) * (1 - edge)
+    assert np.abs(solver.predict(0.7, edge, 0.5, 2.0)[:, 0] - ic).max() < 1e-5
