@@ -637,7 +637,10 @@ pinn_tile_kernel(const PinnKArgs A) {
         constexpr bool WPF = (NW <= 4) && !(VAR & 4);
         constexpr int NQ = HP / 16;
         f32x4 wall[WPF ? NQ : 1][NTW];
+        f32x4 biasn[NTW];              // bias of the NEXT hidden layer, fetched with its weights
         auto load_wall = [&](const float* Wl) {
+#pragma unroll
+            for (int j = 0; j < NTW; ++j) biasn[j] = pinn_ld4(Wl + HP * HP + unit0(j));
 #pragma unroll
             for (int q = 0; q < (WPF ? NQ : 1); ++q)
 #pragma unroll
@@ -653,12 +656,26 @@ pinn_tile_kernel(const PinnKArgs A) {
             for (int mt = 0; mt < MT; ++mt) {
                 const int pt = mt * 16 + lr;
                 f32x4 hv[S], sv[S];
+                // point row and the four weight rows as b128 reads (all issued together: one LDS latency)
+                const f32x4 xlo = pinn_ld4(xs_t + pt * PINN_XS_LD), xhi = pinn_ld4(xs_t + pt * PINN_XS_LD + 4);
+                const f32x4 b1v = pinn_ld4(b1s + n0);
+                f32x4 wlo[4], whi[4];
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    wlo[r] = pinn_ld4(W1s + (n0 + r) * PINN_XS_LD);
+                    whi[r] = pinn_ld4(W1s + (n0 + r) * PINN_XS_LD + 4);      // columns >= d are zero in both operands
+                }
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
                     const int n = n0 + r;
                     float z[S], h[S];
-                    float z0 = b1s[n];
-                    for (int c = 0; c < d; ++c) z0 = fmaf(W1s[n * PINN_XS_LD + c], xs_t[pt * PINN_XS_LD + c], z0);
+                    float z0 = b1v[r];
+#pragma unroll
+                    for (int c = 0; c < 4; ++c) z0 = fmaf(wlo[r][c], xlo[c], z0);
+                    if (d > 4) {
+#pragma unroll
+                        for (int c = 0; c < 4; ++c) z0 = fmaf(whi[r][c], xhi[c], z0);
+                    }
                     z[0] = z0;
 #pragma unroll
                     for (int k = 0; k < ND; ++k) z[1 + k] = W1s[n * PINN_XS_LD + A.dir_cols[k]];
@@ -737,7 +754,7 @@ pinn_tile_kernel(const PinnKArgs A) {
             if (ONEBUF) PINN_SYNC();                       // in place: every wave must be done reading h_{l-1}
             f32x4 biasv[NTW];
 #pragma unroll
-            for (int j = 0; j < NTW; ++j) biasv[j] = pinn_ld4(bl + unit0(j));    // before the prefetch: vmcnt retires in order
+            for (int j = 0; j < NTW; ++j) biasv[j] = WPF ? biasn[j] : pinn_ld4(bl + unit0(j));
             PINN_SCHED_BARRIER();
             if (WPF && li + 1 < lh) load_wall(Wl + A.hidden_stride);
 #pragma unroll
@@ -830,6 +847,32 @@ pinn_tile_kernel(const PinnKArgs A) {
         // ---- (5) reverse through the last layer: gh_s = gnet_s * WL ; dWL += sum gnet_s h_s -------------------------
         f32x4 g[NTW][MT][S];
         f32x4 sv[NTW][MT][S];
+        // saved jets of the activation BELOW the one being reversed: fetched one phase ahead (L2 latency behind a GEMM phase)
+        f32x4 svn[NTW][MT][S];
+        auto load_saved = [&](int a, f32x4 (&dst)[NTW][MT][S]) {
+#pragma unroll
+            for (int j = 0; j < NTW; ++j)
+#pragma unroll
+                for (int mt = 0; mt < MT; ++mt) {
+                    if (a == 0) {
+                        dst[j][mt][0] = *slab_at(0, 0, j, mt);
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) {
+#pragma unroll
+                            for (int k = 0; k < ND; ++k)
+                                dst[j][mt][1 + k][r] = W1s[(unit0(j) + r) * PINN_XS_LD + A.dir_cols[k]];
+#pragma unroll
+                            for (int k = 0; k < N2; ++k) dst[j][mt][1 + ND + k][r] = 0.0f;
+                        }
+                    } else {
+#pragma unroll
+                        for (int s = 0; s < S; ++s) dst[j][mt][s] = *slab_at(a, s, j, mt);
+                    }
+                }
+        };
+        // (only where S*MT*NTW jets leave register head-room: measured -3 % on cfg2/cfg5, +1..5 % on cfg3/cfg4)
+        constexpr bool SVPF = (S * MT * NTW <= 6);
+        if (SVPF && lh > 0) load_saved(lh - 1, svn);
 #pragma unroll
         for (int j = 0; j < NTW; ++j) {
             const int n0 = unit0(j);
@@ -883,24 +926,14 @@ pinn_tile_kernel(const PinnKArgs A) {
             if (top && !ONEBUF) { float* tmp = cur; cur = nxt; nxt = tmp; }   // cur = h_{a-1}, nxt = free (receives gz)
             // recompute h_{a-1} from its saved jets (kept in sv for the next step); stage h_{a-1} and gz_a for the GEMMs
             f32x4 hv[NTW][MT][S];
+            if (!SVPF) load_saved(a - 1, svn);
 #pragma unroll
             for (int j = 0; j < NTW; ++j) {
                 const int n0 = unit0(j);
 #pragma unroll
                 for (int mt = 0; mt < MT; ++mt) {
-                    if (a == 1) {
-                        sv[j][mt][0] = *slab_at(0, 0, j, mt);
 #pragma unroll
-                        for (int r = 0; r < 4; ++r) {
-#pragma unroll
-                            for (int k = 0; k < ND; ++k) sv[j][mt][1 + k][r] = W1s[(n0 + r) * PINN_XS_LD + A.dir_cols[k]];
-#pragma unroll
-                            for (int k = 0; k < N2; ++k) sv[j][mt][1 + ND + k][r] = 0.0f;
-                        }
-                    } else {
-#pragma unroll
-                        for (int s = 0; s < S; ++s) sv[j][mt][s] = *slab_at(a - 1, s, j, mt);
-                    }
+                    for (int s = 0; s < S; ++s) sv[j][mt][s] = svn[j][mt][s];     // fetched one phase ago (or just now)
 #pragma unroll
                     for (int r = 0; r < 4; ++r) {
                         float sv1[S], h[S];
@@ -942,6 +975,7 @@ pinn_tile_kernel(const PinnKArgs A) {
             PH(10)
             PINN_SYNC();
             PH(11)
+            if (SVPF && a >= 2) load_saved(a - 2, svn);    // in flight during the two GEMMs below
             const int li = a - 1;
             const float* Wl = A.params + A.off_wh + (size_t)li * A.hidden_stride;
             float wqall[WPF ? NQ : 1][NTW][4];
