@@ -85,6 +85,15 @@ struct PinnCfg {
     static constexpr int O_PREG = O_SCAL + T * 4;
     static constexpr int O_PADJ = O_PREG + PINN_MAX_REGS * T;
     static constexpr int SMEM_FLOATS = O_PADJ + PINN_MAX_REGS * T;
+    // fast instantiations may keep W^T of the LH hidden layers in LDS (data-gradient A operand as ds_read_b128):
+    static constexpr int O_WT = SMEM_FLOATS;
+    static constexpr int WT_LD = HP + 8;
+    PINN_HOST_DEVICE static constexpr bool wt_fits(int lh) {
+        return lh > 0 && HP <= 64 && (SMEM_FLOATS + lh * HP * WT_LD) * 4 <= 150 * 1024;
+    }
+    PINN_HOST_DEVICE static constexpr int smem_floats(int lh_static) {
+        return SMEM_FLOATS + (wt_fits(lh_static) ? lh_static * HP * WT_LD : 0);
+    }
     PINN_HOST_DEVICE static constexpr size_t slab_vec4_per_wg(int lh) {
         return (size_t)(lh + 1) * S * NTW * MT * NTHREADS;
     }
@@ -529,6 +538,7 @@ pinn_tile_kernel(const PinnKArgs A) {
     constexpr int S = C::S, NT = C::NT, NTW = C::NTW, NW = C::NW, T = C::T, LDA = C::LDA, NTHREADS = C::NTHREADS;
     constexpr bool DWG = (LHC < 0) || (VAR & 1), ONEBUF = C::ONEBUF;
     constexpr int LHREG = DWG ? 1 : PINN_LHMAX;            // layers with register-resident dW accumulators
+    constexpr bool WTL = C::wt_fits(LHC);                  // transposed hidden weights staged in LDS
     const int tid = PINN_TID, lane = tid & 63, wave = tid >> 6;
     const int lr = lane & 15, lq = lane >> 4;
     const int act = (ACTC >= 0) ? ACTC : A.act;
@@ -560,6 +570,14 @@ pinn_tile_kernel(const PinnKArgs A) {
     }
     for (int i = tid; i < HP; i += NTHREADS) { b1s[i] = A.params[A.off_b1 + i]; WLs[i] = A.params[A.off_wl + i]; }
     for (int i = tid; i < PINN_MAX_LAYERS * HP; i += NTHREADS) accB[i] = 0.0f;
+    float* WTs = smem + C::O_WT;
+    if (WTL && train) {
+        // WTs[l][k][n] = W_l[n][k]: coalesced global reads along k, one-time strided LDS writes
+        for (int i = tid; i < (LHC > 0 ? LHC : 0) * HP * HP; i += NTHREADS) {
+            const int l = i / (HP * HP), n = (i / HP) % HP, k = i % HP;
+            WTs[(l * HP + k) * C::WT_LD + n] = A.params[A.off_wh + (size_t)l * A.hidden_stride + n * HP + k];
+        }
+    }
     for (int i = tid; i < PINN_MAX_REGS * T; i += NTHREADS) padj[i] = 0.0f;
     const float bL = A.params[A.off_bl];
 
@@ -979,7 +997,7 @@ pinn_tile_kernel(const PinnKArgs A) {
             const int li = a - 1;
             const float* Wl = A.params + A.off_wh + (size_t)li * A.hidden_stride;
             float wqall[WPF ? NQ : 1][NTW][4];
-            if (WPF) {
+            if (WPF && !WTL) {
 #pragma unroll
                 for (int q = 0; q < NQ; ++q)
 #pragma unroll
@@ -1063,9 +1081,17 @@ pinn_tile_kernel(const PinnKArgs A) {
 #pragma unroll
                     for (int j = 0; j < NTW; ++j)
 #pragma unroll
-                        for (int m = 0; m < 4; ++m)
-                            w[j][m] = WPF ? wqall[WPF ? q : 0][j][m]
-                                          : Wl[(16 * q + 4 * lq + m) * HP + (wave * NTW + j) * 16 + lr];
+                        for (int m = 0; m < 4; ++m) {
+                            if (WTL) {
+                                if (m == 0) {
+                                    const f32x4 wv = pinn_ld4(WTs + (li * HP + (wave * NTW + j) * 16 + lr) * C::WT_LD + 16 * q + 4 * lq);
+                                    w[j][0] = wv[0]; w[j][1] = wv[1]; w[j][2] = wv[2]; w[j][3] = wv[3];
+                                }
+                            } else {
+                                w[j][m] = WPF ? wqall[WPF ? q : 0][j][m]
+                                              : Wl[(16 * q + 4 * lq + m) * HP + (wave * NTW + j) * 16 + lr];
+                            }
+                        }
 #pragma unroll
                     for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
