@@ -72,7 +72,7 @@ struct PinnCfg {
     static constexpr bool ONEBUF = HP > 128;
     // LDS carve (floats); every offset is a multiple of 4 floats (16 B, ds_read_b128 alignment)
     static constexpr int O_XS = 0;
-    static constexpr int O_W1 = O_XS + T * PINN_XS_LD;
+    static constexpr int O_W1 = O_XS + 2 * T * PINN_XS_LD;      // points of a tile, double-buffered
     static constexpr int O_B1 = O_W1 + HP * PINN_XS_LD;
     static constexpr int O_WL = O_B1 + HP;
     static constexpr int O_BUFA = O_WL + HP;
@@ -548,7 +548,7 @@ pinn_tile_kernel(const PinnKArgs A) {
     const bool train = A.mode != PINN_MODE_FORWARD;
 
     PINN_SMEM(smem);
-    float* xs_t = smem + C::O_XS;
+    float* xs_base = smem + C::O_XS;
     float* W1s = smem + C::O_W1;
     float* b1s = smem + C::O_B1;
     float* WLs = smem + C::O_WL;
@@ -629,20 +629,27 @@ pinn_tile_kernel(const PinnKArgs A) {
             xpre[e] = (i < T * PINN_XS_LD && c < d && tile < ntiles && g < A.n_points) ? A.xs[g * d + c] : 0.0f;
         }
     };
-    fetch_points(PINN_BID);
-    PINN_SYNC();
-    PH_DECL
-
-    for (long long tile = PINN_BID; tile < ntiles; tile += PINN_NBLK) {
-        const long long base = tile * T;
-        // ---- (0) stage the points of this tile, start fetching the next tile's ---------------------------------------
+    auto store_points = [&](float* dst) {
 #pragma unroll
         for (int e = 0; e < NPRE; ++e) {
             const int i = tid + e * NTHREADS;
-            if (i < T * PINN_XS_LD) xs_t[i] = xpre[e];
+            if (i < T * PINN_XS_LD) dst[i] = xpre[e];
         }
-        PINN_SYNC();
-        fetch_points(tile + PINN_NBLK);
+    };
+    // the points live in a double-buffered LDS tile: tile k reads buffer k&1 while the points of tile k+1 are written
+    // to the other one in the middle of tile k (several barriers away from both its last reader and its first reader),
+    // so neither the staging nor the end of a tile needs a barrier of its own
+    fetch_points(PINN_BID);
+    store_points(xs_base);
+    fetch_points((long long)PINN_BID + PINN_NBLK);
+    PINN_SYNC();
+    PH_DECL
+
+    int tile_parity = 0;
+    for (long long tile = PINN_BID; tile < ntiles; tile += PINN_NBLK, tile_parity ^= 1) {
+        const long long base = tile * T;
+        float* xs_t = xs_base + tile_parity * T * PINN_XS_LD;
+        float* xs_next = xs_base + (tile_parity ^ 1) * T * PINN_XS_LD;
         PinnPointPre<ND, N2> ppre;
         if (tid < T) pinn_point_prefetch<ND, N2>(A, base + tid, base + tid < A.n_points, pregs + tid, T, ppre);
         PH(0)
@@ -839,7 +846,9 @@ pinn_tile_kernel(const PinnKArgs A) {
         PINN_SYNC();
         PH(7)
 
-        // ---- (4) ansatz + residual + their reverse, one thread per point ------------------------------------------
+        // ---- (4) ansatz + residual + their reverse, one thread per point; all threads: stage the NEXT tile's points ------
+        store_points(xs_next);
+        fetch_points(tile + 2LL * PINN_NBLK);
         if (tid < T) {
             const int pt = tid;
             float net[S];
@@ -889,7 +898,7 @@ pinn_tile_kernel(const PinnKArgs A) {
                 }
         };
         // (only where S*MT*NTW jets leave register head-room: measured -3 % on cfg2/cfg5, +1..5 % on cfg3/cfg4)
-        constexpr bool SVPF = (S * MT * NTW <= 6);
+        constexpr bool SVPF = (S * MT * NTW <= 8) && !ONEBUF;
         if (SVPF && lh > 0) load_saved(lh - 1, svn);
 #pragma unroll
         for (int j = 0; j < NTW; ++j) {
@@ -1151,7 +1160,6 @@ pinn_tile_kernel(const PinnKArgs A) {
             }
         }
         PH(15)
-        PINN_SYNC();      // the first-layer block reads xs_t; the next tile's staging overwrites it
     }
     PH_FLUSH
 
