@@ -242,3 +242,44 @@ def test_default_sampler_trains_on_device(pa):
     assert len(losses) == 600 and losses[-50:].mean() < 0.05 * losses[:10].mean()
     edge = np.linspace(0, 1, 11).astype(np.float32)
     assert np.abs(solver.predict(edge, 0.0) - 1.0).max() < 1e-6 and np.abs(solver.predict(1.0, edge) - 1.0).max() < 1e-6
+
+
+@pytest.mark.parametrize('case', ['poisson_3x64', 'ode_5x64', 'ode2_4x64', 'heat_4x64', 'poisson_4x64_sigmoid', 'poisson_2x64'])
+def test_other_width_64_shapes_against_the_oracle(pa, case):
+    """ the fast width-64 instantiations beyond the BASELINE shapes (and two shapes that fall to the generic kernels):
+    one fused evaluation vs the oracle's nested autograd """
+    from oracle import pinn_oracle as po
+
+    def make(D):
+        if case.startswith('poisson'):
+            depth = {'poisson_3x64': 3, 'poisson_4x64_sigmoid': 4, 'poisson_2x64': 2}[case]
+            act = 'Sigmoid' if 'sigmoid' in case else 'Tanh'
+            eq = lambda f, x, y: D(D(f, x), x) + 2 * D(D(f, y), y) - torch.exp(-x) * torch.sin(np.pi * y)
+            kw = dict(ndims=2, boundary_condition=0.3, layout='fa' * depth + 'f', features=[64] * depth + [1], activation=act)
+        elif case == 'ode_5x64':
+            eq = lambda f, x, e: D(f, x) - e * np.pi * torch.cos(e * np.pi * x)
+            kw = dict(ndims=1, nparams=1, initial_condition=1.5, layout='fa' * 5 + 'f', features=[64] * 5 + [1], activation='Tanh')
+        elif case == 'ode2_4x64':
+            eq = lambda f, x: D(D(f, x), x) + 4 * f - torch.sin(3 * x)
+            kw = dict(ndims=1, boundary_condition=0.0, layout='fa' * 4 + 'f', features=[64] * 4 + [1], activation='Tanh')
+        else:
+            eq = lambda f, x, y, t: D(D(f, x), x) + D(D(f, y), y) - 0.5 * D(f, t)
+            kw = dict(ndims=3, boundary_condition=0, initial_condition=lambda x, y: x * y * (1 - x) * (1 - y),
+                      layout='fa' * 4 + 'f', features=[64] * 4 + [1], activation='Tanh')
+        return eq, kw
+    eq_o, kw = make(po.D)
+    torch.manual_seed(11)
+    oracle = po.OracleSolver(eq_o, **kw)
+    eq_p, kw = make(pa.D)
+    solver = pa.Solver(eq_p, **kw)
+    assert solver.program is not None, solver.program_error
+    load_params(solver, oracle.export_params())
+    d = solver.model.total
+    pts = (np.random.RandomState(5).rand(2000, d) + (np.arange(d) >= kw['ndims'])).astype(np.float32)
+    ev = oracle.evaluate(pts)
+    solver._fused_step(torch.from_numpy(pts).cuda(), 1)
+    lay = solver.model.net.layout
+    assert abs(float(solver.grads[lay.off_loss]) - ev['loss']) <= 1e-5 * ev['loss']
+    for got, want in zip(export_grads(solver), oracle.export_grads()):
+        if want is not None:
+            assert rel_l2(got, want) < 1e-4
