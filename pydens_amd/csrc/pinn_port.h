@@ -37,10 +37,6 @@ PINN_DEVICE float pinn_row_sum16(float v) {
     v += __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, v), 0x140, 0xF, 0xF, true));
     return v;
 }
-// LDS accumulate shared by several waves (ds_add_f32, no return value)
-PINN_DEVICE void pinn_lds_add(float* p, float v) {
-    (void)__hip_atomic_fetch_add(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-}
 // 2^x and 1/x at hardware precision (v_exp_f32 / v_rcp_f32, ~1 ulp)
 PINN_DEVICE float pinn_exp2(float x) { return __builtin_amdgcn_exp2f(x); }
 PINN_DEVICE float pinn_rcp(float x) { return __builtin_amdgcn_rcpf(x); }

@@ -193,15 +193,6 @@ class Net:
             views.append((w, b))
         return views
 
-    def real_mask(self, device):
-        """ uint8 [p_total]: 1 where the flat buffer holds a real network parameter (not padding / loss slot). """
-        mask = torch.zeros(self.layout.p_total, dtype=torch.uint8, device=device)
-        for w, b in self.param_views(mask):
-            w.fill_(1)
-            b.fill_(1)
-        mask[self.layout.off_log_scale] = 1
-        return mask
-
     # ---- kernels ----------------------------------------------------------------------------------------------------
     def _dirs(self, dir_cols):
         dir_cols = list(dir_cols)

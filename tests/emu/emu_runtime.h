@@ -37,7 +37,6 @@ void launch(int grid, int block, size_t smem_bytes, const std::function<void()>&
 static inline f32x4 pinn_mfma16(float a, float b, f32x4 c) { return emu::mfma16(a, b, c); }
 static inline float pinn_shfl_xor(float v, int mask) { return emu::shfl_xor(v, mask); }
 static inline float pinn_row_sum16(float v) { return emu::row_sum16(v); }
-static inline void pinn_lds_add(float* p, float v) { *p += v; }
 static inline float pinn_exp2(float x) { return exp2f(x); }
 static inline float pinn_rcp(float x) { return 1.0f / x; }
 #define PINN_LAUNCH_BOUNDS2(n, w)
