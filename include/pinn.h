@@ -22,9 +22,10 @@
  *   host exposes per-layer nn.Parameter views into this one buffer; padded entries stay zero (Adam mask).
  *   Gradient buffers use the same layout; `loss_slot` receives sum(r^2)/N of the step.
  *
- * Derivative streams (what D(...) needs, model_torch.py:174-178): stream 0 = u; 1..nd = du/dx_c along
- * direction k (input column dir_cols[k]); 1+nd..nd+n2 = d2u/dx_c2 for the first n2 directions.
- * Stream arrays are stream-major: [S][N], S = 1 + nd + n2.
+ * Derivative streams (what D(...) needs, model_torch.py:174-178): stream 0 = u; 1..nd = first derivative along
+ * direction k; 1+nd..nd+n2 = second derivative along the first n2 directions. A direction dir_cols[k] is an input
+ * column c (value c) or the diagonal e_a + e_b of two columns (value a | (b + 1) << 4): the host obtains mixed partials
+ * by polarisation, u_ab = (u_vv - u_aa - u_bb) / 2.  Stream arrays are stream-major: [S][N], S = 1 + nd + n2.
  */
 #ifndef PINN_H
 #define PINN_H

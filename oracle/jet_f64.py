@@ -9,7 +9,8 @@ section 3). This file is the plain-numpy, double-precision statement of exactly 
 
 Stream order (shared with the kernels): index 0 = value; 1..ND = first derivative along direction k;
 1+ND..ND+N2 = second derivative along direction k < N2 (directions that need a second derivative come first).
-`dir_cols[k]` is the input column that direction k differentiates.
+`dir_cols[k]` is the input column that direction k differentiates, or a pair (a, b) for the diagonal direction
+e_a + e_b (mixed partials: u_ab = (u_vv - u_aa - u_bb) / 2).
 """
 import numpy as np
 
@@ -47,6 +48,11 @@ class Spec:
         self.S = 1 + self.nd + self.n2
 
 
+def _cols(direction):
+    """ input columns of a differentiation direction: an int (column) or a pair (a, b) = the diagonal e_a + e_b """
+    return (direction,) if isinstance(direction, (int, np.integer)) else tuple(direction)
+
+
 def mlp_jet_forward(sp, xs):
     """ xs [N,d] -> net streams [S,N]; cache for the reverse sweep. """
     N = xs.shape[0]
@@ -57,7 +63,7 @@ def mlp_jet_forward(sp, xs):
     z = np.zeros((sp.S, N, W.shape[0]))
     z[0] = xs @ W.T + b
     for k, c in enumerate(sp.dir_cols):
-        z[1 + k] = W[:, c][None, :]
+        z[1 + k] = sum(W[:, j] for j in _cols(c))[None, :]
     h_prev = None
     for l in range(L - 1):
         if l > 0:
@@ -109,7 +115,8 @@ def mlp_jet_backward(sp, gnet, fwd_cache):
         else:
             g = gz[0].T @ xs                                             # value stream: z0 = W x + b
             for k, c in enumerate(sp.dir_cols):
-                g[:, c] += gz[1 + k].sum(axis=0)                         # z_k = W[:, col_k]
+                for j in _cols(c):
+                    g[:, j] += gz[1 + k].sum(axis=0)                     # z_k = sum of W[:, col] over the direction
             dW[0] = g
     return dW, db
 
@@ -126,14 +133,19 @@ def _bc_factors(sp, xs):
         p2[j] = -2.0 / (w * w)
     P = np.prod(p, axis=0) if sp.nsp else np.ones(N)
     Pk = np.zeros((sp.nd, N)); Pkk = np.zeros((sp.nd, N))
+    def rest(*skip):
+        out = np.ones(N)
+        for j in range(sp.nsp):
+            if j not in skip:
+                out = out * p[j]
+        return out
     for k, c in enumerate(sp.dir_cols):
-        if c < sp.nsp:
-            rest = np.ones(N)
-            for j in range(sp.nsp):
-                if j != c:
-                    rest = rest * p[j]
-            Pk[k] = p1[c] * rest
-            Pkk[k] = p2[c] * rest
+        sp_cols = [j for j in _cols(c) if j < sp.nsp]
+        for j in sp_cols:
+            Pk[k] += p1[j] * rest(j)
+            Pkk[k] += p2[j] * rest(j)
+        if len(sp_cols) == 2:                                            # diagonal direction: cross term 2 P_ab
+            Pkk[k] += 2.0 * p1[sp_cols[0]] * p1[sp_cols[1]] * rest(*sp_cols)
     return P, Pk, Pkk
 
 
@@ -150,7 +162,7 @@ def _ic_gate(sp, xs):
     dG_ds = -tau * d1
     dGk_ds = np.zeros((sp.nd, N)); dGkk_ds = np.zeros((sp.nd, N))
     for k, c in enumerate(sp.dir_cols):
-        if c == tcol:
+        if tcol in _cols(c):
             Gk[k] = d1 * es
             Gkk[k] = d2 * es * es
             dGk_ds[k] = es * (-tau * d2 - d1)

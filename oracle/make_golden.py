@@ -19,7 +19,7 @@ sys.path.insert(0, ROOT)
 import pinn_configs as pc                                   # noqa: E402
 from oracle.reference_loader import load_reference          # noqa: E402
 
-GOLDEN_N = dict(cfg1=100, cfg2=256, cfg3=128, cfg4=256, cfg5=64, ode_sigmoid=128)
+GOLDEN_N = dict(cfg1=100, cfg2=256, cfg3=128, cfg4=256, cfg5=64, ode_sigmoid=128, mixed=128)
 K_STEPS = 5
 LR = 0.005
 
@@ -46,7 +46,10 @@ def main():
     ref = load_reference()
     out_dir = os.path.join(ROOT, 'tests', 'golden')
     os.makedirs(out_dir, exist_ok=True)
+    only = sys.argv[1:]                                      # `python -m oracle.make_golden mixed`: just these fixtures
     for idx, name in enumerate(GOLDEN_N):
+        if only and name not in only:
+            continue
         torch.manual_seed(100 + idx)
         cfg = pc.make_config(name, ref.D, torch)
         solver = ref.Solver(cfg['equation'], **cfg['solver_kwargs'])

@@ -35,6 +35,12 @@ def stream_form(name):
             d = np.zeros_like(u); d[4] = 1.0; d[3] = -1.0
             return r, d
         return dict(dir_cols=[0, 1], n2=2, residual=residual)
+    if name == 'mixed':                              # u_xx + u_xy + 2 u_yy - sin(3xy); dirs x, y, (x,y) diagonal v:
+        def residual(u, xs):                         # streams u,ux,uy,uv,uxx,uyy,uvv ; u_xy = (uvv - uxx - uyy) / 2
+            r = 0.5 * u[4] + 1.5 * u[5] + 0.5 * u[6] - np.sin(3.0 * xs[:, 0] * xs[:, 1])
+            d = np.zeros_like(u); d[4] = 0.5; d[5] = 1.5; d[6] = 0.5
+            return r, d
+        return dict(dir_cols=[0, 1, (0, 1)], n2=3, residual=residual)
     raise KeyError(name)
 
 

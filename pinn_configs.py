@@ -1,4 +1,4 @@
-""" The five BASELINE.json workloads in pydens form (equation callable + Solver kwargs + point sampler).
+""" The five BASELINE.json workloads (+ two parity-only extras) in pydens form (equation callable + Solver kwargs + point sampler).
 
 Neutral module: depends on neither the product package nor the oracle. `D` and `torch` are passed in so the
 same definitions drive the reference, the oracle and the HIP engine. Column order is pydens' (spatial..., t,
@@ -47,6 +47,13 @@ def make_config(name, D, torch):
             return D(f, x) - e * PI * torch.cos(e * PI * x)
         return dict(equation=equation, solver_kwargs=dict(ndims=1, nparams=1, initial_condition=2.0),
                     n_points=700, low=[0, .5], high=[1, 5.5])
+    if name == 'mixed':                                          # anisotropic diffusion tensor [[1, .5], [.5, 2]]:
+        def equation(f, x, y):                                   # a mixed partial D(D(f, x), y)
+            return D(D(f, x), x) + D(D(f, x), y) + 2 * D(D(f, y), y) - torch.sin(3 * x * y)
+        return dict(equation=equation,
+                    solver_kwargs=dict(ndims=2, boundary_condition=0.5, layout='fa fa f', features=[24, 24, 1],
+                                       activation='Tanh'),
+                    n_points=4096, low=[0, 0], high=[1, 1])
     raise KeyError(name)
 
 

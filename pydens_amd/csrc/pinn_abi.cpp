@@ -119,8 +119,12 @@ void fill_args(const pinn_net* net, PinnKArgs* a, const float* params, const flo
 
 int check_dirs(const pinn_net* net, const int* dir_cols, int nd, int n2) {
     if (nd < 0 || nd > PINN_MAX_DIRS || n2 < 0 || n2 > nd) return fail("bad derivative spec nd=%d n2=%d", nd, n2);
-    for (int k = 0; k < nd; ++k)
-        if (!dir_cols || dir_cols[k] < 0 || dir_cols[k] >= net->lay.d) return fail("dir_cols[%d] out of range", k);
+    for (int k = 0; k < nd; ++k) {
+        // direction code: column a, or the diagonal e_a + e_b as a | (b + 1) << 4 (include/pinn.h)
+        if (!dir_cols || dir_cols[k] < 0 || dir_cols[k] > 255) return fail("dir_cols[%d] out of range", k);
+        const int a = dir_cols[k] & 15, b = ((dir_cols[k] >> 4) & 15) - 1;
+        if (a >= net->lay.d || b >= net->lay.d || a == b) return fail("dir_cols[%d] names a column outside the %d inputs", k, net->lay.d);
+    }
     return 0;
 }
 

@@ -280,7 +280,7 @@ pinn_duo_kernel(const PinnKArgs A) {
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
 #pragma unroll
-                for (int k = 0; k < ND; ++k) sv[1 + k][r] = W1s[(n0 + r) * PINN_XS_LD + A.dir_cols[k]];
+                for (int k = 0; k < ND; ++k) sv[1 + k][r] = pinn_dir_weight(W1s + (n0 + r) * PINN_XS_LD, A.dir_cols[k]);
 #pragma unroll
                 for (int k = 0; k < N2; ++k) sv[1 + ND + k][r] = 0.0f;
             }
@@ -330,7 +330,7 @@ pinn_duo_kernel(const PinnKArgs A) {
                     f32x4 v = gz0[0] * xprev[lr * PINN_XS_LD + c];
 #pragma unroll
                     for (int kk = 0; kk < ND; ++kk)
-                        if (A.dir_cols[kk] == c) v += gz0[1 + kk];
+                        if (pinn_dir_has(A.dir_cols[kk], c)) v += gz0[1 + kk];
 #pragma unroll
                     for (int r = 0; r < 4; ++r) {
                         const float t = pinn_row_sum16(v[r]);
@@ -349,7 +349,7 @@ pinn_duo_kernel(const PinnKArgs A) {
                     for (int c = 0; c < d; ++c) z0 = fmaf(W1s[n * PINN_XS_LD + c], x[c], z0);
                     z[0] = z0;
 #pragma unroll
-                    for (int kk = 0; kk < ND; ++kk) z[1 + kk] = W1s[n * PINN_XS_LD + A.dir_cols[kk]];
+                    for (int kk = 0; kk < ND; ++kk) z[1 + kk] = pinn_dir_weight(W1s + n * PINN_XS_LD, A.dir_cols[kk]);
 #pragma unroll
                     for (int kk = 0; kk < N2; ++kk) z[1 + ND + kk] = 0.0f;
                     pinn_jet_fwd<ND, N2>(z, act, h);

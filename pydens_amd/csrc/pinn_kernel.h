@@ -121,6 +121,17 @@ PINN_DEVICE float pinn_act_d3(float v, float d1, float d2, int act) {
     return d1 * (q * q - 2.0f * d1);
 }
 
+// A differentiation direction is an input column c or the diagonal e_a + e_b of two columns (mixed partials by
+// polarisation: u_ab = (u_vv - u_aa - u_bb) / 2 with v = e_a + e_b). Code: a | (b + 1) << 4, b + 1 == 0 for a single column.
+PINN_DEVICE int pinn_dir_a(int code) { return code & 15; }
+PINN_DEVICE int pinn_dir_b(int code) { return ((code >> 4) & 15) - 1; }
+PINN_DEVICE bool pinn_dir_has(int code, int c) { return pinn_dir_a(code) == c || pinn_dir_b(code) == c; }
+// first-layer pre-activation derivative along a direction: sum of the weight columns it contains
+PINN_DEVICE float pinn_dir_weight(const float* w1row, int code) {
+    const int b = pinn_dir_b(code);
+    return w1row[pinn_dir_a(code)] + (b >= 0 ? w1row[b] : 0.0f);
+}
+
 // Second-order streams. Standard form: stream 1+ND+k is d2/dx_k2 for k < N2. COMB form (N2 == 1): ONE stream
 // sum_k c_k d2/dx_k2 over all ND directions with run-time weights c_k (a Laplacian / wave / heat operator needs only
 // that combination, which saves N2-1 streams through every GEMM). Both are instances of "second stream j collects
@@ -340,17 +351,34 @@ PINN_DEVICE void pinn_point_stage(const PinnKArgs& A, const float (&net)[1 + ND 
         }
 #pragma unroll
         for (int k = 0; k < ND; ++k) {
-            const int c = A.dir_cols[k];
-            if (c < A.nsp) {
-                float rest = 1.0f, q1 = 0.0f, q2 = 0.0f;
+            // directional derivatives of P = prod_j p_j along e_a (+ e_b): first = sum_c p'_c prod_{j != c} p_j,
+            // second = sum_c p''_c prod_{j != c} p_j + 2 p'_a p'_b prod_{j != a,b} p_j (columns outside the spatial block: 0)
+            const int ca = pinn_dir_a(A.dir_cols[k]), cb = pinn_dir_b(A.dir_cols[k]);
+            float first = 0.0f, second = 0.0f, cross = 2.0f;
+            bool both = true;
 #pragma unroll
-                for (int j = 0; j < PINN_MAX_INPUTS; ++j) {
-                    if (j == c) { q1 = p1[j]; q2 = p2[j]; }
-                    else rest *= p[j];
+            for (int t = 0; t < 2; ++t) {
+                const int c = t == 0 ? ca : cb;
+                if (c >= 0 && c < A.nsp) {
+                    float rest = 1.0f, q1 = 0.0f, q2 = 0.0f;
+#pragma unroll
+                    for (int j = 0; j < PINN_MAX_INPUTS; ++j) {
+                        if (j == c) { q1 = p1[j]; q2 = p2[j]; }
+                        else rest *= p[j];
+                    }
+                    first += q1 * rest;
+                    second += q2 * rest;
+                } else {
+                    both = false;
                 }
-                Pk[k] = q1 * rest;
-                Pkk[k] = q2 * rest;
             }
+            if (both) {
+#pragma unroll
+                for (int j = 0; j < PINN_MAX_INPUTS; ++j) cross *= (j == ca || j == cb) ? p1[j] : p[j];
+                second += cross;
+            }
+            Pk[k] = first;
+            Pkk[k] = second;
         }
     }
     // ---- Q = net * P + bc ---------------------------------------------------------------------------------
@@ -386,7 +414,7 @@ PINN_DEVICE void pinn_point_stage(const PinnKArgs& A, const float (&net)[1 + ND 
         dG = -tau * d1;
 #pragma unroll
         for (int k = 0; k < ND; ++k) {
-            if (A.dir_cols[k] == tcol) {
+            if (pinn_dir_has(A.dir_cols[k], tcol)) {
                 Gk[k] = d1 * es; Gkk[k] = d2 * es * es;
                 dGk[k] = es * (-tau * d2 - d1);
                 dGkk[k] = es * es * (-tau * d3 - 2.0f * d2);
@@ -703,7 +731,7 @@ pinn_tile_kernel(const PinnKArgs A) {
                     }
                     z[0] = z0;
 #pragma unroll
-                    for (int k = 0; k < ND; ++k) z[1 + k] = W1s[n * PINN_XS_LD + A.dir_cols[k]];
+                    for (int k = 0; k < ND; ++k) z[1 + k] = pinn_dir_weight(W1s + n * PINN_XS_LD, A.dir_cols[k]);
 #pragma unroll
                     for (int k = 0; k < N2; ++k) z[1 + ND + k] = 0.0f;
                     pinn_jet_fwd<ND, N2, COMB>(z, act, h, cw);
@@ -887,7 +915,7 @@ pinn_tile_kernel(const PinnKArgs A) {
                         for (int r = 0; r < 4; ++r) {
 #pragma unroll
                             for (int k = 0; k < ND; ++k)
-                                dst[j][mt][1 + k][r] = W1s[(unit0(j) + r) * PINN_XS_LD + A.dir_cols[k]];
+                                dst[j][mt][1 + k][r] = pinn_dir_weight(W1s + (unit0(j) + r) * PINN_XS_LD, A.dir_cols[k]);
 #pragma unroll
                             for (int k = 0; k < N2; ++k) dst[j][mt][1 + ND + k][r] = 0.0f;
                         }
@@ -1149,7 +1177,7 @@ pinn_tile_kernel(const PinnKArgs A) {
                         v += gz[j][mt][0] * xs_t[(mt * 16 + lr) * PINN_XS_LD + c];
 #pragma unroll
                         for (int k = 0; k < ND; ++k)
-                            if (A.dir_cols[k] == c) v += gz[j][mt][1 + k];
+                            if (pinn_dir_has(A.dir_cols[k], c)) v += gz[j][mt][1 + k];
                     }
 #pragma unroll
                     for (int r = 0; r < 4; ++r) {

@@ -134,11 +134,16 @@ class Solver:
         """ run the user's callable on stream tensors [S,N] (+ optional IC streams), D resolves to streams. """
         total = self.model.total
         sc = trace.StreamContext(total)
+        full = {}
         for alpha, idx in self.spec.index.items():
             t = streams[idx].view(-1, 1)
             if ic_streams is not None and ic_streams[idx] is not None:
                 t = t + ic_streams[idx]
-            sc.tag(t, alpha)
+            full[idx] = t
+            if all(isinstance(c, int) for c in alpha):          # ('d', a, b) diagonal streams are not user-visible
+                sc.tag(t, alpha)
+        for ab, (ivv, iaa, ibb) in self.spec.mixed.items():      # u_ab = (u_vv - u_aa - u_bb) / 2
+            sc.tag(0.5 * (full[ivv] - full[iaa] - full[ibb]), ab)
         cols = []
         for c in range(total):
             col = xs[:, c:c + 1]
@@ -163,16 +168,22 @@ class Solver:
         out = [None] * spec.n_streams
         out[0] = val.view(-1, 1) if val.numel() > 1 else val.reshape(1, 1).expand(xs.shape[0], 1)
         if val.numel() > 1 and val.requires_grad:
-            for k, c in enumerate(spec.dir_cols):
-                if c >= m.ndims_spatial:
-                    continue
-                (g1,) = torch.autograd.grad(val.sum(), cols[c], create_graph=True, retain_graph=True, allow_unused=True)
+            def along(f, direction):
+                """ directional derivative of f over the SPATIAL columns of a direction (IC ignores t / parameters) """
+                total = None
+                for c in direction:
+                    if c < m.ndims_spatial and f is not None and f.requires_grad:
+                        (g,) = torch.autograd.grad(f.sum(), cols[c], create_graph=True, retain_graph=True, allow_unused=True)
+                        if g is not None:
+                            total = g if total is None else total + g
+                return total
+            for k, direction in enumerate(spec.dirs):
+                g1 = along(val, direction)
                 if g1 is None:
                     continue
                 out[1 + k] = g1.view(-1, 1)
-                if k < spec.n2 and g1.requires_grad:
-                    (g2,) = torch.autograd.grad(g1.sum(), cols[c], create_graph=create_graph, retain_graph=True,
-                                                    allow_unused=True)
+                if k < spec.n2:
+                    g2 = along(g1, direction)
                     if g2 is not None:
                         out[1 + spec.nd + k] = g2.view(-1, 1)
         if not create_graph:

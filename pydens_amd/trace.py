@@ -33,34 +33,52 @@ class TraceUnsupported(Exception):
 # ---------------------------------------------------------------------------------------------------------------
 # stream bookkeeping
 # ---------------------------------------------------------------------------------------------------------------
+def dir_code(direction):
+    """ ABI code of a differentiation direction: column a, or the diagonal e_a + e_b as a | (b + 1) << 4. """
+    return direction[0] if len(direction) == 1 else direction[0] | ((direction[1] + 1) << 4)
+
+
 class StreamSpec:
     """ Which derivative streams the kernels must produce. Multi-indices are sorted tuples of input columns:
-    () = u, (c,) = du/dx_c, (c, c) = d2u/dx_c2. Directions needing a second derivative come first. """
+    () = u, (c,) = du/dx_c, (c, c) = d2u/dx_c2, (a, b) = mixed partial. The kernels differentiate along
+    *directions*: an input column, or -- for a mixed partial -- the diagonal e_a + e_b, whose second derivative
+    u_vv = u_aa + 2 u_ab + u_bb yields u_ab = (u_vv - u_aa - u_bb) / 2 (stream index keyed ('d', a, b)).
+    Directions needing a second derivative come first. """
     def __init__(self, requested):
-        firsts, seconds = set(), set()
+        firsts, seconds, mixed = set(), set(), set()
         for alpha in requested:
             if len(alpha) == 1:
                 firsts.add(alpha[0])
             elif len(alpha) == 2 and alpha[0] == alpha[1]:
-                seconds.add(alpha[0]); firsts.add(alpha[0])
-            elif len(alpha) > 0:
+                seconds.add(alpha[0])
+            elif len(alpha) == 2:
+                mixed.add(tuple(alpha)); seconds.update(alpha)
+            elif len(alpha) > 2:
                 raise NotImplementedError(
-                    f'derivative multi-index {alpha}: the HIP kernels provide pure first and second derivatives '
-                    '(mixed and third-order streams are listed under "next" in DESIGN.md)')
-        self.dir_cols = sorted(seconds) + sorted(firsts - seconds)
-        self.n2 = len(seconds)
-        self.nd = len(self.dir_cols)
+                    f'derivative multi-index {alpha}: the HIP kernels provide first and second derivatives '
+                    '(third order is listed under "next" in DESIGN.md)')
+        firsts |= seconds
+        self.dirs = ([(c,) for c in sorted(seconds)] + sorted(mixed) + [(c,) for c in sorted(firsts - seconds)])
+        self.n2 = len(seconds) + len(mixed)
+        self.nd = len(self.dirs)
         if self.nd > MAX_DIRS:
-            raise NotImplementedError(f'{self.nd} differentiated variables > {MAX_DIRS} supported by the kernels')
+            raise NotImplementedError(f'{self.nd} differentiation directions ({self.dirs}) > {MAX_DIRS} supported by the '
+                                      'kernels (each mixed partial costs one extra direction)')
+        self.dir_cols = [dir_code(d) for d in self.dirs]
         self.n_streams = 1 + self.nd + self.n2
         self.index = {(): 0}
-        for k, c in enumerate(self.dir_cols):
-            self.index[(c,)] = 1 + k
-            if k < self.n2:
-                self.index[(c, c)] = 1 + self.nd + k
+        for k, d in enumerate(self.dirs):
+            if len(d) == 1:
+                self.index[(d[0],)] = 1 + k
+                if k < self.n2:
+                    self.index[(d[0], d[0])] = 1 + self.nd + k
+            else:
+                self.index[('d',) + d] = 1 + self.nd + k
+        self.mixed = {ab: (self.index[('d',) + ab], self.index[(ab[0], ab[0])], self.index[(ab[1], ab[1])])
+                      for ab in sorted(mixed)}
 
     def __repr__(self):
-        return f'StreamSpec(dir_cols={self.dir_cols}, n2={self.n2})'
+        return f'StreamSpec(dirs={self.dirs}, n2={self.n2})'
 
 
 class StreamContext:
@@ -217,8 +235,14 @@ class Sym:
 
 def sym_D(y, x):
     """ `D` on symbolic operands: only d(stream)/d(input column). """
-    if isinstance(y, Sym) and y.kind == 'stream' and isinstance(x, Sym) and x.kind == 'input':
-        return Sym('stream', alpha=tuple(sorted(y.alpha + (x.col,))))
+    if (isinstance(y, Sym) and y.kind == 'stream' and isinstance(x, Sym) and x.kind == 'input'
+            and all(isinstance(c, int) for c in y.alpha)):
+        alpha = tuple(sorted(y.alpha + (x.col,)))
+        if len(alpha) == 2 and alpha[0] != alpha[1]:
+            # mixed partial by polarisation over the diagonal direction e_a + e_b
+            a, b = alpha
+            return (Sym('stream', alpha=('d', a, b)) - Sym('stream', alpha=(a, a)) - Sym('stream', alpha=(b, b))) * 0.5
+        return Sym('stream', alpha=alpha)
     raise TraceUnsupported('D of a composite expression')
 
 

@@ -51,3 +51,11 @@ def export_grads(solver):
 def make_solver(name, pa, **kwargs):
     cfg = pc.make_config(name, pa.D, torch)
     return cfg, pa.Solver(cfg['equation'], **cfg['solver_kwargs'], **kwargs)
+
+
+def fit_rtol(name):
+    """ tolerance of a K-step Adam trajectory against the reference's fp32 golden losses. 2e-5 everywhere, except the
+    `mixed` fixture: there the REFERENCE's own fp32 trajectory sits 2.4e-5 off the fp64 trajectory at step 3
+    (0.07043399 vs 0.07043566; Adam's g/sqrt(g^2) turns rounding of near-zero gradients into +-lr moves) while the
+    kernels stay within 5e-6 of fp64 -- so the bound has to cover the fixture's noise, not ours. """
+    return 4e-5 if name == 'mixed' else 2e-5

@@ -8,11 +8,11 @@ import torch
 
 import pinn_configs as pc
 from conftest import Golden, rel_l2
-from helpers import FixedBatches, export_grads, export_params, load_params, make_solver
+from helpers import FixedBatches, export_grads, export_params, fit_rtol, load_params, make_solver
 
 pytestmark = pytest.mark.gpu
 
-SUPPORTED = ('cfg1', 'cfg2', 'cfg3', 'cfg4', 'cfg5', 'ode_sigmoid')
+SUPPORTED = ('cfg1', 'cfg2', 'cfg3', 'cfg4', 'cfg5', 'ode_sigmoid', 'mixed')
 
 
 @pytest.fixture(scope='module')
@@ -59,9 +59,9 @@ def test_fit_matches_reference_golden(pa, name, path):
     solver.fit(niters=len(g.losses), batch_size=g.points.shape[1], sampler=FixedBatches(g.points), lr=g.lr)
     assert solver.last_fit_path == path
     losses = np.array([float(v) for v in solver.losses])
-    np.testing.assert_allclose(losses, g.losses, rtol=2e-5)
+    np.testing.assert_allclose(losses, g.losses, rtol=fit_rtol(name))
     for got, want in zip(export_params(solver), g.finals):
-        assert rel_l2(got, want) < 2e-5
+        assert rel_l2(got, want) < fit_rtol(name)
 
 
 def test_streams_match_fp64_jets(pa):
@@ -155,13 +155,14 @@ def test_adam_matches_torch(pa):
     assert int(step) == 20
 
 
-@pytest.mark.parametrize('which', ['nonlinear', 'variable_coefficient'])
+@pytest.mark.parametrize('which', ['nonlinear', 'variable_coefficient', 'mixed_affine', 'mixed_nonlinear'])
 def test_residual_kinds_match_the_oracle(pa, which):
     """ residual PROGRAM (nonlinear Burgers-type, interpreter inside the tile kernel) and AFFINE residual with
     x-dependent coefficients (pre-pass rows) against the oracle's nested autograd on the same points """
     from oracle import pinn_oracle as po
-    from test_emu_engine import _nonlinear_problem, _variable_coefficient_problem
-    problem, kind = (_nonlinear_problem, 0) if which == 'nonlinear' else (_variable_coefficient_problem, 1)
+    import test_emu_engine as te
+    problem, kind = dict(nonlinear=(te._nonlinear_problem, 0), variable_coefficient=(te._variable_coefficient_problem, 1),
+                         mixed_affine=(te._mixed_affine_problem, 1), mixed_nonlinear=(te._mixed_nonlinear_problem, 0))[which]
     eq_o, kw = problem(po.D, torch)
     oracle = po.OracleSolver(eq_o, **kw)
     eq_p, kw = problem(pa.D, torch)

@@ -26,11 +26,20 @@ def test_discover_poisson_heat_wave():
     assert (spec.dir_cols, spec.n2, spec.n_streams) == ([0], 0, 2)
 
 
-def test_mixed_partials_are_rejected_loudly():
-    with pytest.raises(NotImplementedError, match='mixed'):
-        trace.discover(lambda f, x, y: D(D(f, x), y), run, 2)
-    with pytest.raises(NotImplementedError):
+def test_mixed_partials_take_a_diagonal_direction():
+    spec, _ = trace.discover(lambda f, x, y: D(D(f, x), y), run, 2)
+    assert spec.dirs == [(0,), (1,), (0, 1)] and spec.n2 == 3
+    assert spec.dir_cols == [0, 1, 0 | (1 + 1) << 4]                       # ABI direction codes (include/pinn.h)
+    assert spec.mixed == {(0, 1): (spec.index[('d', 0, 1)], spec.index[(0, 0)], spec.index[(1, 1)])}
+    eq = lambda f, x, y: D(D(f, x), x) + D(D(f, y), x) + 2 * D(D(f, y), y)
+    spec, _ = trace.discover(eq, run, 2)
+    plan = trace.lower_residual(trace.symbolic(eq, run, 2), spec, 2)
+    assert trace.combine_second_order(plan, spec)
+    np.testing.assert_allclose(plan.comb_w, [0.5, 1.5, 0.5])               # u_xy = (u_vv - u_xx - u_yy) / 2
+    with pytest.raises(NotImplementedError, match='third order'):
         trace.discover(lambda f, x: D(D(D(f, x), x), x), run, 1)
+    with pytest.raises(NotImplementedError, match='directions'):           # 3 columns + 2 diagonals > 3 directions
+        trace.discover(lambda f, x, y, z: D(D(f, x), y) + D(D(f, y), z), run, 3)
 
 
 def test_non_field_D_uses_autograd_fallback():
