@@ -47,8 +47,12 @@ extern "C" {
 #define PINN_MAX_STREAMS  7    /* 1 + nd + n2 */
 #define PINN_MAX_AUX      8    /* per-point rows produced by the x-only pre-pass */
 
+#define PINN_MAX_SKIPS    4    /* skip connections ('R ... +') per net */
+
 #define PINN_ACT_TANH     0
 #define PINN_ACT_SIGMOID  1
+#define PINN_ACT_SIN      2
+#define PINN_ACT_IDENTITY 3    /* no 'a' between two 'f' of the layout */
 
 typedef struct pinn_net pinn_t;
 
@@ -118,6 +122,13 @@ typedef struct pinn_residual {
 int pinn_create(const int* layer_dims, int n_layers, int act, int ndims, int nparams,
                 int has_bc, int has_ic, const float* dom_lo, const float* dom_hi, float bc_value,
                 pinn_t** out);
+/* General form of the descriptor: per-layer activations and skip connections of the reference's layout strings
+ * ('faR fa fa+ f', model_torch.py:143-156).  acts[a], a = 0 .. n_layers-2, is the activation after hidden layer a
+ * (PINN_ACT_*).  Skip k adds the output of activation skip_src[k] to the output of activation skip_dst[k]
+ * (0 <= src < dst <= n_layers-2, equal widths, intervals not overlapping: dst[k] <= src[k+1]). */
+int pinn_create_ex(const int* layer_dims, int n_layers, const int* acts, int n_skips, const int* skip_src,
+                   const int* skip_dst, int ndims, int nparams, int has_bc, int has_ic, const float* dom_lo,
+                   const float* dom_hi, float bc_value, pinn_t** out);
 int pinn_destroy(pinn_t* net);
 int pinn_layout(const pinn_t* net, pinn_layout_t* out);
 

@@ -40,21 +40,21 @@ def V(name, *args, **kwargs):
     return getattr(model, name)
 
 
+def _shim_block():
+    """ the batchflow stand-in's Block (oracle/batchflow_shim, the same class the reference is run with) """
+    import importlib.util
+    import os
+    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'batchflow_shim', 'batchflow', 'models', 'torch',
+                        '__init__.py')
+    spec = importlib.util.spec_from_file_location('_oracle_batchflow_block', path)
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    return mod.Block
+
+
 def build_mlp(n_in, layout, features, activation):
-    """ 'f' -> nn.Linear (PyTorch default init), 'a' -> activation module; spaces ignored. """
-    features = list(features)
-    layers = []
-    for letter in layout.replace(' ', ''):
-        if letter == 'f':
-            n_out = features.pop(0)
-            layers.append(nn.Linear(n_in, n_out, bias=True))
-            n_in = n_out
-        elif letter == 'a':
-            act = getattr(nn, activation) if isinstance(activation, str) else activation
-            layers.append(act() if isinstance(act, type) else act)
-        else:
-            raise NotImplementedError(letter)
-    return nn.Sequential(*layers)
+    """ 'f' -> nn.Linear (PyTorch default init), 'a' -> activation module, 'R' / '+' skip connection; spaces ignored. """
+    return _shim_block()(inputs=torch.zeros((2, n_in)), layout=layout, features=list(features), activation=activation)
 
 
 class OracleModel(nn.Module):

@@ -33,13 +33,17 @@ def _stale(target, deps):
 
 def build(force=False, verbose=False, extra_flags=(), out=None, obj_dir=None, widths=WIDTHS):
     global OUT, OBJ
+    import fcntl
     OUT_, OBJ_ = OUT, OBJ
     if out is not None:
         OUT, OBJ = out, obj_dir or (out + '.obj')
-    try:
-        return _build(force, verbose, extra_flags, widths)
-    finally:
-        OUT, OBJ = OUT_, OBJ_
+    os.makedirs(OBJ, exist_ok=True)
+    with open(os.path.join(OBJ, '.lock'), 'w') as lock:          # concurrent builds (pytest + a shell) share the objects
+        fcntl.flock(lock, fcntl.LOCK_EX)
+        try:
+            return _build(force, verbose, extra_flags, widths)
+        finally:
+            OUT, OBJ = OUT_, OBJ_
 
 
 def _build(force, verbose, extra_flags, widths):

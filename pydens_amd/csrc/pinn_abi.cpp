@@ -35,7 +35,9 @@ int g_pinn_debug_flags = 0;
 
 struct pinn_net {
     pinn_layout_t lay;
-    int n_layers, act, ndims, nparams, has_bc, has_ic, nsp;
+    int n_layers, act, ndims, nparams, has_bc, has_ic, nsp;      // act: uniform activation code or -1
+    unsigned act_codes;                                           // 2 bits per activation index
+    int n_skips, skip_src[PINN_MAX_SKIPS], skip_dst[PINN_MAX_SKIPS];
     int dims[PINN_MAX_LAYERS + 1];
     float lo[PINN_MAX_INPUTS], hi[PINN_MAX_INPUTS], bc_value;
     int n_cu;
@@ -81,6 +83,8 @@ int make_plan(const pinn_net* net, int64_t n_points, int nd, int n2, Plan* plan,
     memset(&probe, 0, sizeof(probe));
     probe.lh = net->lay.lh;
     probe.act = net->act;
+    probe.act_codes = net->act_codes;
+    probe.n_skips = net->n_skips;
     probe.mode = mode;
     probe.res_kind = res_kind;
     probe.comb = comb;
@@ -104,7 +108,9 @@ void fill_args(const pinn_net* net, PinnKArgs* a, const float* params, const flo
     memset(a, 0, sizeof(*a));
     const pinn_layout_t& L = net->lay;
     a->params = params; a->xs = xs; a->ic_streams = ic_streams; a->n_points = n;
-    a->lh = L.lh; a->d = L.d; a->act = net->act;
+    a->lh = L.lh; a->d = L.d; a->act = net->act; a->act_codes = net->act_codes;
+    a->n_skips = net->n_skips;
+    for (int k = 0; k < PINN_MAX_SKIPS; ++k) { a->skip_src[k] = net->skip_src[k]; a->skip_dst[k] = net->skip_dst[k]; }
     a->off_b1 = L.off_b1; a->off_wh = L.off_wh; a->hidden_stride = L.hidden_stride; a->off_wl = L.off_wl;
     a->off_bl = L.off_bl; a->off_ls = L.off_log_scale; a->off_loss = L.off_loss; a->p_core = L.p_core;
     a->ndims = net->ndims; a->nsp = net->nsp; a->has_bc = net->has_bc; a->has_ic = net->has_ic;
@@ -202,9 +208,30 @@ const char* pinn_backend(void) {
 
 int pinn_create(const int* layer_dims, int n_layers, int act, int ndims, int nparams, int has_bc, int has_ic,
                 const float* dom_lo, const float* dom_hi, float bc_value, pinn_t** out) {
-    if (!layer_dims || !out) return fail("null argument");
     if (n_layers < 2 || n_layers > PINN_MAX_LAYERS) return fail("n_layers=%d outside [2, %d]", n_layers, PINN_MAX_LAYERS);
-    if (act != PINN_ACT_TANH && act != PINN_ACT_SIGMOID) return fail("unknown activation code %d", act);
+    int acts[PINN_MAX_LAYERS];
+    for (int a = 0; a < PINN_MAX_LAYERS; ++a) acts[a] = act;
+    return pinn_create_ex(layer_dims, n_layers, acts, 0, nullptr, nullptr, ndims, nparams, has_bc, has_ic, dom_lo, dom_hi,
+                          bc_value, out);
+}
+
+int pinn_create_ex(const int* layer_dims, int n_layers, const int* acts, int n_skips, const int* skip_src,
+                   const int* skip_dst, int ndims, int nparams, int has_bc, int has_ic, const float* dom_lo,
+                   const float* dom_hi, float bc_value, pinn_t** out) {
+    if (!layer_dims || !out || !acts) return fail("null argument");
+    if (n_layers < 2 || n_layers > PINN_MAX_LAYERS) return fail("n_layers=%d outside [2, %d]", n_layers, PINN_MAX_LAYERS);
+    for (int a = 0; a + 1 < n_layers; ++a)
+        if (acts[a] < PINN_ACT_TANH || acts[a] > PINN_ACT_IDENTITY) return fail("unknown activation code %d (activation %d)", acts[a], a);
+    if (n_skips < 0 || n_skips > PINN_MAX_SKIPS || (n_skips > 0 && (!skip_src || !skip_dst)))
+        return fail("n_skips=%d outside [0, %d]", n_skips, PINN_MAX_SKIPS);
+    for (int k = 0; k < n_skips; ++k) {
+        if (skip_src[k] < 0 || skip_src[k] >= skip_dst[k] || skip_dst[k] > n_layers - 2)
+            return fail("skip %d: activations %d -> %d outside 0 <= src < dst <= %d", k, skip_src[k], skip_dst[k], n_layers - 2);
+        if (layer_dims[skip_src[k] + 1] != layer_dims[skip_dst[k] + 1])
+            return fail("skip %d joins widths %d and %d", k, layer_dims[skip_src[k] + 1], layer_dims[skip_dst[k] + 1]);
+        if (k > 0 && skip_dst[k - 1] > skip_src[k]) return fail("skip connections %d and %d overlap (nested skips are not supported)", k - 1, k);
+    }
+    const int act = acts[0];
     const int d = ndims + nparams;
     if (ndims < 1 || nparams < 0 || d > PINN_MAX_INPUTS) return fail("ndims+nparams=%d outside [1, %d]", d, PINN_MAX_INPUTS);
     if (layer_dims[0] != d) return fail("layer_dims[0]=%d must equal ndims+nparams=%d", layer_dims[0], d);
@@ -224,6 +251,12 @@ int pinn_create(const int* layer_dims, int n_layers, int act, int ndims, int npa
     if (!net) return fail("out of memory");
     memset(net, 0, sizeof(*net));
     net->n_layers = n_layers; net->act = act; net->ndims = ndims; net->nparams = nparams;
+    for (int a = 0; a + 1 < n_layers; ++a) {
+        net->act_codes |= (unsigned)acts[a] << (2 * a);
+        if (acts[a] != act) net->act = -1;
+    }
+    net->n_skips = n_skips;
+    for (int k = 0; k < n_skips; ++k) { net->skip_src[k] = skip_src[k]; net->skip_dst[k] = skip_dst[k]; }
     net->has_bc = has_bc ? 1 : 0; net->has_ic = has_ic ? 1 : 0; net->bc_value = bc_value;
     net->nsp = has_ic ? ndims - 1 : ndims;
     for (int l = 0; l <= n_layers; ++l) net->dims[l] = layer_dims[l];

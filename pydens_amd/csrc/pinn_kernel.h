@@ -38,7 +38,10 @@ struct PinnKArgs {
     long long* prof;             // optional per-phase cycle counters (PINN_PROFILE_PHASES builds only)
     int debug_flags;             // bit 0: two-team kernel runs team 0 only (experiments)
     long long n_points;
-    int lh, d, act, mode;
+    int lh, d, act, mode;        // act: the activation code shared by every layer, or -1 when they differ (act_codes)
+    unsigned act_codes;          // 2 bits per activation index a = 0..lh (a = 0: first layer)
+    int n_skips;                 // skip connections 'R ... +': h_out[skip_dst] += h_out[skip_src] (activation indices)
+    int skip_src[PINN_MAX_SKIPS], skip_dst[PINN_MAX_SKIPS];
     int off_b1, off_wh, hidden_stride, off_wl, off_bl, off_ls, off_loss, p_core;
     int ndims, nsp, has_bc, has_ic;
     float bc_value, t0, ic_const, inv_n;
@@ -94,8 +97,9 @@ struct PinnCfg {
     PINN_HOST_DEVICE static constexpr int smem_floats(int lh_static) {
         return SMEM_FLOATS + (wt_fits(lh_static) ? lh_static * HP * WT_LD : 0);
     }
-    PINN_HOST_DEVICE static constexpr size_t slab_vec4_per_wg(int lh) {
-        return (size_t)(lh + 1) * S * NTW * MT * NTHREADS;
+    // one slot of S jets per activation (+ one per skip connection: the skipped activations, later their gradient)
+    PINN_HOST_DEVICE static constexpr size_t slab_vec4_per_wg(int lh, int n_skips = 0) {
+        return (size_t)(lh + 1 + n_skips) * S * NTW * MT * NTHREADS;
     }
 };
 
@@ -109,16 +113,28 @@ PINN_DEVICE float pinn_act(float z, int act) {
         const float e = pinn_exp2(z * 2.8853900817779268f);       // 2 log2(e)
         return 1.0f - 2.0f * pinn_rcp(1.0f + e);
     }
-    return pinn_rcp(1.0f + pinn_exp2(z * -1.4426950408889634f));
+    if (act == PINN_ACT_SIGMOID) return pinn_rcp(1.0f + pinn_exp2(z * -1.4426950408889634f));
+    if (act == PINN_ACT_SIN) return sinf(z);
+    return z;                                                     // PINN_ACT_IDENTITY ('f f': no activation in between)
 }
-PINN_DEVICE void pinn_act_d12(float v, int act, float& d1, float& d2) {
-    if (act == PINN_ACT_TANH) { d1 = 1.0f - v * v; d2 = -2.0f * v * d1; }
-    else { d1 = v * (1.0f - v); d2 = d1 * (1.0f - 2.0f * v); }
+// what the reverse half keeps of an activation: its VALUE (tanh, sigmoid, identity: all derivatives follow from it) or,
+// for sin, the pre-activation (cos z is not a function of sin z)
+PINN_DEVICE float pinn_act_saved(float v, float z, int act) { return act == PINN_ACT_SIN ? z : v; }
+PINN_DEVICE float pinn_act_value(float saved, int act) { return act == PINN_ACT_SIN ? sinf(saved) : saved; }
+PINN_DEVICE void pinn_act_d12(float sv, int act, float& d1, float& d2) {
+    if (act == PINN_ACT_TANH) { d1 = 1.0f - sv * sv; d2 = -2.0f * sv * d1; }
+    else if (act == PINN_ACT_SIGMOID) { d1 = sv * (1.0f - sv); d2 = d1 * (1.0f - 2.0f * sv); }
+    else if (act == PINN_ACT_SIN) { d1 = cosf(sv); d2 = -sinf(sv); }
+    else { d1 = 1.0f; d2 = 0.0f; }
 }
-PINN_DEVICE float pinn_act_d3(float v, float d1, float d2, int act) {
-    if (act == PINN_ACT_TANH) return d1 * (6.0f * v * v - 2.0f);
-    const float q = 1.0f - 2.0f * v;
-    return d1 * (q * q - 2.0f * d1);
+PINN_DEVICE float pinn_act_d3(float sv, float d1, float d2, int act) {
+    if (act == PINN_ACT_TANH) return d1 * (6.0f * sv * sv - 2.0f);
+    if (act == PINN_ACT_SIGMOID) {
+        const float q = 1.0f - 2.0f * sv;
+        return d1 * (q * q - 2.0f * d1);
+    }
+    if (act == PINN_ACT_SIN) return -d1;
+    return 0.0f;
 }
 
 // A differentiation direction is an input column c or the diagonal e_a + e_b of two columns (mixed partials by
@@ -150,7 +166,7 @@ PINN_DEVICE void pinn_jet_fwd(const float (&z)[1 + ND + N2], int act, float (&h)
     using J = PinnJet<ND, N2, COMB>;
     const float v = pinn_act(z[0], act);
     float d1, d2;
-    pinn_act_d12(v, act, d1, d2);
+    pinn_act_d12(pinn_act_saved(v, z[0], act), act, d1, d2);
     h[0] = v;
 #pragma unroll
     for (int k = 0; k < ND; ++k) h[1 + k] = d1 * z[1 + k];
@@ -168,7 +184,7 @@ PINN_DEVICE void pinn_jet_recompute(const float (&sv)[1 + ND + N2], int act, flo
     using J = PinnJet<ND, N2, COMB>;
     float d1, d2;
     pinn_act_d12(sv[0], act, d1, d2);
-    h[0] = sv[0];
+    h[0] = pinn_act_value(sv[0], act);
 #pragma unroll
     for (int k = 0; k < ND; ++k) h[1 + k] = d1 * sv[1 + k];
 #pragma unroll
@@ -552,7 +568,9 @@ PINN_DEVICE f32x4 pinn_ld4(const float* p) { return *reinterpret_cast<const f32x
 PINN_DEVICE void pinn_st4(float* p, f32x4 v) { *reinterpret_cast<f32x4*>(p) = v; }
 
 // VAR (experiment bits): 1 = accumulate dW in the partial buffer although the layer count is static, 2 = two waves per
-// SIMD (two workgroups per CU), 4 = no whole-layer weight prefetch.
+// SIMD (two workgroups per CU), 4 = no whole-layer weight prefetch; 8 = layout breadth: Sin / identity activations and
+// skip connections ('R ... +' layouts; the skipped activations ride in registers through the forward half and in extra
+// slab slots through the reverse half).
 template <int HP, int ND, int N2, int MT, int LHC, int ACTC, bool COMB = false, int VAR = 0>
 // occupancy hint: the fused kernel of a 64/128-wide net wants the whole register file of a SIMD (one wave per SIMD,
 // no spills); narrower nets (1-2 waves per workgroup) run several workgroups per CU
@@ -564,13 +582,29 @@ PINN_GLOBAL void PINN_LAUNCH_BOUNDS2((PinnCfg<HP, ND, N2, MT>::NTHREADS),
 pinn_tile_kernel(const PinnKArgs A) {
     using C = PinnCfg<HP, ND, N2, MT>;
     constexpr int S = C::S, NT = C::NT, NTW = C::NTW, NW = C::NW, T = C::T, LDA = C::LDA, NTHREADS = C::NTHREADS;
-    constexpr bool DWG = (LHC < 0) || (VAR & 1), ONEBUF = C::ONEBUF;
+    constexpr bool DWG = (LHC < 0) || (VAR & 1), ONEBUF = C::ONEBUF, SKIPS = (VAR & 8) != 0;
     constexpr int LHREG = DWG ? 1 : PINN_LHMAX;            // layers with register-resident dW accumulators
     constexpr bool WTL = C::wt_fits(LHC);                  // transposed hidden weights staged in LDS
     const int tid = PINN_TID, lane = tid & 63, wave = tid >> 6;
     const int lr = lane & 15, lq = lane >> 4;
-    const int act = (ACTC >= 0) ? ACTC : A.act;
     const int lh = (LHC >= 0) ? LHC : A.lh;
+    // activation of index a (0: first layer ... lh: last hidden layer)
+    // (plain instantiations only know tanh / sigmoid -- one bit, which lets the compiler drop the sin / identity paths;
+    //  the full set runs on the VAR 8 instantiations, see the launcher)
+    auto act_at = [&](int a) -> int {
+        return (ACTC >= 0) ? ACTC : (int)((A.act_codes >> (2 * a)) & (SKIPS ? 3u : 1u));
+    };
+    // skip connection ending / starting at activation a (or -1); slab slot of skip k
+    auto skip_into = [&](int a) -> int {
+        int k = -1;
+        if (SKIPS) for (int i = 0; i < A.n_skips; ++i) if (A.skip_dst[i] == a) k = i;
+        return k;
+    };
+    auto skip_from = [&](int a) -> int {
+        int k = -1;
+        if (SKIPS) for (int i = 0; i < A.n_skips; ++i) if (A.skip_src[i] == a) k = i;
+        return k;
+    };
     const float* cw = A.comb_w;
     const int d = A.d;
     const bool train = A.mode != PINN_MODE_FORWARD;
@@ -635,7 +669,7 @@ pinn_tile_kernel(const PinnKArgs A) {
     for (int j = 0; j < NTW; ++j) accWL[j] = f32x4{0.f, 0.f, 0.f, 0.f};
     float sum_loss = 0.0f, sum_ls = 0.0f, sum_bl = 0.0f;
 
-    f32x4* slab = A.slab ? A.slab + (size_t)PINN_BID * C::slab_vec4_per_wg(lh) : nullptr;
+    f32x4* slab = A.slab ? A.slab + (size_t)PINN_BID * C::slab_vec4_per_wg(lh, SKIPS ? A.n_skips : 0) : nullptr;
     auto slab_at = [&](int a, int s, int j, int mt) -> f32x4* {
         return slab + ((((size_t)a * S + s) * NTW + j) * MT + mt) * NTHREADS + tid;
     };
@@ -687,7 +721,10 @@ pinn_tile_kernel(const PinnKArgs A) {
         f32x4 svtop[NTW][MT][S];       // saved jets of the LAST hidden activation: they never leave the registers
         f32x4 htop[NTW][MT][S];        // ... and its activations (last-layer dot and dWL need them again)
         // whole-layer weight fragments are fetched one phase ahead (L2 latency hidden behind the previous epilogue)
-        constexpr bool WPF = (NW <= 4) && !(VAR & 4);
+        // (not in the VAR 8 kernels: with the four-way activation code between the prefetch and its first use, hipcc
+        //  7.2 produced a width-64 kernel whose last prefetched K quad arrived wrong on gfx950 -- reproducible, cured by
+        //  -amdgpu-waitcnt-forcezero, by dropping the prefetch, or by the two-way activation)
+        constexpr bool WPF = (NW <= 4) && !(VAR & 4) && !(VAR & 8);
         constexpr int NQ = HP / 16;
         f32x4 wall[WPF ? NQ : 1][NTW];
         f32x4 biasn[NTW];              // bias of the NEXT hidden layer, fetched with its weights
@@ -701,6 +738,8 @@ pinn_tile_kernel(const PinnKArgs A) {
                     wall[q][j] = pinn_ld4(Wl + ((wave * NTW + j) * 16 + lr) * HP + 16 * q + 4 * lq);
         };
         if (WPF && lh > 0) load_wall(A.params + A.off_wh);
+        f32x4 hskip[SKIPS ? NTW : 1][SKIPS ? MT : 1][S];      // activations carried by the open skip connection
+        const int act0 = act_at(0);
         // ---- (1) first layer on the VALU: z0 = W1 x + b1, z_k = W1[:, col_k], z_kk = 0 ------------------------
 #pragma unroll
         for (int j = 0; j < NTW; ++j) {
@@ -734,9 +773,13 @@ pinn_tile_kernel(const PinnKArgs A) {
                     for (int k = 0; k < ND; ++k) z[1 + k] = pinn_dir_weight(W1s + n * PINN_XS_LD, A.dir_cols[k]);
 #pragma unroll
                     for (int k = 0; k < N2; ++k) z[1 + ND + k] = 0.0f;
-                    pinn_jet_fwd<ND, N2, COMB>(z, act, h, cw);
+                    pinn_jet_fwd<ND, N2, COMB>(z, act0, h, cw);
 #pragma unroll
-                    for (int s = 0; s < S; ++s) { hv[s][r] = h[s]; sv[s][r] = (s == 0) ? h[0] : z[s]; }
+                    for (int s = 0; s < S; ++s) { hv[s][r] = h[s]; sv[s][r] = (s == 0) ? pinn_act_saved(h[0], z[0], act0) : z[s]; }
+                }
+                if (SKIPS && skip_from(0) >= 0) {
+#pragma unroll
+                    for (int s = 0; s < S; ++s) hskip[SKIPS ? j : 0][SKIPS ? mt : 0][s] = hv[s];
                 }
 #pragma unroll
                 for (int s = 0; s < S; ++s) pinn_st4(cur + (s * T + pt) * LDA + n0, hv[s]);
@@ -762,6 +805,7 @@ pinn_tile_kernel(const PinnKArgs A) {
         for (int li = 0; li < lh; ++li) {
             const float* Wl = A.params + A.off_wh + (size_t)li * A.hidden_stride;
             const float* bl = Wl + HP * HP;
+            const int act = act_at(li + 1), sk_in = skip_into(li + 1), sk_out = skip_from(li + 1);
             f32x4 acc[NTW][MT][S];
 #pragma unroll
             for (int j = 0; j < NTW; ++j)
@@ -826,7 +870,20 @@ pinn_tile_kernel(const PinnKArgs A) {
                         z[0] += bias[r];
                         pinn_jet_fwd<ND, N2, COMB>(z, act, h, cw);
 #pragma unroll
-                        for (int s = 0; s < S; ++s) { hv[s][r] = h[s]; sv[s][r] = (s == 0) ? h[0] : z[s]; }
+                        for (int s = 0; s < S; ++s) { hv[s][r] = h[s]; sv[s][r] = (s == 0) ? pinn_act_saved(h[0], z[0], act) : z[s]; }
+                    }
+                    if (SKIPS && sk_in >= 0) {
+                        // '+': add the activations saved at 'R'; the reverse half needs them again (slab slot of the skip)
+#pragma unroll
+                        for (int s = 0; s < S; ++s) {
+                            const f32x4 hs = hskip[SKIPS ? j : 0][SKIPS ? mt : 0][s];
+                            hv[s] += hs;
+                            if (train) *slab_at(lh + 1 + sk_in, s, j, mt) = hs;
+                        }
+                    }
+                    if (SKIPS && sk_out >= 0) {
+#pragma unroll
+                        for (int s = 0; s < S; ++s) hskip[SKIPS ? j : 0][SKIPS ? mt : 0][s] = hv[s];
                     }
                     if (li + 1 == lh) {
 #pragma unroll
@@ -949,6 +1006,21 @@ pinn_tile_kernel(const PinnKArgs A) {
         //          accumulators are addressed statically (they must stay in registers) ----------------------------
         auto act_reverse = [&](int a, f32x4 (&gz)[NTW][MT][S]) {
             // gz_a = jet-reverse(gh, saved_a);  db_a += sum_pt gz_a,0 (DPP row sum over the 16 points of the lane row)
+            const int act = act_at(a);
+            if (SKIPS) {
+                // h_out(a) feeds a later '+': its gradient arrives through the skip slot; h_out(a) = act(z_a) + skipped
+                // activations: the whole gradient is handed down the skip (slot re-used: its activations are consumed)
+                const int k_out = skip_from(a), k_in = skip_into(a);
+#pragma unroll
+                for (int j = 0; j < NTW; ++j)
+#pragma unroll
+                    for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+                        for (int s = 0; s < S; ++s) {
+                            if (k_out >= 0) g[j][mt][s] += *slab_at(lh + 1 + k_out, s, j, mt);
+                            if (k_in >= 0) *slab_at(lh + 1 + k_in, s, j, mt) = g[j][mt][s];
+                        }
+            }
 #pragma unroll
             for (int j = 0; j < NTW; ++j) {
                 f32x4 bsum = f32x4{0.f, 0.f, 0.f, 0.f};
@@ -982,6 +1054,7 @@ pinn_tile_kernel(const PinnKArgs A) {
             // recompute h_{a-1} from its saved jets (kept in sv for the next step); stage h_{a-1} and gz_a for the GEMMs
             f32x4 hv[NTW][MT][S];
             if (!SVPF) load_saved(a - 1, svn);
+            const int act = act_at(a - 1), sk_prev = skip_into(a - 1);
 #pragma unroll
             for (int j = 0; j < NTW; ++j) {
                 const int n0 = unit0(j);
@@ -997,6 +1070,10 @@ pinn_tile_kernel(const PinnKArgs A) {
                         pinn_jet_recompute<ND, N2, COMB>(sv1, act, h, cw);
 #pragma unroll
                         for (int s = 0; s < S; ++s) hv[j][mt][s][r] = h[s];
+                    }
+                    if (SKIPS && sk_prev >= 0) {
+#pragma unroll
+                        for (int s = 0; s < S; ++s) hv[j][mt][s] += *slab_at(lh + 1 + sk_prev, s, j, mt);
                     }
                 }
             }

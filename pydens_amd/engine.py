@@ -17,7 +17,7 @@ MAX_LAYERS, MAX_INPUTS, MAX_DIRS, EXTRA_SLOTS = 16, 8, 3, 16
 MAX_OPS, MAX_CONSTS, MAX_REGS = 64, 32, 40
 MAX_STREAMS, MAX_AUX = 7, 8
 RES_PROGRAM, RES_AFFINE = 0, 1
-ACT_CODES = {'tanh': 0, 'sigmoid': 1}
+ACT_CODES = {'tanh': 0, 'sigmoid': 1, 'sin': 2, 'identity': 3}
 
 OPS = dict(CONST=0, ADD=1, SUB=2, MUL=3, DIV=4, NEG=5, SIN=6, COS=7, EXP=8, LOG=9, TANH=10, SQRT=11, POW=12,
            ABS=13, SIGMOID=14, RECIP=15, COPY=16, STORE=17)
@@ -77,6 +77,8 @@ def bind(lib):
     lib.pinn_backend.restype = ctypes.c_char_p
     lib.pinn_create.argtypes = [ip, i32, i32, i32, i32, i32, i32, ctypes.POINTER(f32), ctypes.POINTER(f32), f32,
                                 ctypes.POINTER(vp)]
+    lib.pinn_create_ex.argtypes = [ip, i32, ip, i32, ip, ip, i32, i32, i32, i32, ctypes.POINTER(f32), ctypes.POINTER(f32),
+                                   f32, ctypes.POINTER(vp)]
     lib.pinn_destroy.argtypes = [vp]
     lib.pinn_layout.argtypes = [vp, ctypes.POINTER(Layout)]
     lib.pinn_workspace_bytes.argtypes = [vp, i64, i32, i32]
@@ -91,13 +93,13 @@ def bind(lib):
     lib.pinn_profile_tile.argtypes = [i32]
     lib.pinn_profile_tile.restype = i32
     lib.pinn_last_tile_ms.restype = f32
-    for name in ('pinn_create', 'pinn_destroy', 'pinn_layout', 'pinn_jet_forward', 'pinn_jet_backward',
+    for name in ('pinn_create', 'pinn_create_ex', 'pinn_destroy', 'pinn_layout', 'pinn_jet_forward', 'pinn_jet_backward',
                  'pinn_residual_step', 'pinn_residual_adam_step', 'pinn_adam_step'):
         getattr(lib, name).restype = i32
     return lib
 
 
-ABI_SYMBOLS = ('pinn_create', 'pinn_destroy', 'pinn_layout', 'pinn_workspace_bytes', 'pinn_jet_forward',
+ABI_SYMBOLS = ('pinn_create', 'pinn_create_ex', 'pinn_destroy', 'pinn_layout', 'pinn_workspace_bytes', 'pinn_jet_forward',
                'pinn_jet_backward', 'pinn_residual_step', 'pinn_residual_adam_step', 'pinn_adam_step', 'pinn_profile_tile', 'pinn_last_tile_ms',
                'pinn_last_error', 'pinn_backend')
 
@@ -143,18 +145,29 @@ def _check(t, name, dtype=torch.float32):
 class Net:
     """ pinn_t handle + its flat padded parameter layout. """
     def __init__(self, layer_dims, activation, ndims, nparams=0, has_bc=False, bc_value=0.0, has_ic=False,
-                 domain=None, lib=None):
+                 domain=None, lib=None, skips=()):
+        """ activation: one name for every hidden layer or a sequence with one name per hidden layer;
+        skips: (src, dst) hidden-layer indices, output of dst += output of src ('R ... +' layouts). """
         self.lib = lib if lib is not None else load_library()
-        act = ACT_CODES.get(str(activation).lower())
-        if act is None:
-            raise NotImplementedError(f'activation {activation!r}: the HIP kernels implement Tanh and Sigmoid')
+        n_hidden = len(layer_dims) - 2
+        names = [activation] * n_hidden if isinstance(activation, str) else list(activation)
+        if len(names) != n_hidden:
+            raise ValueError(f'{n_hidden} hidden layers need {n_hidden} activations, got {names}')
+        codes = [ACT_CODES.get(str(name).lower()) for name in names]
+        if None in codes:
+            raise NotImplementedError(f'activation {names[codes.index(None)]!r}: the HIP kernels implement Tanh, Sigmoid '
+                                      'and Sin (and the identity)')
+        skips = sorted(skips)
         domain = list(domain) if domain is not None else [(0.0, 1.0)] * ndims
         dims = (ctypes.c_int * len(layer_dims))(*layer_dims)
         lo = (ctypes.c_float * ndims)(*[float(d[0]) for d in domain])
         hi = (ctypes.c_float * ndims)(*[float(d[1]) for d in domain])
         handle = ctypes.c_void_p()
-        rc = self.lib.pinn_create(dims, len(layer_dims) - 1, act, ndims, nparams, int(has_bc), int(has_ic), lo, hi,
-                                  float(bc_value), ctypes.byref(handle))
+        acts = (ctypes.c_int * max(1, n_hidden))(*codes)
+        src = (ctypes.c_int * max(1, len(skips)))(*[s for s, _ in skips])
+        dst = (ctypes.c_int * max(1, len(skips)))(*[d for _, d in skips])
+        rc = self.lib.pinn_create_ex(dims, len(layer_dims) - 1, acts, len(skips), src, dst, ndims, nparams, int(has_bc),
+                                     int(has_ic), lo, hi, float(bc_value), ctypes.byref(handle))
         self._raise(rc)
         self.handle = handle
         lay = Layout()

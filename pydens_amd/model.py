@@ -82,30 +82,73 @@ class FlatLinear(nn.Module):
         return nn.functional.linear(x, self.weight, self.bias)
 
 
+def _activation_name(act):
+    if isinstance(act, str):
+        return act
+    if isinstance(act, type):
+        return act.__name__
+    if isinstance(act, nn.Module):
+        return type(act).__name__
+    if act is torch.sin:
+        return 'Sin'
+    if act is torch.tanh:
+        return 'Tanh'
+    if act is torch.sigmoid:
+        return 'Sigmoid'
+    raise NotImplementedError(f'activation {act!r}: the HIP kernels implement Tanh, Sigmoid and Sin')
+
+
 def parse_fc_layout(layout, features, activation):
-    """ 'fa fa f' -> widths; only alternating dense/activation layouts ending in a 1-unit dense layer run on the
-    kernels (reference documents more letters at model_torch.py:142-156; DESIGN.md lists them as out of scope). """
+    """ layout string -> (widths, one activation name per hidden layer, skip connections) for the kernels.
+
+    Letters (reference model_torch.py:142-156): 'f' dense layer, 'a' activation (a shared one or a sequence with one
+    entry per 'a'), 'R' start / '+' end of a skip connection; spaces are ignored. The net must end in a 1-unit dense
+    layer. A hidden 'f' without an 'a' gets the identity. 'R' and '+' must sit right behind an activation (or a '+'),
+    skips join layers of equal width and do not nest; conv letters are out of scope. Skips are returned as
+    (src, dst) hidden-layer indices: the output of layer dst gets the output of layer src added. """
     letters = layout.replace(' ', '')
     features = list(features)
+    if set(letters) - set('faR+'):
+        raise NotImplementedError(f"layout {layout!r}: only 'f' (dense), 'a' (activation), 'R' and '+' (skip) are supported")
     n_f = letters.count('f')
-    if set(letters) - set('fa'):
-        raise NotImplementedError(f"layout {layout!r}: only 'f' (dense) and 'a' (activation) letters are supported")
-    if letters != 'fa' * (n_f - 1) + 'f' or n_f < 2:
-        raise NotImplementedError(f"layout {layout!r}: expected 'fa' repeated and a final 'f' (at least two dense layers)")
+    if n_f < 2 or not letters.endswith('f'):
+        raise NotImplementedError(f"layout {layout!r}: expected at least two dense layers, the last one (1 unit) at the end")
     if len(features) < n_f:
         raise ValueError(f'layout {layout!r} needs {n_f} entries in `features`, got {features}')
     features = features[:n_f]
     if features[-1] != 1:
         raise NotImplementedError('the last dense layer must have one unit (the scalar solution approximation)')
-    if isinstance(activation, (list, tuple)):
-        if len(set(map(str, activation))) != 1:
-            raise NotImplementedError('per-layer activation lists with different activations are not supported')
-        activation = activation[0]
-    if isinstance(activation, type):
-        activation = activation.__name__
-    elif isinstance(activation, nn.Module):
-        activation = type(activation).__name__
-    return features, str(activation)
+    act_list = list(activation) if isinstance(activation, (list, tuple)) else None
+    if act_list is not None and len(act_list) < letters.count('a'):
+        raise ValueError(f'layout {layout!r} needs {letters.count("a")} activations, got {len(act_list)}')
+    acts, skips, open_skip, layer = [], [], None, -1
+    for letter in letters:
+        if letter == 'f':
+            if layer >= 0 and len(acts) == layer:
+                acts.append('Identity')
+            layer += 1
+        elif letter == 'a':
+            if layer < 0 or len(acts) > layer:
+                raise NotImplementedError(f"layout {layout!r}: every 'a' must follow its own dense layer")
+            acts.append(_activation_name(act_list.pop(0) if act_list is not None else activation))
+        else:
+            if layer < 0 or len(acts) != layer + 1:
+                raise NotImplementedError(f"layout {layout!r}: {letter!r} must come right after an activation "
+                                          '(skips join activation outputs)')
+            if letter == 'R':
+                if open_skip is not None:
+                    raise NotImplementedError(f'layout {layout!r}: nested skip connections are not supported')
+                open_skip = layer
+            else:
+                if open_skip is None or open_skip == layer:
+                    raise NotImplementedError(f"layout {layout!r}: '+' needs an open 'R' with a layer in between")
+                if features[open_skip] != features[layer]:
+                    raise ValueError(f"layout {layout!r}: skip connection joins widths {features[open_skip]} and {features[layer]}")
+                skips.append((open_skip, layer))
+                open_skip = None
+    if open_skip is not None:
+        raise ValueError(f"layout {layout!r}: 'R' without a closing '+'")
+    return features, acts, skips
 
 
 class _ModelForward(torch.autograd.Function):
@@ -136,13 +179,13 @@ class ConvBlockModel(TorchModel):
         features = kwargs.pop('units', features)                  # README.md:41-42 spells it `units`
         super().__init__(ndims=ndims, initial_condition=initial_condition, boundary_condition=boundary_condition,
                          domain=domain, nparams=nparams, **kwargs)
-        widths, act_name = parse_fc_layout(layout, features, activation)
-        self.activation_name = act_name
+        widths, act_names, skips = parse_fc_layout(layout, features, activation)
+        self.activation_names, self.skips = act_names, skips
         self.device = torch.device(device) if device is not None else default_device()
         self.layer_dims = [self.total] + widths
-        self.net = engine.Net(self.layer_dims, act_name, ndims, nparams,
+        self.net = engine.Net(self.layer_dims, act_names, ndims, nparams,
                               has_bc=boundary_condition is not None, bc_value=boundary_condition or 0.0,
-                              has_ic=initial_condition is not None, domain=self.domain, lib=lib)
+                              has_ic=initial_condition is not None, domain=self.domain, lib=lib, skips=skips)
         lay = self.net.layout
         # flat kernel buffer; PyTorch-default nn.Linear init drawn in the reference's order
         # (fake inputs first, model_torch.py:167, then the layers of Block, :168)

@@ -313,6 +313,69 @@ def test_mixed_partial_generic_path(pa, emu_lib):
         assert rel_l2(got, want) < 3e-5
 
 
+LAYOUTS = {
+    # docstring example of the reference (model_torch.py:155): skip over two hidden layers
+    'skip': dict(layout='faR fa fa+ f', features=[16, 12, 16, 1], activation='Tanh'),
+    # two skips back to back ('+' output is the next 'R' input), per-layer activations incl. Sin
+    'two_skips': dict(layout='fa R fa + R fa fa + f', features=[16, 16, 16, 16, 1],
+                      activation=['Tanh', 'Sin', 'Sigmoid', 'Tanh']),
+    'sin': dict(layout='fa fa f', features=[16, 16, 1], activation='Sin'),
+    # a hidden dense layer without activation
+    'identity': dict(layout='fa f fa f', features=[16, 16, 16, 1], activation='Tanh'),
+    'skip_to_top_wide': dict(layout='fa R fa fa + f', features=[40, 40, 40, 1], activation='Sigmoid'),
+    # every unit of a 64-wide net real (no zero padding to hide a wrong lane / K quad)
+    'full64': dict(layout='fa R fa fa + f', features=[64, 64, 64, 1], activation=['Sin', 'Tanh', 'Sigmoid']),
+}
+
+
+def _layout_problems(D, torch, which, net):
+    if which == 'poisson':                           # combined second-order stream
+        eq = lambda f, x, y: D(D(f, x), x) + D(D(f, y), y) - 5 * torch.sin(np.pi * (x + y))
+        return eq, dict(ndims=2, boundary_condition=1, **net)
+    eq = lambda f, x, t: D(f, t) + f * D(f, x) - 0.05 * D(D(f, x), x)      # residual program, IC + BC
+    return eq, dict(ndims=2, boundary_condition=0, initial_condition=lambda x: torch.sin(np.pi * x), **net)
+
+
+@pytest.mark.parametrize('net', sorted(LAYOUTS))
+@pytest.mark.parametrize('which', ['poisson', 'burgers'])
+def test_layout_breadth_matches_the_oracle(pa, emu_lib, net, which):
+    """ skip connections 'R ... +', per-layer activation lists, Sin and activation-free dense layers (reference
+    model_torch.py:142-156) against the oracle's nested autograd: fused step, generic step and predict """
+    from oracle import pinn_oracle as po
+    if net in ('skip_to_top_wide', 'full64') and which == 'burgers':
+        pytest.skip('one case per wide net is enough for the emulator')
+    eq_o, kw = _layout_problems(po.D, torch, which, LAYOUTS[net])
+    oracle = po.OracleSolver(eq_o, **kw)
+    eq_p, kw = _layout_problems(pa.D, torch, which, LAYOUTS[net])
+    pts = np.random.RandomState(10).rand(3, 40, 2).astype(np.float32)
+    oracle_start = oracle.export_params()
+    oracle.fit(niters=3, batch_size=40, points=pts, lr=0.01)
+    for path in ('fused', 'generic'):
+        solver = pa.Solver(eq_p, **kw, **emu_kwargs(emu_lib))
+        assert solver.program is not None, solver.program_error
+        if path == 'generic':
+            solver.program = None
+        load_params(solver, oracle_start)
+        solver.fit(niters=3, batch_size=40, sampler=FixedBatches(pts), lr=0.01)
+        assert solver.last_fit_path == path
+        np.testing.assert_allclose([float(v) for v in solver.losses], [float(v) for v in oracle.losses], rtol=3e-5)
+        for got, want in zip(export_params(solver), oracle.export_params()):
+            assert rel_l2(got, want) < 3e-5
+    xs = [pts[0][:, i] for i in range(2)]
+    assert np.abs(solver.predict(*xs) - oracle.predict(*xs)).max() < 2e-5
+
+
+def test_layout_errors_are_loud(pa, emu_lib):
+    for layout, features, exc in [('fa R fa f', [8, 8, 1], ValueError),                   # unclosed skip
+                                  ('fa R fa + f', [8, 12, 1], ValueError),                # widths differ
+                                  ('fa R fa R fa + + f', [8, 8, 8, 1], NotImplementedError),   # nested
+                                  ('R fa fa + f', [8, 8, 1], NotImplementedError),        # skip from the inputs
+                                  ('fa R f + a f', [8, 8, 1], NotImplementedError),       # pre-activation add
+                                  ('ca f', [8, 1], NotImplementedError)]:
+        with pytest.raises(exc):
+            pa.Solver(lambda f, x: pa.D(f, x), ndims=1, layout=layout, features=features, **emu_kwargs(emu_lib))
+
+
 @pytest.mark.parametrize('name', ['cfg4'])          # (Laplacian-type residuals take the combined-stream solo kernel)
 def test_two_team_kernel_agrees_with_solo_kernel(pa, emu_lib, name):
     """ the experimental two-team form of the tile kernel (pinn_duo_kernel.h, off by default) must produce the same

@@ -178,6 +178,70 @@ def test_residual_kinds_match_the_oracle(pa, which):
         assert rel_l2(got, want) < 3e-5
 
 
+@pytest.mark.parametrize('width', [16, 24, 32, 48, 64, 100, 128, 200, 256])
+@pytest.mark.parametrize('depth', [1, 2, 4])
+def test_every_width_and_depth_uses_all_its_units(pa, width, depth):
+    """ predict, loss and parameter gradients of nets whose hidden layers are exactly `width` wide (all padded lanes
+    and K quads of the kernels carry real data) against the oracle: regression test for a width-64 kernel whose last
+    K quad was wrong while narrower (zero-padded) nets passed """
+    from oracle import pinn_oracle as po
+    eq = lambda D: (lambda f, x, t: D(f, t) - 0.1 * D(D(f, x), x) + f * D(f, x))
+    kw = dict(ndims=2, boundary_condition=0, initial_condition=lambda x: torch.sin(np.pi * x),
+              layout='fa' * depth + 'f', features=[width] * depth + [1], activation='Tanh')
+    torch.manual_seed(width * 10 + depth)
+    oracle = po.OracleSolver(eq(po.D), **kw)
+    solver = pa.Solver(eq(pa.D), **kw)
+    assert solver.program is not None, solver.program_error
+    load_params(solver, oracle.export_params())
+    pts = np.random.RandomState(3).rand(1, 500, 2).astype(np.float32)
+    xs = [pts[0][:, i] for i in range(2)]
+    assert np.abs(solver.predict(*xs) - oracle.predict(*xs)).max() < 2e-6
+    loss_o = oracle.evaluate(pts[0])['loss']
+    grads_o = oracle.export_grads()
+    for path in ('fused', 'generic'):
+        if path == 'generic':
+            solver.program = None
+        solver.grads.zero_()
+        xs_dev = torch.from_numpy(pts[0].copy()).cuda()
+        if path == 'fused':
+            solver._fused_step(xs_dev, 1)
+        else:
+            solver._generic_step(xs_dev, ('equation',), (), torch.nn.MSELoss(), 1)
+        lay = solver.model.net.layout
+        assert abs(float(solver.grads[lay.off_loss]) - loss_o) <= 2e-5 * abs(loss_o), path
+        for got, want in zip(export_grads(solver), grads_o):
+            if want is not None:
+                assert rel_l2(got, want) < 2e-4, path
+
+
+@pytest.mark.parametrize('net', ['skip', 'two_skips', 'sin', 'identity', 'skip_to_top_wide', 'full64'])
+@pytest.mark.parametrize('which', ['poisson', 'burgers'])
+def test_layout_breadth_matches_the_oracle(pa, net, which):
+    """ skip connections 'R ... +', per-layer activation lists, Sin, activation-free dense layers (reference
+    model_torch.py:142-156): fused and generic Adam trajectories and predict against the oracle """
+    from oracle import pinn_oracle as po
+    import test_emu_engine as te
+    eq_o, kw = te._layout_problems(po.D, torch, which, te.LAYOUTS[net])
+    oracle = po.OracleSolver(eq_o, **kw)
+    eq_p, kw = te._layout_problems(pa.D, torch, which, te.LAYOUTS[net])
+    pts = np.random.RandomState(10).rand(3, 700, 2).astype(np.float32)
+    start = oracle.export_params()
+    oracle.fit(niters=3, batch_size=700, points=pts, lr=0.01)
+    for path in ('fused', 'generic'):
+        solver = pa.Solver(eq_p, **kw)
+        assert solver.program is not None, solver.program_error
+        if path == 'generic':
+            solver.program = None
+        load_params(solver, start)
+        solver.fit(niters=3, batch_size=700, sampler=FixedBatches(pts), lr=0.01)
+        assert solver.last_fit_path == path
+        np.testing.assert_allclose([float(v) for v in solver.losses], [float(v) for v in oracle.losses], rtol=3e-5)
+        for got, want in zip(export_params(solver), oracle.export_params()):
+            assert rel_l2(got, want) < 3e-5
+    xs = [pts[0][:, i] for i in range(2)]
+    assert np.abs(solver.predict(*xs) - oracle.predict(*xs)).max() < 2e-5
+
+
 def test_deep_network_and_full_size_cfg5(pa):
     """ depth beyond the register-resident accumulators (8 hidden layers) and BASELINE config 5 (6x256) at a larger batch:
     loss and gradients against the oracle evaluated in chunks """

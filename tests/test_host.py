@@ -42,16 +42,28 @@ def test_samplers():
         NumpySampler('no_such_distribution')
 
 
-def test_layout_parsing_errors_are_loud():
+def test_layout_parsing():
     from pydens_amd.model import parse_fc_layout
-    assert parse_fc_layout('fa fa fa f', [10, 12, 15, 1], 'Tanh') == ([10, 12, 15, 1], 'Tanh')
-    assert parse_fc_layout('fafaf', (20, 30, 1), torch.nn.Sigmoid) == ([20, 30, 1], 'Sigmoid')
+    assert parse_fc_layout('fa fa fa f', [10, 12, 15, 1], 'Tanh') == ([10, 12, 15, 1], ['Tanh'] * 3, [])
+    assert parse_fc_layout('fafaf', (20, 30, 1), torch.nn.Sigmoid) == ([20, 30, 1], ['Sigmoid'] * 2, [])
+    # the reference's docstring example with a skip (model_torch.py:155): output of layer 2 += output of layer 0
+    assert parse_fc_layout('faR fa fa+ f', [5, 10, 5, 1], 'Sigmoid') == ([5, 10, 5, 1], ['Sigmoid'] * 3, [(0, 2)])
+    assert parse_fc_layout('fa R fa + R fa + f', [8, 8, 8, 1], ['Tanh', torch.sin, torch.nn.Sigmoid()])[1:] == \
+        (['Tanh', 'Sin', 'Sigmoid'], [(0, 1), (1, 2)])
+    assert parse_fc_layout('ff', [5, 1], 'Sigmoid') == ([5, 1], ['Identity'], [])
+    assert parse_fc_layout('fa f fa f', [5, 4, 3, 1], 'Tanh')[1] == ['Tanh', 'Identity', 'Tanh']
     with pytest.raises(NotImplementedError):
-        parse_fc_layout('faR fa fa+ f', [5, 10, 5, 1], 'Sigmoid')
+        parse_fc_layout('fafaf', [5, 10, 3], 'Sigmoid')              # vector-valued output
     with pytest.raises(NotImplementedError):
-        parse_fc_layout('fafaf', [5, 10, 3], 'Sigmoid')
+        parse_fc_layout('fafa', [5, 1], 'Sigmoid')                   # activation on the output
     with pytest.raises(NotImplementedError):
-        parse_fc_layout('ff', [5, 1], 'Sigmoid')
+        parse_fc_layout('faaf', [5, 1], 'Sigmoid')
+    with pytest.raises(NotImplementedError):
+        parse_fc_layout('cafaf', [5, 5, 1], 'Sigmoid')               # conv letters are out of scope
+    with pytest.raises(ValueError):
+        parse_fc_layout('faR fa+ f', [5, 6, 1], 'Sigmoid')           # skip joins different widths
+    with pytest.raises(ValueError):
+        parse_fc_layout('fafaf', [5, 5, 1], ['Tanh'])                # too few activations
 
 
 def test_domain_validation_matches_reference():
