@@ -98,6 +98,8 @@ def main():
     ap.add_argument('--warmup', type=int, default=20)
     ap.add_argument('--batch', type=int, default=BATCH_PER_GPU)
     ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--unfused', action='store_true',
+                    help='diagnostic: run the N > 1 step path (step, all-reduce, Adam as separate launches) at any N')
     args = ap.parse_args()
 
     import pydens_amd as pa
@@ -111,7 +113,9 @@ def main():
     torch.cuda.set_device(local_rank)
     device = torch.device('cuda', local_rank)
     dist = torch.distributed
-    if world > 1:
+    if world > 1 or args.unfused:
+        if 'MASTER_ADDR' not in os.environ:
+            os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT='29533', RANK='0', WORLD_SIZE='1')
         dist.init_process_group('nccl', device_id=device)
 
     torch.manual_seed(0)
@@ -132,7 +136,7 @@ def main():
         dist.broadcast(model.flat, src=0)
 
     def step(i):
-        if world == 1:
+        if world == 1 and not args.unfused:
             solver._fused_step(pool[i % POOL], 1, adam=solver.optimizer)    # Adam fused into the reduction launch
         else:
             solver._fused_step(pool[i % POOL], world)
@@ -197,7 +201,9 @@ def main():
             'config': {'workload': 'BASELINE cfg2: 2D Poisson u_xx+u_yy=5sin(pi(x+y)), BC=1, 4x64 Tanh MLP, '
                                    f'{n} collocation points per GPU per step, Adam lr 0.005',
                        'points_per_gpu': n, 'global_points': n * world, 'streams': spec.n_streams,
-                       'parallelism': f'dp{world}', 'step_path': 'fused'},
+                       'parallelism': f'dp{world}',
+                       'step_path': 'fused (Adam inside the reduction launch)' if world == 1 and not args.unfused
+                       else 'fused step + all-reduce + Adam launch'},
             'final_loss': loss,
             'roofline': {'bound': 'mfma', 'kernel': KERNEL, 'achieved': achieved,
                          'peak': PEAK_FP32_MFMA_TFLOPS, 'unit': 'TFLOP/s', 'frac': achieved / PEAK_FP32_MFMA_TFLOPS,
@@ -211,7 +217,7 @@ def main():
         if not args.no_cpu_baseline:
             out['cpu_baseline'] = cpu_baseline()
         print(json.dumps(out))
-    if world > 1:
+    if world > 1 or args.unfused:
         dist.destroy_process_group()
 
 

@@ -179,6 +179,12 @@ int pinn_residual_adam_step(pinn_t* net, const pinn_residual_t* residual, float*
  * replayed from a hipGraph; the kernel increments it. */
 int pinn_adam_step(float* params, const float* grads, float* exp_avg, float* exp_avg_sq, const uint8_t* mask,
                    int64_t n, int32_t* step_ptr, float lr, float beta1, float beta2, float eps, void* stream);
+/* Same update with the 1-based step passed by value (the host counts, as torch.optim does): ONE launch instead of
+ * two; the value is also stored to step_ptr[0] so that the forms can be mixed. Data-parallel ranks call this after the
+ * gradient all-reduce. */
+int pinn_adam_step_at(float* params, const float* grads, float* exp_avg, float* exp_avg_sq, const uint8_t* mask,
+                      int64_t n, int32_t* step_ptr, int32_t step, float lr, float beta1, float beta2, float eps,
+                      void* stream);
 
 /* Measurement hook (bench.py `roofline`): with enable != 0 the step/backward entry points bracket their TILE
  * kernel launch with hipEvents on the launch stream; pinn_last_tile_ms() waits for the last bracket and returns

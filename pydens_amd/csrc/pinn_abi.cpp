@@ -488,21 +488,32 @@ int pinn_residual_adam_step(pinn_t* net, const pinn_residual_t* residual, float*
                               1.0f / (float)n_points, grads, workspace, workspace_bytes, stream, &adam);
 }
 
-int pinn_adam_step(float* params, const float* grads, float* exp_avg, float* exp_avg_sq, const uint8_t* mask, int64_t n,
-                   int32_t* step_ptr, float lr, float beta1, float beta2, float eps, void* stream) {
+static int adam_launch(float* params, const float* grads, float* exp_avg, float* exp_avg_sq, const uint8_t* mask, int64_t n,
+                       int32_t* step_ptr, int32_t step, float lr, float beta1, float beta2, float eps, void* stream) {
     if (!params || !grads || !exp_avg || !exp_avg_sq || !step_ptr) return fail("null argument");
     if (n <= 0) return 0;
     const int blocks = (int)((n + 255) / 256);
 #ifdef PINN_EMU
-    emu::launch(1, 64, 0, [&] { pinn_tick_kernel(step_ptr); });
-    emu::launch(blocks, 256, 0, [&] { pinn_adam_kernel(params, grads, exp_avg, exp_avg_sq, mask, n, step_ptr, lr, beta1, beta2, eps); });
+    if (step <= 0) emu::launch(1, 64, 0, [&] { pinn_tick_kernel(step_ptr); });
+    emu::launch(blocks, 256, 0, [&] { pinn_adam_kernel(params, grads, exp_avg, exp_avg_sq, mask, n, step_ptr, step, lr, beta1, beta2, eps); });
 #else
-    hipLaunchKernelGGL(pinn_tick_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, step_ptr);
+    if (step <= 0) hipLaunchKernelGGL(pinn_tick_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, step_ptr);
     hipLaunchKernelGGL(pinn_adam_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, params, grads, exp_avg,
-                       exp_avg_sq, mask, (long long)n, (const int*)step_ptr, lr, beta1, beta2, eps);
+                       exp_avg_sq, mask, (long long)n, (int*)step_ptr, (int)step, lr, beta1, beta2, eps);
     if (hipGetLastError() != hipSuccess) return fail("adam kernel launch failed");
 #endif
     return 0;
+}
+
+int pinn_adam_step(float* params, const float* grads, float* exp_avg, float* exp_avg_sq, const uint8_t* mask, int64_t n,
+                   int32_t* step_ptr, float lr, float beta1, float beta2, float eps, void* stream) {
+    return adam_launch(params, grads, exp_avg, exp_avg_sq, mask, n, step_ptr, 0, lr, beta1, beta2, eps, stream);
+}
+
+int pinn_adam_step_at(float* params, const float* grads, float* exp_avg, float* exp_avg_sq, const uint8_t* mask, int64_t n,
+                      int32_t* step_ptr, int32_t step, float lr, float beta1, float beta2, float eps, void* stream) {
+    if (step < 1) return fail("step must be >= 1");
+    return adam_launch(params, grads, exp_avg, exp_avg_sq, mask, n, step_ptr, step, lr, beta1, beta2, eps, stream);
 }
 
 }  // extern "C"

@@ -93,9 +93,12 @@ PINN_GLOBAL void PINN_LAUNCH_BOUNDS(64) pinn_tick_kernel(int* step_ptr) {
 
 PINN_GLOBAL void PINN_LAUNCH_BOUNDS(256)
 pinn_adam_kernel(float* params, const float* grads, float* m, float* v, const unsigned char* mask, long long n,
-                 const int* step_ptr, float lr, float b1, float b2, float eps) {
+                 int* step_ptr, int step_value, float lr, float b1, float b2, float eps) {
+    // step_value > 0: the host counts (and the count is mirrored to step_ptr); otherwise the count lives on the device
     const long long i = (long long)PINN_BID * 256 + PINN_TID;
+    const int step = step_value > 0 ? step_value : step_ptr[0];
+    if (step_value > 0 && i == 0) step_ptr[0] = step_value;
     if (i >= n) return;
     if (mask && !mask[i]) return;
-    pinn_adam_update(params, grads[i], m, v, i, (double)step_ptr[0], lr, b1, b2, eps);
+    pinn_adam_update(params, grads[i], m, v, i, (double)step, lr, b1, b2, eps);
 }

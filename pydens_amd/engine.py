@@ -88,19 +88,20 @@ def bind(lib):
     lib.pinn_residual_step.argtypes = [vp, ctypes.POINTER(Residual), vp, vp, i64, ip, i32, i32, vp, f32, f32, vp, vp,
                                        ctypes.c_size_t, vp]
     lib.pinn_adam_step.argtypes = [vp, vp, vp, vp, vp, i64, vp, f32, f32, f32, f32, vp]
+    lib.pinn_adam_step_at.argtypes = [vp, vp, vp, vp, vp, i64, vp, i32, f32, f32, f32, f32, vp]
     lib.pinn_residual_adam_step.argtypes = [vp, ctypes.POINTER(Residual), vp, vp, i64, ip, i32, i32, vp, f32, vp, vp, vp, vp,
                                             vp, i32, f32, f32, f32, f32, vp, ctypes.c_size_t, vp]
     lib.pinn_profile_tile.argtypes = [i32]
     lib.pinn_profile_tile.restype = i32
     lib.pinn_last_tile_ms.restype = f32
     for name in ('pinn_create', 'pinn_create_ex', 'pinn_destroy', 'pinn_layout', 'pinn_jet_forward', 'pinn_jet_backward',
-                 'pinn_residual_step', 'pinn_residual_adam_step', 'pinn_adam_step'):
+                 'pinn_residual_step', 'pinn_residual_adam_step', 'pinn_adam_step', 'pinn_adam_step_at'):
         getattr(lib, name).restype = i32
     return lib
 
 
 ABI_SYMBOLS = ('pinn_create', 'pinn_create_ex', 'pinn_destroy', 'pinn_layout', 'pinn_workspace_bytes', 'pinn_jet_forward',
-               'pinn_jet_backward', 'pinn_residual_step', 'pinn_residual_adam_step', 'pinn_adam_step', 'pinn_profile_tile', 'pinn_last_tile_ms',
+               'pinn_jet_backward', 'pinn_residual_step', 'pinn_residual_adam_step', 'pinn_adam_step', 'pinn_adam_step_at', 'pinn_profile_tile', 'pinn_last_tile_ms',
                'pinn_last_error', 'pinn_backend')
 
 _LIB = None
@@ -263,11 +264,17 @@ class Net:
             float(lr), float(betas[0]), float(betas[1]), float(eps), _ptr(workspace),
             workspace.numel() * workspace.element_size(), _stream(xs)))
 
-    def adam_step(self, params, grads, exp_avg, exp_avg_sq, mask, step, lr, betas=(0.9, 0.999), eps=1e-8):
+    def adam_step(self, params, grads, exp_avg, exp_avg_sq, mask, step, lr, betas=(0.9, 0.999), eps=1e-8, at=0):
+        """ `step`: int32 device counter; at > 0: the host's 1-based step count (one launch, counter mirrored) """
         for t, name in ((params, 'params'), (grads, 'grads'), (exp_avg, 'exp_avg'), (exp_avg_sq, 'exp_avg_sq')):
             _check(t, name)
         _check(mask, 'mask', torch.uint8)
         _check(step, 'step', torch.int32)
+        if at > 0:
+            self._raise(self.lib.pinn_adam_step_at(_ptr(params), _ptr(grads), _ptr(exp_avg), _ptr(exp_avg_sq), _ptr(mask),
+                                                   params.numel(), _ptr(step), int(at), float(lr), float(betas[0]),
+                                                   float(betas[1]), float(eps), _stream(params)))
+            return
         self._raise(self.lib.pinn_adam_step(_ptr(params), _ptr(grads), _ptr(exp_avg), _ptr(exp_avg_sq), _ptr(mask),
                                             params.numel(), _ptr(step), float(lr), float(betas[0]), float(betas[1]),
                                             float(eps), _stream(params)))

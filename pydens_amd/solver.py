@@ -43,7 +43,7 @@ class FlatAdam:
     def step(self, grads):
         self.t += 1
         self.model.net.adam_step(self.model.flat, grads, self.exp_avg, self.exp_avg_sq, self.mask, self.step_count,
-                                 self.lr, self.betas, self.eps)
+                                 self.lr, self.betas, self.eps, at=self.t)
 
 
 class TorchOptimizerAdapter:

@@ -141,11 +141,12 @@ def test_adam_matches_torch(emu_lib):
     mask = torch.ones(n, dtype=torch.uint8); mask[::7] = 0
     keep = p.clone()
     net = engine.Net([2, 16, 1], 'tanh', 2, lib=emu_lib)
-    for _ in range(12):
+    for k in range(12):
         grad = torch.randn(n)
         ref.grad = grad.clone()
         opt.step()
-        net.adam_step(p, grad, m, v, mask, step, 0.01)
+        # odd steps: the count lives on the device (two launches); even steps: the host passes it (one launch)
+        net.adam_step(p, grad, m, v, mask, step, 0.01, at=0 if k % 2 == 0 else k + 1)
     live = mask.bool()
     assert torch.equal(p[~live], keep[~live])
     assert rel_l2(p[live].numpy(), ref.detach()[live].numpy()) < 1e-6

@@ -144,11 +144,12 @@ def test_adam_matches_torch(pa):
     mask = torch.ones(n, dtype=torch.uint8, device='cuda'); mask[::7] = 0
     keep = p.clone()
     net = engine.Net([2, 16, 1], 'tanh', 2)
-    for _ in range(20):
+    for k in range(20):
         grad = torch.randn(n, device='cuda')
         ref.grad = grad.clone()
         opt.step()
-        net.adam_step(p, grad, m, v, mask, step, 0.01)
+        # odd steps: the count lives on the device (two launches); even steps: the host passes it (one launch)
+        net.adam_step(p, grad, m, v, mask, step, 0.01, at=0 if k % 2 == 0 else k + 1)
     live = mask.bool()
     assert torch.equal(p[~live], keep[~live])
     assert rel_l2(p[live].cpu().numpy(), ref.detach()[live].cpu().numpy()) < 1e-6
