@@ -121,7 +121,10 @@ class Solver:
             n = 17
             streams = torch.rand((self.spec.n_streams, n), device=self.device) * 2 - 1
             pts = torch.rand((n, total), device=self.device) + 0.25
-            want = self._eval_equation(streams, pts, requires_grad=False).reshape(-1).double().cpu().numpy()
+            # (an equation that differentiates composite expressions needs autograd over its own pointwise ops)
+            probe = streams.clone().requires_grad_() if self.needs_x_grad else streams
+            want = self._eval_equation(probe, pts, requires_grad=self.needs_x_grad)
+            want = want.detach().reshape(-1).double().cpu().numpy()
             got = trace.run_residual_numpy(plan, streams.cpu().numpy(), pts.cpu().numpy())
             if not np.allclose(got, want, rtol=1e-4, atol=1e-5):
                 raise trace.TraceUnsupported('traced program disagrees with the callable (data-dependent control flow?)')
@@ -151,11 +154,7 @@ class Solver:
                 col = col.clone().requires_grad_()
             col._pinn_col = c
             cols.append(col)
-        token = trace.active_streams.set(sc)
-        try:
-            return self.ctx.run(self.equation, sc.tensors[()], *cols)
-        finally:
-            trace.active_streams.reset(token)
+        return self.ctx.run(trace.call_with_streams, sc, self.equation, sc.tensors[()], *cols)
 
     def _ic_streams(self, xs, create_graph):
         """ IC(x_spatial) and its derivative streams as a list over stream indices ([N,1] tensors or None). """

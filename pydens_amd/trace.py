@@ -111,6 +111,16 @@ class StreamContext:
         return list(self.tensors.items())
 
 
+def call_with_streams(sc, equation, *args):
+    """ run the user's callable with `sc` as the active stream context. Must itself be what `ctx.run` invokes: a
+    ContextVar set outside is not visible inside the solver's own contextvars.Context (model_torch.py:316-317). """
+    token = active_streams.set(sc)
+    try:
+        return equation(*args)
+    finally:
+        active_streams.reset(token)
+
+
 def discover(equation, ctx_run, n_inputs, device='cpu'):
     """ fake run (reference model_torch.py:319-325): which streams does the equation request?
     Returns (StreamSpec, needs_x_grad). """
@@ -122,11 +132,7 @@ def discover(equation, ctx_run, n_inputs, device='cpu'):
         x._pinn_col = c
         xs.append(x)
     u = sc.tag(torch.rand((3, 1), device=device).requires_grad_(), ())
-    token = active_streams.set(sc)
-    try:
-        ctx_run(equation, u, *xs)
-    finally:
-        active_streams.reset(token)
+    ctx_run(call_with_streams, sc, equation, u, *xs)
     return StreamSpec(sc.requested), sc.used_autograd_fallback
 
 
@@ -233,17 +239,93 @@ class Sym:
         raise TraceUnsupported(f'tensor attribute .{name} is not expressible in a residual program')
 
 
-def sym_D(y, x):
-    """ `D` on symbolic operands: only d(stream)/d(input column). """
-    if (isinstance(y, Sym) and y.kind == 'stream' and isinstance(x, Sym) and x.kind == 'input'
-            and all(isinstance(c, int) for c in y.alpha)):
-        alpha = tuple(sorted(y.alpha + (x.col,)))
+def _is_const(node, value=None):
+    return node.kind == 'const' and (value is None or node.value == value)
+
+
+def _s_add(a, b):
+    return b if _is_const(a, 0.0) else a if _is_const(b, 0.0) else Sym.make('ADD', a, b)
+
+
+def _s_sub(a, b):
+    return a if _is_const(b, 0.0) else Sym.make('NEG', b) if _is_const(a, 0.0) else Sym.make('SUB', a, b)
+
+
+def _s_mul(a, b):
+    if _is_const(a, 0.0) or _is_const(b, 0.0):
+        return Sym('const', value=0.0)
+    return b if _is_const(a, 1.0) else a if _is_const(b, 1.0) else Sym.make('MUL', a, b)
+
+
+def _differentiate(node, col, memo):
+    """ symbolic d(node)/d(input column `col`): streams step to the next derivative stream (`D` of the field), x-only
+    sub-expressions differentiate in closed form, everything else by the chain rule. """
+    key = id(node)
+    if key in memo:
+        return memo[key]
+    zero, one = Sym('const', value=0.0), Sym('const', value=1.0)
+    if node.kind == 'const':
+        out = zero
+    elif node.kind == 'input':
+        out = one if node.col == col else zero
+    elif node.kind == 'stream':
+        if not all(isinstance(c, int) for c in node.alpha) or len(node.alpha) >= 2:
+            raise TraceUnsupported('derivative of a second-order stream (third order)')
+        alpha = tuple(sorted(node.alpha + (col,)))
         if len(alpha) == 2 and alpha[0] != alpha[1]:
             # mixed partial by polarisation over the diagonal direction e_a + e_b
             a, b = alpha
-            return (Sym('stream', alpha=('d', a, b)) - Sym('stream', alpha=(a, a)) - Sym('stream', alpha=(b, b))) * 0.5
-        return Sym('stream', alpha=alpha)
-    raise TraceUnsupported('D of a composite expression')
+            out = (Sym('stream', alpha=('d', a, b)) - Sym('stream', alpha=(a, a)) - Sym('stream', alpha=(b, b))) * 0.5
+        else:
+            out = Sym('stream', alpha=alpha)
+    else:
+        op, args = node.op, node.args
+        d = [_differentiate(a, col, memo) for a in args]
+        a = args[0]
+        if op == 'ADD':
+            out = _s_add(d[0], d[1])
+        elif op == 'SUB':
+            out = _s_sub(d[0], d[1])
+        elif op == 'MUL':
+            out = _s_add(_s_mul(d[0], args[1]), _s_mul(a, d[1]))
+        elif op == 'DIV':
+            b = args[1]
+            out = _s_sub(Sym.make('DIV', d[0], b) if not _is_const(d[0], 0.0) else zero,
+                         _s_mul(Sym.make('DIV', a, Sym.make('MUL', b, b)), d[1]))
+        elif op in ('NEG', 'COPY'):
+            out = Sym.make('NEG', d[0]) if op == 'NEG' and not _is_const(d[0], 0.0) else d[0]
+        elif _is_const(d[0], 0.0):
+            out = zero
+        elif op == 'SIN':
+            out = _s_mul(Sym.make('COS', a), d[0])
+        elif op == 'COS':
+            out = _s_mul(Sym.make('NEG', Sym.make('SIN', a)), d[0])
+        elif op == 'EXP':
+            out = _s_mul(node, d[0])
+        elif op == 'LOG':
+            out = Sym.make('DIV', d[0], a)
+        elif op == 'TANH':
+            out = _s_mul(Sym.make('SUB', 1.0, Sym.make('MUL', node, node)), d[0])
+        elif op == 'SIGMOID':
+            out = _s_mul(Sym.make('MUL', node, Sym.make('SUB', 1.0, node)), d[0])
+        elif op == 'SQRT':
+            out = Sym.make('DIV', d[0], Sym.make('MUL', 2.0, node))
+        elif op == 'RECIP':
+            out = Sym.make('NEG', _s_mul(Sym.make('MUL', node, node), d[0]))
+        elif op == 'POW':
+            out = _s_mul(Sym.make('MUL', node.value, a ** (node.value - 1.0)), d[0])
+        else:
+            raise TraceUnsupported(f'D through {op}')
+    memo[key] = out
+    return out
+
+
+def sym_D(y, x):
+    """ `D` on symbolic operands: d(stream)/d(input column) is the next stream; composite expressions -- D(f * f, x),
+    D(a(x) * D(f, x), x) -- are differentiated symbolically (chain rule down to the streams). """
+    if not (isinstance(x, Sym) and x.kind == 'input'):
+        raise TraceUnsupported('D with respect to something that is not an input column')
+    return _differentiate(Sym.wrap(y), x.col, {})
 
 
 def symbolic(equation, ctx_run, n_inputs):

@@ -277,8 +277,22 @@ def _mixed_nonlinear_problem(D, torch):
                     layout='fafaf', features=[16, 16, 1], activation='Tanh')
 
 
+def _divergence_form_problem(D, torch):
+    def eq(f, x, y):                                 # D of composite expressions: div(a(x) grad u), still affine in u
+        return D((1 + x * y) * D(f, x), x) + D(torch.exp(-x) * D(f, y), y) - x * torch.sin(y)
+    return eq, dict(ndims=2, boundary_condition=0.5, layout='fafaf', features=[16, 16, 1], activation='Tanh')
+
+
+def _conservative_burgers_problem(D, torch):
+    def eq(f, x, t):                                 # D(f * f, x): chain rule through a product containing the field
+        return D(f, t) + 0.5 * D(f * f, x) - 0.05 * D(D(f, x), x) + D(torch.sin(f), x) * x
+    return eq, dict(ndims=2, boundary_condition=0, initial_condition=lambda x: torch.sin(np.pi * x),
+                    layout='fafaf', features=[16, 16, 1], activation='Tanh')
+
+
 @pytest.mark.parametrize('problem,kind', [(_nonlinear_problem, 0), (_variable_coefficient_problem, 1),
-                                          (_mixed_affine_problem, 1), (_mixed_nonlinear_problem, 0)])
+                                          (_mixed_affine_problem, 1), (_mixed_nonlinear_problem, 0),
+                                          (_divergence_form_problem, 1), (_conservative_burgers_problem, 0)])
 def test_residual_kinds_match_the_oracle(pa, emu_lib, problem, kind):
     from oracle import pinn_oracle as po
     eq_o, kw = problem(po.D, torch)
@@ -296,12 +310,15 @@ def test_residual_kinds_match_the_oracle(pa, emu_lib, problem, kind):
         assert rel_l2(got, want) < 3e-5
 
 
-def test_mixed_partial_generic_path(pa, emu_lib):
-    """ D(D(f, x), y) through the generic path: torch code sees u_xy = (u_vv - u_xx - u_yy) / 2 built from the streams """
+@pytest.mark.parametrize('problem', ['mixed', 'composite'])
+def test_mixed_partial_and_composite_D_generic_path(pa, emu_lib, problem):
+    """ generic path (kernel streams -> the user's torch code -> kernel backward): D(D(f, x), y) seen as
+    u_xy = (u_vv - u_xx - u_yy) / 2 built from the streams; D(f * f, x) by the chain rule over the streams """
     from oracle import pinn_oracle as po
-    eq_o, kw = _mixed_affine_problem(po.D, torch)
+    make = _mixed_affine_problem if problem == 'mixed' else _conservative_burgers_problem
+    eq_o, kw = make(po.D, torch)
     oracle = po.OracleSolver(eq_o, **kw)
-    eq_p, kw = _mixed_affine_problem(pa.D, torch)
+    eq_p, kw = make(pa.D, torch)
     solver = pa.Solver(eq_p, **kw, **emu_kwargs(emu_lib))
     solver.program = None
     load_params(solver, oracle.export_params())

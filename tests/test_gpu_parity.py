@@ -156,14 +156,17 @@ def test_adam_matches_torch(pa):
     assert int(step) == 20
 
 
-@pytest.mark.parametrize('which', ['nonlinear', 'variable_coefficient', 'mixed_affine', 'mixed_nonlinear'])
+@pytest.mark.parametrize('which', ['nonlinear', 'variable_coefficient', 'mixed_affine', 'mixed_nonlinear', 'divergence_form',
+                                   'conservative_burgers'])
 def test_residual_kinds_match_the_oracle(pa, which):
     """ residual PROGRAM (nonlinear Burgers-type, interpreter inside the tile kernel) and AFFINE residual with
     x-dependent coefficients (pre-pass rows) against the oracle's nested autograd on the same points """
     from oracle import pinn_oracle as po
     import test_emu_engine as te
     problem, kind = dict(nonlinear=(te._nonlinear_problem, 0), variable_coefficient=(te._variable_coefficient_problem, 1),
-                         mixed_affine=(te._mixed_affine_problem, 1), mixed_nonlinear=(te._mixed_nonlinear_problem, 0))[which]
+                         mixed_affine=(te._mixed_affine_problem, 1), mixed_nonlinear=(te._mixed_nonlinear_problem, 0),
+                         divergence_form=(te._divergence_form_problem, 1),
+                         conservative_burgers=(te._conservative_burgers_problem, 0))[which]
     eq_o, kw = problem(po.D, torch)
     oracle = po.OracleSolver(eq_o, **kw)
     eq_p, kw = problem(pa.D, torch)

@@ -86,7 +86,7 @@ def test_program_reproduces_the_callable(eq, n_inputs):
 def test_untraceable_equations_fall_back():
     par = torch.nn.Parameter(torch.tensor([1.0]))
     for eq in (lambda f, x: D(f, x) + par,                                     # trainable variable
-               lambda f, x: D(x * D(f, x), x),                                 # D of a composite expression
+               lambda f, x: D(torch.abs(f), x),                                # D through an op without a smooth rule
                lambda f, x: D(f, x) + torch.cumsum(x, 0),                      # op outside the program ISA
                lambda f, x: D(f, x) * torch.arange(3.0)):                      # tensor constant
         with pytest.raises(trace.TraceUnsupported):
@@ -189,3 +189,19 @@ def test_second_derivatives_are_combined_into_one_stream_when_possible():
     want = (streams[spec.index[(1, 1)]] - 4 * streams[spec.index[(0, 0)]] + 3 * streams[spec.index[(0,)]]
             - np.cos(xs[:, 0] * xs[:, 1]))
     np.testing.assert_allclose(trace.run_residual_numpy(plan, streams, xs), want, rtol=1e-6)
+
+
+def test_D_of_composite_expressions_is_differentiated_symbolically():
+    """ D(a(x) D(f, x), x) and D(f * f, x): the tracer applies the chain rule down to the streams, so these equations
+    keep the fused path; the lowered program must agree with the product-rule expansion written by hand """
+    eq = lambda f, x, y: D((1 + x * y) * D(f, x), x) + D(f * f, y) - torch.sin(x)
+    by_hand = lambda f, x, y: y * D(f, x) + (1 + x * y) * D(D(f, x), x) + 2 * f * D(f, y) - torch.sin(x)
+    spec, _ = trace.discover(eq, run, 2)
+    assert spec.dirs == [(0,), (1,)] and spec.n2 == 1
+    plans = [trace.lower_residual(trace.symbolic(e, run, 2), spec, 2) for e in (eq, by_hand)]
+    rng = np.random.RandomState(0)
+    streams, pts = rng.randn(spec.n_streams, 9), rng.rand(9, 2)
+    got, want = [trace.run_residual_numpy(p, streams, pts) for p in plans]
+    np.testing.assert_allclose(got, want, rtol=1e-12)
+    with pytest.raises(trace.TraceUnsupported, match='third order'):
+        trace.symbolic(lambda f, x: D(x * D(D(f, x), x), x), run, 1)
