@@ -204,8 +204,7 @@ pinn_duo_kernel(const PinnKArgs A) {
                 sv[s] = svv[s];
                 float part = hv[s][0] * wv[0];
                 part = fmaf(hv[s][1], wv[1], part); part = fmaf(hv[s][2], wv[2], part); part = fmaf(hv[s][3], wv[3], part);
-                part += pinn_shfl_xor(part, 16);
-                part += pinn_shfl_xor(part, 32);
+                part = pinn_rows_sum(part);
                 if (lq == 0) netp[(wave * S + s) * T + lr] = part;
             }
         } else {

@@ -922,8 +922,7 @@ pinn_tile_kernel(const PinnKArgs A) {
                     part = fmaf(hv[0], wv[0], part); part = fmaf(hv[1], wv[1], part);
                     part = fmaf(hv[2], wv[2], part); part = fmaf(hv[3], wv[3], part);
                 }
-                part += pinn_shfl_xor(part, 16);
-                part += pinn_shfl_xor(part, 32);
+                part = pinn_rows_sum(part);
                 if (lq == 0) netp[(wave * S + s) * T + pt] = part;
             }
         }

@@ -27,6 +27,20 @@ PINN_DEVICE f32x4 pinn_mfma16(float a, float b, f32x4 c) {
     return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0);
 }
 PINN_DEVICE float pinn_shfl_xor(float v, int mask) { return __shfl_xor(v, mask, 64); }
+// lane-wise sum over the four 16-lane rows of the wave (every lane gets x[l] + x[l^16] + x[l^32] + x[l^48]) with the
+// gfx950 row swaps: v_permlane16_swap exchanges the odd rows of its first operand with the even rows of the second,
+// v_permlane32_swap the upper half of the first with the lower half of the second, so (a', b') = swap(x, x) holds x[l]
+// and x[l ^ 16] (resp. x[l ^ 32]) in every lane. Two VALU ops per step instead of a ds_bpermute round trip. Inline asm:
+// hipcc 7.2 lowers the __builtin_amdgcn_permlane*_swap builtins to code that adds the FIRST result to itself
+// (tools/ubench/permlane_swap.cpp checks the asm form against __shfl_xor on the device).
+PINN_DEVICE float pinn_rows_sum(float x) {
+    float y = x;
+    asm volatile("s_nop 1\n\tv_permlane16_swap_b32 %0, %1\n\ts_nop 1" : "+v"(x), "+v"(y));
+    x += y;
+    y = x;
+    asm volatile("s_nop 1\n\tv_permlane32_swap_b32 %0, %1\n\ts_nop 1" : "+v"(x), "+v"(y));
+    return x + y;
+}
 
 // sum over the 16 lanes of a DPP row (lanes sharing lane>>4); every lane of the row gets the sum.
 // quad_perm [1,0,3,2], quad_perm [2,3,0,1], row_half_mirror, row_mirror: four full-rate VALU adds, no LDS.

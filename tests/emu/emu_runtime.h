@@ -36,6 +36,11 @@ void launch(int grid, int block, size_t smem_bytes, const std::function<void()>&
 
 static inline f32x4 pinn_mfma16(float a, float b, f32x4 c) { return emu::mfma16(a, b, c); }
 static inline float pinn_shfl_xor(float v, int mask) { return emu::shfl_xor(v, mask); }
+static inline float pinn_rows_sum(float x) {
+    x += emu::shfl_xor(x, 16);
+    x += emu::shfl_xor(x, 32);
+    return x;
+}
 static inline float pinn_row_sum16(float v) { return emu::row_sum16(v); }
 static inline float pinn_exp2(float x) { return exp2f(x); }
 static inline float pinn_rcp(float x) { return 1.0f / x; }
