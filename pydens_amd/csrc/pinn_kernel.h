@@ -65,7 +65,10 @@ struct PinnCfg {
     static constexpr int HP = HP_, ND = ND_, N2 = N2_, MT = MT_;
     static constexpr int S = 1 + ND + N2;
     static constexpr int NT = HP / 16;                       // 16-wide unit tiles
-    static constexpr int NW = (NT <= 4) ? NT : 8;            // waves per workgroup
+#ifndef PINN_NW_MAX
+#define PINN_NW_MAX 8
+#endif
+    static constexpr int NW = (NT <= 4) ? NT : PINN_NW_MAX;  // waves per workgroup
     static constexpr int NTW = NT / NW;                      // unit tiles per wave
     static constexpr int T = 16 * MT;                        // points per tile
     static constexpr int LDA = HP + 8;                       // row stride of point-major activation buffers (bank spread)
@@ -724,7 +727,7 @@ pinn_tile_kernel(const PinnKArgs A) {
         // (not in the VAR 8 kernels: with the four-way activation code between the prefetch and its first use, hipcc
         //  7.2 produced a width-64 kernel whose last prefetched K quad arrived wrong on gfx950 -- reproducible, cured by
         //  -amdgpu-waitcnt-forcezero, by dropping the prefetch, or by the two-way activation)
-        constexpr bool WPF = (NW <= 4) && !(VAR & 4) && !(VAR & 8);
+        constexpr bool WPF = (HP <= 64) && !(VAR & 4) && !(VAR & 8);
         constexpr int NQ = HP / 16;
         f32x4 wall[WPF ? NQ : 1][NTW];
         f32x4 biasn[NTW];              // bias of the NEXT hidden layer, fetched with its weights
@@ -833,8 +836,9 @@ pinn_tile_kernel(const PinnKArgs A) {
                 load_q(0, wf[0], hf[0]);
 #pragma unroll
                 for (int q = 0; q < HP / 16; ++q) {
-                    if (q + 1 < HP / 16) load_q(q + 1, wf[(q + 1) & 1], hf[(q + 1) & 1]);
                     PINN_SCHED_BARRIER();
+                    if (q + 1 < HP / 16) load_q(q + 1, wf[(q + 1) & 1], hf[(q + 1) & 1]);
+                    if (!PINN_SCHED_IL) PINN_SCHED_BARRIER();
 #pragma unroll
                     for (int m = 0; m < 4; ++m)
 #pragma unroll
@@ -844,6 +848,7 @@ pinn_tile_kernel(const PinnKArgs A) {
 #pragma unroll
                                 for (int j = 0; j < NTW; ++j)
                                     acc[j][mt][s] = pinn_mfma16(wf[q & 1][j][m], hf[q & 1][mt][s][m], acc[j][mt][s]);
+                    if (q + 1 < HP / 16) pinn_sched_interleave<4 * MT * S * NTW, MT * S + (WPF ? 0 : NTW)>();
                     PINN_SCHED_BARRIER();
                 }
             }
@@ -1137,8 +1142,9 @@ pinn_tile_kernel(const PinnKArgs A) {
                 load_ms(0, bq[0], aq[0]);
 #pragma unroll
                 for (int ms = 0; ms < MT * S; ++ms) {
-                    if (ms + 1 < MT * S) load_ms(ms + 1, bq[(ms + 1) & 1], aq[(ms + 1) & 1]);
                     PINN_SCHED_BARRIER();
+                    if (ms + 1 < MT * S) load_ms(ms + 1, bq[(ms + 1) & 1], aq[(ms + 1) & 1]);
+                    if (!PINN_SCHED_IL) PINN_SCHED_BARRIER();
 #pragma unroll
                     for (int m = 0; m < 4; ++m)
 #pragma unroll
@@ -1146,37 +1152,96 @@ pinn_tile_kernel(const PinnKArgs A) {
 #pragma unroll
                             for (int j = 0; j < NTW; ++j)
                                 dw[o][j] = pinn_mfma16(aq[ms & 1][o][m], bq[ms & 1][j][m], dw[o][j]);
+                    // (the 4 * (NT + NTW) column reads usually pair up into ds_read2_b32)
+                    if (ms + 1 < MT * S) pinn_sched_interleave<4 * NT * NTW, 2 * (NT + NTW)>();
                     PINN_SCHED_BARRIER();
                 }
             } else {
-                // accumulators in the workgroup's partial buffer: one output tile row at a time (any depth, any width)
-                for (int o = 0; o < NT; ++o) {
-                    f32x4 dwt[NTW];
+                if constexpr (ONEBUF) {
+                    // width 256: the kernel sits at its 256-VGPR limit (two waves per SIMD) and already spills; the plain
+                    // loop (one output tile row at a time, NTW = 2 chains, no extra buffers) measured 4 % faster than the
+                    // blocked / pipelined form below
+                    for (int o = 0; o < NT; ++o) {
+                        f32x4 dwt[NTW];
 #pragma unroll
-                    for (int j = 0; j < NTW; ++j)
+                        for (int j = 0; j < NTW; ++j)
 #pragma unroll
-                        for (int r = 0; r < 4; ++r) dwt[j][r] = *dwg_ptr(li, o, j, r);
+                            for (int r = 0; r < 4; ++r) dwt[j][r] = *dwg_ptr(li, o, j, r);
 #pragma unroll
-                    for (int ms = 0; ms < MT * S; ++ms) {
-                        const int mt = ms / S, s = ms % S;
-                        float aq[4], bq[NTW][4];
+                        for (int ms = 0; ms < MT * S; ++ms) {
+                            const int mt = ms / S, s = ms % S;
+                            float aq[4];
 #pragma unroll
-                        for (int m = 0; m < 4; ++m) {
-                            const int row = (s * T + mt * 16 + wg_pt(m)) * LDA;
-                            aq[m] = nxt[row + o * 16 + lr];
+                            for (int m = 0; m < 4; ++m) aq[m] = nxt[(s * T + mt * 16 + wg_pt(m)) * LDA + o * 16 + lr];
 #pragma unroll
-                            for (int j = 0; j < NTW; ++j)
-                                bq[j][m] = ONEBUF ? hfrag[ONEBUF ? ms : 0][j][m] : cur[row + (wave * NTW + j) * 16 + lr];
+                            for (int m = 0; m < 4; ++m)
+#pragma unroll
+                                for (int j = 0; j < NTW; ++j) dwt[j] = pinn_mfma16(aq[m], hfrag[ONEBUF ? ms : 0][j][m], dwt[j]);
                         }
 #pragma unroll
-                        for (int m = 0; m < 4; ++m)
+                        for (int j = 0; j < NTW; ++j)
 #pragma unroll
-                            for (int j = 0; j < NTW; ++j) dwt[j] = pinn_mfma16(aq[m], bq[j][m], dwt[j]);
+                            for (int r = 0; r < 4; ++r) *dwg_ptr(li, o, j, r) = dwt[j][r];
                     }
+                } else {
+                    // accumulators in the workgroup's partial buffer (any depth, any width): OB output tile rows at a time --
+                    // OB independent MFMA chains per B fragment (a lone chain stalls on its own 8-pass latency), the tiles of
+                    // the NEXT block fetched from the partial buffer (L2) while this block computes, the LDS operands of the
+                    // next (mt, s) row tile read between the MFMAs of the current one
+                    constexpr int OB = (NTW >= 4) ? 1 : ((4 / NTW < NT) ? 4 / NTW : NT);     // OB * NTW = 4 chains where possible
+                    f32x4 dwn[OB][NTW];
+                    auto load_dw = [&](int ob, f32x4 (&dst)[OB][NTW]) {
 #pragma unroll
-                    for (int j = 0; j < NTW; ++j)
+                        for (int oo = 0; oo < OB; ++oo)
 #pragma unroll
-                        for (int r = 0; r < 4; ++r) *dwg_ptr(li, o, j, r) = dwt[j][r];
+                            for (int j = 0; j < NTW; ++j)
+#pragma unroll
+                                for (int r = 0; r < 4; ++r) dst[oo][j][r] = *dwg_ptr(li, ob * OB + oo, j, r);
+                    };
+                    load_dw(0, dwn);
+                    for (int ob = 0; ob < NT / OB; ++ob) {
+                        f32x4 dwt[OB][NTW];
+#pragma unroll
+                        for (int oo = 0; oo < OB; ++oo)
+#pragma unroll
+                            for (int j = 0; j < NTW; ++j) dwt[oo][j] = dwn[oo][j];
+                        if (ob + 1 < NT / OB) load_dw(ob + 1, dwn);
+                        float aq[2][OB][4], bq[2][NTW][4];
+                        auto load_ms = [&](int ms, float (&a_)[OB][4], float (&b)[NTW][4]) {
+                            const int mt = ms / S, s = ms % S;
+#pragma unroll
+                            for (int m = 0; m < 4; ++m) {
+                                const int row = (s * T + mt * 16 + wg_pt(m)) * LDA;
+#pragma unroll
+                                for (int oo = 0; oo < OB; ++oo) a_[oo][m] = nxt[row + (ob * OB + oo) * 16 + lr];
+#pragma unroll
+                                for (int j = 0; j < NTW; ++j)
+                                    b[j][m] = ONEBUF ? hfrag[ONEBUF ? ms : 0][j][m] : cur[row + (wave * NTW + j) * 16 + lr];
+                            }
+                        };
+                        load_ms(0, aq[0], bq[0]);
+#pragma unroll
+                        for (int ms = 0; ms < MT * S; ++ms) {
+                            PINN_SCHED_BARRIER();
+                            if (ms + 1 < MT * S) load_ms(ms + 1, aq[(ms + 1) & 1], bq[(ms + 1) & 1]);
+                            if (!PINN_SCHED_IL) PINN_SCHED_BARRIER();
+#pragma unroll
+                            for (int m = 0; m < 4; ++m)
+#pragma unroll
+                                for (int oo = 0; oo < OB; ++oo)
+#pragma unroll
+                                    for (int j = 0; j < NTW; ++j)
+                                        dwt[oo][j] = pinn_mfma16(aq[ms & 1][oo][m], bq[ms & 1][j][m], dwt[oo][j]);
+                            if (ms + 1 < MT * S) pinn_sched_interleave<4 * OB * NTW, 2 * (OB + (ONEBUF ? 0 : NTW))>();
+                            PINN_SCHED_BARRIER();
+                        }
+#pragma unroll
+                        for (int oo = 0; oo < OB; ++oo)
+#pragma unroll
+                            for (int j = 0; j < NTW; ++j)
+#pragma unroll
+                                for (int r = 0; r < 4; ++r) *dwg_ptr(li, ob * OB + oo, j, r) = dwt[oo][j][r];
+                    }
                 }
             }
             PH(12)
@@ -1214,8 +1279,9 @@ pinn_tile_kernel(const PinnKArgs A) {
                 load_q(0, wq[0], gf[0]);
 #pragma unroll
                 for (int q = 0; q < HP / 16; ++q) {
-                    if (q + 1 < HP / 16) load_q(q + 1, wq[(q + 1) & 1], gf[(q + 1) & 1]);
                     PINN_SCHED_BARRIER();
+                    if (q + 1 < HP / 16) load_q(q + 1, wq[(q + 1) & 1], gf[(q + 1) & 1]);
+                    if (!PINN_SCHED_IL) PINN_SCHED_BARRIER();
 #pragma unroll
                     for (int m = 0; m < 4; ++m)
 #pragma unroll
@@ -1225,6 +1291,8 @@ pinn_tile_kernel(const PinnKArgs A) {
 #pragma unroll
                                 for (int j = 0; j < NTW; ++j)
                                     g[j][mt][s] = pinn_mfma16(wq[q & 1][j][m], gf[q & 1][mt][s][m], g[j][mt][s]);
+                    if (q + 1 < HP / 16)
+                        pinn_sched_interleave<4 * MT * S * NTW, MT * S + (WTL ? NTW : (WPF ? 0 : 4 * NTW))>();
                     PINN_SCHED_BARRIER();
                 }
             }

@@ -56,6 +56,27 @@ PINN_DEVICE float pinn_exp2(float x) { return __builtin_amdgcn_exp2f(x); }
 PINN_DEVICE float pinn_rcp(float x) { return __builtin_amdgcn_rcpf(x); }
 #define PINN_LAUNCH_BOUNDS2(n, w) __launch_bounds__(n, w)
 #define PINN_SCHED_BARRIER() __builtin_amdgcn_sched_barrier(0)
+// Interleaved issue order inside one scheduling region (between two PINN_SCHED_BARRIERs): N_MEM memory reads (LDS
+// and/or global: the operands of the NEXT pipeline stage) spread evenly between the N_MFMA matrix instructions of the
+// current stage. A wave issues in order; reads bunched in front of the MFMAs leave the matrix pipe idle while they issue
+// (about 70 cycles per 512-cycle batch in the weight-gradient loop), reads placed between two MFMAs issue in the shadow
+// of the 32-cycle MFMA before them.
+#ifndef PINN_SCHED_IL
+#define PINN_SCHED_IL 1
+#endif
+template <int N_MFMA, int N_MEM>
+PINN_DEVICE void pinn_sched_interleave() {
+#if PINN_SCHED_IL
+    constexpr int PER = (N_MEM > 0) ? (N_MFMA / N_MEM > 0 ? N_MFMA / N_MEM : 1) : N_MFMA;
+    constexpr int USED = (N_MEM > 0) ? (PER * N_MEM < N_MFMA ? PER * N_MEM : N_MFMA) : 0;
+#pragma unroll
+    for (int i = 0; i < N_MEM; ++i) {
+        __builtin_amdgcn_sched_group_barrier(0x008, PER, 0);      // MFMA
+        __builtin_amdgcn_sched_group_barrier(0x120, 1, 0);        // one DS read or VMEM read
+    }
+    if (N_MFMA - USED > 0) __builtin_amdgcn_sched_group_barrier(0x008, N_MFMA - USED > 0 ? N_MFMA - USED : 1, 0);
+#endif
+}
 #define PINN_INLINE_LAMBDA __attribute__((always_inline))
 #define PINN_SETPRIO(n) __builtin_amdgcn_s_setprio(n)
 #endif

@@ -46,5 +46,7 @@ static inline float pinn_exp2(float x) { return exp2f(x); }
 static inline float pinn_rcp(float x) { return 1.0f / x; }
 #define PINN_LAUNCH_BOUNDS2(n, w)
 #define PINN_SCHED_BARRIER()
+#define PINN_SCHED_IL 0
+template <int N_MFMA, int N_MEM> static inline void pinn_sched_interleave() {}
 #define PINN_INLINE_LAMBDA
 #define PINN_SETPRIO(n)
