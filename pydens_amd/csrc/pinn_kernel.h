@@ -670,6 +670,21 @@ pinn_tile_kernel(const PinnKArgs A) {
     f32x4 accWL[NTW];
 #pragma unroll
     for (int j = 0; j < NTW; ++j) accWL[j] = f32x4{0.f, 0.f, 0.f, 0.f};
+    // fast instantiations: the bias gradients (and the first W1R columns of dW1) are summed per LANE in registers over
+    // all tiles and reduced over the 16 points of a lane row ONCE at the end, instead of 4 DPP adds per value plus an
+    // LDS read-modify-write in every tile
+    // (only where the jets leave register head-room: the S = 4, 32-point kernel of cfg2 uses all 512 registers and
+    //  started to spill with these 32 more -- measured +3.7 % time there, -4.8 % on the S = 2 kernel of cfg4)
+    constexpr bool REGB = !DWG && (S * MT * NTW <= 6);
+    constexpr int W1R = 4;
+    f32x4 accBr[REGB ? PINN_LHMAX + 1 : 1][NTW], accW1r[REGB ? W1R : 1][NTW];
+#pragma unroll
+    for (int j = 0; j < NTW; ++j) {
+#pragma unroll
+        for (int a = 0; a < (REGB ? PINN_LHMAX + 1 : 1); ++a) accBr[a][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int c = 0; c < (REGB ? W1R : 1); ++c) accW1r[c][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+    }
     float sum_loss = 0.0f, sum_ls = 0.0f, sum_bl = 0.0f;
 
     f32x4* slab = A.slab ? A.slab + (size_t)PINN_BID * C::slab_vec4_per_wg(lh, SKIPS ? A.n_skips : 0) : nullptr;
@@ -1008,7 +1023,7 @@ pinn_tile_kernel(const PinnKArgs A) {
 
         // ---- (6) reverse through the activations / hidden layers; the layer index is unrolled so that the dW
         //          accumulators are addressed statically (they must stay in registers) ----------------------------
-        auto act_reverse = [&](int a, f32x4 (&gz)[NTW][MT][S]) {
+        auto act_reverse = [&](int a, f32x4 (&gz)[NTW][MT][S], f32x4 (&bacc)[NTW]) {
             // gz_a = jet-reverse(gh, saved_a);  db_a += sum_pt gz_a,0 (DPP row sum over the 16 points of the lane row)
             const int act = act_at(a);
             if (SKIPS) {
@@ -1040,19 +1055,23 @@ pinn_tile_kernel(const PinnKArgs A) {
                         for (int s = 0; s < S; ++s) gz[j][mt][s][r] = gz1[s];
                         bsum[r] += gz1[0];
                     }
+                if (REGB) {
+                    bacc[j] += bsum;
+                } else {
 #pragma unroll
-                for (int r = 0; r < 4; ++r) bsum[r] = pinn_row_sum16(bsum[r]);
-                if (lr == 0) {
-                    float* dst = accB + a * HP + unit0(j);
-                    pinn_st4(dst, pinn_ld4(dst) + bsum);
+                    for (int r = 0; r < 4; ++r) bsum[r] = pinn_row_sum16(bsum[r]);
+                    if (lr == 0) {
+                        float* dst = accB + a * HP + unit0(j);
+                        pinn_st4(dst, pinn_ld4(dst) + bsum);
+                    }
                 }
             }
         };
         // after the forward half `nxt` still holds h_{lh-1} (the input of the last hidden layer): the top reverse step
         // uses it in place and stages only gz
-        auto hidden_reverse = [&](int a, f32x4 (&dw)[DWG ? 1 : NT][NTW]) {
+        auto hidden_reverse = [&](int a, f32x4 (&dw)[DWG ? 1 : NT][NTW], f32x4 (&bacc)[NTW]) {
             f32x4 gz[NTW][MT][S];
-            act_reverse(a, gz);
+            act_reverse(a, gz, bacc);
             const bool top = (a == lh);
             if (top && !ONEBUF) { float* tmp = cur; cur = nxt; nxt = tmp; }   // cur = h_{a-1}, nxt = free (receives gz)
             // recompute h_{a-1} from its saved jets (kept in sv for the next step); stage h_{a-1} and gz_a for the GEMMs
@@ -1301,20 +1320,34 @@ pinn_tile_kernel(const PinnKArgs A) {
             PH(14)
         };
         if constexpr (DWG) {
-            for (int a = lh; a >= 1; --a) hidden_reverse(a, dW[0]);
+            for (int a = lh; a >= 1; --a) hidden_reverse(a, dW[0], accBr[0]);
         } else {
 #pragma unroll
             for (int a = PINN_LHMAX; a >= 1; --a) {
-                if (a <= lh) hidden_reverse(a, dW[a - 1]);
+                if (a <= lh) hidden_reverse(a, dW[a - 1], accBr[REGB ? a : 0]);
             }
         }
         {
             // first layer: db_0, dW1[n][c] += sum_pt gz0 x_c  (+ sum_pt gz_k when c == col_k)
             f32x4 gz[NTW][MT][S];
-            act_reverse(0, gz);
+            act_reverse(0, gz, accBr[0]);
 #pragma unroll
             for (int j = 0; j < NTW; ++j) {
-                for (int c = 0; c < d; ++c) {
+                if (REGB) {
+#pragma unroll
+                    for (int c = 0; c < W1R; ++c) {
+                        if (c < d) {
+#pragma unroll
+                            for (int mt = 0; mt < MT; ++mt) {
+                                accW1r[REGB ? c : 0][j] += gz[j][mt][0] * xs_t[(mt * 16 + lr) * PINN_XS_LD + c];
+#pragma unroll
+                                for (int k = 0; k < ND; ++k)
+                                    if (pinn_dir_has(A.dir_cols[k], c)) accW1r[REGB ? c : 0][j] += gz[j][mt][1 + k];
+                            }
+                        }
+                    }
+                }
+                for (int c = REGB ? W1R : 0; c < d; ++c) {
                     f32x4 v = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
                     for (int mt = 0; mt < MT; ++mt) {
@@ -1336,6 +1369,32 @@ pinn_tile_kernel(const PinnKArgs A) {
     PH_FLUSH
 
     if (!train) return;
+    if (REGB) {
+        // one row reduction for everything the lanes summed privately; each (wave, j, lq) owns its units: plain LDS adds
+#pragma unroll
+        for (int j = 0; j < NTW; ++j) {
+#pragma unroll
+            for (int a = 0; a <= PINN_LHMAX; ++a) {
+                if (a <= lh) {
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const float t = pinn_row_sum16(accBr[REGB ? a : 0][j][r]);
+                        if (lr == 0) accB[a * HP + unit0(j) + r] += t;
+                    }
+                }
+            }
+#pragma unroll
+            for (int c = 0; c < W1R; ++c) {
+                if (c < d) {
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const float t = pinn_row_sum16(accW1r[REGB ? c : 0][j][r]);
+                        if (lr == 0) accW1[(unit0(j) + r) * PINN_XS_LD + c] += t;
+                    }
+                }
+            }
+        }
+    }
     // ---- write this workgroup's partial gradient ---------------------------------------------------------------
     PINN_SYNC();
     float* part = A.partials + (size_t)PINN_BID * A.p_core;
