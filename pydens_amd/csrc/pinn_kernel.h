@@ -675,7 +675,10 @@ pinn_tile_kernel(const PinnKArgs A) {
     // LDS read-modify-write in every tile
     // (only where the jets leave register head-room: the S = 4, 32-point kernel of cfg2 uses all 512 registers and
     //  started to spill with these 32 more -- measured +3.7 % time there, -4.8 % on the S = 2 kernel of cfg4)
-    constexpr bool REGB = !DWG && (S * MT * NTW <= 6);
+#ifndef PINN_REGB_MAX
+#define PINN_REGB_MAX 6
+#endif
+    constexpr bool REGB = !DWG && (S * MT * NTW <= PINN_REGB_MAX);
     constexpr int W1R = 4;
     f32x4 accBr[REGB ? PINN_LHMAX + 1 : 1][NTW], accW1r[REGB ? W1R : 1][NTW];
 #pragma unroll
@@ -1002,7 +1005,10 @@ pinn_tile_kernel(const PinnKArgs A) {
                 }
         };
         // (only where S*MT*NTW jets leave register head-room: measured -3 % on cfg2/cfg5, +1..5 % on cfg3/cfg4)
-        constexpr bool SVPF = (S * MT * NTW <= 8) && !ONEBUF;
+#ifndef PINN_SVPF_MAX
+#define PINN_SVPF_MAX 8
+#endif
+        constexpr bool SVPF = (S * MT * NTW <= PINN_SVPF_MAX) && !ONEBUF;
         if (SVPF && lh > 0) load_saved(lh - 1, svn);
 #pragma unroll
         for (int j = 0; j < NTW; ++j) {
