@@ -161,6 +161,11 @@ int launch_reduce(const float* partials, int n_wg, int p_core, float* grads, int
 }
 
 size_t align256(size_t v) { return (v + 255) / 256 * 256; }
+
+// widths >= 128 (PinnCfg::WTG): room for the transposed copy of the lh hidden->hidden matrices
+size_t wt_workspace_bytes(const pinn_net* net) {
+    return (net->lay.hp >= 128 && net->lay.lh > 0) ? align256((size_t)net->lay.lh * net->lay.hp * net->lay.hp * sizeof(float)) : 0;
+}
 }  // namespace
 
 extern "C" {
@@ -319,7 +324,7 @@ size_t pinn_workspace_bytes(const pinn_t* net, int64_t n_points, int nd, int n2)
                          align256((size_t)plan.grid * plan.slab_vec4_per_wg * 16);
         if (v > need) need = v;
     }
-    return need + align256((size_t)PINN_MAX_AUX * (size_t)n_points * sizeof(float)) + 256;
+    return need + align256((size_t)PINN_MAX_AUX * (size_t)n_points * sizeof(float)) + wt_workspace_bytes(net) + 256;
 }
 
 int pinn_jet_forward(pinn_t* net, const float* params, const float* xs, int64_t n_points, const int* dir_cols, int nd,
@@ -343,8 +348,9 @@ static int run_train(pinn_t* net, PinnKArgs* a, const Plan& plan, int nd, float*
     const size_t part_bytes = align256((size_t)plan.grid * net->lay.p_core * sizeof(float));
     const size_t slab_bytes = align256((size_t)plan.grid * plan.slab_vec4_per_wg * 16);
     const size_t aux_bytes = (pre && a->n_aux > 0) ? align256((size_t)a->n_aux * (size_t)a->n_points * sizeof(float)) : 0;
-    if (!workspace || workspace_bytes < part_bytes + slab_bytes + aux_bytes)
-        return fail("workspace too small: need %zu bytes, got %zu", part_bytes + slab_bytes + aux_bytes, workspace_bytes);
+    const size_t wt_bytes = wt_workspace_bytes(net);
+    if (!workspace || workspace_bytes < part_bytes + slab_bytes + aux_bytes + wt_bytes)
+        return fail("workspace too small: need %zu bytes, got %zu", part_bytes + slab_bytes + aux_bytes + wt_bytes, workspace_bytes);
     if (((uintptr_t)workspace & 15) != 0) return fail("workspace must be 16-byte aligned");
     a->prof = g_phase_prof;
     a->debug_flags = g_pinn_debug_flags;
@@ -360,6 +366,21 @@ static int run_train(pinn_t* net, PinnKArgs* a, const Plan& plan, int nd, float*
         hipLaunchKernelGGL(pinn_aux_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, a->xs, a->n_points, a->d,
                            *pre, aux);
         if (hipGetLastError() != hipSuccess) return fail("pre-pass kernel launch failed");
+#endif
+    }
+    if (wt_bytes) {
+        // widths >= 128: transposed copy of the hidden weights for the data-gradient GEMM (the weights change every step)
+        float* wt = reinterpret_cast<float*>(reinterpret_cast<char*>(workspace) + part_bytes + slab_bytes + aux_bytes);
+        a->wt = wt;
+        const int hp = net->lay.hp, blocks = (hp / 32) * (hp / 32) * net->lay.lh;
+        const float* wh = a->params + net->lay.off_wh;
+        const int stride = net->lay.hidden_stride;
+#ifdef PINN_EMU
+        emu::launch(blocks, 256, 32 * 33 * sizeof(float), [&] { pinn_transpose_kernel(wh, stride, hp, wt); });
+#else
+        hipLaunchKernelGGL(pinn_transpose_kernel, dim3(blocks), dim3(256), 32 * 33 * sizeof(float), (hipStream_t)stream, wh,
+                           stride, hp, wt);
+        if (hipGetLastError() != hipSuccess) return fail("transpose kernel launch failed");
 #endif
     }
 #ifndef PINN_EMU

@@ -87,6 +87,20 @@ pinn_reduce_kernel(const float* partials, int n_wg, int p_core, float* grads, in
 // ------------------------------------------------------------------------------------------------------------
 // Adam (torch.optim.Adam single-tensor form, model_torch.py:461): exp_avg/exp_avg_sq EMA, bias-corrected step
 // ------------------------------------------------------------------------------------------------------------
+// wt[l][in][out] = W_l[out][in] for the lh hidden->hidden matrices (hp x hp, row stride hp, layer stride hidden_stride):
+// 32 x 32 tiles through LDS, both sides coalesced. Grid: (hp/32)^2 * lh workgroups of 256 threads.
+PINN_GLOBAL void PINN_LAUNCH_BOUNDS(256) pinn_transpose_kernel(const float* wh, int hidden_stride, int hp, float* wt) {
+    PINN_SMEM(tile);                                     // [32][33]
+    const int tiles = hp / 32;
+    const int l = PINN_BID / (tiles * tiles), t = PINN_BID % (tiles * tiles), tr = t / tiles, tc = t % tiles;
+    const float* src = wh + (size_t)l * hidden_stride;
+    float* dst = wt + (size_t)l * hp * hp;
+    const int x = PINN_TID & 31, y0 = PINN_TID >> 5;
+    for (int y = y0; y < 32; y += 8) tile[y * 33 + x] = src[(size_t)(tr * 32 + y) * hp + tc * 32 + x];
+    PINN_SYNC();
+    for (int y = y0; y < 32; y += 8) dst[(size_t)(tc * 32 + y) * hp + tr * 32 + x] = tile[x * 33 + y];
+}
+
 PINN_GLOBAL void PINN_LAUNCH_BOUNDS(64) pinn_tick_kernel(int* step_ptr) {
     if (PINN_TID == 0 && PINN_BID == 0) step_ptr[0] += 1;
 }

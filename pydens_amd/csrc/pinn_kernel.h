@@ -35,6 +35,7 @@ struct PinnKArgs {
     float* out_streams;          // MODE_FORWARD: [S_user][N]
     float* partials;             // [nWG][p_core]
     f32x4* slab;                 // saved activations, lane private
+    const float* wt;             // widths >= 128: transposed copy of the hidden weights, [lh][in][out] (pinn_transpose_kernel)
     long long* prof;             // optional per-phase cycle counters (PINN_PROFILE_PHASES builds only)
     int debug_flags;             // bit 0: two-team kernel runs team 0 only (experiments)
     long long n_points;
@@ -76,6 +77,7 @@ struct PinnCfg {
     // widths above 128: ONE activation buffer (two would not fit the 160 KB of LDS): the forward pass works in place and
     // the reverse pass keeps the weight-gradient B fragments of h_{a-1} in registers while gz_a replaces it in LDS
     static constexpr bool ONEBUF = HP > 128;
+    static constexpr bool WTG = HP >= 128;                   // data-gradient GEMM reads a transposed weight copy (A.wt)
     // LDS carve (floats); every offset is a multiple of 4 floats (16 B, ds_read_b128 alignment)
     static constexpr int O_XS = 0;
     static constexpr int O_W1 = O_XS + 2 * T * PINN_XS_LD;      // points of a tile, double-buffered
@@ -588,6 +590,9 @@ pinn_tile_kernel(const PinnKArgs A) {
     constexpr bool DWG = (LHC < 0) || (VAR & 1), ONEBUF = C::ONEBUF, SKIPS = (VAR & 8) != 0;
     constexpr int LHREG = DWG ? 1 : PINN_LHMAX;            // layers with register-resident dW accumulators
     constexpr bool WTL = C::wt_fits(LHC);                  // transposed hidden weights staged in LDS
+    // widths >= 128: the data-gradient A operand comes from a transposed copy of the weights in global memory (one b128 per
+    // K quad like the forward GEMM) instead of four strided global_load_dword per quad
+    constexpr bool WTG = C::WTG;
     const int tid = PINN_TID, lane = tid & 63, wave = tid >> 6;
     const int lr = lane & 15, lq = lane >> 4;
     const int lh = (LHC >= 0) ? LHC : A.lh;
@@ -1285,7 +1290,12 @@ pinn_tile_kernel(const PinnKArgs A) {
                     for (int j = 0; j < NTW; ++j)
 #pragma unroll
                         for (int m = 0; m < 4; ++m) {
-                            if (WTL) {
+                            if (WTG) {
+                                if (m == 0) {
+                                    const f32x4 wv = pinn_ld4(A.wt + ((size_t)li * HP + (wave * NTW + j) * 16 + lr) * HP + 16 * q + 4 * lq);
+                                    w[j][0] = wv[0]; w[j][1] = wv[1]; w[j][2] = wv[2]; w[j][3] = wv[3];
+                                }
+                            } else if (WTL) {
                                 if (m == 0) {
                                     const f32x4 wv = pinn_ld4(WTs + (li * HP + (wave * NTW + j) * 16 + lr) * C::WT_LD + 16 * q + 4 * lq);
                                     w[j][0] = wv[0]; w[j][1] = wv[1]; w[j][2] = wv[2]; w[j][3] = wv[3];
@@ -1317,7 +1327,7 @@ pinn_tile_kernel(const PinnKArgs A) {
                                 for (int j = 0; j < NTW; ++j)
                                     g[j][mt][s] = pinn_mfma16(wq[q & 1][j][m], gf[q & 1][mt][s][m], g[j][mt][s]);
                     if (q + 1 < HP / 16)
-                        pinn_sched_interleave<4 * MT * S * NTW, MT * S + (WTL ? NTW : (WPF ? 0 : 4 * NTW))>();
+                        pinn_sched_interleave<4 * MT * S * NTW, MT * S + ((WTL || WTG) ? NTW : (WPF ? 0 : 4 * NTW))>();
                     PINN_SCHED_BARRIER();
                 }
             }
