@@ -310,6 +310,29 @@ struct PinnPointOut {
 
 // per-point values that come from global memory (pre-pass rows, IC streams): fetched at the START of the tile by the
 // point's thread, so that their latency is not paid inside the serial point stage
+// Shape facts the point stage and the first layer branch on. SPEC 0 reads all of them from the kernel arguments (any
+// problem). SPEC 1 fixes them at compile time for the commonest training shape -- a Dirichlet box problem: hard boundary
+// binding over all ND = d inputs, no initial condition, direction k = input column k, training step with an affine
+// residual whose coefficients are constants (source term constant or one pre-pass row). The launcher checks the
+// arguments against exactly this list before it picks a SPEC 1 instantiation. What it buys: dozens of loop-invariant
+// conditions (j < nsp, c < d, "does direction k contain column c", ...) no longer live as 64-bit lane masks in SGPRs --
+// the general form keeps so many of them that hipcc spills SGPRs to VGPR lanes (several hundred v_readlane per tile) --
+// and the serial one-thread-per-point stage shrinks to the arithmetic it needs.
+template <int SPEC, int ND>
+struct PinnShape {
+    static constexpr bool FIXED = SPEC == 1;
+    static PINN_DEVICE int d(const PinnKArgs& A) { return FIXED ? ND : A.d; }
+    static PINN_DEVICE int nsp(const PinnKArgs& A) { return FIXED ? ND : A.nsp; }
+    static PINN_DEVICE int ndims(const PinnKArgs& A) { return FIXED ? ND : A.ndims; }
+    static PINN_DEVICE bool has_bc(const PinnKArgs& A) { return FIXED ? true : A.has_bc != 0; }
+    static PINN_DEVICE bool has_ic(const PinnKArgs& A) { return FIXED ? false : A.has_ic != 0; }
+    static PINN_DEVICE int dir(const PinnKArgs& A, int k) { return FIXED ? k : A.dir_cols[k]; }
+    static PINN_DEVICE int mode(const PinnKArgs& A) { return FIXED ? (int)PINN_MODE_STEP : A.mode; }
+    static PINN_DEVICE int res_kind(const PinnKArgs& A) { return FIXED ? (int)PINN_RES_AFFINE : A.res_kind; }
+    static PINN_DEVICE int s_user(const PinnKArgs& A) { return FIXED ? 99 : A.s_user; }
+    static PINN_DEVICE int coef_row(const PinnKArgs& A, int s) { return FIXED ? -1 : A.coef_row[s]; }
+};
+
 template <int ND, int N2>
 struct PinnPointPre {
     float src;                       // affine source term F
@@ -317,52 +340,56 @@ struct PinnPointPre {
     float ic[1 + ND + N2];           // IC streams
 };
 
-template <int ND, int N2>
+template <int ND, int N2, int SPEC = 0>
 PINN_DEVICE void pinn_point_prefetch(const PinnKArgs& A, long long gidx, bool valid, float* pregs, int T,
                                      PinnPointPre<ND, N2>& pre) {
     constexpr int S = 1 + ND + N2;
+    using SH = PinnShape<SPEC, ND>;
     const long long gi = valid ? gidx : 0;
     pre.src = A.src_const;
 #pragma unroll
     for (int s = 0; s < S; ++s) { pre.cs[s] = 0.0f; pre.ic[s] = 0.0f; }
-    if (A.mode == PINN_MODE_STEP) {
-        if (A.res_kind == PINN_RES_AFFINE) {
+    if (SH::mode(A) == PINN_MODE_STEP) {
+        if (SH::res_kind(A) == PINN_RES_AFFINE) {
             if (A.src_row >= 0) pre.src = A.aux[(long long)A.src_row * A.n_points + gi];
 #pragma unroll
             for (int s = 0; s < S; ++s)
-                if (s < A.s_user) pre.cs[s] = (A.coef_row[s] >= 0) ? A.aux[(long long)A.coef_row[s] * A.n_points + gi] : A.coef[s];
+                if (s < SH::s_user(A))
+                    pre.cs[s] = (SH::coef_row(A, s) >= 0) ? A.aux[(long long)SH::coef_row(A, s) * A.n_points + gi] : A.coef[s];
         } else {
-            for (int m = 0; m < A.n_aux; ++m) pregs[(S + A.d + m) * T] = A.aux[(long long)m * A.n_points + gi];
+            for (int m = 0; m < A.n_aux; ++m) pregs[(S + SH::d(A) + m) * T] = A.aux[(long long)m * A.n_points + gi];
         }
     }
-    if (A.has_ic) {
+    if (SH::has_ic(A)) {
         if (A.ic_streams) {
 #pragma unroll
             for (int s = 0; s < S; ++s)
-                if (s < A.s_user && valid) pre.ic[s] = A.ic_streams[(long long)s * A.n_points + gidx];
+                if (s < SH::s_user(A) && valid) pre.ic[s] = A.ic_streams[(long long)s * A.n_points + gidx];
         } else {
             pre.ic[0] = A.ic_const;
         }
     }
 }
 
-template <int ND, int N2, bool WITH_PROGRAMS = true, bool COMB = false>
+template <int ND, int N2, bool WITH_PROGRAMS = true, bool COMB = false, int SPEC = 0>
 PINN_DEVICE void pinn_point_stage(const PinnKArgs& A, const float (&net)[1 + ND + N2], const float* x /*[d]*/,
                                   long long gidx, bool valid, float* pregs, float* padj, int T,
                                   const PinnPointPre<ND, N2>& pre, PinnPointOut<ND, N2>& out) {
     constexpr int S = 1 + ND + N2;
     using J = PinnJet<ND, N2, COMB>;
+    using SH = PinnShape<SPEC, ND>;
+    constexpr int NIN = SH::FIXED ? ND : PINN_MAX_INPUTS;        // input columns the box factors may range over
     const float* cw = A.comb_w;
     // ---- BC factor P and its direction derivatives --------------------------------------------------------
     float P = 1.0f, Pk[ND > 0 ? ND : 1], Pkk[ND > 0 ? ND : 1];
 #pragma unroll
     for (int k = 0; k < ND; ++k) { Pk[k] = 0.0f; Pkk[k] = 0.0f; }
-    if (A.has_bc) {
-        float p[PINN_MAX_INPUTS], p1[PINN_MAX_INPUTS], p2[PINN_MAX_INPUTS];
+    if (SH::has_bc(A)) {
+        float p[NIN], p1[NIN], p2[NIN];
 #pragma unroll
-        for (int j = 0; j < PINN_MAX_INPUTS; ++j) {
+        for (int j = 0; j < NIN; ++j) {
             p[j] = 1.0f; p1[j] = 0.0f; p2[j] = 0.0f;
-            if (j < A.nsp) {
+            if (j < SH::nsp(A)) {
                 const float lo = A.lo[j], hi = A.hi[j], iw = A.inv_w[j], xj = x[j];
                 p[j] = ((xj - lo) * iw) * ((hi - xj) * iw);
                 p1[j] = (lo + hi - 2.0f * xj) * (iw * iw);
@@ -374,16 +401,16 @@ PINN_DEVICE void pinn_point_stage(const PinnKArgs& A, const float (&net)[1 + ND 
         for (int k = 0; k < ND; ++k) {
             // directional derivatives of P = prod_j p_j along e_a (+ e_b): first = sum_c p'_c prod_{j != c} p_j,
             // second = sum_c p''_c prod_{j != c} p_j + 2 p'_a p'_b prod_{j != a,b} p_j (columns outside the spatial block: 0)
-            const int ca = pinn_dir_a(A.dir_cols[k]), cb = pinn_dir_b(A.dir_cols[k]);
+            const int ca = pinn_dir_a(SH::dir(A, k)), cb = pinn_dir_b(SH::dir(A, k));
             float first = 0.0f, second = 0.0f, cross = 2.0f;
             bool both = true;
 #pragma unroll
             for (int t = 0; t < 2; ++t) {
                 const int c = t == 0 ? ca : cb;
-                if (c >= 0 && c < A.nsp) {
+                if (c >= 0 && c < SH::nsp(A)) {
                     float rest = 1.0f, q1 = 0.0f, q2 = 0.0f;
 #pragma unroll
-                    for (int j = 0; j < PINN_MAX_INPUTS; ++j) {
+                    for (int j = 0; j < NIN; ++j) {
                         if (j == c) { q1 = p1[j]; q2 = p2[j]; }
                         else rest *= p[j];
                     }
@@ -395,7 +422,7 @@ PINN_DEVICE void pinn_point_stage(const PinnKArgs& A, const float (&net)[1 + ND 
             }
             if (both) {
 #pragma unroll
-                for (int j = 0; j < PINN_MAX_INPUTS; ++j) cross *= (j == ca || j == cb) ? p1[j] : p[j];
+                for (int j = 0; j < NIN; ++j) cross *= (j == ca || j == cb) ? p1[j] : p[j];
                 second += cross;
             }
             Pk[k] = first;
@@ -406,7 +433,7 @@ PINN_DEVICE void pinn_point_stage(const PinnKArgs& A, const float (&net)[1 + ND 
     float Q[S];
 #pragma unroll
     for (int s = 0; s < S; ++s) Q[s] = net[s];
-    if (A.has_bc) {
+    if (SH::has_bc(A)) {
         Q[0] = net[0] * P + A.bc_value;
 #pragma unroll
         for (int k = 0; k < ND; ++k) Q[1 + k] = net[1 + k] * P + net[0] * Pk[k];
@@ -423,8 +450,8 @@ PINN_DEVICE void pinn_point_stage(const PinnKArgs& A, const float (&net)[1 + ND 
     float G = 1.0f, Gk[ND > 0 ? ND : 1], Gkk[ND > 0 ? ND : 1], dG = 0.0f, dGk[ND > 0 ? ND : 1], dGkk[ND > 0 ? ND : 1];
 #pragma unroll
     for (int k = 0; k < ND; ++k) { Gk[k] = 0.0f; Gkk[k] = 0.0f; dGk[k] = 0.0f; dGkk[k] = 0.0f; }
-    if (A.has_ic) {
-        const int tcol = A.ndims - 1;
+    if (SH::has_ic(A)) {
+        const int tcol = SH::ndims(A) - 1;
         const float es = expf(-A.params[A.off_ls]);
         const float tau = (x[tcol] - A.t0) * es;
         const float sg = pinn_sigmoidf(tau);
@@ -435,7 +462,7 @@ PINN_DEVICE void pinn_point_stage(const PinnKArgs& A, const float (&net)[1 + ND 
         dG = -tau * d1;
 #pragma unroll
         for (int k = 0; k < ND; ++k) {
-            if (pinn_dir_has(A.dir_cols[k], tcol)) {
+            if (pinn_dir_has(SH::dir(A, k), tcol)) {
                 Gk[k] = d1 * es; Gkk[k] = d2 * es * es;
                 dGk[k] = es * (-tau * d2 - d1);
                 dGkk[k] = es * es * (-tau * d3 - 2.0f * d2);
@@ -457,17 +484,17 @@ PINN_DEVICE void pinn_point_stage(const PinnKArgs& A, const float (&net)[1 + ND 
 #pragma unroll
     for (int s = 0; s < S; ++s) gu[s] = 0.0f;
     out.loss = 0.0f;
-    if (A.mode == PINN_MODE_FORWARD) {
+    if (SH::mode(A) == PINN_MODE_FORWARD) {
         if (valid) {
 #pragma unroll
             for (int s = 0; s < S; ++s)
-                if (s < A.s_user) A.out_streams[(long long)s * A.n_points + gidx] = u[s];
+                if (s < SH::s_user(A)) A.out_streams[(long long)s * A.n_points + gidx] = u[s];
         }
 #pragma unroll
         for (int s = 0; s < S; ++s) out.gnet[s] = 0.0f;
         out.g_ls = 0.0f;
         return;
-    } else if (A.mode == PINN_MODE_STEP && A.res_kind == PINN_RES_AFFINE) {
+    } else if (SH::mode(A) == PINN_MODE_STEP && SH::res_kind(A) == PINN_RES_AFFINE) {
         // r = sum_s C_s u_s + F, coefficients constant or per-point rows of the x-only pre-pass
         float r = pre.src;
 #pragma unroll
@@ -476,24 +503,24 @@ PINN_DEVICE void pinn_point_stage(const PinnKArgs& A, const float (&net)[1 + ND 
 #pragma unroll
         for (int s = 0; s < S; ++s) gu[s] = w * pre.cs[s];
         out.loss = valid ? r * r * A.inv_n : 0.0f;
-    } else if (WITH_PROGRAMS && A.mode == PINN_MODE_STEP) {
+    } else if (WITH_PROGRAMS && SH::mode(A) == PINN_MODE_STEP) {
         // registers: S streams (the INSTANTIATION's S), d input columns, n_aux pre-pass rows (already staged by
         // pinn_point_prefetch), then temporaries
 #pragma unroll
         for (int s = 0; s < S; ++s) pregs[s * T] = u[s];
-        for (int c = 0; c < A.d; ++c) pregs[(S + c) * T] = x[c];
+        for (int c = 0; c < SH::d(A); ++c) pregs[(S + c) * T] = x[c];
         const float r = pinn_prog_forward(A.prog, pregs, T);
         pinn_prog_backward(A.prog, pregs, padj, T);
         const float w = valid ? 2.0f * r * A.inv_n : 0.0f;
 #pragma unroll
         for (int s = 0; s < S; ++s) { gu[s] = w * padj[s * T]; padj[s * T] = 0.0f; }
-        for (int c = 0; c < A.d + A.n_aux; ++c) padj[(S + c) * T] = 0.0f;
+        for (int c = 0; c < SH::d(A) + A.n_aux; ++c) padj[(S + c) * T] = 0.0f;
         out.loss = valid ? r * r * A.inv_n : 0.0f;
     } else {
         if (valid) {
 #pragma unroll
             for (int s = 0; s < S; ++s)
-                if (s < A.s_user) gu[s] = A.gin[(long long)s * A.n_points + gidx];
+                if (s < SH::s_user(A)) gu[s] = A.gin[(long long)s * A.n_points + gidx];
         }
     }
     // ---- reverse: u -> Q (gate) ---------------------------------------------------------------------------------
@@ -501,7 +528,7 @@ PINN_DEVICE void pinn_point_stage(const PinnKArgs& A, const float (&net)[1 + ND 
 #pragma unroll
     for (int s = 0; s < S; ++s) gQ[s] = gu[s];
     float g_ls = 0.0f;
-    if (A.has_ic) {
+    if (SH::has_ic(A)) {
         float gG = gu[0] * Q[0];
         gQ[0] = gu[0] * G;
 #pragma unroll
@@ -529,7 +556,7 @@ PINN_DEVICE void pinn_point_stage(const PinnKArgs& A, const float (&net)[1 + ND 
     // ---- reverse: Q -> net (BC factor) -----------------------------------------------------------------------
 #pragma unroll
     for (int s = 0; s < S; ++s) out.gnet[s] = gQ[s];
-    if (A.has_bc) {
+    if (SH::has_bc(A)) {
         float g0 = gQ[0] * P;
 #pragma unroll
         for (int j = 0; j < N2; ++j) out.gnet[1 + ND + j] = gQ[1 + ND + j] * P;
@@ -575,7 +602,7 @@ PINN_DEVICE void pinn_st4(float* p, f32x4 v) { *reinterpret_cast<f32x4*>(p) = v;
 // VAR (experiment bits): 1 = accumulate dW in the partial buffer although the layer count is static, 2 = two waves per
 // SIMD (two workgroups per CU), 4 = no whole-layer weight prefetch; 8 = layout breadth: Sin / identity activations and
 // skip connections ('R ... +' layouts; the skipped activations ride in registers through the forward half and in extra
-// slab slots through the reverse half).
+// slab slots through the reverse half); 16 = shape facts of a Dirichlet-box training step fixed at compile time (PinnShape).
 template <int HP, int ND, int N2, int MT, int LHC, int ACTC, bool COMB = false, int VAR = 0>
 // occupancy hint: the fused kernel of a 64/128-wide net wants the whole register file of a SIMD (one wave per SIMD,
 // no spills); narrower nets (1-2 waves per workgroup) run several workgroups per CU
@@ -593,6 +620,8 @@ pinn_tile_kernel(const PinnKArgs A) {
     // widths >= 128: the data-gradient A operand comes from a transposed copy of the weights in global memory (one b128 per
     // K quad like the forward GEMM) instead of four strided global_load_dword per quad
     constexpr bool WTG = C::WTG;
+    constexpr int SPEC = (VAR & 16) ? 1 : 0;               // VAR 16: Dirichlet-box training shape fixed at compile time
+    using SH = PinnShape<SPEC, ND>;
     const int tid = PINN_TID, lane = tid & 63, wave = tid >> 6;
     const int lr = lane & 15, lq = lane >> 4;
     const int lh = (LHC >= 0) ? LHC : A.lh;
@@ -614,8 +643,8 @@ pinn_tile_kernel(const PinnKArgs A) {
         return k;
     };
     const float* cw = A.comb_w;
-    const int d = A.d;
-    const bool train = A.mode != PINN_MODE_FORWARD;
+    const int d = SH::d(A);
+    const bool train = SH::mode(A) != PINN_MODE_FORWARD;
 
     PINN_SMEM(smem);
     float* xs_base = smem + C::O_XS;
@@ -739,7 +768,7 @@ pinn_tile_kernel(const PinnKArgs A) {
         float* xs_t = xs_base + tile_parity * T * PINN_XS_LD;
         float* xs_next = xs_base + (tile_parity ^ 1) * T * PINN_XS_LD;
         PinnPointPre<ND, N2> ppre;
-        if (tid < T) pinn_point_prefetch<ND, N2>(A, base + tid, base + tid < A.n_points, pregs + tid, T, ppre);
+        if (tid < T) pinn_point_prefetch<ND, N2, SPEC>(A, base + tid, base + tid < A.n_points, pregs + tid, T, ppre);
         PH(0)
 
         float* cur = bufA;
@@ -796,7 +825,7 @@ pinn_tile_kernel(const PinnKArgs A) {
                     }
                     z[0] = z0;
 #pragma unroll
-                    for (int k = 0; k < ND; ++k) z[1 + k] = pinn_dir_weight(W1s + n * PINN_XS_LD, A.dir_cols[k]);
+                    for (int k = 0; k < ND; ++k) z[1 + k] = pinn_dir_weight(W1s + n * PINN_XS_LD, SH::dir(A, k));
 #pragma unroll
                     for (int k = 0; k < N2; ++k) z[1 + ND + k] = 0.0f;
                     pinn_jet_fwd<ND, N2, COMB>(z, act0, h, cw);
@@ -972,7 +1001,7 @@ pinn_tile_kernel(const PinnKArgs A) {
                 net[s] = v;
             }
             PinnPointOut<ND, N2> po;
-            pinn_point_stage<ND, N2, true, COMB>(A, net, xs_t + pt * PINN_XS_LD, base + pt, base + pt < A.n_points,
+            pinn_point_stage<ND, N2, SPEC == 0, COMB, SPEC>(A, net, xs_t + pt * PINN_XS_LD, base + pt, base + pt < A.n_points,
                                      pregs + pt, padj + pt, T, ppre, po);
 #pragma unroll
             for (int s = 0; s < S; ++s) gnetb[s * T + pt] = po.gnet[s];
@@ -999,7 +1028,7 @@ pinn_tile_kernel(const PinnKArgs A) {
                         for (int r = 0; r < 4; ++r) {
 #pragma unroll
                             for (int k = 0; k < ND; ++k)
-                                dst[j][mt][1 + k][r] = pinn_dir_weight(W1s + (unit0(j) + r) * PINN_XS_LD, A.dir_cols[k]);
+                                dst[j][mt][1 + k][r] = pinn_dir_weight(W1s + (unit0(j) + r) * PINN_XS_LD, SH::dir(A, k));
 #pragma unroll
                             for (int k = 0; k < N2; ++k) dst[j][mt][1 + ND + k][r] = 0.0f;
                         }
@@ -1358,7 +1387,7 @@ pinn_tile_kernel(const PinnKArgs A) {
                                 accW1r[REGB ? c : 0][j] += gz[j][mt][0] * xs_t[(mt * 16 + lr) * PINN_XS_LD + c];
 #pragma unroll
                                 for (int k = 0; k < ND; ++k)
-                                    if (pinn_dir_has(A.dir_cols[k], c)) accW1r[REGB ? c : 0][j] += gz[j][mt][1 + k];
+                                    if (pinn_dir_has(SH::dir(A, k), c)) accW1r[REGB ? c : 0][j] += gz[j][mt][1 + k];
                             }
                         }
                     }
@@ -1370,7 +1399,7 @@ pinn_tile_kernel(const PinnKArgs A) {
                         v += gz[j][mt][0] * xs_t[(mt * 16 + lr) * PINN_XS_LD + c];
 #pragma unroll
                         for (int k = 0; k < ND; ++k)
-                            if (pinn_dir_has(A.dir_cols[k], c)) v += gz[j][mt][1 + k];
+                            if (pinn_dir_has(SH::dir(A, k), c)) v += gz[j][mt][1 + k];
                     }
 #pragma unroll
                     for (int r = 0; r < 4; ++r) {

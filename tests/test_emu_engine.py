@@ -49,6 +49,8 @@ def test_fused_fit_matches_reference_golden(pa, emu_lib, name):
     niters = 2 if name == 'cfg3' else len(g.losses)        # 8-wave / 128-wide emulation is slow: two steps suffice
     solver.fit(niters=niters, batch_size=pts.shape[1], sampler=FixedBatches(pts), lr=g.lr)
     assert solver.last_fit_path == 'fused'
+    # the Poisson configs take the shape-specialised instantiation (PinnShape<1>), everything else the general one
+    assert emu_lib.pinn_debug_last_kernel() == (2 if name in ('cfg1', 'cfg2') else 0)
     np.testing.assert_allclose(np.array([float(v) for v in solver.losses]), g.losses[:niters], rtol=fit_rtol(name))
     if niters == len(g.losses):
         for got, want in zip(export_params(solver), g.finals):
