@@ -311,21 +311,24 @@ struct PinnPointOut {
 // per-point values that come from global memory (pre-pass rows, IC streams): fetched at the START of the tile by the
 // point's thread, so that their latency is not paid inside the serial point stage
 // Shape facts the point stage and the first layer branch on. SPEC 0 reads all of them from the kernel arguments (any
-// problem). SPEC 1 fixes them at compile time for the commonest training shape -- a Dirichlet box problem: hard boundary
-// binding over all ND = d inputs, no initial condition, direction k = input column k, training step with an affine
-// residual whose coefficients are constants (source term constant or one pre-pass row). The launcher checks the
-// arguments against exactly this list before it picks a SPEC 1 instantiation. What it buys: dozens of loop-invariant
-// conditions (j < nsp, c < d, "does direction k contain column c", ...) no longer live as 64-bit lane masks in SGPRs --
-// the general form keeps so many of them that hipcc spills SGPRs to VGPR lanes (several hundred v_readlane per tile) --
-// and the serial one-thread-per-point stage shrinks to the arithmetic it needs.
+// problem). SPEC 1..3 fix them at compile time for the commonest training shapes -- always: direction k = input column
+// k, training step with an affine residual whose coefficients are constants (source term constant or one pre-pass row):
+//   1  Dirichlet box: hard boundary binding over all ND = d inputs, no initial condition           (Poisson, Helmholtz)
+//   2  evolution in a box: boundary binding over the first ND-1 inputs, initial condition in the last (heat, wave)
+//   3  ODE family: one differentiated input (t), initial condition, no boundary binding, d - 1 parameters
+// The launcher checks the arguments against exactly this list before it picks a SPEC instantiation (pinn_spec_of).
+// What it buys: dozens of loop-invariant conditions (j < nsp, c < d, "does direction k contain column c", ...) no longer
+// live as 64-bit lane masks in SGPRs -- the general form keeps so many of them that hipcc spills SGPRs to VGPR lanes
+// (several hundred v_readlane per tile) and the kernel needs ~95 registers more -- and the serial one-thread-per-point
+// stage shrinks to the arithmetic it needs (cfg2 kernel: 0.237 -> 0.207 ms).
 template <int SPEC, int ND>
 struct PinnShape {
-    static constexpr bool FIXED = SPEC == 1;
-    static PINN_DEVICE int d(const PinnKArgs& A) { return FIXED ? ND : A.d; }
-    static PINN_DEVICE int nsp(const PinnKArgs& A) { return FIXED ? ND : A.nsp; }
-    static PINN_DEVICE int ndims(const PinnKArgs& A) { return FIXED ? ND : A.ndims; }
-    static PINN_DEVICE bool has_bc(const PinnKArgs& A) { return FIXED ? true : A.has_bc != 0; }
-    static PINN_DEVICE bool has_ic(const PinnKArgs& A) { return FIXED ? false : A.has_ic != 0; }
+    static constexpr bool FIXED = SPEC != 0;
+    static PINN_DEVICE int d(const PinnKArgs& A) { return (SPEC == 1 || SPEC == 2) ? ND : A.d; }
+    static PINN_DEVICE int nsp(const PinnKArgs& A) { return SPEC == 1 ? ND : SPEC == 2 ? ND - 1 : SPEC == 3 ? 0 : A.nsp; }
+    static PINN_DEVICE int ndims(const PinnKArgs& A) { return (SPEC == 1 || SPEC == 2) ? ND : SPEC == 3 ? 1 : A.ndims; }
+    static PINN_DEVICE bool has_bc(const PinnKArgs& A) { return (SPEC == 1 || SPEC == 2) ? true : SPEC == 3 ? false : A.has_bc != 0; }
+    static PINN_DEVICE bool has_ic(const PinnKArgs& A) { return SPEC == 1 ? false : FIXED ? true : A.has_ic != 0; }
     static PINN_DEVICE int dir(const PinnKArgs& A, int k) { return FIXED ? k : A.dir_cols[k]; }
     static PINN_DEVICE int mode(const PinnKArgs& A) { return FIXED ? (int)PINN_MODE_STEP : A.mode; }
     static PINN_DEVICE int res_kind(const PinnKArgs& A) { return FIXED ? (int)PINN_RES_AFFINE : A.res_kind; }
@@ -378,7 +381,7 @@ PINN_DEVICE void pinn_point_stage(const PinnKArgs& A, const float (&net)[1 + ND 
     constexpr int S = 1 + ND + N2;
     using J = PinnJet<ND, N2, COMB>;
     using SH = PinnShape<SPEC, ND>;
-    constexpr int NIN = SH::FIXED ? ND : PINN_MAX_INPUTS;        // input columns the box factors may range over
+    constexpr int NIN = SH::FIXED ? (ND > 0 ? ND : 1) : PINN_MAX_INPUTS;   // input columns the box factors may range over
     const float* cw = A.comb_w;
     // ---- BC factor P and its direction derivatives --------------------------------------------------------
     float P = 1.0f, Pk[ND > 0 ? ND : 1], Pkk[ND > 0 ? ND : 1];
@@ -602,7 +605,7 @@ PINN_DEVICE void pinn_st4(float* p, f32x4 v) { *reinterpret_cast<f32x4*>(p) = v;
 // VAR (experiment bits): 1 = accumulate dW in the partial buffer although the layer count is static, 2 = two waves per
 // SIMD (two workgroups per CU), 4 = no whole-layer weight prefetch; 8 = layout breadth: Sin / identity activations and
 // skip connections ('R ... +' layouts; the skipped activations ride in registers through the forward half and in extra
-// slab slots through the reverse half); 16 = shape facts of a Dirichlet-box training step fixed at compile time (PinnShape).
+// slab slots through the reverse half); 16, 32, 48 = shape facts of a common training step (PinnShape 1, 2, 3) fixed at compile time.
 template <int HP, int ND, int N2, int MT, int LHC, int ACTC, bool COMB = false, int VAR = 0>
 // occupancy hint: the fused kernel of a 64/128-wide net wants the whole register file of a SIMD (one wave per SIMD,
 // no spills); narrower nets (1-2 waves per workgroup) run several workgroups per CU
@@ -620,7 +623,7 @@ pinn_tile_kernel(const PinnKArgs A) {
     // widths >= 128: the data-gradient A operand comes from a transposed copy of the weights in global memory (one b128 per
     // K quad like the forward GEMM) instead of four strided global_load_dword per quad
     constexpr bool WTG = C::WTG;
-    constexpr int SPEC = (VAR & 16) ? 1 : 0;               // VAR 16: Dirichlet-box training shape fixed at compile time
+    constexpr int SPEC = (VAR >> 4) & 3;                   // VAR 16/32/48: training shape 1/2/3 fixed at compile time
     using SH = PinnShape<SPEC, ND>;
     const int tid = PINN_TID, lane = tid & 63, wave = tid >> 6;
     const int lr = lane & 15, lq = lane >> 4;

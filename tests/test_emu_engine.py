@@ -49,8 +49,9 @@ def test_fused_fit_matches_reference_golden(pa, emu_lib, name):
     niters = 2 if name == 'cfg3' else len(g.losses)        # 8-wave / 128-wide emulation is slow: two steps suffice
     solver.fit(niters=niters, batch_size=pts.shape[1], sampler=FixedBatches(pts), lr=g.lr)
     assert solver.last_fit_path == 'fused'
-    # the Poisson configs take the shape-specialised instantiation (PinnShape<1>), everything else the general one
-    assert emu_lib.pinn_debug_last_kernel() == (2 if name in ('cfg1', 'cfg2') else 0)
+    # the BASELINE shapes take a shape-specialised instantiation (PinnShape 1: Poisson, 2: heat, 3: ODE family), the
+    # 32-wide sigmoid net and the mixed-partial operator (a diagonal direction) the general one
+    assert emu_lib.pinn_debug_last_kernel() == (2 if name in ('cfg1', 'cfg2', 'cfg3', 'cfg4') else 0)
     np.testing.assert_allclose(np.array([float(v) for v in solver.losses]), g.losses[:niters], rtol=fit_rtol(name))
     if niters == len(g.losses):
         for got, want in zip(export_params(solver), g.finals):
@@ -408,7 +409,7 @@ def test_two_team_kernel_agrees_with_solo_kernel(pa, emu_lib, name):
             _, solver = make_solver(name, pa, **emu_kwargs(emu_lib))
             load_params(solver, g.params)
             solver._fused_step(torch.from_numpy(g.points[0].copy()), 1)
-            assert emu_lib.pinn_debug_last_kernel() == (0 if disable else 1)
+            assert emu_lib.pinn_debug_last_kernel() == (2 if disable else 1)     # 2: the shape-specialised default kernel
             grads[disable] = solver.grads.clone().numpy()
     finally:
         emu_lib.pinn_debug_disable_duo(1)
