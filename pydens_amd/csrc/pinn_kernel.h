@@ -715,7 +715,10 @@ pinn_tile_kernel(const PinnKArgs A) {
 #ifndef PINN_REGB_MAX
 #define PINN_REGB_MAX 6
 #endif
-    constexpr bool REGB = !DWG && (S * MT * NTW <= PINN_REGB_MAX);
+#ifndef PINN_REGB_MAX_SPEC
+#define PINN_REGB_MAX_SPEC 8
+#endif
+    constexpr bool REGB = !DWG && (S * MT * NTW <= (SPEC != 0 ? PINN_REGB_MAX_SPEC : PINN_REGB_MAX));
     constexpr int W1R = 4;
     f32x4 accBr[REGB ? PINN_LHMAX + 1 : 1][NTW], accW1r[REGB ? W1R : 1][NTW];
 #pragma unroll
@@ -970,20 +973,36 @@ pinn_tile_kernel(const PinnKArgs A) {
         }
 
         // ---- (3) last layer (out = 1): net_s[pt] = WL . h_s[pt]; per-wave partials, summed by the point stage ------
+        {
+            // (weights read once, all dot products first, then the row sums, then ONE predicated block of stores: written
+            //  the short way the compiler re-read WL and opened an exec-mask region for every (mt, s) pair, eight LDS
+            //  round trips in a row)
+            f32x4 wlv[NTW];
 #pragma unroll
-        for (int mt = 0; mt < MT; ++mt) {
-            const int pt = mt * 16 + lr;
+            for (int j = 0; j < NTW; ++j) wlv[j] = pinn_ld4(WLs + unit0(j));
+            float part[MT][S];
 #pragma unroll
-            for (int s = 0; s < S; ++s) {
-                float part = 0.0f;
+            for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
-                for (int j = 0; j < NTW; ++j) {
-                    const f32x4 hv = htop[j][mt][s], wv = pinn_ld4(WLs + unit0(j));
-                    part = fmaf(hv[0], wv[0], part); part = fmaf(hv[1], wv[1], part);
-                    part = fmaf(hv[2], wv[2], part); part = fmaf(hv[3], wv[3], part);
+                for (int s = 0; s < S; ++s) {
+                    float acc1 = 0.0f;
+#pragma unroll
+                    for (int j = 0; j < NTW; ++j) {
+                        const f32x4 hv = htop[j][mt][s];
+                        acc1 = fmaf(hv[0], wlv[j][0], acc1); acc1 = fmaf(hv[1], wlv[j][1], acc1);
+                        acc1 = fmaf(hv[2], wlv[j][2], acc1); acc1 = fmaf(hv[3], wlv[j][3], acc1);
+                    }
+                    part[mt][s] = acc1;
                 }
-                part = pinn_rows_sum(part);
-                if (lq == 0) netp[(wave * S + s) * T + pt] = part;
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+                for (int s = 0; s < S; ++s) part[mt][s] = pinn_rows_sum(part[mt][s]);
+            if (lq == 0) {
+#pragma unroll
+                for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+                    for (int s = 0; s < S; ++s) netp[(wave * S + s) * T + mt * 16 + lr] = part[mt][s];
             }
         }
         PH(6)
