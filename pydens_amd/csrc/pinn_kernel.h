@@ -1064,7 +1064,7 @@ pinn_tile_kernel(const PinnKArgs A) {
 #ifndef PINN_SVPF_MAX
 #define PINN_SVPF_MAX 8
 #endif
-        constexpr bool SVPF = (S * MT * NTW <= PINN_SVPF_MAX) && !ONEBUF;
+        constexpr bool SVPF = (S * MT * NTW <= PINN_SVPF_MAX) && !ONEBUF && NW <= 4;    // (8-wave kernels: registers first)
         if (SVPF && lh > 0) load_saved(lh - 1, svn);
 #pragma unroll
         for (int j = 0; j < NTW; ++j) {
@@ -1269,7 +1269,10 @@ pinn_tile_kernel(const PinnKArgs A) {
                     // OB independent MFMA chains per B fragment (a lone chain stalls on its own 8-pass latency), the tiles of
                     // the NEXT block fetched from the partial buffer (L2) while this block computes, the LDS operands of the
                     // next (mt, s) row tile read between the MFMAs of the current one
-                    constexpr int OB = (NTW >= 4) ? 1 : ((4 / NTW < NT) ? 4 / NTW : NT);     // OB * NTW = 4 chains where possible
+    #ifndef PINN_OB_CHAINS
+#define PINN_OB_CHAINS 4
+#endif
+                constexpr int OB = (NTW >= PINN_OB_CHAINS) ? 1 : ((PINN_OB_CHAINS / NTW < NT) ? PINN_OB_CHAINS / NTW : NT);   // OB * NTW chains
                     f32x4 dwn[OB][NTW];
                     auto load_dw = [&](int ob, f32x4 (&dst)[OB][NTW]) {
 #pragma unroll
