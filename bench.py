@@ -32,7 +32,7 @@ PEAK_FP32_MFMA_TFLOPS = 157.3   # /opt/skills/guides/MI355X_MICROARCH.md "Peak F
 WORKLOAD = 'cfg2'
 BATCH_PER_GPU = 65536
 POOL = 8                        # distinct pre-generated point batches cycled through
-KERNEL = 'pinn_tile_kernel<64,2,1,2,3,0,true,0>'
+KERNEL = 'pinn_tile_kernel<64,2,1,2,3,0,true,16>'
 
 
 def flops_per_point(layer_dims, n_streams):
