@@ -31,6 +31,7 @@ hipEvent_t g_ev0 = nullptr, g_ev1 = nullptr;
 
 int g_pinn_disable_duo = 1;      // the two-team kernel is an experiment; off by default
 int g_pinn_last_kernel = -1;
+int g_pinn_prepass_in_kernel = 1;   // debug switch: 0 = x-only pre-pass as its own launch (pinn_aux_kernel)
 int g_pinn_debug_flags = 0;
 
 struct pinn_net {
@@ -175,6 +176,11 @@ const char* pinn_last_error(void) { return g_err; }
 int pinn_debug_set_flags(int flags) { g_pinn_debug_flags = flags; return 0; }
 
 int pinn_debug_last_kernel(void) { return g_pinn_last_kernel; }
+
+int pinn_debug_prepass_in_kernel(int enable) {
+    g_pinn_prepass_in_kernel = enable ? 1 : 0;
+    return 0;
+}
 
 int pinn_debug_disable_duo(int disable) {
     g_pinn_disable_duo = disable ? 1 : 0;
@@ -359,14 +365,18 @@ static int run_train(pinn_t* net, PinnKArgs* a, const Plan& plan, int nd, float*
     if (aux_bytes) {
         float* aux = reinterpret_cast<float*>(reinterpret_cast<char*>(workspace) + part_bytes + slab_bytes);
         a->aux = aux;
-        const int blocks = (int)((a->n_points + 255) / 256);
+        if (g_pinn_prepass_in_kernel && g_pinn_disable_duo) {
+            a->pre = *pre;          // evaluated in the prologue of the tile kernel: one launch (and one dependent-launch gap) less
+        } else {
+            const int blocks = (int)((a->n_points + 255) / 256);
 #ifdef PINN_EMU
-        emu::launch(blocks, 256, 0, [&] { pinn_aux_kernel(a->xs, a->n_points, a->d, *pre, aux); });
+            emu::launch(blocks, 256, 0, [&] { pinn_aux_kernel(a->xs, a->n_points, a->d, *pre, aux); });
 #else
-        hipLaunchKernelGGL(pinn_aux_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, a->xs, a->n_points, a->d,
-                           *pre, aux);
-        if (hipGetLastError() != hipSuccess) return fail("pre-pass kernel launch failed");
+            hipLaunchKernelGGL(pinn_aux_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, a->xs, a->n_points, a->d,
+                               *pre, aux);
+            if (hipGetLastError() != hipSuccess) return fail("pre-pass kernel launch failed");
 #endif
+        }
     }
     if (wt_bytes) {
         // widths >= 128: transposed copy of the hidden weights for the data-gradient GEMM (the weights change every step)

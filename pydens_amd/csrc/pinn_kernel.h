@@ -57,8 +57,10 @@ struct PinnKArgs {
     float src_const;
     float coef[PINN_MAX_STREAMS];
     int coef_row[PINN_MAX_STREAMS];
-    const float* aux;            // [n_aux][N] rows of the x-only pre-pass
+    float* aux;                  // [n_aux][N] rows of the x-only pre-pass
     pinn_program_t prog;
+    pinn_program_t pre;          // n_ops > 0: the tile kernel evaluates the pre-pass itself for the points of its own tiles
+                                 // (kernel prologue) instead of a separate launch in front of it
 };
 
 template <int HP_, int ND_, int N2_, int MT_ = 1>
@@ -264,6 +266,41 @@ PINN_DEVICE float pinn_prog_forward(const pinn_program_t& pg, float* regs, int T
         last = dst;
     }
     return regs[last * T];
+}
+
+// x-only pre-pass of ONE point inside the tile kernel: registers 0..d-1 = the input columns, PINN_OP_STORE writes a
+// register to aux row b (read back by the same thread in pinn_point_prefetch). Same arithmetic as pinn_aux_kernel.
+PINN_DEVICE void pinn_prepass_point(const pinn_program_t& pg, const float* x, int d, float* aux, long long n, long long gi) {
+    constexpr int T = 1;
+    float regs[PINN_MAX_REGS];                 // private (scratch): the program indexes it at run time
+    for (int c = 0; c < d; ++c) regs[c * T] = x[c];
+    for (int i = 0; i < pg.n_ops; ++i) {
+        const unsigned w = pg.code[i];
+        const int op = w & 255, dst = (w >> 8) & 255, a = (w >> 16) & 255, b = (w >> 24) & 255;
+        if (op == PINN_OP_STORE) { aux[(long long)b * n + gi] = regs[a * T]; continue; }
+        const float xa = (op == PINN_OP_CONST) ? 0.0f : regs[a * T];
+        float y;
+        switch (op) {
+            case PINN_OP_CONST: y = pg.consts[a]; break;
+            case PINN_OP_ADD: y = xa + regs[b * T]; break;
+            case PINN_OP_SUB: y = xa - regs[b * T]; break;
+            case PINN_OP_MUL: y = xa * regs[b * T]; break;
+            case PINN_OP_DIV: y = xa / regs[b * T]; break;
+            case PINN_OP_NEG: y = -xa; break;
+            case PINN_OP_SIN: y = sinf(xa); break;
+            case PINN_OP_COS: y = cosf(xa); break;
+            case PINN_OP_EXP: y = expf(xa); break;
+            case PINN_OP_LOG: y = logf(xa); break;
+            case PINN_OP_TANH: y = tanhf(xa); break;
+            case PINN_OP_SQRT: y = sqrtf(xa); break;
+            case PINN_OP_POW: y = powf(xa, pg.consts[b]); break;
+            case PINN_OP_ABS: y = fabsf(xa); break;
+            case PINN_OP_SIGMOID: y = pinn_sigmoidf(xa); break;
+            case PINN_OP_RECIP: y = 1.0f / xa; break;
+            default: y = xa; break;    // COPY
+        }
+        regs[dst * T] = y;
+    }
 }
 
 // reverse sweep: adj[] must be zero on entry for every register; adj[result] is seeded with 1.
@@ -762,6 +799,16 @@ pinn_tile_kernel(const PinnKArgs A) {
     // the points live in a double-buffered LDS tile: tile k reads buffer k&1 while the points of tile k+1 are written
     // to the other one in the middle of tile k (several barriers away from both its last reader and its first reader),
     // so neither the staging nor the end of a tile needs a barrier of its own
+    if (A.pre.n_ops > 0) {
+        // x-only pre-pass (source terms, variable coefficients) for the points of this workgroup's own tiles, all threads,
+        // NTHREADS / T tiles per sweep; the rows land in A.aux and are read back (by the point-stage threads of the same
+        // workgroup, hence the fence + the barrier below) at the top of each tile
+        for (long long tile = PINN_BID + (long long)(tid / T) * PINN_NBLK; tile < ntiles; tile += (long long)(NTHREADS / T) * PINN_NBLK) {
+            const long long gi = tile * T + tid % T;
+            if (gi < A.n_points) pinn_prepass_point(A.pre, A.xs + gi * d, d, A.aux, A.n_points, gi);
+        }
+        PINN_FENCE_BLOCK();
+    }
     fetch_points(PINN_BID);
     store_points(xs_base);
     fetch_points((long long)PINN_BID + PINN_NBLK);

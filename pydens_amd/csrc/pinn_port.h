@@ -18,6 +18,7 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 #define PINN_BID ((int)blockIdx.x)
 #define PINN_NBLK ((int)gridDim.x)
 #define PINN_SYNC() __syncthreads()
+#define PINN_FENCE_BLOCK() __threadfence_block()
 #define PINN_SMEM(name) extern __shared__ __attribute__((aligned(16))) float name[]
 #define PINN_LAUNCH_BOUNDS(n) __launch_bounds__(n)
 

@@ -31,6 +31,7 @@ void launch(int grid, int block, size_t smem_bytes, const std::function<void()>&
 #define PINN_BID (emu::bid())
 #define PINN_NBLK (emu::nblk())
 #define PINN_SYNC() emu::sync_block()
+#define PINN_FENCE_BLOCK()
 #define PINN_SMEM(name) float* name = emu::smem()
 #define PINN_LAUNCH_BOUNDS(n)
 
