@@ -142,20 +142,22 @@ struct AdamArgs {
 
 int launch_reduce(const float* partials, int n_wg, int p_core, float* grads, int accumulate, void* stream,
                   const AdamArgs* adam = nullptr) {
-    const int blocks = (p_core + 63) / 64;
+    const int blocks = (p_core + PINN_REDUCE_PB - 1) / PINN_REDUCE_PB;
     const size_t smem = 1024 * sizeof(float);
     AdamArgs z = {nullptr, nullptr, nullptr, nullptr, nullptr, 0, 0.f, 0.f, 0.f, 0.f};
     const AdamArgs& a = adam ? *adam : z;
     const int do_adam = adam ? 1 : 0;
+    float step_size = 0.0f, bc2_sqrt = 1.0f;
+    if (adam) pinn_adam_scalars((double)a.step_value, a.lr, a.b1, a.b2, &step_size, &bc2_sqrt);
 #ifdef PINN_EMU
     emu::launch(blocks, 1024, smem, [&] {
         pinn_reduce_kernel(partials, n_wg, p_core, grads, accumulate, do_adam, a.params, a.m, a.v, a.mask, a.step_value,
-                           a.lr, a.b1, a.b2, a.eps, a.step_ptr);
+                           step_size, bc2_sqrt, a.b1, a.b2, a.eps, a.step_ptr);
     });
 #else
     hipLaunchKernelGGL(pinn_reduce_kernel, dim3(blocks), dim3(1024), smem, (hipStream_t)stream, partials, n_wg, p_core,
-                       grads, accumulate, do_adam, a.params, a.m, a.v, a.mask, a.step_value, a.lr, a.b1, a.b2, a.eps,
-                       a.step_ptr);
+                       grads, accumulate, do_adam, a.params, a.m, a.v, a.mask, a.step_value, step_size, bc2_sqrt, a.b1, a.b2,
+                       a.eps, a.step_ptr);
     if (hipGetLastError() != hipSuccess) return fail("reduce kernel launch failed");
 #endif
     return 0;
@@ -524,13 +526,15 @@ static int adam_launch(float* params, const float* grads, float* exp_avg, float*
     if (!params || !grads || !exp_avg || !exp_avg_sq || !step_ptr) return fail("null argument");
     if (n <= 0) return 0;
     const int blocks = (int)((n + 255) / 256);
+    float step_size = 0.0f, bc2_sqrt = 1.0f;
+    if (step > 0) pinn_adam_scalars((double)step, lr, beta1, beta2, &step_size, &bc2_sqrt);
 #ifdef PINN_EMU
     if (step <= 0) emu::launch(1, 64, 0, [&] { pinn_tick_kernel(step_ptr); });
-    emu::launch(blocks, 256, 0, [&] { pinn_adam_kernel(params, grads, exp_avg, exp_avg_sq, mask, n, step_ptr, step, lr, beta1, beta2, eps); });
+    emu::launch(blocks, 256, 0, [&] { pinn_adam_kernel(params, grads, exp_avg, exp_avg_sq, mask, n, step_ptr, step, lr, step_size, bc2_sqrt, beta1, beta2, eps); });
 #else
     if (step <= 0) hipLaunchKernelGGL(pinn_tick_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, step_ptr);
     hipLaunchKernelGGL(pinn_adam_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, params, grads, exp_avg,
-                       exp_avg_sq, mask, (long long)n, (int*)step_ptr, (int)step, lr, beta1, beta2, eps);
+                       exp_avg_sq, mask, (long long)n, (int*)step_ptr, (int)step, lr, step_size, bc2_sqrt, beta1, beta2, eps);
     if (hipGetLastError() != hipSuccess) return fail("adam kernel launch failed");
 #endif
     return 0;

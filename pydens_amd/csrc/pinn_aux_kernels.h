@@ -47,13 +47,17 @@ pinn_aux_kernel(const float* xs, long long n, int d, pinn_program_t pg, float* a
 // workgroups (every wave reads whole 256-B rows), LDS tree over the chunks; optionally the Adam update of those 64
 // parameters right behind it (single-rank steps: no all-reduce in between, two launches less).
 // ------------------------------------------------------------------------------------------------------------
-PINN_DEVICE void pinn_adam_update(float* params, float gi, float* m, float* v, long long i, double t, float lr, float b1,
-                                  float b2, float eps) {
-    // bias corrections in double like torch's Python-side scalars (1 - beta ** step)
+// bias corrections in double like torch's Python-side scalars (1 - beta ** step); the host computes them when it knows
+// the step (two double pow per thread in the tail of every block otherwise)
+PINN_HOST_DEVICE inline void pinn_adam_scalars(double t, float lr, float b1, float b2, float* step_size, float* bc2_sqrt) {
     const double bc1 = 1.0 - pow((double)b1, t);
     const double bc2 = 1.0 - pow((double)b2, t);
-    const float step_size = (float)((double)lr / bc1);
-    const float bc2_sqrt = (float)sqrt(bc2);
+    *step_size = (float)((double)lr / bc1);
+    *bc2_sqrt = (float)sqrt(bc2);
+}
+
+PINN_DEVICE void pinn_adam_update(float* params, float gi, float* m, float* v, long long i, float step_size, float bc2_sqrt,
+                                  float b1, float b2, float eps) {
     const float mi = m[i] + (1.0f - b1) * (gi - m[i]);       // exp_avg.lerp_(grad, 1 - beta1)
     const float vi = fmaf(1.0f - b2, gi * gi, b2 * v[i]);    // exp_avg_sq.mul_(beta2).addcmul_(grad, grad, 1 - beta2)
     m[i] = mi; v[i] = vi;
@@ -61,25 +65,29 @@ PINN_DEVICE void pinn_adam_update(float* params, float gi, float* m, float* v, l
     params[i] -= step_size * (mi / denom);
 }
 
+#ifndef PINN_REDUCE_PB
+#define PINN_REDUCE_PB 32
+#endif
 PINN_GLOBAL void PINN_LAUNCH_BOUNDS(1024)
 pinn_reduce_kernel(const float* partials, int n_wg, int p_core, float* grads, int accumulate, int do_adam, float* params,
-                   float* m, float* v, const unsigned char* mask, int step_value, float lr, float b1, float b2, float eps,
-                   int* step_ptr) {
+                   float* m, float* v, const unsigned char* mask, int step_value, float step_size, float bc2_sqrt, float b1,
+                   float b2, float eps, int* step_ptr) {
     PINN_SMEM(red);
     const int tid = PINN_TID;
-    const int pl = tid & 63, ch = tid >> 6;                   // 64 parameters x 16 chunks
-    const int p = PINN_BID * 64 + pl;
+    constexpr int PB = PINN_REDUCE_PB, CH = 1024 / PB;        // PB parameters x CH chunks of workgroups per block
+    const int pl = tid % PB, ch = tid / PB;
+    const int p = PINN_BID * PB + pl;
     float s = 0.0f;
     if (p < p_core)
-        for (int w = ch; w < n_wg; w += 16) s += partials[(size_t)w * p_core + p];
-    red[ch * 64 + pl] = s;
+        for (int w = ch; w < n_wg; w += CH) s += partials[(size_t)w * p_core + p];
+    red[ch * PB + pl] = s;
     PINN_SYNC();
-    if (tid < 64 && p < p_core) {
+    if (tid < PB && p < p_core) {
         float t = 0.0f;
-        for (int c = 0; c < 16; ++c) t += red[c * 64 + tid];
+        for (int c = 0; c < CH; ++c) t += red[c * PB + tid];
         if (accumulate) t += grads[p];
         grads[p] = t;
-        if (do_adam && (!mask || mask[p])) pinn_adam_update(params, t, m, v, p, (double)step_value, lr, b1, b2, eps);
+        if (do_adam && (!mask || mask[p])) pinn_adam_update(params, t, m, v, p, step_size, bc2_sqrt, b1, b2, eps);
     }
     if (do_adam && PINN_BID == 0 && tid == 0) step_ptr[0] = step_value;
 }
@@ -107,12 +115,13 @@ PINN_GLOBAL void PINN_LAUNCH_BOUNDS(64) pinn_tick_kernel(int* step_ptr) {
 
 PINN_GLOBAL void PINN_LAUNCH_BOUNDS(256)
 pinn_adam_kernel(float* params, const float* grads, float* m, float* v, const unsigned char* mask, long long n,
-                 int* step_ptr, int step_value, float lr, float b1, float b2, float eps) {
-    // step_value > 0: the host counts (and the count is mirrored to step_ptr); otherwise the count lives on the device
+                 int* step_ptr, int step_value, float lr, float step_size, float bc2_sqrt, float b1, float b2, float eps) {
+    // step_value > 0: the host counts (step_size / bc2_sqrt come with it, the count is mirrored to step_ptr); otherwise
+    // the count lives on the device and the bias corrections are computed here
     const long long i = (long long)PINN_BID * 256 + PINN_TID;
-    const int step = step_value > 0 ? step_value : step_ptr[0];
     if (step_value > 0 && i == 0) step_ptr[0] = step_value;
     if (i >= n) return;
     if (mask && !mask[i]) return;
-    pinn_adam_update(params, grads[i], m, v, i, (double)step, lr, b1, b2, eps);
+    if (step_value <= 0) pinn_adam_scalars((double)step_ptr[0], lr, b1, b2, &step_size, &bc2_sqrt);
+    pinn_adam_update(params, grads[i], m, v, i, step_size, bc2_sqrt, b1, b2, eps);
 }
