@@ -154,7 +154,7 @@ int pinn_jet_backward(pinn_t* net, const float* params, const float* xs, int64_t
                       void* stream);
 
 /* One fused residual + gradient evaluation: forward jets, ansatz, residual program, mean-square loss and the
- * full reverse sweep, in one launch (+ the x-only pre-pass and a reduction launch).  Replaces model_torch.py:437-460
+ * full reverse sweep, in one launch (the x-only pre-pass runs in its prologue) + a reduction launch.  Replaces model_torch.py:437-460
  * (forward, equation, MSELoss vs zeros, backward).  grads[0..p_core) receives d(loss)/dparams with
  * loss = inv_n_global * sum r^2 over THIS call's points (data-parallel ranks pass 1/N_global and all-reduce
  * the buffer); grads[off_loss] receives this call's share of the loss. */
