@@ -214,7 +214,7 @@ def main():
                          'traffic': hbm_traffic(KERNEL) if n == BATCH_PER_GPU else None,
                          'traffic_source': 'profiles/r01_cfg2_pmc.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes)'},
         }
-        if not args.no_cpu_baseline:
+        if not args.no_cpu_baseline and world == 1:      # reported at N = 1 only (the other ranks would wait on it)
             out['cpu_baseline'] = cpu_baseline()
         print(json.dumps(out))
     if world > 1 or args.unfused:
