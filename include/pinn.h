@@ -46,6 +46,7 @@ extern "C" {
 #define PINN_MAX_REGS     40   /* residual program registers (inputs included) */
 #define PINN_MAX_STREAMS  7    /* 1 + nd + n2 */
 #define PINN_MAX_AUX      8    /* per-point rows produced by the x-only pre-pass */
+#define PINN_MAX_VARS     8    /* trainable V(...) scalars a residual program may read (user slots 0..n_vars-1) */
 
 #define PINN_MAX_SKIPS    4    /* skip connections ('R ... +') per net */
 
@@ -96,7 +97,11 @@ typedef struct pinn_program {
  *   kind PINN_RES_AFFINE   r = sum_s C_s * u_s + F with C_s = coef[s] or aux row coef_row[s] (if >= 0) and
  *                          F = src_const or aux row src_row (if >= 0): every linear PDE; no interpreter in the step.
  *   kind PINN_RES_PROGRAM  general pointwise program over streams, inputs and aux rows (registers
- *                          S+d .. S+d+n_aux-1), interpreted per point with its reverse sweep inside the tile kernel. */
+ *                          S+d .. S+d+n_aux-1), interpreted per point with its reverse sweep inside the tile kernel.
+ *                          n_vars > 0: registers S+d+n_aux .. +n_vars-1 hold the trainable V(...) scalars of user slots
+ *                          0..n_vars-1 (model_torch.py:180-188; inverse problems, tutorial :633-645), read from
+ *                          params[off_extra + k]; d(loss)/d(slot k) is returned in grads[off_extra + k] like every other
+ *                          parameter gradient. */
 #define PINN_RES_PROGRAM 0
 #define PINN_RES_AFFINE  1
 
@@ -113,6 +118,7 @@ typedef struct pinn_residual {
      * the nd directions -- what a Laplacian / wave / heat operator needs -- instead of one stream per direction. */
     int combined;
     float comb_w[PINN_MAX_DIRS];
+    int n_vars;
 } pinn_residual_t;
 
 /* Descriptor of network + ansatz.  Replaces ConvBlockModel.__init__/TorchModel.__init__ bookkeeping

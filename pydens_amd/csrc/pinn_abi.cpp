@@ -113,7 +113,9 @@ void fill_args(const pinn_net* net, PinnKArgs* a, const float* params, const flo
     a->n_skips = net->n_skips;
     for (int k = 0; k < PINN_MAX_SKIPS; ++k) { a->skip_src[k] = net->skip_src[k]; a->skip_dst[k] = net->skip_dst[k]; }
     a->off_b1 = L.off_b1; a->off_wh = L.off_wh; a->hidden_stride = L.hidden_stride; a->off_wl = L.off_wl;
-    a->off_bl = L.off_bl; a->off_ls = L.off_log_scale; a->off_loss = L.off_loss; a->p_core = L.p_core;
+    a->off_bl = L.off_bl; a->off_ls = L.off_log_scale; a->off_loss = L.off_loss;
+    a->p_core = L.p_total;          // partial rows / gradient buffer span the user slots too (V gradients of residual programs)
+    a->off_extra = L.off_extra;
     a->ndims = net->ndims; a->nsp = net->nsp; a->has_bc = net->has_bc; a->has_ic = net->has_ic;
     a->bc_value = net->bc_value; a->t0 = net->lo[net->ndims - 1]; a->ic_const = ic_const;
     for (int i = 0; i < PINN_MAX_INPUTS; ++i) {
@@ -167,7 +169,7 @@ size_t align256(size_t v) { return (v + 255) / 256 * 256; }
 
 // widths >= 128 (PinnCfg::WTG): room for the transposed copy of the lh hidden->hidden matrices
 size_t wt_workspace_bytes(const pinn_net* net) {
-    return (net->lay.hp >= 128 && net->lay.lh > 0) ? align256((size_t)net->lay.lh * net->lay.hp * net->lay.hp * sizeof(float)) : 0;
+    return (net->lay.hp >= PINN_WTG_MIN_HP && net->lay.lh > 0) ? align256((size_t)net->lay.lh * net->lay.hp * net->lay.hp * sizeof(float)) : 0;
 }
 }  // namespace
 
@@ -328,7 +330,7 @@ size_t pinn_workspace_bytes(const pinn_t* net, int64_t n_points, int nd, int n2)
             if (comb) continue;
             return 0;
         }
-        const size_t v = align256((size_t)plan.grid * net->lay.p_core * sizeof(float)) +
+        const size_t v = align256((size_t)plan.grid * net->lay.p_total * sizeof(float)) +
                          align256((size_t)plan.grid * plan.slab_vec4_per_wg * 16);
         if (v > need) need = v;
     }
@@ -353,7 +355,7 @@ int pinn_jet_forward(pinn_t* net, const float* params, const float* xs, int64_t 
 static int run_train(pinn_t* net, PinnKArgs* a, const Plan& plan, int nd, float* grads, int accumulate, void* workspace,
                      size_t workspace_bytes, void* stream, const pinn_program_t* pre = nullptr,
                      const AdamArgs* adam = nullptr) {
-    const size_t part_bytes = align256((size_t)plan.grid * net->lay.p_core * sizeof(float));
+    const size_t part_bytes = align256((size_t)plan.grid * net->lay.p_total * sizeof(float));
     const size_t slab_bytes = align256((size_t)plan.grid * plan.slab_vec4_per_wg * 16);
     const size_t aux_bytes = (pre && a->n_aux > 0) ? align256((size_t)a->n_aux * (size_t)a->n_points * sizeof(float)) : 0;
     const size_t wt_bytes = wt_workspace_bytes(net);
@@ -407,7 +409,7 @@ static int run_train(pinn_t* net, PinnKArgs* a, const Plan& plan, int nd, float*
 #ifndef PINN_EMU
     if (g_profile) { hipEventRecord(g_ev1, (hipStream_t)stream); g_have_bracket = true; }
 #endif
-    return launch_reduce(a->partials, plan.grid, net->lay.p_core, grads, accumulate, stream, adam);
+    return launch_reduce(a->partials, plan.grid, net->lay.p_total, grads, accumulate, stream, adam);
 }
 
 int pinn_jet_backward(pinn_t* net, const float* params, const float* xs, int64_t n_points, const int* dir_cols, int nd,
@@ -465,6 +467,10 @@ static int residual_step_impl(pinn_t* net, const pinn_residual_t* residual, cons
     fill_args(net, &a, params, xs, n_points, dir_cols, nd, n2, ic_streams, ic_const);
     a.res_kind = residual->kind;
     a.n_aux = residual->n_aux;
+    a.n_vars = residual->n_vars;
+    if (a.n_vars < 0 || a.n_vars > PINN_MAX_VARS || a.n_vars > PINN_EXTRA_SLOTS)
+        return fail("n_vars=%d outside [0, %d]", a.n_vars, PINN_MAX_VARS);
+    if (a.n_vars > 0 && residual->kind != PINN_RES_PROGRAM) return fail("trainable variables need a residual program (kind PINN_RES_PROGRAM)");
     a.comb = comb;
     for (int k = 0; k < PINN_MAX_DIRS; ++k) a.comb_w[k] = (comb && k < nd) ? residual->comb_w[k] : 0.0f;
     if (residual->n_aux > 0 && check_program(residual->pre, d, PINN_MAX_CONSTS, true, residual->n_aux, "pre-pass")) return 1;
@@ -480,7 +486,7 @@ static int residual_step_impl(pinn_t* net, const pinn_residual_t* residual, cons
     } else {
         const pinn_program_t* program = &residual->program;
         if (program->n_ops < 1) return fail("empty residual program");
-        if (check_program(*program, s_user + d + residual->n_aux, PINN_MAX_CONSTS, false, 0, "residual")) return 1;
+        if (check_program(*program, s_user + d + residual->n_aux + residual->n_vars, PINN_MAX_CONSTS, false, 0, "residual")) return 1;
         // the program addresses registers with the caller's stream count; re-base everything behind the streams
         // onto the instantiation's stream count (extra second-derivative streams sit in between)
         a.prog = *program;

@@ -43,7 +43,9 @@ struct PinnKArgs {
     unsigned act_codes;          // 2 bits per activation index a = 0..lh (a = 0: first layer)
     int n_skips;                 // skip connections 'R ... +': h_out[skip_dst] += h_out[skip_src] (activation indices)
     int skip_src[PINN_MAX_SKIPS], skip_dst[PINN_MAX_SKIPS];
-    int off_b1, off_wh, hidden_stride, off_wl, off_bl, off_ls, off_loss, p_core;
+    int off_b1, off_wh, hidden_stride, off_wl, off_bl, off_ls, off_loss;
+    int p_core;                  // row stride of `partials` = length of the gradient buffer (user slots included)
+    int off_extra, n_vars;       // first user slot; V(...) scalars a residual program reads (registers S+d+n_aux+k)
     int ndims, nsp, has_bc, has_ic;
     float bc_value, t0, ic_const, inv_n;
     float lo[PINN_MAX_INPUTS], hi[PINN_MAX_INPUTS];
@@ -79,7 +81,10 @@ struct PinnCfg {
     // widths above 128: ONE activation buffer (two would not fit the 160 KB of LDS): the forward pass works in place and
     // the reverse pass keeps the weight-gradient B fragments of h_{a-1} in registers while gz_a replaces it in LDS
     static constexpr bool ONEBUF = HP > 128;
-    static constexpr bool WTG = HP >= 128;                   // data-gradient GEMM reads a transposed weight copy (A.wt)
+#ifndef PINN_WTG_MIN_HP
+#define PINN_WTG_MIN_HP 128                                  // (experiment builds lower it: W^T from global memory instead of LDS)
+#endif
+    static constexpr bool WTG = HP >= PINN_WTG_MIN_HP;       // data-gradient GEMM reads a transposed weight copy (A.wt)
     // LDS carve (floats); every offset is a multiple of 4 floats (16 B, ds_read_b128 alignment)
     static constexpr int O_XS = 0;
     static constexpr int O_W1 = O_XS + 2 * T * PINN_XS_LD;      // points of a tile, double-buffered
@@ -99,7 +104,7 @@ struct PinnCfg {
     static constexpr int O_WT = SMEM_FLOATS;
     static constexpr int WT_LD = HP + 8;
     PINN_HOST_DEVICE static constexpr bool wt_fits(int lh) {
-        return lh > 0 && HP <= 64 && (SMEM_FLOATS + lh * HP * WT_LD) * 4 <= 150 * 1024;
+        return lh > 0 && HP <= 64 && !WTG && (SMEM_FLOATS + lh * HP * WT_LD) * 4 <= 150 * 1024;
     }
     PINN_HOST_DEVICE static constexpr int smem_floats(int lh_static) {
         return SMEM_FLOATS + (wt_fits(lh_static) ? lh_static * HP * WT_LD : 0);
@@ -303,10 +308,10 @@ PINN_DEVICE void pinn_prepass_point(const pinn_program_t& pg, const float* x, in
     }
 }
 
-// reverse sweep: adj[] must be zero on entry for every register; adj[result] is seeded with 1.
-PINN_DEVICE void pinn_prog_backward(const pinn_program_t& pg, const float* regs, float* adj, int T) {
+// reverse sweep: adj[] must be zero on entry for every register; adj[result] is seeded with `seed`.
+PINN_DEVICE void pinn_prog_backward(const pinn_program_t& pg, const float* regs, float* adj, int T, float seed = 1.0f) {
     if (pg.n_ops == 0) return;
-    adj[((pg.code[pg.n_ops - 1] >> 8) & 255) * T] = 1.0f;
+    adj[((pg.code[pg.n_ops - 1] >> 8) & 255) * T] = seed;
     for (int i = pg.n_ops - 1; i >= 0; --i) {
         const unsigned w = pg.code[i];
         const int op = w & 255, dst = (w >> 8) & 255, a = (w >> 16) & 255, b = (w >> 24) & 255;
@@ -549,11 +554,15 @@ PINN_DEVICE void pinn_point_stage(const PinnKArgs& A, const float (&net)[1 + ND 
 #pragma unroll
         for (int s = 0; s < S; ++s) pregs[s * T] = u[s];
         for (int c = 0; c < SH::d(A); ++c) pregs[(S + c) * T] = x[c];
+        // trainable V(...) scalars: registers behind the aux rows; the adjoints of these registers are never cleared,
+        // so they add up d(loss)/dV over all points this thread sees (summed over the tile's threads at the end of the kernel)
+        const int vbase = S + SH::d(A) + A.n_aux;
+        for (int k = 0; k < A.n_vars; ++k) pregs[(vbase + k) * T] = A.params[A.off_extra + k];
         const float r = pinn_prog_forward(A.prog, pregs, T);
-        pinn_prog_backward(A.prog, pregs, padj, T);
         const float w = valid ? 2.0f * r * A.inv_n : 0.0f;
+        pinn_prog_backward(A.prog, pregs, padj, T, w);          // seeded with d(loss)/dr: adjoints come out scaled
 #pragma unroll
-        for (int s = 0; s < S; ++s) { gu[s] = w * padj[s * T]; padj[s * T] = 0.0f; }
+        for (int s = 0; s < S; ++s) { gu[s] = padj[s * T]; padj[s * T] = 0.0f; }
         for (int c = 0; c < SH::d(A) + A.n_aux; ++c) padj[(S + c) * T] = 0.0f;
         out.loss = valid ? r * r * A.inv_n : 0.0f;
     } else {
@@ -1551,5 +1560,13 @@ pinn_tile_kernel(const PinnKArgs A) {
         part[A.off_ls] = l1;
         part[A.off_bl] = l2;
         for (int i = A.off_loss + 1; i < A.p_core; ++i) part[i] = 0.0f;
+        if (SPEC == 0 && SH::mode(A) == PINN_MODE_STEP && A.res_kind == PINN_RES_PROGRAM) {
+            const int vbase = S + d + A.n_aux;
+            for (int k = 0; k < A.n_vars; ++k) {
+                float g = 0.0f;
+                for (int i = 0; i < T; ++i) g += padj[(vbase + k) * T + i];
+                part[A.off_extra + k] = g;
+            }
+        }
     }
 }

@@ -15,7 +15,7 @@ LIB_NAME = 'libpinn_hip.so'
 
 MAX_LAYERS, MAX_INPUTS, MAX_DIRS, EXTRA_SLOTS = 16, 8, 3, 16
 MAX_OPS, MAX_CONSTS, MAX_REGS = 64, 32, 40
-MAX_STREAMS, MAX_AUX = 7, 8
+MAX_STREAMS, MAX_AUX, MAX_VARS = 7, 8, 8
 RES_PROGRAM, RES_AFFINE = 0, 1
 ACT_CODES = {'tanh': 0, 'sigmoid': 1, 'sin': 2, 'identity': 3}
 
@@ -51,12 +51,12 @@ class Residual(ctypes.Structure):
     _fields_ = [('kind', ctypes.c_int), ('n_aux', ctypes.c_int), ('pre', Program), ('program', Program),
                 ('coef', ctypes.c_float * MAX_STREAMS), ('coef_row', ctypes.c_int * MAX_STREAMS),
                 ('src_const', ctypes.c_float), ('src_row', ctypes.c_int),
-                ('combined', ctypes.c_int), ('comb_w', ctypes.c_float * MAX_DIRS)]
+                ('combined', ctypes.c_int), ('comb_w', ctypes.c_float * MAX_DIRS), ('n_vars', ctypes.c_int)]
 
     @classmethod
-    def build(cls, kind, n_aux, pre, program=None, coef=(), coef_row=(), src_const=0.0, src_row=-1, comb_w=None):
+    def build(cls, kind, n_aux, pre, program=None, coef=(), coef_row=(), src_const=0.0, src_row=-1, comb_w=None, n_vars=0):
         res = cls()
-        res.kind, res.n_aux = kind, n_aux
+        res.kind, res.n_aux, res.n_vars = kind, n_aux, n_vars
         res.pre = Program.from_lists(*pre) if pre is not None else Program()
         res.program = Program.from_lists(*program) if program is not None else Program()
         for i in range(MAX_STREAMS):

@@ -114,7 +114,7 @@ class Solver:
         """ lower the equation to a residual program and cross-check it numerically against the callable. """
         total = self.model.total
         try:
-            root = trace.symbolic(self.equation, self.ctx.run, total)
+            root = trace.symbolic(self.equation, self.ctx.run, total, variable_slot=self._variable_slot)
             plan = trace.lower_residual(root, self.spec, total)
             trace.combine_second_order(plan, self.spec)
             # validation on random data: program (fp64 host interpreter) vs the user's callable on tagged tensors
@@ -125,13 +125,25 @@ class Solver:
             probe = streams.clone().requires_grad_() if self.needs_x_grad else streams
             want = self._eval_equation(probe, pts, requires_grad=self.needs_x_grad)
             want = want.detach().reshape(-1).double().cpu().numpy()
-            got = trace.run_residual_numpy(plan, streams.cpu().numpy(), pts.cpu().numpy())
+            lay = self.model.net.layout
+            var_values = self.model.flat[lay.off_extra:lay.off_extra + plan.n_vars].detach().cpu().numpy()
+            got = trace.run_residual_numpy(plan, streams.cpu().numpy(), pts.cpu().numpy(), var_values)
             if not np.allclose(got, want, rtol=1e-4, atol=1e-5):
                 raise trace.TraceUnsupported('traced program disagrees with the callable (data-dependent control flow?)')
             self.residual_plan = plan
             return plan.to_struct(), None
         except trace.TraceUnsupported as err:
             return None, str(err)
+
+    def _variable_slot(self, param):
+        """ user slot (index behind `off_extra` in the flat buffer) of a scalar trainable V(...), else None. """
+        if param.numel() != 1:
+            return None
+        lay = self.model.net.layout
+        for name, (off, n) in self.model.variables.items():
+            if getattr(self.model, name) is param and n == 1:
+                return off - lay.off_extra
+        return None
 
     def _eval_equation(self, streams, xs, ic_streams=None, requires_grad=True):
         """ run the user's callable on stream tensors [S,N] (+ optional IC streams), D resolves to streams. """

@@ -52,4 +52,12 @@ def V(name, *args, **kwargs):
         param = nn.Parameter(*args, **kwargs)
         register = getattr(model, 'register_variable', None)
         setattr(model, name, register(name, param) if register is not None else param)
-    return getattr(model, name)
+    param = getattr(model, name)
+    lookup = trace._variable_slot.get()
+    if lookup is not None:
+        # symbolic trace of the equation (trace.symbolic): a scalar variable is a register of the residual program, so
+        # that expressions of variables alone (`0.1 * V('a') * V('b')`) stay symbolic as well
+        slot = lookup(param)
+        if slot is not None and slot < trace.MAX_VARS:
+            return trace.Sym('var', col=slot)
+    return param

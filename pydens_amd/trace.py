@@ -21,9 +21,11 @@ from contextvars import ContextVar
 import numpy as np
 import torch
 
-from .engine import OPS, MAX_OPS, MAX_CONSTS, MAX_REGS, MAX_DIRS, MAX_AUX, RES_AFFINE, RES_PROGRAM
+from .engine import OPS, MAX_OPS, MAX_CONSTS, MAX_REGS, MAX_DIRS, MAX_AUX, MAX_VARS, RES_AFFINE, RES_PROGRAM
 
 active_streams = ContextVar('pinn_active_streams', default=None)
+# during `symbolic`: maps a trainable V(...) parameter to its user slot (or None), see Solver._variable_slot
+_variable_slot = ContextVar('pinn_variable_slot', default=None)
 
 
 class TraceUnsupported(Exception):
@@ -152,7 +154,12 @@ def _as_const(value):
     if isinstance(value, Sym):
         return None
     if isinstance(value, torch.nn.Parameter):
-        raise TraceUnsupported('trainable variable inside the equation')
+        lookup = _variable_slot.get()
+        slot = lookup(value) if lookup is not None else None
+        if slot is None or slot >= MAX_VARS:
+            raise TraceUnsupported('trainable variable inside the equation that is not one of the first '
+                                   f'{MAX_VARS} scalar V(...) slots of the model')
+        return None
     if isinstance(value, (numbers.Real, np.floating, np.integer)) and not isinstance(value, bool):
         return float(value)
     if isinstance(value, np.ndarray) and value.size == 1:
@@ -163,7 +170,8 @@ def _as_const(value):
 
 
 class Sym:
-    """ node of the traced expression DAG. kind: 'stream' (alpha), 'input' (col), 'const' (value), 'op'. """
+    """ node of the traced expression DAG. kind: 'stream' (alpha), 'input' (col), 'const' (value), 'op',
+    'var' (col = user slot of a trainable scalar V(...)). """
     __array_priority__ = 1000
     __array_ufunc__ = None
 
@@ -173,7 +181,12 @@ class Sym:
     # -- construction helpers ------------------------------------------------------------------------------------
     @staticmethod
     def wrap(value):
-        return value if isinstance(value, Sym) else Sym('const', value=_as_const(value))
+        if isinstance(value, Sym):
+            return value
+        const = _as_const(value)
+        if const is None:                       # a scalar trainable V(...): lives in a program register of its own
+            return Sym('var', col=_variable_slot.get()(value))
+        return Sym('const', value=const)
 
     @staticmethod
     def make(op, *args):
@@ -194,7 +207,7 @@ class Sym:
     def __pos__(self): return self
 
     def __pow__(self, o):
-        e = _as_const(o)
+        e = None if isinstance(o, torch.nn.Parameter) else _as_const(o)
         if e is None:
             raise TraceUnsupported('power with a non-constant exponent')
         if e == 2.0:
@@ -204,7 +217,9 @@ class Sym:
         return Sym('op', op='POW', args=(self,), value=e)
 
     def __rpow__(self, o):
-        base = _as_const(o)
+        base = None if isinstance(o, torch.nn.Parameter) else _as_const(o)
+        if base is None:
+            raise TraceUnsupported('power with a non-constant base')
         return Sym.make('EXP', Sym.make('MUL', self, math.log(base)))
 
     # -- torch.* interception ------------------------------------------------------------------------------------
@@ -264,7 +279,7 @@ def _differentiate(node, col, memo):
     if key in memo:
         return memo[key]
     zero, one = Sym('const', value=0.0), Sym('const', value=1.0)
-    if node.kind == 'const':
+    if node.kind in ('const', 'var'):
         out = zero
     elif node.kind == 'input':
         out = one if node.col == col else zero
@@ -328,12 +343,23 @@ def sym_D(y, x):
     return _differentiate(Sym.wrap(y), x.col, {})
 
 
-def symbolic(equation, ctx_run, n_inputs):
-    """ -> root Sym of the residual. Raises TraceUnsupported. """
+def _call_with_variables(lookup, equation, *args):
+    """ run the callable with `lookup` resolving trainable V(...) parameters (must itself be what ctx.run invokes,
+    cf. call_with_streams) """
+    token = _variable_slot.set(lookup)
+    try:
+        return Sym.wrap(equation(*args))
+    finally:
+        _variable_slot.reset(token)
+
+
+def symbolic(equation, ctx_run, n_inputs, variable_slot=None):
+    """ -> root Sym of the residual. Raises TraceUnsupported. `variable_slot(param)` -> user slot of a scalar
+    trainable V(...) or None. """
     u = Sym('stream', alpha=())
     xs = [Sym('input', col=c) for c in range(n_inputs)]
     try:
-        root = ctx_run(equation, u, *xs)
+        root = ctx_run(_call_with_variables, variable_slot, equation, u, *xs)
     except TraceUnsupported:
         raise
     except (TypeError, ValueError, AttributeError, RuntimeError, LookupError) as err:
@@ -385,7 +411,8 @@ class _Emitter:
 def _uses_streams(node, memo):
     key = id(node)
     if key not in memo:
-        memo[key] = node.kind == 'stream' or any(_uses_streams(a, memo) for a in node.args)
+        # (expressions of trainable variables stay in the main program too: the pre-pass has no reverse sweep)
+        memo[key] = node.kind in ('stream', 'var') or any(_uses_streams(a, memo) for a in node.args)
     return memo[key]
 
 
@@ -401,6 +428,8 @@ def _affine(node, spec, memo):
         out = ({spec.index[node.alpha]: Sym('const', value=1.0)}, Sym('const', value=0.0))
     elif node.kind in ('input', 'const'):
         out = ({}, node)
+    elif node.kind == 'var':
+        out = None                                                 # trainable coefficient: needs the program's reverse sweep
     else:
         parts = [_affine(a, spec, memo) for a in node.args]
         if all(p is not None for p in parts):
@@ -427,8 +456,9 @@ def _affine(node, spec, memo):
 class ResidualPlan:
     """ host-side description of a lowered residual (see pinn_residual_t in include/pinn.h). """
     def __init__(self, kind, n_inputs, n_streams, pre, n_aux, program=None, coef=None, coef_row=None, src_const=0.0,
-                 src_row=-1):
+                 src_row=-1, n_vars=0):
         self.kind, self.n_inputs, self.n_streams = kind, n_inputs, n_streams
+        self.n_vars = n_vars        # trainable V(...) scalars (user slots 0..n_vars-1) the program reads as registers
         self.pre, self.n_aux, self.program = pre, n_aux, program
         self.coef = coef or [0.0] * n_streams
         self.coef_row = coef_row or [-1] * n_streams
@@ -443,7 +473,7 @@ class ResidualPlan:
     def to_struct(self):
         from .engine import Residual
         return Residual.build(self.kind, self.n_aux, self.pre if self.n_aux else None, self.program, self.coef,
-                              self.coef_row, self.src_const, self.src_row, self.comb_w)
+                              self.coef_row, self.src_const, self.src_row, self.comb_w, n_vars=self.n_vars)
 
 
 def combine_second_order(plan, spec):
@@ -515,11 +545,25 @@ def lower_residual(root, spec, n_inputs):
             collect(a)
     collect(root)
     n_aux = len(rows)
-    main = _Emitter(first_temp=S + n_inputs + n_aux)
+    slots = set()
+
+    def find_vars(node, seen):
+        if id(node) in seen:
+            return
+        seen.add(id(node))
+        if node.kind == 'var':
+            slots.add(node.col)
+        for a in node.args:
+            find_vars(a, seen)
+    find_vars(root, set())
+    n_vars = max(slots) + 1 if slots else 0
+    main = _Emitter(first_temp=S + n_inputs + n_aux + n_vars)
 
     def main_leaf(node):
         if id(node) in aux_of:
             return S + n_inputs + aux_of[id(node)]
+        if node.kind == 'var':
+            return S + n_inputs + n_aux + node.col
         if node.kind == 'stream':
             if node.alpha not in spec.index:
                 raise TraceUnsupported(f'stream {node.alpha} not in {spec}')
@@ -529,7 +573,8 @@ def lower_residual(root, spec, n_inputs):
     res = main.visit(root, main_leaf)
     if not main.code or main.code[-1][1] != res:
         main.emit('COPY', res)                      # the residual must be the value of the last instruction
-    return ResidualPlan(RES_PROGRAM, n_inputs, S, (pre.code, pre.consts), n_aux, program=(main.code, main.consts))
+    return ResidualPlan(RES_PROGRAM, n_inputs, S, (pre.code, pre.consts), n_aux, program=(main.code, main.consts),
+                        n_vars=n_vars)
 
 
 def compile_program(root, spec, n_inputs):
@@ -575,8 +620,9 @@ def _run_code_numpy(code, consts, regs, n, aux=None):
     return out
 
 
-def run_residual_numpy(plan, streams, xs):
-    """ fp64 host interpreter of a ResidualPlan (validation of the trace; never on the step path). """
+def run_residual_numpy(plan, streams, xs, var_values=None):
+    """ fp64 host interpreter of a ResidualPlan (validation of the trace; never on the step path). `var_values`: current
+    values of the user slots 0..n_vars-1. """
     n, d, S = xs.shape[0], xs.shape[1], streams.shape[0]
     aux = {}
     if plan.n_aux:
@@ -599,6 +645,8 @@ def run_residual_numpy(plan, streams, xs):
         regs[S + c] = xs[:, c].astype(np.float64)
     for m in range(plan.n_aux):
         regs[S + d + m] = aux[m]
+    for k in range(plan.n_vars):
+        regs[S + d + plan.n_aux + k] = np.full(n, float(var_values[k]), dtype=np.float64)
     return _run_code_numpy(plan.program[0], plan.program[1], regs, n)
 
 

@@ -177,7 +177,7 @@ def _paired(pa, emu_lib, **fit_kwargs):
 
 def test_trainable_variable_and_constraint_follow_the_reference(pa, emu_lib):
     oracle, solver = _paired(pa, emu_lib)
-    assert solver.program is None and 'trainable' in solver.program_error
+    assert solver.program is not None and solver.residual_plan.n_vars == 1    # V('new_var') is a program register
     pts = np.random.RandomState(3).rand(6, 40, 1).astype(np.float32)
     terms = ['equation', 'constraint_0']
     oracle.fit(niters=6, batch_size=40, points=pts, lr=0.05, loss_terms=terms)
@@ -185,6 +185,51 @@ def test_trainable_variable_and_constraint_follow_the_reference(pa, emu_lib):
     assert solver.last_fit_path == 'generic'
     np.testing.assert_allclose([float(v) for v in solver.losses], [float(v) for v in oracle.losses], rtol=5e-5)
     assert abs(float(solver.model.new_var) - float(oracle.model.new_var)) < 1e-5
+    for got, want in zip(export_params(solver), oracle.export_params()):
+        assert rel_l2(got, want) < 5e-5
+
+
+def test_trainable_variable_on_the_fused_path(pa, emu_lib):
+    """ equation-only loss: the scalar V(...) is a register of the residual program, its gradient comes out of the tile
+    kernel (user slot of the flat gradient buffer) and Adam updates it with the network. """
+    oracle, solver = _paired(pa, emu_lib)
+    pts = np.random.RandomState(5).rand(6, 40, 1).astype(np.float32)
+    oracle.fit(niters=6, batch_size=40, points=pts, lr=0.05)
+    solver.fit(niters=6, batch_size=40, sampler=FixedBatches(pts), lr=0.05)
+    assert solver.last_fit_path == 'fused'
+    np.testing.assert_allclose([float(v) for v in solver.losses], [float(v) for v in oracle.losses], rtol=5e-5)
+    assert float(solver.model.new_var) != 1.0
+    assert abs(float(solver.model.new_var) - float(oracle.model.new_var)) < 1e-5
+    for got, want in zip(export_params(solver), oracle.export_params()):
+        assert rel_l2(got, want) < 5e-5
+
+
+def _inverse_problem(D, V, torch):
+    def heat_with_unknowns(u, x, t):                # tutorial-style inverse problem: diffusivity and source scale are trainable
+        a = V('diffusivity', data=torch.Tensor([0.7]))
+        q = V('source', data=torch.Tensor([1.3]))
+        return D(u, t) - a * D(D(u, x), x) - q * torch.sin(np.pi * x) * torch.exp(-t) + 0.1 * a * q * u * u
+    return heat_with_unknowns
+
+
+def test_two_trainable_coefficients_in_a_nonlinear_program(pa, emu_lib):
+    from oracle import pinn_oracle as po
+    kw = dict(ndims=2, initial_condition=lambda x: torch.sin(np.pi * x), boundary_condition=0.0, layout='fafaf',
+              features=[16, 16, 1], activation='Tanh')
+    oracle = po.OracleSolver(_inverse_problem(po.D, po.V, torch), **kw)
+    solver = pa.Solver(_inverse_problem(pa.D, pa.V, torch), **kw, **emu_kwargs(emu_lib))
+    load_params(solver, oracle.export_params())
+    plan = solver.residual_plan
+    assert solver.program is not None, solver.program_error
+    assert plan.n_vars == 2 and plan.n_aux >= 1
+    pts = np.random.RandomState(6).rand(5, 48, 2).astype(np.float32)
+    oracle.fit(niters=5, batch_size=48, points=pts, lr=0.02)
+    solver.fit(niters=5, batch_size=48, sampler=FixedBatches(pts), lr=0.02)
+    assert solver.last_fit_path == 'fused'
+    np.testing.assert_allclose([float(v) for v in solver.losses], [float(v) for v in oracle.losses], rtol=5e-5)
+    for name in ('diffusivity', 'source'):
+        assert abs(float(getattr(solver.model, name)) - float(getattr(oracle.model, name))) < 2e-5
+    assert float(solver.model.diffusivity) != float(np.float32(0.7))
     for got, want in zip(export_params(solver), oracle.export_params()):
         assert rel_l2(got, want) < 5e-5
 

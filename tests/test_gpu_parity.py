@@ -281,7 +281,7 @@ def test_trainable_variable_constraint_and_freezing_on_the_gpu(pa):
     constraint term through model(xs), freeze/unfreeze through the Adam mask): tutorial cells 50-60 vs the oracle """
     from test_emu_engine import _paired
     oracle, solver = _paired(pa, None)
-    assert solver.program is None and 'trainable' in solver.program_error
+    assert solver.program is not None and solver.residual_plan.n_vars == 1
     pts = np.random.RandomState(3).rand(8, 256, 1).astype(np.float32)
     terms = ['equation', 'constraint_0']
     oracle.fit(niters=4, batch_size=256, points=pts[:4], lr=0.05, loss_terms=terms)
@@ -299,6 +299,38 @@ def test_trainable_variable_constraint_and_freezing_on_the_gpu(pa):
         assert rel_l2(got, want) < 1e-4
     xs = np.linspace(0, 1, 9).astype(np.float32)
     assert np.abs(solver.predict(xs) - oracle.predict(xs)).max() < 2e-5
+
+
+def test_trainable_variables_on_the_fused_path_on_the_gpu(pa):
+    """ scalar V(...) as registers of the residual program: their gradients come out of the tile kernel (user slots of the
+    gradient buffer) and the fused Adam launch updates them -- tutorial's ODE with a variable and a two-coefficient
+    inverse problem (IC + BC, nonlinear term) vs the oracle, with ragged batches (tail tiles must not contribute) """
+    from test_emu_engine import _paired, _inverse_problem
+    from oracle import pinn_oracle as po
+    oracle, solver = _paired(pa, None)
+    pts = np.random.RandomState(5).rand(6, 1000, 1).astype(np.float32)
+    oracle.fit(niters=6, batch_size=1000, points=pts, lr=0.05)
+    solver.fit(niters=6, batch_size=1000, sampler=FixedBatches(pts), lr=0.05)
+    assert solver.last_fit_path == 'fused'
+    np.testing.assert_allclose([float(v) for v in solver.losses], [float(v) for v in oracle.losses], rtol=5e-5)
+    assert abs(float(solver.model.new_var) - float(oracle.model.new_var.detach())) < 2e-5
+    assert float(solver.model.new_var) != 1.0
+
+    kw = dict(ndims=2, initial_condition=lambda x: torch.sin(np.pi * x), boundary_condition=0.0, layout='fafafaf',
+              features=[64, 64, 64, 1], activation='Tanh')
+    oracle = po.OracleSolver(_inverse_problem(po.D, po.V, torch), **kw)
+    solver = pa.Solver(_inverse_problem(pa.D, pa.V, torch), **kw)
+    load_params(solver, oracle.export_params())
+    assert solver.program is not None and solver.residual_plan.n_vars == 2, solver.program_error
+    pts = np.random.RandomState(6).rand(5, 4099, 2).astype(np.float32)
+    oracle.fit(niters=5, batch_size=4099, points=pts, lr=0.02)
+    solver.fit(niters=5, batch_size=4099, sampler=FixedBatches(pts), lr=0.02)
+    assert solver.last_fit_path == 'fused'
+    np.testing.assert_allclose([float(v) for v in solver.losses], [float(v) for v in oracle.losses], rtol=5e-5)
+    for name in ('diffusivity', 'source'):
+        assert abs(float(getattr(solver.model, name)) - float(getattr(oracle.model, name).detach())) < 2e-5
+    for got, want in zip(export_params(solver), oracle.export_params()):
+        assert rel_l2(got, want) < 1e-4
 
 
 def test_default_sampler_trains_on_device(pa):
