@@ -1,0 +1,128 @@
+""" Every problem the reference's own notebooks solve (tutorials/1. Solving PDEs.ipynb, examples/_torch_examples.ipynb; the
+cells are cited per problem), written against the current API (model_torch.py:299-300, :364-365), run for a few
+iterations on the product and on the oracle from the same weights and the same point batches: losses of the
+trajectory, every parameter afterwards and the predicted field must agree.  CPU run: the kernels compiled for the SIMT
+emulator (tests/emu); GPU run (-m gpu): the HIP library through the C-ABI. """
+import numpy as np
+import pytest
+import torch
+
+from conftest import rel_l2
+from helpers import FixedBatches, export_params, load_params
+
+
+def _problems(D, V, NS):
+    """ name -> (equation, Solver kwargs, fit kwargs, batch shape, sampler columns (low, high), expected step path) """
+    def ode(f, x):                                                       # tutorial cell 12
+        return D(f, x) - 2 * np.pi * torch.cos(2 * np.pi * x)
+
+    def poisson(f, x, y):                                                # tutorial cell 19
+        return D(D(f, x), x) + D(D(f, y), y) - 5 * torch.sin(np.pi * (x + y))
+
+    def odeparam(f, x, e):                                               # tutorial cell 28
+        return D(f, x) - e * np.pi * torch.cos(e * np.pi * x)
+
+    def heat(f, x, y, t, a):                                             # tutorial cell 37
+        return D(D(f, x), x) + D(D(f, y), y) - a * D(f, t)
+
+    def source(x, y):                                                    # examples cell 25
+        return 100 * x * (1 - x) * 4 * y * (.5 - y) * (1 - y) * torch.exp(-70 * (x - y) ** 2)
+
+    def poisson_source(f, x, y):                                         # examples cell 26
+        return D(D(f, x), x) + D(D(f, y), y) - source(x, y)
+
+    def odevar(f, x):                                                    # tutorial cell 50
+        return D(f, x) - 2 * np.pi * torch.cos(2 * np.pi * x) + V('new_var', data=torch.Tensor([1.0]))
+
+    def plain_ode(u, t):                                                 # examples cell 80
+        return D(u, t) - 2 * np.pi * torch.cos(2 * np.pi * t)
+
+    def initial(*args):                                                  # examples cell 80: trainable initial value
+        return V('init', data=torch.Tensor([4.0]))
+
+    unit = ((0.0, 1.0),)
+    return {
+        'ode_tanh': (ode, dict(ndims=1, initial_condition=.5, activation='Tanh', layout='fafaf', features=[12, 10, 1]),
+                     dict(lr=0.02), 400, unit, 'fused'),                                           # cells 13-14
+        'poisson_bc1': (poisson, dict(ndims=2, boundary_condition=1, layout='fafaf', features=[10, 10, 1],
+                                      activation='Tanh'), dict(lr=0.02), 400, unit * 2, 'fused'),  # cells 20-21
+        'ode_family_default_net': (odeparam, dict(ndims=1, initial_condition=2.0, nparams=1), dict(lr=0.01), 700,
+                                   ((0.0, 1.0), (0.5, 5.5)), 'fused'),                             # cells 29-31, 377
+        'heat_family_sigmoid': (heat, dict(ndims=3, nparams=1,
+                                           initial_condition=lambda x, y: 10 * x * y * (1 - x) * (1 - y),
+                                           boundary_condition=0, layout='fafaf', features=[30, 40, 1],
+                                           activation='Sigmoid'), dict(lr=0.001), 300,
+                                ((0.0, 1.0), (0.0, 1.0), (0.0, 0.5), (0.1, 4.0)), 'fused'),        # cells 38-40, 491
+        'ode_tensor_ic_default_net': (ode, dict(ndims=1, initial_condition=torch.tensor(.5)), {}, 400, unit,
+                                      'fused'),                                                    # examples cells 8-9
+        'poisson_gaussian_source': (poisson_source, dict(ndims=2, boundary_condition=1), dict(lr=0.05), 400, unit * 2,
+                                    'fused'),                                                      # examples 27-28
+        'ode_with_variable': (odevar, dict(ndims=1, initial_condition=1,
+                                           constraints=lambda f, x: f(torch.tensor([0.5]))), dict(lr=0.1), 500, unit,
+                              'fused'),                                                            # cells 51-54
+        'ode_with_variable_and_constraint': (odevar, dict(ndims=1, initial_condition=1,
+                                                          constraints=lambda f, x: f(torch.tensor([0.5]))),
+                                             dict(lr=0.1, loss_terms=['equation', 'constraint_0']), 100, unit,
+                                             'generic'),                                           # cell 60
+        'trainable_initial_value': (plain_ode, dict(ndims=1, initial_condition=initial,
+                                                    constraints=lambda u, t: u(torch.tensor([0.5])) - 2),
+                                    dict(lr=0.05, loss_terms=['equation', 'constraint_0']), 500, unit,
+                                    'generic'),                                                    # examples 81-88
+    }
+
+
+NAMES = sorted(_problems(None, None, None))
+
+
+def _variables(model):
+    return {name: float(getattr(model, name).detach()) for name in ('new_var', 'init') if hasattr(model, name)}
+
+
+def _run(pa, name, solver_extra, niters=4):
+    from oracle import pinn_oracle as po
+    eq_o, kw_o, fit_kw, batch, cols, path = _problems(po.D, po.V, None)[name]
+    eq_p, kw_p, _, _, _, _ = _problems(pa.D, pa.V, pa.NumpySampler)[name]
+    torch.manual_seed(11)
+    oracle = po.OracleSolver(eq_o, **kw_o)
+    solver = pa.Solver(eq_p, **kw_p, **solver_extra)
+    load_params(solver, oracle.export_params())
+    rng = np.random.RandomState(7)
+    pts = np.stack([rng.uniform(lo, hi, size=(niters, batch)) for lo, hi in cols], axis=-1).astype(np.float32)
+    oracle.fit(niters=niters, batch_size=batch, points=pts, **fit_kw)
+    solver.fit(niters=niters, batch_size=batch, sampler=FixedBatches(pts), **fit_kw)
+    assert solver.last_fit_path == path, (solver.last_fit_path, solver.program_error)
+    np.testing.assert_allclose([float(v) for v in solver.losses], [float(v) for v in oracle.losses], rtol=5e-5)
+    for got, want in zip(export_params(solver), oracle.export_params()):
+        assert rel_l2(got, want) < 1e-4
+    got_vars, want_vars = _variables(solver.model), _variables(oracle.model)
+    assert got_vars.keys() == want_vars.keys()
+    for key in got_vars:
+        assert abs(got_vars[key] - want_vars[key]) < 5e-5 * max(1.0, abs(want_vars[key]))
+    grid = [np.linspace(lo, hi, 7).astype(np.float32) for lo, hi in cols]
+    u_got, u_want = solver.predict(*grid), oracle.predict(*grid)
+    assert u_got.shape == u_want.shape == (7, 1)
+    assert np.abs(u_got - u_want).max() < 2e-5 * max(1.0, float(np.abs(u_want).max()))
+
+
+@pytest.fixture(scope='module')
+def emu_lib():
+    import ctypes
+    import os
+    import sys
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), 'emu'))
+    import build_emu
+    from pydens_amd import engine
+    return engine.bind(ctypes.CDLL(build_emu.build()))
+
+
+@pytest.mark.parametrize('name', NAMES)
+def test_notebook_problem_on_the_emulated_kernels(name, emu_lib):
+    import pydens_amd as pa
+    _run(pa, name, dict(lib=emu_lib, device='cpu'))
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('name', NAMES)
+def test_notebook_problem_on_the_gpu(name):
+    import pydens_amd as pa
+    _run(pa, name, {})
