@@ -645,6 +645,19 @@ PINN_DEVICE void pinn_point_stage(const PinnKArgs& A, const float (&net)[1 + ND 
 #define PH_FLUSH
 #endif
 
+// experiments on the partial-buffer weight gradient of the width-256 kernels: 0 = read-modify-write (product),
+// 1 = no read (wrong sums; timing only), 2 = no read, no write (timing only), 3 = fire-and-forget atomic add
+#ifndef PINN_EXP_WGRAD
+#define PINN_EXP_WGRAD 0
+#endif
+#ifndef PINN_EMU
+PINN_DEVICE void pinn_atomic_add_wg(float* p, float v) {
+    (void)__hip_atomic_fetch_add(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+}
+#else
+PINN_DEVICE void pinn_atomic_add_wg(float* p, float v) { *p += v; }
+#endif
+
 PINN_DEVICE f32x4 pinn_ld4(const float* p) { return *reinterpret_cast<const f32x4*>(p); }
 PINN_DEVICE void pinn_st4(float* p, f32x4 v) { *reinterpret_cast<f32x4*>(p) = v; }
 
@@ -1303,7 +1316,7 @@ pinn_tile_kernel(const PinnKArgs A) {
 #pragma unroll
                         for (int j = 0; j < NTW; ++j)
 #pragma unroll
-                            for (int r = 0; r < 4; ++r) dwt[j][r] = *dwg_ptr(li, o, j, r);
+                            for (int r = 0; r < 4; ++r) dwt[j][r] = PINN_EXP_WGRAD ? 0.0f : *dwg_ptr(li, o, j, r);
 #pragma unroll
                         for (int ms = 0; ms < MT * S; ++ms) {
                             const int mt = ms / S, s = ms % S;
@@ -1318,7 +1331,11 @@ pinn_tile_kernel(const PinnKArgs A) {
 #pragma unroll
                         for (int j = 0; j < NTW; ++j)
 #pragma unroll
-                            for (int r = 0; r < 4; ++r) *dwg_ptr(li, o, j, r) = dwt[j][r];
+                            for (int r = 0; r < 4; ++r) {
+                                if (PINN_EXP_WGRAD == 0 || PINN_EXP_WGRAD == 1) *dwg_ptr(li, o, j, r) = dwt[j][r];
+                                if (PINN_EXP_WGRAD == 3) pinn_atomic_add_wg(dwg_ptr(li, o, j, r), dwt[j][r]);
+                                if (PINN_EXP_WGRAD == 2 && dwt[j][r] == 12345.678f) *dwg_ptr(li, o, j, r) = dwt[j][r];
+                            }
                     }
                 } else {
                     // accumulators in the workgroup's partial buffer (any depth, any width): OB output tile rows at a time --
