@@ -172,12 +172,14 @@ int pinn_residual_step(pinn_t* net, const pinn_residual_t* residual, const float
 /* Single-rank form of one whole `fit` iteration (model_torch.py:437-461): pinn_residual_step with inv_n = 1/n_points and
  * the Adam update of pinn_adam_step fused into the gradient-reduction launch (no all-reduce can sit in between, so
  * data-parallel ranks use the two separate calls). `step` is the 1-based Adam step of THIS update; it is also stored
- * to step_ptr[0] so that the two forms can be mixed. grads still receives the gradient and the loss slot. */
+ * to step_ptr[0] so that the two forms can be mixed. grads still receives the gradient and the loss slot; loss_out
+ * (nullable) is one more device address that receives the loss -- the host points it at entry i of its loss history
+ * (`self.losses.append(...)`, model_torch.py:464) so that recording an iteration costs no launch and no synchronisation. */
 int pinn_residual_adam_step(pinn_t* net, const pinn_residual_t* residual, float* params, const float* xs,
                             int64_t n_points, const int* dir_cols, int nd, int n2, const float* ic_streams,
                             float ic_const, float* grads, float* exp_avg, float* exp_avg_sq, const uint8_t* mask,
                             int32_t* step_ptr, int32_t step, float lr, float beta1, float beta2, float eps,
-                            void* workspace, size_t workspace_bytes, void* stream);
+                            float* loss_out, void* workspace, size_t workspace_bytes, void* stream);
 
 /* torch.optim.Adam.step (model_torch.py:461; defaults beta=(0.9,0.999), eps=1e-8, no weight decay) on the flat
  * buffer.  mask[i]==0 freezes entry i (padding, frozen layers/variables: model_torch.py:56-105, :420-421).

@@ -140,13 +140,14 @@ int check_dirs(const pinn_net* net, const int* dir_cols, int nd, int n2) {
 struct AdamArgs {
     float* params; float* m; float* v; const unsigned char* mask; int* step_ptr;
     int step_value; float lr, b1, b2, eps;
+    float* loss_out; int off_loss;
 };
 
 int launch_reduce(const float* partials, int n_wg, int p_core, float* grads, int accumulate, void* stream,
                   const AdamArgs* adam = nullptr) {
     const int blocks = (p_core + PINN_REDUCE_PB - 1) / PINN_REDUCE_PB;
     const size_t smem = 1024 * sizeof(float);
-    AdamArgs z = {nullptr, nullptr, nullptr, nullptr, nullptr, 0, 0.f, 0.f, 0.f, 0.f};
+    AdamArgs z = {nullptr, nullptr, nullptr, nullptr, nullptr, 0, 0.f, 0.f, 0.f, 0.f, nullptr, -1};
     const AdamArgs& a = adam ? *adam : z;
     const int do_adam = adam ? 1 : 0;
     float step_size = 0.0f, bc2_sqrt = 1.0f;
@@ -154,12 +155,12 @@ int launch_reduce(const float* partials, int n_wg, int p_core, float* grads, int
 #ifdef PINN_EMU
     emu::launch(blocks, 1024, smem, [&] {
         pinn_reduce_kernel(partials, n_wg, p_core, grads, accumulate, do_adam, a.params, a.m, a.v, a.mask, a.step_value,
-                           step_size, bc2_sqrt, a.b1, a.b2, a.eps, a.step_ptr);
+                           step_size, bc2_sqrt, a.b1, a.b2, a.eps, a.step_ptr, a.loss_out, a.off_loss);
     });
 #else
     hipLaunchKernelGGL(pinn_reduce_kernel, dim3(blocks), dim3(1024), smem, (hipStream_t)stream, partials, n_wg, p_core,
                        grads, accumulate, do_adam, a.params, a.m, a.v, a.mask, a.step_value, step_size, bc2_sqrt, a.b1, a.b2,
-                       a.eps, a.step_ptr);
+                       a.eps, a.step_ptr, a.loss_out, a.off_loss);
     if (hipGetLastError() != hipSuccess) return fail("reduce kernel launch failed");
 #endif
     return 0;
@@ -519,10 +520,10 @@ int pinn_residual_adam_step(pinn_t* net, const pinn_residual_t* residual, float*
                             int64_t n_points, const int* dir_cols, int nd, int n2, const float* ic_streams,
                             float ic_const, float* grads, float* exp_avg, float* exp_avg_sq, const uint8_t* mask,
                             int32_t* step_ptr, int32_t step, float lr, float beta1, float beta2, float eps,
-                            void* workspace, size_t workspace_bytes, void* stream) {
-    if (!exp_avg || !exp_avg_sq || !step_ptr) return fail("null argument");
+                            float* loss_out, void* workspace, size_t workspace_bytes, void* stream) {
+    if (!net || !exp_avg || !exp_avg_sq || !step_ptr) return fail("null argument");
     if (step < 1) return fail("step must be >= 1");
-    AdamArgs adam = {params, exp_avg, exp_avg_sq, mask, step_ptr, step, lr, beta1, beta2, eps};
+    AdamArgs adam = {params, exp_avg, exp_avg_sq, mask, step_ptr, step, lr, beta1, beta2, eps, loss_out, net->lay.off_loss};
     return residual_step_impl(net, residual, params, xs, n_points, dir_cols, nd, n2, ic_streams, ic_const,
                               1.0f / (float)n_points, grads, workspace, workspace_bytes, stream, &adam);
 }

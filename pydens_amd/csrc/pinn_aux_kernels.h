@@ -71,7 +71,7 @@ PINN_DEVICE void pinn_adam_update(float* params, float gi, float* m, float* v, l
 PINN_GLOBAL void PINN_LAUNCH_BOUNDS(1024)
 pinn_reduce_kernel(const float* partials, int n_wg, int p_core, float* grads, int accumulate, int do_adam, float* params,
                    float* m, float* v, const unsigned char* mask, int step_value, float step_size, float bc2_sqrt, float b1,
-                   float b2, float eps, int* step_ptr) {
+                   float b2, float eps, int* step_ptr, float* loss_out, int off_loss) {
     PINN_SMEM(red);
     const int tid = PINN_TID;
     constexpr int PB = PINN_REDUCE_PB, CH = 1024 / PB;        // PB parameters x CH chunks of workgroups per block
@@ -87,6 +87,7 @@ pinn_reduce_kernel(const float* partials, int n_wg, int p_core, float* grads, in
         for (int c = 0; c < CH; ++c) t += red[c * PB + tid];
         if (accumulate) t += grads[p];
         grads[p] = t;
+        if (loss_out && p == off_loss) loss_out[0] = t;
         if (do_adam && (!mask || mask[p])) pinn_adam_update(params, t, m, v, p, step_size, bc2_sqrt, b1, b2, eps);
     }
     if (do_adam && PINN_BID == 0 && tid == 0) step_ptr[0] = step_value;

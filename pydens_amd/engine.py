@@ -90,7 +90,7 @@ def bind(lib):
     lib.pinn_adam_step.argtypes = [vp, vp, vp, vp, vp, i64, vp, f32, f32, f32, f32, vp]
     lib.pinn_adam_step_at.argtypes = [vp, vp, vp, vp, vp, i64, vp, i32, f32, f32, f32, f32, vp]
     lib.pinn_residual_adam_step.argtypes = [vp, ctypes.POINTER(Residual), vp, vp, i64, ip, i32, i32, vp, f32, vp, vp, vp, vp,
-                                            vp, i32, f32, f32, f32, f32, vp, ctypes.c_size_t, vp]
+                                            vp, i32, f32, f32, f32, f32, vp, vp, ctypes.c_size_t, vp]
     lib.pinn_profile_tile.argtypes = [i32]
     lib.pinn_profile_tile.restype = i32
     lib.pinn_last_tile_ms.restype = f32
@@ -134,6 +134,9 @@ def _stream(t):
     if t.is_cuda:
         return ctypes.c_void_p(torch.cuda.current_stream(t.device).cuda_stream)
     return None
+
+
+stream_of = _stream
 
 
 def _check(t, name, dtype=torch.float32):
@@ -251,7 +254,10 @@ class Net:
                                                 _stream(xs)))
 
     def residual_adam_step(self, residual, params, xs, grads, workspace, exp_avg, exp_avg_sq, mask, step_tensor, step,
-                           lr, betas=(0.9, 0.999), eps=1e-8, dir_cols=(), n2=0, ic_streams=None, ic_const=0.0):
+                           lr, betas=(0.9, 0.999), eps=1e-8, dir_cols=(), n2=0, ic_streams=None, ic_const=0.0,
+                           loss_out=None, stream=None):
+        """ `loss_out`: device ADDRESS (int) that also receives the loss of the step; `stream`: handle from `stream_of`
+        when the caller has looked it up already (a fit loop asks once, not per iteration). """
         for t, name in ((params, 'params'), (xs, 'xs'), (grads, 'grads'), (ic_streams, 'ic_streams'),
                         (exp_avg, 'exp_avg'), (exp_avg_sq, 'exp_avg_sq')):
             _check(t, name)
@@ -261,8 +267,9 @@ class Net:
         self._raise(self.lib.pinn_residual_adam_step(
             self.handle, ctypes.byref(residual), _ptr(params), _ptr(xs), xs.shape[0], dirs, nd, n2, _ptr(ic_streams),
             float(ic_const), _ptr(grads), _ptr(exp_avg), _ptr(exp_avg_sq), _ptr(mask), _ptr(step_tensor), int(step),
-            float(lr), float(betas[0]), float(betas[1]), float(eps), _ptr(workspace),
-            workspace.numel() * workspace.element_size(), _stream(xs)))
+            float(lr), float(betas[0]), float(betas[1]), float(eps),
+            None if loss_out is None else ctypes.c_void_p(loss_out), _ptr(workspace),
+            workspace.numel() * workspace.element_size(), _stream(xs) if stream is None else stream))
 
     def adam_step(self, params, grads, exp_avg, exp_avg_sq, mask, step, lr, betas=(0.9, 0.999), eps=1e-8, at=0):
         """ `step`: int32 device counter; at > 0: the host's 1-based step count (one launch, counter mirrored) """

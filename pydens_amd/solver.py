@@ -288,22 +288,26 @@ class Solver:
         lay = model.net.layout
         history = torch.zeros(niters, dtype=torch.float32, device=self.device)
         self.last_fit_path = 'fused' if fused else 'generic'
+        one_launch = fused and world == 1 and isinstance(self.optimizer, FlatAdam)
+        stream = engine.stream_of(model.flat)           # looked up once per call, not per iteration
+        history_ptr = history.data_ptr()
         for it in tqdm(range(niters), disable=None):
             xs = self._sample(batch_size, sampler)
-            if fused and world == 1 and isinstance(self.optimizer, FlatAdam):
-                self._fused_step(xs, 1, adam=self.optimizer)  # Adam rides in the gradient-reduction launch
+            if one_launch:
+                # Adam rides in the gradient-reduction launch, which also drops the loss into history[it]
+                self._fused_step(xs, 1, adam=self.optimizer, loss_out=history_ptr + 4 * it, stream=stream)
+                continue
+            if fused:
+                self._fused_step(xs, world)
             else:
-                if fused:
-                    self._fused_step(xs, world)
-                else:
-                    self._generic_step(xs, loss_terms, nums_constraints, criterion, world)
-                if world > 1:
-                    torch.distributed.all_reduce(self.grads)  # flat [p_total]: network, log_scale, loss slot, V slots
-                self.optimizer.step(self.grads)
+                self._generic_step(xs, loss_terms, nums_constraints, criterion, world)
+            if world > 1:
+                torch.distributed.all_reduce(self.grads)  # flat [p_total]: network, log_scale, loss slot, V slots
+            self.optimizer.step(self.grads)
             history[it:it + 1].copy_(self.grads[lay.off_loss:lay.off_loss + 1])
         self._pending.append(history)
 
-    def _fused_step(self, xs, world, adam=None):
+    def _fused_step(self, xs, world, adam=None, loss_out=None, stream=None):
         model, spec = self.model, self.spec
         comb_w = self.residual_plan.comb_w if self.residual_plan is not None else None
         n2 = spec.n2 if comb_w is None else 1               # combined second-order stream: [u, firsts, sum_k c_k u_kk]
@@ -324,7 +328,7 @@ class Solver:
             model.net.residual_adam_step(self.program, model.flat, xs, self.grads, ws, adam.exp_avg, adam.exp_avg_sq,
                                          adam.mask, adam.step_count, adam.t, adam.lr, adam.betas, adam.eps,
                                          dir_cols=spec.dir_cols, n2=n2, ic_streams=ic_streams,
-                                         ic_const=model.kernel_ic_const())
+                                         ic_const=model.kernel_ic_const(), loss_out=loss_out, stream=stream)
             return
         model.net.residual_step(self.program, model.flat, xs, self.grads, ws, spec.dir_cols, n2,
                                 ic_streams=ic_streams, ic_const=model.kernel_ic_const(),

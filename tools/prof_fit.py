@@ -1,0 +1,14 @@
+import sys, time, cProfile, pstats
+sys.path.insert(0, '/root/repo')
+import torch, pinn_configs as pc, pydens_amd as pa
+torch.manual_seed(0)
+cfg = pc.make_config('cfg1', pa.D, torch)
+solver = pa.Solver(cfg['equation'], **cfg['solver_kwargs'])
+solver.fit(niters=200, batch_size=100)
+torch.cuda.synchronize()
+pr = cProfile.Profile(); pr.enable()
+solver.fit(niters=3000, batch_size=100)
+torch.cuda.synchronize()
+pr.disable()
+pstats.Stats(pr).sort_stats('cumulative').print_stats(18)
+t0 = time.perf_counter(); solver.fit(niters=3000, batch_size=100); torch.cuda.synchronize(); print('us/it', (time.perf_counter() - t0) / 3000 * 1e6)
