@@ -200,6 +200,19 @@ int pinn_adam_step_at(float* params, const float* grads, float* exp_avg, float* 
 int pinn_profile_tile(int enable);
 float pinn_last_tile_ms(void);
 
+/* Collocation points drawn on the device: replaces the host-side sampling of model_torch.py:430-434 (d independent
+ * `torch.rand((N,1))` columns, or `sampler.sample(N)` of a NumpySampler product `a & b & ...`, README.md:82) with ONE
+ * launch that fills xs [n_points][d] row-major.  Column c is kind[c]: PINN_SAMPLE_UNIFORM a[c] + (b[c] - a[c]) * u,
+ * u in [0,1) with 24 random bits; PINN_SAMPLE_NORMAL a[c] + b[c] * z (Box-Muller); PINN_SAMPLE_CONST a[c].
+ * kind / a / b are HOST arrays of length d.  Generator: Philox4x32-10 keyed by `seed`, counter = (point index,
+ * call_index, column block): the same (seed, call_index) always gives the same batch, any two differ; data-parallel
+ * ranks pass different seeds.  oracle/philox.py restates the generator (bit-exact for uniform / constant columns). */
+#define PINN_SAMPLE_UNIFORM 0
+#define PINN_SAMPLE_NORMAL  1
+#define PINN_SAMPLE_CONST   2
+int pinn_sample_points(float* xs, int64_t n_points, int d, const int* kind, const float* a, const float* b,
+                       uint64_t seed, uint64_t call_index, void* stream);
+
 const char* pinn_last_error(void);
 const char* pinn_backend(void);   /* "hip-gfx950" for the product library */
 

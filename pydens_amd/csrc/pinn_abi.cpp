@@ -178,6 +178,31 @@ extern "C" {
 
 const char* pinn_last_error(void) { return g_err; }
 
+int pinn_sample_points(float* xs, int64_t n_points, int d, const int* kind, const float* a, const float* b,
+                       uint64_t seed, uint64_t call_index, void* stream) {
+    if (!xs || !kind || !a || !b) return fail("null argument");
+    if (d < 1 || d > PINN_MAX_INPUTS) return fail("d=%d outside [1, %d]", d, PINN_MAX_INPUTS);
+    if (n_points <= 0) return 0;
+    PinnSampleSpec spec;
+    memset(&spec, 0, sizeof(spec));
+    spec.d = d;
+    for (int c = 0; c < d; ++c) {
+        if (kind[c] < PINN_SAMPLE_UNIFORM || kind[c] > PINN_SAMPLE_CONST) return fail("column %d: unknown sampler kind %d", c, kind[c]);
+        spec.kind[c] = kind[c]; spec.a[c] = a[c]; spec.b[c] = b[c];
+    }
+    const unsigned k0 = (unsigned)(seed & 0xffffffffull), k1 = (unsigned)(seed >> 32);
+    const unsigned c_lo = (unsigned)(call_index & 0xffffffffull), c_hi = (unsigned)(call_index >> 32);
+    const int blocks = (int)((n_points + 255) / 256);
+#ifdef PINN_EMU
+    emu::launch(blocks, 256, 0, [&] { pinn_sample_kernel(xs, (long long)n_points, spec, k0, k1, c_lo, c_hi); });
+#else
+    hipLaunchKernelGGL(pinn_sample_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, xs, (long long)n_points, spec,
+                       k0, k1, c_lo, c_hi);
+    if (hipGetLastError() != hipSuccess) return fail("sampler kernel launch failed");
+#endif
+    return 0;
+}
+
 int pinn_debug_set_flags(int flags) { g_pinn_debug_flags = flags; return 0; }
 
 int pinn_debug_last_kernel(void) { return g_pinn_last_kernel; }

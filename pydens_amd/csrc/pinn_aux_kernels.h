@@ -126,3 +126,66 @@ pinn_adam_kernel(float* params, const float* grads, float* m, float* v, const un
     if (step_value <= 0) pinn_adam_scalars((double)step_ptr[0], lr, b1, b2, &step_size, &bc2_sqrt);
     pinn_adam_update(params, grads[i], m, v, i, step_size, bc2_sqrt, b1, b2, eps);
 }
+
+// ------------------------------------------------------------------------------------------------------------
+// Collocation sampler on the device: replaces the host-side draws of reference model_torch.py:430-434 (`torch.rand`
+// per input column, or `sampler.sample(batch_size)` of a batchflow NumpySampler product `a & b & ...`).
+// Counter-based generator Philox4x32-10 (Salmon, Moraes, Dror, Shaw: "Parallel random numbers: as easy as 1, 2, 3",
+// SC'11; constants of the Random123 library): no state in memory, one launch per batch whatever the number of columns,
+// every (seed, call, point, column) addresses its own random word, so a batch does not depend on the launch geometry.
+// oracle/philox.py restates it in numpy (pinned to the Random123 known-answer vectors); tests compare bit for bit.
+// ------------------------------------------------------------------------------------------------------------
+struct PinnSampleSpec {
+    int d;
+    int kind[PINN_MAX_INPUTS];      // PINN_SAMPLE_UNIFORM / _NORMAL / _CONST
+    float a[PINN_MAX_INPUTS], b[PINN_MAX_INPUTS];
+};
+
+PINN_DEVICE void pinn_philox4x32_10(unsigned c0, unsigned c1, unsigned c2, unsigned c3, unsigned k0, unsigned k1,
+                                    unsigned (&out)[4]) {
+#pragma unroll
+    for (int round = 0; round < 10; ++round) {
+        const unsigned long long p0 = (unsigned long long)0xD2511F53u * c0;
+        const unsigned long long p1 = (unsigned long long)0xCD9E8D57u * c2;
+        const unsigned n0 = (unsigned)(p1 >> 32) ^ c1 ^ k0, n1 = (unsigned)p1;
+        const unsigned n2 = (unsigned)(p0 >> 32) ^ c3 ^ k1, n3 = (unsigned)p0;
+        c0 = n0; c1 = n1; c2 = n2; c3 = n3;
+        k0 += 0x9E3779B9u; k1 += 0xBB67AE85u;
+    }
+    out[0] = c0; out[1] = c1; out[2] = c2; out[3] = c3;
+}
+
+// products / sums that must round like the numpy oracle: separately, never contracted into a fused multiply-add
+// (hipcc's __fmul_rn / __fadd_rn are plain operators and do get contracted, hence the pragma in the function bodies)
+PINN_DEVICE float pinn_mul_then_add(float a, float w, float u) {
+#pragma clang fp contract(off)
+    const float t = w * u;
+    return a + t;
+}
+
+// one thread per point. Counter = (point low, point high, call low, call high | block << 28): block b < 8 supplies the
+// uniform words of columns 4b .. 4b+3, block 8 + c the two extra words of a normal column c (Box-Muller).
+PINN_GLOBAL void PINN_LAUNCH_BOUNDS(256)
+pinn_sample_kernel(float* xs, long long n, PinnSampleSpec spec, unsigned k0, unsigned k1, unsigned call_lo, unsigned call_hi) {
+    const long long i = (long long)PINN_BID * 256 + PINN_TID;
+    if (i >= n) return;
+    const unsigned i_lo = (unsigned)((unsigned long long)i & 0xffffffffull), i_hi = (unsigned)((unsigned long long)i >> 32);
+    unsigned r[4] = {0u, 0u, 0u, 0u};
+    for (int c = 0; c < spec.d; ++c) {
+        if ((c & 3) == 0) pinn_philox4x32_10(i_lo, i_hi, call_lo, (call_hi & 0x0fffffffu) | ((unsigned)(c >> 2) << 28), k0, k1, r);
+        const float a = spec.a[c], b = spec.b[c];
+        float v = a;
+        if (spec.kind[c] == PINN_SAMPLE_UNIFORM) {
+            const float u = (float)(r[c & 3] >> 8) * 5.9604644775390625e-8f;              // 24 bits -> [0, 1)
+            v = pinn_mul_then_add(a, b - a, u);
+        } else if (spec.kind[c] == PINN_SAMPLE_NORMAL) {
+            unsigned q[4];
+            pinn_philox4x32_10(i_lo, i_hi, call_lo, (call_hi & 0x0fffffffu) | ((unsigned)(8 + c) << 28), k0, k1, q);
+            const float u1 = (float)((q[0] >> 8) + 1u) * 5.9604644775390625e-8f;          // (0, 1]
+            const float u2 = (float)(q[1] >> 8) * 5.9604644775390625e-8f;
+            const float z = sqrtf(-2.0f * logf(u1)) * cosf(6.283185307179586f * u2);
+            v = pinn_mul_then_add(a, b, z);
+        }
+        xs[i * spec.d + c] = v;
+    }
+}

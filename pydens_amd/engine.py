@@ -16,6 +16,7 @@ LIB_NAME = 'libpinn_hip.so'
 MAX_LAYERS, MAX_INPUTS, MAX_DIRS, EXTRA_SLOTS = 16, 8, 3, 16
 MAX_OPS, MAX_CONSTS, MAX_REGS = 64, 32, 40
 MAX_STREAMS, MAX_AUX, MAX_VARS = 7, 8, 8
+SAMPLE_UNIFORM, SAMPLE_NORMAL, SAMPLE_CONST = 0, 1, 2
 RES_PROGRAM, RES_AFFINE = 0, 1
 ACT_CODES = {'tanh': 0, 'sigmoid': 1, 'sin': 2, 'identity': 3}
 
@@ -91,6 +92,8 @@ def bind(lib):
     lib.pinn_adam_step_at.argtypes = [vp, vp, vp, vp, vp, i64, vp, i32, f32, f32, f32, f32, vp]
     lib.pinn_residual_adam_step.argtypes = [vp, ctypes.POINTER(Residual), vp, vp, i64, ip, i32, i32, vp, f32, vp, vp, vp, vp,
                                             vp, i32, f32, f32, f32, f32, vp, vp, ctypes.c_size_t, vp]
+    lib.pinn_sample_points.argtypes = [vp, i64, i32, ip, ctypes.POINTER(f32), ctypes.POINTER(f32), ctypes.c_uint64,
+                                       ctypes.c_uint64, vp]
     lib.pinn_profile_tile.argtypes = [i32]
     lib.pinn_profile_tile.restype = i32
     lib.pinn_last_tile_ms.restype = f32
@@ -101,7 +104,8 @@ def bind(lib):
 
 
 ABI_SYMBOLS = ('pinn_create', 'pinn_create_ex', 'pinn_destroy', 'pinn_layout', 'pinn_workspace_bytes', 'pinn_jet_forward',
-               'pinn_jet_backward', 'pinn_residual_step', 'pinn_residual_adam_step', 'pinn_adam_step', 'pinn_adam_step_at', 'pinn_profile_tile', 'pinn_last_tile_ms',
+               'pinn_jet_backward', 'pinn_residual_step', 'pinn_residual_adam_step', 'pinn_adam_step', 'pinn_adam_step_at', 'pinn_sample_points', 'pinn_profile_tile',
+               'pinn_last_tile_ms',
                'pinn_last_error', 'pinn_backend')
 
 _LIB = None
@@ -270,6 +274,20 @@ class Net:
             float(lr), float(betas[0]), float(betas[1]), float(eps),
             None if loss_out is None else ctypes.c_void_p(loss_out), _ptr(workspace),
             workspace.numel() * workspace.element_size(), _stream(xs) if stream is None else stream))
+
+    def sample_points(self, xs, columns, seed, call_index, stream=None):
+        """ fill xs [N, d] on the device: columns = [(kind, a, b), ...] with kind SAMPLE_UNIFORM (a + (b - a) u),
+        SAMPLE_NORMAL (a + b z) or SAMPLE_CONST (a); Philox4x32-10 keyed by (seed, call_index), include/pinn.h. """
+        _check(xs, 'xs')
+        d = len(columns)
+        if xs.dim() != 2 or xs.shape[1] != d:
+            raise ValueError(f'xs must be [N, {d}]')
+        kind = (ctypes.c_int * d)(*[int(c[0]) for c in columns])
+        a = (ctypes.c_float * d)(*[float(c[1]) for c in columns])
+        b = (ctypes.c_float * d)(*[float(c[2]) for c in columns])
+        self._raise(self.lib.pinn_sample_points(_ptr(xs), xs.shape[0], d, kind, a, b, int(seed) & (2 ** 64 - 1),
+                                                int(call_index), _stream(xs) if stream is None else stream))
+        return xs
 
     def adam_step(self, params, grads, exp_avg, exp_avg_sq, mask, step, lr, betas=(0.9, 0.999), eps=1e-8, at=0):
         """ `step`: int32 device counter; at > 0: the host's 1-based step count (one launch, counter mirrored) """

@@ -4,7 +4,10 @@
 
 `batchflow` itself is third-party and not vendored by the reference; only the numpy-distribution samplers and
 `&` are restated. On top of the numpy surface every sampler offers `sample_device(size, device)`, which draws the
-batch directly in HBM (uniform / normal), so that `Solver.fit` keeps the host out of the step path.
+batch directly in HBM (uniform / normal), so that `Solver.fit` keeps the host out of the step path, and `columns()`:
+the per-column description (kind, a, b) of include/pinn.h `pinn_sample_points` when the sampler is a product of
+independent uniform / normal / constant columns -- `Solver.fit` then draws the whole batch with ONE launch of the
+Philox kernel instead of a handful of torch ops per iteration.
 """
 import numpy as np
 import torch
@@ -24,6 +27,11 @@ class Sampler:
         """ default: numpy draw + one host-to-device copy. """
         return torch.from_numpy(np.asarray(self.sample(size), dtype=np.float32)).to(device)
 
+    def columns(self):
+        """ [(kind, a, b)] per column for the device sampler kernel (0 uniform on [a, b), 1 normal a + b z, 2 constant a),
+        or None when the sampler is not such a product (then `sample_device` / `sample` are used). """
+        return None
+
     def __and__(self, other):
         if isinstance(other, (int, float)):
             other = ConstantSampler(other)
@@ -42,6 +50,10 @@ class _ConcatSampler(Sampler):
         return torch.cat([self.left.sample_device(size, device, generator),
                           self.right.sample_device(size, device, generator)], dim=1)
 
+    def columns(self):
+        left, right = self.left.columns(), self.right.columns()
+        return None if left is None or right is None else left + right
+
 
 class ConstantSampler(Sampler):
     def __init__(self, value, dim=1):
@@ -52,6 +64,9 @@ class ConstantSampler(Sampler):
 
     def sample_device(self, size, device, generator=None):
         return torch.full((size, self.dim), self.value, dtype=torch.float32, device=device)
+
+    def columns(self):
+        return [(2, self.value, 0.0)] * self.dim
 
 
 class NumpySampler(Sampler):
@@ -79,6 +94,17 @@ class NumpySampler(Sampler):
             out = torch.randn((size, self.dim), dtype=torch.float32, device=device, generator=generator)
             return out * float(self.kwargs.get('scale', 1.0)) + float(self.kwargs.get('loc', 0.0))
         return super().sample_device(size, device, generator)
+
+    def columns(self):
+        if self.name == 'uniform' and not (set(self.kwargs) - {'low', 'high'}):
+            low, high = self.kwargs.get('low', 0.0), self.kwargs.get('high', 1.0)
+            if np.ndim(low) == 0 and np.ndim(high) == 0:
+                return [(0, float(low), float(high))] * self.dim
+        if self.name == 'normal' and not (set(self.kwargs) - {'loc', 'scale'}):
+            loc, scale = self.kwargs.get('loc', 0.0), self.kwargs.get('scale', 1.0)
+            if np.ndim(loc) == 0 and np.ndim(scale) == 0:
+                return [(1, float(loc), float(scale))] * self.dim
+        return None
 
 
 NS = NumpySampler

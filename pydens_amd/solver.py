@@ -91,6 +91,7 @@ class Solver:
         lay = self.model.net.layout
         self.grads = torch.zeros(lay.p_total, dtype=torch.float32, device=self.device)
         self._generator = None
+        self._sample_seed, self._sample_calls = None, 0      # Philox key / batch counter of the device sampler
         self._broadcast_done = False
 
         # "fake run" (:319-325): materialises V-variables and, here, tells which derivative streams D(...) needs
@@ -246,22 +247,32 @@ class Solver:
             return dist.get_rank(), dist.get_world_size()
         return 0, 1
 
-    def _sample(self, batch_size, sampler):
+    def _sample(self, batch_size, sampler, stream=None):
         """ reference model_torch.py:430-434: default U[0,1) columns (domain is ignored, trap 3 of SURVEY 8a),
-        or `sampler.sample(batch_size)`. Drawn in HBM whenever the sampler can (`sample_device`). """
+        or `sampler.sample(batch_size)`. Products of independent uniform / normal / constant columns -- the default
+        sampler and every `NumpySampler(...) & ...` of the reference's examples -- are drawn in HBM by ONE launch of the
+        Philox kernel (pinn_sample_points); other samplers through `sample_device` or, last, numpy + a copy. """
+        total = self.model.total
+        columns = [(engine.SAMPLE_UNIFORM, 0.0, 1.0)] * total if sampler is None else \
+            (sampler.columns() if hasattr(sampler, 'columns') else None)
+        if columns is not None and len(columns) == total and total <= engine.MAX_INPUTS:
+            if self._sample_seed is None:
+                rank, _ = self._world()
+                self._sample_seed = (torch.initial_seed() + 7919 * rank) & (2 ** 64 - 1)
+            xs = torch.empty((batch_size, total), dtype=torch.float32, device=self.device)
+            self.model.net.sample_points(xs, columns, self._sample_seed, self._sample_calls, stream=stream)
+            self._sample_calls += 1
+            return xs
         if self._generator is None:
             rank, _ = self._world()
             self._generator = torch.Generator(device=self.device)
             self._generator.manual_seed(torch.initial_seed() + 7919 * rank)
-        if sampler is None:
-            return torch.rand((batch_size, self.model.total), dtype=torch.float32, device=self.device,
-                              generator=self._generator)
         if hasattr(sampler, 'sample_device'):
             xs = sampler.sample_device(batch_size, self.device, self._generator)
         else:
             xs = torch.from_numpy(np.asarray(sampler.sample(batch_size)).astype(np.float32)).to(self.device)
-        if xs.shape[1] != self.model.total:
-            raise ValueError(f'sampler produced {xs.shape[1]} columns, the problem has {self.model.total}')
+        if xs.shape[1] != total:
+            raise ValueError(f'sampler produced {xs.shape[1]} columns, the problem has {total}')
         return xs.contiguous()
 
     def fit(self, niters, batch_size, sampler=None, loss_terms='equation', optimizer='Adam',
@@ -292,7 +303,7 @@ class Solver:
         stream = engine.stream_of(model.flat)           # looked up once per call, not per iteration
         history_ptr = history.data_ptr()
         for it in tqdm(range(niters), disable=None):
-            xs = self._sample(batch_size, sampler)
+            xs = self._sample(batch_size, sampler, stream)
             if one_launch:
                 # Adam rides in the gradient-reduction launch, which also drops the loss into history[it]
                 self._fused_step(xs, 1, adam=self.optimizer, loss_out=history_ptr + 4 * it, stream=stream)
