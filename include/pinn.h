@@ -168,6 +168,13 @@ int pinn_residual_step(pinn_t* net, const pinn_residual_t* residual, const float
                        int64_t n_points, const int* dir_cols, int nd, int n2, const float* ic_streams,
                        float ic_const, float inv_n_global, float* grads, void* workspace, size_t workspace_bytes,
                        void* stream);
+/* Same, ADDING gradient and loss to what `grads` already holds: the further terms of a summed loss
+ * (model_torch.py:441-457: `loss += criterion(constraint(...), 0)` -- a constraint term is a residual program over the
+ * value stream alone, evaluated on the few fixed points the constraint names, nd = n2 = 0). */
+int pinn_residual_step_add(pinn_t* net, const pinn_residual_t* residual, const float* params, const float* xs,
+                           int64_t n_points, const int* dir_cols, int nd, int n2, const float* ic_streams,
+                           float ic_const, float inv_n_global, float* grads, void* workspace, size_t workspace_bytes,
+                           void* stream);
 
 /* Single-rank form of one whole `fit` iteration (model_torch.py:437-461): pinn_residual_step with inv_n = 1/n_points and
  * the Adam update of pinn_adam_step fused into the gradient-reduction launch (no all-reduce can sit in between, so

@@ -478,7 +478,7 @@ static int check_program(const pinn_program_t& pg, int first_temp, int n_consts_
 static int residual_step_impl(pinn_t* net, const pinn_residual_t* residual, const float* params, const float* xs,
                               int64_t n_points, const int* dir_cols, int nd, int n2, const float* ic_streams,
                               float ic_const, float inv_n_global, float* grads, void* workspace, size_t workspace_bytes,
-                              void* stream, const AdamArgs* adam) {
+                              void* stream, const AdamArgs* adam, int accumulate = 0) {
     if (!net || !residual || !params || !xs || !grads) return fail("null argument");
     if (n_points <= 0) return fail("n_points must be positive");
     if (check_dirs(net, dir_cols, nd, n2)) return 1;
@@ -531,7 +531,7 @@ static int residual_step_impl(pinn_t* net, const pinn_residual_t* residual, cons
     }
     a.mode = PINN_MODE_STEP;
     a.inv_n = inv_n_global;
-    return run_train(net, &a, plan, nd, grads, 0, workspace, workspace_bytes, stream, &residual->pre, adam);
+    return run_train(net, &a, plan, nd, grads, accumulate, workspace, workspace_bytes, stream, &residual->pre, adam);
 }
 
 int pinn_residual_step(pinn_t* net, const pinn_residual_t* residual, const float* params, const float* xs,
@@ -539,6 +539,13 @@ int pinn_residual_step(pinn_t* net, const pinn_residual_t* residual, const float
                        float inv_n_global, float* grads, void* workspace, size_t workspace_bytes, void* stream) {
     return residual_step_impl(net, residual, params, xs, n_points, dir_cols, nd, n2, ic_streams, ic_const, inv_n_global,
                               grads, workspace, workspace_bytes, stream, nullptr);
+}
+
+int pinn_residual_step_add(pinn_t* net, const pinn_residual_t* residual, const float* params, const float* xs,
+                           int64_t n_points, const int* dir_cols, int nd, int n2, const float* ic_streams, float ic_const,
+                           float inv_n_global, float* grads, void* workspace, size_t workspace_bytes, void* stream) {
+    return residual_step_impl(net, residual, params, xs, n_points, dir_cols, nd, n2, ic_streams, ic_const, inv_n_global,
+                              grads, workspace, workspace_bytes, stream, nullptr, 1);
 }
 
 int pinn_residual_adam_step(pinn_t* net, const pinn_residual_t* residual, float* params, const float* xs,

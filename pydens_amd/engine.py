@@ -88,6 +88,7 @@ def bind(lib):
     lib.pinn_jet_backward.argtypes = [vp, vp, vp, i64, ip, i32, i32, vp, f32, vp, vp, i32, vp, ctypes.c_size_t, vp]
     lib.pinn_residual_step.argtypes = [vp, ctypes.POINTER(Residual), vp, vp, i64, ip, i32, i32, vp, f32, f32, vp, vp,
                                        ctypes.c_size_t, vp]
+    lib.pinn_residual_step_add.argtypes = lib.pinn_residual_step.argtypes
     lib.pinn_adam_step.argtypes = [vp, vp, vp, vp, vp, i64, vp, f32, f32, f32, f32, vp]
     lib.pinn_adam_step_at.argtypes = [vp, vp, vp, vp, vp, i64, vp, i32, f32, f32, f32, f32, vp]
     lib.pinn_residual_adam_step.argtypes = [vp, ctypes.POINTER(Residual), vp, vp, i64, ip, i32, i32, vp, f32, vp, vp, vp, vp,
@@ -104,7 +105,7 @@ def bind(lib):
 
 
 ABI_SYMBOLS = ('pinn_create', 'pinn_create_ex', 'pinn_destroy', 'pinn_layout', 'pinn_workspace_bytes', 'pinn_jet_forward',
-               'pinn_jet_backward', 'pinn_residual_step', 'pinn_residual_adam_step', 'pinn_adam_step', 'pinn_adam_step_at', 'pinn_sample_points', 'pinn_profile_tile',
+               'pinn_jet_backward', 'pinn_residual_step', 'pinn_residual_step_add', 'pinn_residual_adam_step', 'pinn_adam_step', 'pinn_adam_step_at', 'pinn_sample_points', 'pinn_profile_tile',
                'pinn_last_tile_ms',
                'pinn_last_error', 'pinn_backend')
 
@@ -246,13 +247,14 @@ class Net:
                                                _stream(xs)))
 
     def residual_step(self, residual, params, xs, grads, workspace, dir_cols=(), n2=0, ic_streams=None, ic_const=0.0,
-                      inv_n_global=None):
+                      inv_n_global=None, accumulate=False):
         for t, name in ((params, 'params'), (xs, 'xs'), (grads, 'grads'), (ic_streams, 'ic_streams')):
             _check(t, name)
         dirs, nd = self._dirs(dir_cols)
         n = xs.shape[0]
         inv_n = 1.0 / n if inv_n_global is None else inv_n_global
-        self._raise(self.lib.pinn_residual_step(self.handle, ctypes.byref(residual), _ptr(params), _ptr(xs), n, dirs, nd,
+        fn = self.lib.pinn_residual_step_add if accumulate else self.lib.pinn_residual_step
+        self._raise(fn(self.handle, ctypes.byref(residual), _ptr(params), _ptr(xs), n, dirs, nd,
                                                 n2, _ptr(ic_streams), float(ic_const), float(inv_n), _ptr(grads),
                                                 _ptr(workspace), workspace.numel() * workspace.element_size(),
                                                 _stream(xs)))

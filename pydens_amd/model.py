@@ -28,6 +28,10 @@ class TorchModel(ABC, nn.Module):
         self.nparams = nparams
         self.total = ndims + nparams
         self.variables = {}
+        # variables the reference would not have created yet: a V(...) that appears only inside a constraint comes to life
+        # in the first iteration that evaluates the constraint (model_torch.py:457), AFTER that fit call has built its
+        # optimizer (:420), so that call does not train it. The solver keeps such names here until then.
+        self.dormant_variables = set()
         if initial_condition is None:
             self.initial_condition = None
             self.ic_constant = None
@@ -243,8 +247,14 @@ class ConvBlockModel(TorchModel):
             b.fill_(1 if lin.bias.requires_grad else 0)
         mask[lay.off_log_scale] = 1 if self.log_scale.requires_grad else 0
         for name, (off, n) in self.variables.items():
-            mask[off:off + n] = 1 if getattr(self, name).requires_grad else 0
+            mask[off:off + n] = 1 if getattr(self, name).requires_grad and name not in self.dormant_variables else 0
         return mask
+
+    def optimizer_parameters(self):
+        """ what the reference hands to the optimizer at the start of a fit call (model_torch.py:420): every parameter
+        with requires_grad that EXISTS at that moment (see `dormant_variables`). """
+        dormant = {id(getattr(self, name)) for name in self.dormant_variables}
+        return [p for p in self.parameters() if p.requires_grad and id(p) not in dormant]
 
     def ic_values(self, xs):
         """ IC(x_spatial) as [N,1] on the device (callable ICs only; differentiable w.r.t. V-variables). """

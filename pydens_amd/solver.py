@@ -51,7 +51,7 @@ class TorchOptimizerAdapter:
     parameter views in place; their .grad are views of the flat gradient buffer the kernels fill. """
     def __init__(self, model, name, lr, **kwargs):
         self.model = model
-        self.params = [p for p in model.parameters() if p.requires_grad]
+        self.params = model.optimizer_parameters()
         self.opt = getattr(torch.optim, name)(self.params, lr=lr, **kwargs)
 
     def refresh(self):
@@ -78,6 +78,7 @@ class Solver:
             self.constraints = (constraints, )
         self._losses = []
         self._pending = []
+        self.use_fused = True       # diagnostic switch: False keeps every fit on the generic step path
         self.optimizer = None
 
         self.model = model(**kwargs, ndims=ndims, initial_condition=initial_condition,
@@ -102,6 +103,18 @@ class Solver:
         self.ic_trainable = self._ic_depends_on_variables()
         self.residual_plan = None
         self.program, self.program_error = self._try_compile()
+        # constraint terms (:451-457) the tracer can lower run as further residual programs over the value stream on
+        # their own few points; the others keep the generic path (entry None, reason in constraint_errors)
+        self.constraint_plans, self.constraint_errors = [], []
+        self._born_in_constraint = {}        # constraint number -> variables first created by tracing it (dormant until
+        self._constraints_seen = set()       # a fit call has evaluated that constraint: reference :420 vs :457)
+        for num, constraint in enumerate(self.constraints):
+            before = set(self.model.variables)
+            plan, err = self._try_compile_constraint(constraint)
+            self.constraint_plans.append(plan)
+            self.constraint_errors.append(err)
+            self._born_in_constraint[num] = set(self.model.variables) - before
+            self.model.dormant_variables |= self._born_in_constraint[num]
 
     # ---- tracing ---------------------------------------------------------------------------------------------------
     def _ic_depends_on_variables(self):
@@ -135,6 +148,48 @@ class Solver:
             return plan.to_struct(), None
         except trace.TraceUnsupported as err:
             return None, str(err)
+
+    def _try_compile_constraint(self, constraint):
+        """ -> ({'program', 'plan', 'points', 'ic'}, None) or (None, reason). """
+        model, total = self.model, self.model.total
+        if self.ic_trainable:
+            return None, 'initial condition holds trainable variables'
+        try:
+            root, pts = trace.symbolic_constraint(
+                constraint, self.ctx.run, total,
+                lambda args: self.reshape_and_concat(args).numpy(), variable_slot=self._variable_slot)
+            spec0 = trace.StreamSpec(set())
+            plan = trace.lower_residual(root, spec0, total)
+            # validation: the program (fp64 host interpreter) vs the callable fed with a stand-in for the model's values
+            values = torch.rand((pts.shape[0], 1), device=self.device) * 2 - 1
+            cols = [torch.from_numpy(pts[:, c:c + 1].copy()).to(self.device) for c in range(total)]
+            try:
+                want = self.ctx.run(constraint, lambda *args: values, *cols)
+            except (TypeError, ValueError, AttributeError, RuntimeError, LookupError) as err:
+                raise trace.TraceUnsupported(f'{type(err).__name__}: {err}') from err
+            want = torch.as_tensor(want).detach().reshape(-1).double().cpu().numpy()
+            lay = model.net.layout
+            var_values = model.flat[lay.off_extra:lay.off_extra + plan.n_vars].detach().cpu().numpy()
+            got = trace.run_residual_numpy(plan, values.cpu().numpy().reshape(1, -1), pts, var_values)
+            if got.shape != want.shape or not np.allclose(got, want, rtol=1e-4, atol=1e-5):
+                raise trace.TraceUnsupported('traced constraint disagrees with the callable')
+        except trace.TraceUnsupported as err:
+            return None, str(err)
+        points = torch.from_numpy(pts).to(self.device).contiguous()
+        ic = None
+        if model.initial_condition is not None and model.ic_constant is None:
+            with torch.no_grad():
+                ic = self.ctx.run(model.ic_values, points).expand(points.shape[0], 1).reshape(1, -1).float().contiguous()
+        return dict(program=plan.to_struct(), plan=plan, points=points, ic=ic), None
+
+    def _constraint_step(self, num, world, accumulate):
+        """ gradient + loss of constraint term `num` (mean of its squared values, reference :457), added to / stored in
+        `self.grads`; every data-parallel rank evaluates it, hence the 1 / world in front of the all-reduce. """
+        cp, model = self.constraint_plans[num], self.model
+        n_c = cp['points'].shape[0]
+        model.net.residual_step(cp['program'], model.flat, cp['points'], self.grads, model.workspace(n_c, 0, 0), (), 0,
+                                ic_streams=cp['ic'], ic_const=model.kernel_ic_const(),
+                                inv_n_global=1.0 / (n_c * world), accumulate=accumulate)
 
     def _variable_slot(self, param):
         """ user slot (index behind `off_extra` in the flat buffer) of a scalar trainable V(...), else None. """
@@ -279,6 +334,8 @@ class Solver:
             criterion=nn.MSELoss(), lr=0.005, **kwargs):
         """ reference model_torch.py:364-464. `batch_size` is per rank under torch.distributed. """
         model = self.model
+        for num in self._constraints_seen:          # variables an earlier fit call brought to life are trainable now
+            model.dormant_variables -= self._born_in_constraint.get(num, set())
         if optimizer is not None:                                                          # :419-422
             self.optimizer = (FlatAdam(model, lr=lr, **kwargs) if optimizer == 'Adam'
                               else TorchOptimizerAdapter(model, optimizer, lr, **kwargs))
@@ -289,9 +346,13 @@ class Solver:
         loss_terms = loss_terms if isinstance(loss_terms, (tuple, list)) else (loss_terms, )
         nums_constraints = [int(term.replace('constraint', '').replace('_', ''))
                             for term in loss_terms if 'constraint' in term]
+        self._constraints_seen |= {num for num in nums_constraints if num < len(self.constraints)}
         mse_mean = isinstance(criterion, nn.MSELoss) and criterion.reduction == 'mean'
-        fused = (self.program is not None and tuple(loss_terms) == ('equation',) and mse_mean
-                 and not self.ic_trainable)
+        lowered = all(num < len(self.constraint_plans) and self.constraint_plans[num] is not None
+                      for num in nums_constraints)
+        only_known_terms = all(term == 'equation' or 'constraint' in term for term in loss_terms)
+        fused = (self.use_fused and mse_mean and not self.ic_trainable and only_known_terms and lowered
+                 and len(loss_terms) > 0 and (self.program is not None or 'equation' not in loss_terms))
         rank, world = self._world()
         if world > 1 and not self._broadcast_done:
             torch.distributed.broadcast(model.flat, src=0)
@@ -299,7 +360,7 @@ class Solver:
         lay = model.net.layout
         history = torch.zeros(niters, dtype=torch.float32, device=self.device)
         self.last_fit_path = 'fused' if fused else 'generic'
-        one_launch = fused and world == 1 and isinstance(self.optimizer, FlatAdam)
+        one_launch = fused and world == 1 and isinstance(self.optimizer, FlatAdam) and tuple(loss_terms) == ('equation',)
         stream = engine.stream_of(model.flat)           # looked up once per call, not per iteration
         history_ptr = history.data_ptr()
         for it in tqdm(range(niters), disable=None):
@@ -309,7 +370,14 @@ class Solver:
                 self._fused_step(xs, 1, adam=self.optimizer, loss_out=history_ptr + 4 * it, stream=stream)
                 continue
             if fused:
-                self._fused_step(xs, world)
+                # summed loss (:441-457): the equation term stores gradient + loss, every constraint term adds its own
+                first = True
+                if 'equation' in loss_terms:
+                    self._fused_step(xs, world)
+                    first = False
+                for num in nums_constraints:
+                    self._constraint_step(num, world, accumulate=not first)
+                    first = False
             else:
                 self._generic_step(xs, loss_terms, nums_constraints, criterion, world)
             if world > 1:

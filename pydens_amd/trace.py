@@ -367,6 +367,46 @@ def symbolic(equation, ctx_run, n_inputs, variable_slot=None):
     return Sym.wrap(root)
 
 
+def _depends_on_inputs(node, memo):
+    key = id(node)
+    if key not in memo:
+        memo[key] = node.kind == 'input' or any(_depends_on_inputs(a, memo) for a in node.args)
+    return memo[key]
+
+
+def symbolic_constraint(constraint, ctx_run, n_inputs, to_points, variable_slot=None):
+    """ Trace a constraint callable `constraint(f, *xs)` (reference model_torch.py:451-457: `f` evaluates the model on
+    whatever points it is given, e.g. `lambda f, x: f(torch.tensor([0.5]))`). Supported form: ONE call of `f` on
+    constants -- numbers, arrays, tensors, cast by `to_points` exactly like the reference's `reshape_and_concat` -- and
+    a pointwise expression of its value and trainable variables that does not touch the batch columns.
+    Returns (root Sym over the value stream, points [n_c, n_inputs] float32). Raises TraceUnsupported otherwise. """
+    calls = []
+
+    def model_at(*args):
+        if any(isinstance(a, Sym) for a in args):
+            raise TraceUnsupported('constraint evaluates the model on the batch points')
+        if calls:
+            raise TraceUnsupported('constraint evaluates the model more than once')
+        pts = np.asarray(to_points(args), dtype=np.float32)
+        if pts.ndim != 2 or pts.shape[1] != n_inputs:
+            raise TraceUnsupported(f'constraint calls the model with {pts.shape[-1]} columns, the problem has {n_inputs}')
+        calls.append(pts)
+        return Sym('stream', alpha=())
+
+    xs = [Sym('input', col=c) for c in range(n_inputs)]
+    try:
+        root = ctx_run(_call_with_variables, variable_slot, constraint, model_at, *xs)
+    except TraceUnsupported:
+        raise
+    except (TypeError, ValueError, AttributeError, RuntimeError, LookupError) as err:
+        raise TraceUnsupported(f'{type(err).__name__}: {err}') from err
+    if not calls:
+        raise TraceUnsupported('constraint does not evaluate the model')
+    if _depends_on_inputs(root, {}):
+        raise TraceUnsupported('constraint depends on the batch points')
+    return root, calls[0]
+
+
 class _Emitter:
     """ register-code emitter shared by the pre-pass and the main program. """
     def __init__(self, first_temp):

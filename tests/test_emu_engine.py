@@ -180,6 +180,7 @@ def test_trainable_variable_and_constraint_follow_the_reference(pa, emu_lib):
     assert solver.program is not None and solver.residual_plan.n_vars == 1    # V('new_var') is a program register
     pts = np.random.RandomState(3).rand(6, 40, 1).astype(np.float32)
     terms = ['equation', 'constraint_0']
+    solver.use_fused = False                        # this test pins the GENERIC path (the fused form: next test)
     oracle.fit(niters=6, batch_size=40, points=pts, lr=0.05, loss_terms=terms)
     solver.fit(niters=6, batch_size=40, sampler=FixedBatches(pts), lr=0.05, loss_terms=terms)
     assert solver.last_fit_path == 'generic'
@@ -187,6 +188,60 @@ def test_trainable_variable_and_constraint_follow_the_reference(pa, emu_lib):
     assert abs(float(solver.model.new_var) - float(oracle.model.new_var)) < 1e-5
     for got, want in zip(export_params(solver), oracle.export_params()):
         assert rel_l2(got, want) < 5e-5
+
+
+def test_constraint_terms_as_residual_programs(pa, emu_lib):
+    """ loss_terms with constraints (reference :451-457) on the fused path: the constraint is traced to a program over the
+    value stream on its own fixed points and ADDS gradient + loss to the equation's (pinn_residual_step_add) """
+    oracle, solver = _paired(pa, emu_lib)
+    assert solver.constraint_plans[0] is not None, solver.constraint_errors
+    assert solver.constraint_plans[0]['points'].shape == (1, 1)
+    pts = np.random.RandomState(8).rand(9, 40, 1).astype(np.float32)
+    for terms, lo in ((['equation', 'constraint_0'], 0), (['constraint_0'], 3), ('equation', 6)):
+        oracle.fit(niters=3, batch_size=40, points=pts[lo:lo + 3], lr=0.05, loss_terms=terms)
+        solver.fit(niters=3, batch_size=40, sampler=FixedBatches(pts[lo:lo + 3]), lr=0.05, loss_terms=terms)
+        assert solver.last_fit_path == 'fused'
+    np.testing.assert_allclose([float(v) for v in solver.losses], [float(v) for v in oracle.losses], rtol=5e-5)
+    assert abs(float(solver.model.new_var) - float(oracle.model.new_var.detach())) < 1e-5
+    for got, want in zip(export_params(solver), oracle.export_params()):
+        assert rel_l2(got, want) < 5e-5
+
+    # several points, a variable inside the constraint, a callable initial condition
+    from oracle import pinn_oracle as po
+
+    def problem(D, V):
+        def eq(u, x, t):
+            return D(u, t) - 0.3 * D(D(u, x), x)
+        def con(f, x, t):
+            return f(np.array([0.25, 0.5, 0.75]), 0.5) - V('level', data=torch.Tensor([0.4])) * 2.0
+        return eq, con
+    kw = dict(ndims=2, initial_condition=lambda x: torch.sin(np.pi * x), boundary_condition=0.0, layout='fafaf',
+              features=[16, 16, 1], activation='Tanh')
+    eq_o, con_o = problem(po.D, po.V)
+    eq_p, con_p = problem(pa.D, pa.V)
+    oracle = po.OracleSolver(eq_o, constraints=con_o, **kw)
+    solver = pa.Solver(eq_p, constraints=con_p, **kw, **emu_kwargs(emu_lib))
+    load_params(solver, oracle.export_params())
+    cp = solver.constraint_plans[0]
+    assert cp is not None and cp['points'].shape == (3, 2) and cp['plan'].n_vars == 1 and cp['ic'] is not None
+    pts = np.random.RandomState(9).rand(7, 33, 2).astype(np.float32)
+    terms = ['equation', 'constraint_0']
+    # a variable that lives only in a constraint is born in the reference's first iteration that evaluates the constraint
+    # (:457), after that fit call built its optimizer (:420): the first call leaves it alone, the next one trains it
+    oracle.fit(niters=4, batch_size=33, points=pts[:4], lr=0.02, loss_terms=terms)
+    solver.fit(niters=4, batch_size=33, sampler=FixedBatches(pts[:4]), lr=0.02, loss_terms=terms)
+    assert solver.last_fit_path == 'fused'
+    assert float(solver.model.level) == float(oracle.model.level.detach()) == float(np.float32(0.4))
+    oracle.fit(niters=3, batch_size=33, points=pts[4:], lr=0.02, loss_terms=terms)
+    solver.fit(niters=3, batch_size=33, sampler=FixedBatches(pts[4:]), lr=0.02, loss_terms=terms)
+    np.testing.assert_allclose([float(v) for v in solver.losses], [float(v) for v in oracle.losses], rtol=5e-5)
+    assert abs(float(solver.model.level) - float(oracle.model.level.detach())) < 1e-5
+    assert float(solver.model.level) != float(np.float32(0.4))
+    for got, want in zip(export_params(solver), oracle.export_params()):
+        assert rel_l2(got, want) < 5e-5
+    # a constraint on the batch points cannot be lowered and says why
+    other = pa.Solver(eq_p, constraints=lambda f, x, t: f(x, 0.0), **kw, **emu_kwargs(emu_lib))
+    assert other.constraint_plans[0] is None and 'batch points' in other.constraint_errors[0]
 
 
 def test_trainable_variable_on_the_fused_path(pa, emu_lib):

@@ -319,6 +319,7 @@ def test_trainable_variable_constraint_and_freezing_on_the_gpu(pa):
     assert solver.program is not None and solver.residual_plan.n_vars == 1
     pts = np.random.RandomState(3).rand(8, 256, 1).astype(np.float32)
     terms = ['equation', 'constraint_0']
+    solver.use_fused = False                        # the generic path is what this test pins
     oracle.fit(niters=4, batch_size=256, points=pts[:4], lr=0.05, loss_terms=terms)
     solver.fit(niters=4, batch_size=256, sampler=FixedBatches(pts[:4]), lr=0.05, loss_terms=terms)
     assert solver.last_fit_path == 'generic'
@@ -327,6 +328,7 @@ def test_trainable_variable_constraint_and_freezing_on_the_gpu(pa):
     oracle.model.new_var.requires_grad = False
     solver.model.freeze_trainable(variables=('new_var',))
     frozen = float(solver.model.new_var)
+    solver.use_fused = True
     oracle.fit(niters=2, batch_size=256, points=pts[4:6], lr=0.05)
     solver.fit(niters=2, batch_size=256, sampler=FixedBatches(pts[4:6]), lr=0.05)
     assert float(solver.model.new_var) == frozen
@@ -364,6 +366,52 @@ def test_trainable_variables_on_the_fused_path_on_the_gpu(pa):
     np.testing.assert_allclose([float(v) for v in solver.losses], [float(v) for v in oracle.losses], rtol=5e-5)
     for name in ('diffusivity', 'source'):
         assert abs(float(getattr(solver.model, name)) - float(getattr(oracle.model, name).detach())) < 2e-5
+    for got, want in zip(export_params(solver), oracle.export_params()):
+        assert rel_l2(got, want) < 1e-4
+
+
+def test_constraint_terms_on_the_fused_path_on_the_gpu(pa):
+    """ constraint loss terms (reference :451-457) as residual programs over the value stream on their own points, added to
+    the equation's gradient by pinn_residual_step_add: tutorial cells 50-60 term by term, then two fit calls of a
+    heat-type problem with a variable that only the constraint knows (born late in the reference: trap documented in
+    DESIGN.md) """
+    from test_emu_engine import _paired
+    from oracle import pinn_oracle as po
+    oracle, solver = _paired(pa, None)
+    assert solver.constraint_plans[0] is not None, solver.constraint_errors
+    pts = np.random.RandomState(8).rand(9, 1000, 1).astype(np.float32)
+    for terms, lo in ((['equation', 'constraint_0'], 0), (['constraint_0'], 3), ('equation', 6)):
+        oracle.fit(niters=3, batch_size=1000, points=pts[lo:lo + 3], lr=0.05, loss_terms=terms)
+        solver.fit(niters=3, batch_size=1000, sampler=FixedBatches(pts[lo:lo + 3]), lr=0.05, loss_terms=terms)
+        assert solver.last_fit_path == 'fused'
+    np.testing.assert_allclose([float(v) for v in solver.losses], [float(v) for v in oracle.losses], rtol=5e-5)
+    assert abs(float(solver.model.new_var) - float(oracle.model.new_var.detach())) < 2e-5
+
+    def problem(D, V):
+        def eq(u, x, t):
+            return D(u, t) - 0.3 * D(D(u, x), x)
+
+        def con(f, x, t):
+            return f(np.array([0.25, 0.5, 0.75]), 0.5) - V('level', data=torch.Tensor([0.4])) * 2.0
+        return eq, con
+    kw = dict(ndims=2, initial_condition=lambda x: torch.sin(np.pi * x), boundary_condition=0.0, layout='fafafaf',
+              features=[64, 64, 64, 1], activation='Tanh')
+    eq_o, con_o = problem(po.D, po.V)
+    eq_p, con_p = problem(pa.D, pa.V)
+    oracle = po.OracleSolver(eq_o, constraints=con_o, **kw)
+    solver = pa.Solver(eq_p, constraints=con_p, **kw)
+    load_params(solver, oracle.export_params())
+    pts = np.random.RandomState(9).rand(7, 4099, 2).astype(np.float32)
+    terms = ['equation', 'constraint_0']
+    oracle.fit(niters=4, batch_size=4099, points=pts[:4], lr=0.02, loss_terms=terms)
+    solver.fit(niters=4, batch_size=4099, sampler=FixedBatches(pts[:4]), lr=0.02, loss_terms=terms)
+    assert solver.last_fit_path == 'fused'
+    assert float(solver.model.level) == float(oracle.model.level.detach()) == float(np.float32(0.4))
+    oracle.fit(niters=3, batch_size=4099, points=pts[4:], lr=0.02, loss_terms=terms)
+    solver.fit(niters=3, batch_size=4099, sampler=FixedBatches(pts[4:]), lr=0.02, loss_terms=terms)
+    np.testing.assert_allclose([float(v) for v in solver.losses], [float(v) for v in oracle.losses], rtol=5e-5)
+    assert abs(float(solver.model.level) - float(oracle.model.level.detach())) < 2e-5
+    assert float(solver.model.level) != float(np.float32(0.4))
     for got, want in zip(export_params(solver), oracle.export_params()):
         assert rel_l2(got, want) < 1e-4
 

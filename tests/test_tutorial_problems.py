@@ -63,7 +63,7 @@ def _problems(D, V, NS):
         'ode_with_variable_and_constraint': (odevar, dict(ndims=1, initial_condition=1,
                                                           constraints=lambda f, x: f(torch.tensor([0.5]))),
                                              dict(lr=0.1, loss_terms=['equation', 'constraint_0']), 100, unit,
-                                             'generic'),                                           # cell 60
+                                             'fused'),                                             # cell 60
         'trainable_initial_value': (plain_ode, dict(ndims=1, initial_condition=initial,
                                                     constraints=lambda u, t: u(torch.tensor([0.5])) - 2),
                                     dict(lr=0.05, loss_terms=['equation', 'constraint_0']), 500, unit,

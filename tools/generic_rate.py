@@ -1,0 +1,22 @@
+""" Solver.fit rate of the generic step path (constraint term + trainable variable: tutorial cells 50-60) next to the
+fused path of the same problem. """
+import os, sys, time
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import numpy as np, torch
+import pydens_amd as pa
+from pydens_amd import D, V
+
+def odevar(f, x):
+    return D(f, x) - 2 * np.pi * torch.cos(2 * np.pi * x) + V('new_var', data=torch.Tensor([1.0]))
+
+for batch in (500, 65536):
+    solver = pa.Solver(odevar, ndims=1, initial_condition=1, constraints=lambda f, x: f(torch.tensor([0.5])))
+    for terms in ('equation', ['equation', 'constraint_0']):
+        solver.fit(niters=20, batch_size=batch, lr=0.01, loss_terms=terms)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        solver.fit(niters=200, batch_size=batch, lr=0.01, loss_terms=terms)
+        torch.cuda.synchronize()
+        dt = (time.perf_counter() - t0) / 200
+        print(f'batch {batch:6d} terms {terms!s:32s} path {solver.last_fit_path:8s} {dt * 1e3:8.3f} ms/it', flush=True)

@@ -1,0 +1,16 @@
+import os, sys, time, cProfile, pstats
+sys.path.insert(0, '/root/repo')
+import numpy as np, torch
+import pydens_amd as pa
+from pydens_amd import D, V
+def odevar(f, x):
+    return D(f, x) - 2 * np.pi * torch.cos(2 * np.pi * x) + V('new_var', data=torch.Tensor([1.0]))
+solver = pa.Solver(odevar, ndims=1, initial_condition=1, constraints=lambda f, x: f(torch.tensor([0.5])))
+terms = ['equation', 'constraint_0']
+solver.fit(niters=20, batch_size=500, lr=0.01, loss_terms=terms)
+torch.cuda.synchronize()
+pr = cProfile.Profile(); pr.enable()
+solver.fit(niters=300, batch_size=500, lr=0.01, loss_terms=terms)
+torch.cuda.synchronize()
+pr.disable()
+st = pstats.Stats(pr); st.sort_stats('tottime').print_stats(8); st.print_callers('_check')
