@@ -119,6 +119,10 @@ typedef struct pinn_residual {
     int combined;
     float comb_w[PINN_MAX_DIRS];
     int n_vars;
+    /* 1 + user slot of a TRAINABLE constant initial value (`initial_condition=lambda *a: V('init', ...)`, reference
+     * examples notebook cells 80-88), 0 = none: the ansatz then adds params[off_extra + slot] instead of the `ic_const`
+     * argument and d(loss)/d(slot) = sum over points of d(loss)/du is added to grads[off_extra + slot]. */
+    int ic_var1;
 } pinn_residual_t;
 
 /* Descriptor of network + ansatz.  Replaces ConvBlockModel.__init__/TorchModel.__init__ bookkeeping

@@ -497,6 +497,9 @@ static int residual_step_impl(pinn_t* net, const pinn_residual_t* residual, cons
     if (a.n_vars < 0 || a.n_vars > PINN_MAX_VARS || a.n_vars > PINN_EXTRA_SLOTS)
         return fail("n_vars=%d outside [0, %d]", a.n_vars, PINN_MAX_VARS);
     if (a.n_vars > 0 && residual->kind != PINN_RES_PROGRAM) return fail("trainable variables need a residual program (kind PINN_RES_PROGRAM)");
+    a.ic_var1 = residual->ic_var1;
+    if (a.ic_var1 < 0 || a.ic_var1 > PINN_EXTRA_SLOTS) return fail("ic_var1=%d outside [0, %d]", a.ic_var1, PINN_EXTRA_SLOTS);
+    if (a.ic_var1 > 0 && (!net->has_ic || ic_streams)) return fail("ic_var1 needs a problem with an initial condition and no ic_streams");
     a.comb = comb;
     for (int k = 0; k < PINN_MAX_DIRS; ++k) a.comb_w[k] = (comb && k < nd) ? residual->comb_w[k] : 0.0f;
     if (residual->n_aux > 0 && check_program(residual->pre, d, PINN_MAX_CONSTS, true, residual->n_aux, "pre-pass")) return 1;

@@ -46,6 +46,7 @@ struct PinnKArgs {
     int off_b1, off_wh, hidden_stride, off_wl, off_bl, off_ls, off_loss;
     int p_core;                  // row stride of `partials` = length of the gradient buffer (user slots included)
     int off_extra, n_vars;       // first user slot; V(...) scalars a residual program reads (registers S+d+n_aux+k)
+    int ic_var1;                 // 1 + user slot holding a trainable constant initial value (0: the ic_const argument)
     int ndims, nsp, has_bc, has_ic;
     float bc_value, t0, ic_const, inv_n;
     float lo[PINN_MAX_INPUTS], hi[PINN_MAX_INPUTS];
@@ -348,6 +349,7 @@ template <int ND, int N2>
 struct PinnPointOut {
     float gnet[1 + ND + N2];
     float loss, g_ls;
+    float g_ic;        // d(loss)/du of the point = its share of d(loss)/d(constant initial value)
 };
 
 // per-point values that come from global memory (pre-pass rows, IC streams): fetched at the START of the tile by the
@@ -411,7 +413,7 @@ PINN_DEVICE void pinn_point_prefetch(const PinnKArgs& A, long long gidx, bool va
             for (int s = 0; s < S; ++s)
                 if (s < SH::s_user(A) && valid) pre.ic[s] = A.ic_streams[(long long)s * A.n_points + gidx];
         } else {
-            pre.ic[0] = A.ic_const;
+            pre.ic[0] = (SPEC == 0 && A.ic_var1 > 0) ? A.params[A.off_extra + A.ic_var1 - 1] : A.ic_const;
         }
     }
 }
@@ -538,6 +540,7 @@ PINN_DEVICE void pinn_point_stage(const PinnKArgs& A, const float (&net)[1 + ND 
 #pragma unroll
         for (int s = 0; s < S; ++s) out.gnet[s] = 0.0f;
         out.g_ls = 0.0f;
+        out.g_ic = 0.0f;
         return;
     } else if (SH::mode(A) == PINN_MODE_STEP && SH::res_kind(A) == PINN_RES_AFFINE) {
         // r = sum_s C_s u_s + F, coefficients constant or per-point rows of the x-only pre-pass
@@ -623,6 +626,7 @@ PINN_DEVICE void pinn_point_stage(const PinnKArgs& A, const float (&net)[1 + ND 
         out.gnet[0] = g0;
     }
     out.g_ls = g_ls;
+    out.g_ic = gu[0];
 }
 
 // ------------------------------------------------------------------------------------------------------------
@@ -787,7 +791,7 @@ pinn_tile_kernel(const PinnKArgs A) {
 #pragma unroll
         for (int c = 0; c < (REGB ? W1R : 1); ++c) accW1r[c][j] = f32x4{0.f, 0.f, 0.f, 0.f};
     }
-    float sum_loss = 0.0f, sum_ls = 0.0f, sum_bl = 0.0f;
+    float sum_loss = 0.0f, sum_ls = 0.0f, sum_bl = 0.0f, sum_ic = 0.0f;
 
     f32x4* slab = A.slab ? A.slab + (size_t)PINN_BID * C::slab_vec4_per_wg(lh, SKIPS ? A.n_skips : 0) : nullptr;
     auto slab_at = [&](int a, int s, int j, int mt) -> f32x4* {
@@ -1097,6 +1101,7 @@ pinn_tile_kernel(const PinnKArgs A) {
 #pragma unroll
             for (int s = 0; s < S; ++s) gnetb[s * T + pt] = po.gnet[s];
             sum_loss += po.loss; sum_ls += po.g_ls; sum_bl += po.gnet[0];
+            if (SPEC == 0) sum_ic += po.g_ic;
         }
         PH(8)
         PINN_SYNC();
@@ -1568,7 +1573,7 @@ pinn_tile_kernel(const PinnKArgs A) {
             if (lr == 0) part[A.off_wl + unit0(j) + r] = v;
         }
     }
-    if (tid < T) { scal[tid * 4 + 0] = sum_loss; scal[tid * 4 + 1] = sum_ls; scal[tid * 4 + 2] = sum_bl; }
+    if (tid < T) { scal[tid * 4 + 0] = sum_loss; scal[tid * 4 + 1] = sum_ls; scal[tid * 4 + 2] = sum_bl; scal[tid * 4 + 3] = sum_ic; }
     PINN_SYNC();
     if (tid == 0) {
         float l0 = 0.0f, l1 = 0.0f, l2 = 0.0f;
@@ -1584,6 +1589,11 @@ pinn_tile_kernel(const PinnKArgs A) {
                 for (int i = 0; i < T; ++i) g += padj[(vbase + k) * T + i];
                 part[A.off_extra + k] = g;
             }
+        }
+        if (SPEC == 0 && A.ic_var1 > 0 && SH::mode(A) == PINN_MODE_STEP) {
+            float l3 = 0.0f;
+            for (int i = 0; i < T; ++i) l3 += scal[i * 4 + 3];
+            part[A.off_extra + A.ic_var1 - 1] += l3;
         }
     }
 }

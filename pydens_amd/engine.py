@@ -52,7 +52,8 @@ class Residual(ctypes.Structure):
     _fields_ = [('kind', ctypes.c_int), ('n_aux', ctypes.c_int), ('pre', Program), ('program', Program),
                 ('coef', ctypes.c_float * MAX_STREAMS), ('coef_row', ctypes.c_int * MAX_STREAMS),
                 ('src_const', ctypes.c_float), ('src_row', ctypes.c_int),
-                ('combined', ctypes.c_int), ('comb_w', ctypes.c_float * MAX_DIRS), ('n_vars', ctypes.c_int)]
+                ('combined', ctypes.c_int), ('comb_w', ctypes.c_float * MAX_DIRS), ('n_vars', ctypes.c_int),
+                ('ic_var1', ctypes.c_int)]
 
     @classmethod
     def build(cls, kind, n_aux, pre, program=None, coef=(), coef_row=(), src_const=0.0, src_row=-1, comb_w=None, n_vars=0):

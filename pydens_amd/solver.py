@@ -100,7 +100,11 @@ class Solver:
             fake = torch.rand((3, self.model.total), device=self.device)
             self.ctx.run(self.model.ic_values, fake)
         self.spec, self.needs_x_grad = trace.discover(self.equation, self.ctx.run, self.model.total, self.device)
-        self.ic_trainable = self._ic_depends_on_variables()
+        # a callable initial condition that IS one scalar trainable variable (`lambda *a: V('init', ...)`, reference
+        # examples notebook cells 80-88) stays on the fused path: the kernels read it from its user slot and return its
+        # gradient there (pinn_residual_t::ic_var1); any other dependence on variables needs torch autograd (generic path)
+        self.ic_var_slot = self._ic_variable_slot()
+        self.ic_trainable = self.ic_var_slot is None and self._ic_depends_on_variables()
         self.residual_plan = None
         self.program, self.program_error = self._try_compile()
         # constraint terms (:451-457) the tracer can lower run as further residual programs over the value stream on
@@ -117,6 +121,16 @@ class Solver:
             self.model.dormant_variables |= self._born_in_constraint[num]
 
     # ---- tracing ---------------------------------------------------------------------------------------------------
+    def _ic_variable_slot(self):
+        m = self.model
+        if m.initial_condition is None or m.ic_constant is not None:
+            return None
+        cols = [torch.rand(3, device=self.device) for _ in range(m.ndims_spatial)]
+        val = self.ctx.run(m.initial_condition, *cols)
+        if isinstance(val, nn.Parameter) and val.numel() == 1 and val.requires_grad:
+            return self._variable_slot(val)
+        return None
+
     def _ic_depends_on_variables(self):
         m = self.model
         if m.initial_condition is None or m.ic_constant is not None:
@@ -145,7 +159,7 @@ class Solver:
             if not np.allclose(got, want, rtol=1e-4, atol=1e-5):
                 raise trace.TraceUnsupported('traced program disagrees with the callable (data-dependent control flow?)')
             self.residual_plan = plan
-            return plan.to_struct(), None
+            return self._with_ic_variable(plan.to_struct()), None
         except trace.TraceUnsupported as err:
             return None, str(err)
 
@@ -177,10 +191,14 @@ class Solver:
             return None, str(err)
         points = torch.from_numpy(pts).to(self.device).contiguous()
         ic = None
-        if model.initial_condition is not None and model.ic_constant is None:
+        if model.initial_condition is not None and model.ic_constant is None and self.ic_var_slot is None:
             with torch.no_grad():
                 ic = self.ctx.run(model.ic_values, points).expand(points.shape[0], 1).reshape(1, -1).float().contiguous()
-        return dict(program=plan.to_struct(), plan=plan, points=points, ic=ic), None
+        return dict(program=self._with_ic_variable(plan.to_struct()), plan=plan, points=points, ic=ic), None
+
+    def _with_ic_variable(self, residual):
+        residual.ic_var1 = 0 if self.ic_var_slot is None else self.ic_var_slot + 1
+        return residual
 
     def _constraint_step(self, num, world, accumulate):
         """ gradient + loss of constraint term `num` (mean of its squared values, reference :457), added to / stored in
@@ -391,7 +409,7 @@ class Solver:
         comb_w = self.residual_plan.comb_w if self.residual_plan is not None else None
         n2 = spec.n2 if comb_w is None else 1               # combined second-order stream: [u, firsts, sum_k c_k u_kk]
         ic_streams = None
-        if model.initial_condition is not None and model.ic_constant is None:
+        if model.initial_condition is not None and model.ic_constant is None and self.ic_var_slot is None:
             parts = self._ic_streams(xs, create_graph=False)
             ic_streams = torch.zeros((1 + spec.nd + n2, xs.shape[0]), dtype=torch.float32, device=self.device)
             for i, t in enumerate(parts):

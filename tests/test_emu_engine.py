@@ -330,12 +330,17 @@ def test_other_torch_optimizer_by_name(pa, emu_lib):
         assert rel_l2(got, want) < 2e-5
 
 
-def test_callable_ic_with_variable(pa, emu_lib):
-    """ README.md:111-118: the initial condition itself is a trainable V(...) """
+@pytest.mark.parametrize('form', ['variable_fused', 'variable_generic', 'expression'])
+def test_callable_ic_with_variable(pa, emu_lib, form):
+    """ README.md:111-118: the initial condition itself is a trainable V(...). A bare scalar variable rides in the kernels
+    (pinn_residual_t::ic_var1: value read from its user slot, gradient = sum of d(loss)/du returned there), also through
+    the constraint term; an expression of variables needs torch autograd and keeps the generic path. """
     from oracle import pinn_oracle as po
 
     def problem(D, V):
-        return (lambda u, t: D(u, t) - 2 * np.pi * torch.cos(2 * np.pi * t)), (lambda *a: V('init', data=torch.Tensor([3.0])))
+        ic = (lambda *a: V('init', data=torch.Tensor([3.0]))) if form != 'expression' else \
+            (lambda *a: 1.5 * V('init', data=torch.Tensor([2.0])))
+        return (lambda u, t: D(u, t) - 2 * np.pi * torch.cos(2 * np.pi * t)), ic
     kw = dict(ndims=1, layout='fafaf', features=[8, 8, 1], activation='Tanh')
     eq_o, ic_o = problem(po.D, po.V)
     oracle = po.OracleSolver(eq_o, initial_condition=ic_o, constraints=lambda u, t: u(torch.tensor([0.5])), **kw)
@@ -343,13 +348,23 @@ def test_callable_ic_with_variable(pa, emu_lib):
     solver = pa.Solver(eq_p, initial_condition=ic_p, constraints=lambda u, t: u(torch.tensor([0.5])), **kw,
                        **emu_kwargs(emu_lib))
     load_params(solver, oracle.export_params())
-    assert solver.ic_trainable
-    pts = np.random.RandomState(5).rand(5, 24, 1).astype(np.float32)
+    if form == 'expression':
+        assert solver.ic_trainable and solver.ic_var_slot is None
+    else:
+        assert not solver.ic_trainable and solver.ic_var_slot == 0 and solver.constraint_plans[0] is not None
+        solver.use_fused = form == 'variable_fused'
+    pts = np.random.RandomState(5).rand(8, 24, 1).astype(np.float32)
     terms = ('equation', 'constraint_0')
-    oracle.fit(niters=5, batch_size=24, points=pts, lr=0.05, loss_terms=terms)
-    solver.fit(niters=5, batch_size=24, sampler=FixedBatches(pts), lr=0.05, loss_terms=terms)
+    oracle.fit(niters=5, batch_size=24, points=pts[:5], lr=0.05, loss_terms=terms)
+    solver.fit(niters=5, batch_size=24, sampler=FixedBatches(pts[:5]), lr=0.05, loss_terms=terms)
+    assert solver.last_fit_path == ('fused' if form == 'variable_fused' else 'generic')
+    oracle.fit(niters=3, batch_size=24, points=pts[5:], lr=0.05)
+    solver.fit(niters=3, batch_size=24, sampler=FixedBatches(pts[5:]), lr=0.05)
     np.testing.assert_allclose([float(v) for v in solver.losses], [float(v) for v in oracle.losses], rtol=5e-5)
     assert abs(float(solver.model.init) - float(oracle.model.init)) < 2e-5
+    assert float(solver.model.init) not in (2.0, 3.0)
+    for got, want in zip(export_params(solver), oracle.export_params()):
+        assert rel_l2(got, want) < 5e-5
     xs = np.linspace(0, 1, 7).astype(np.float32)
     assert np.abs(solver.predict(xs) - oracle.predict(xs)).max() < 2e-5
 

@@ -67,7 +67,9 @@ def _problems(D, V, NS):
         'trainable_initial_value': (plain_ode, dict(ndims=1, initial_condition=initial,
                                                     constraints=lambda u, t: u(torch.tensor([0.5])) - 2),
                                     dict(lr=0.05, loss_terms=['equation', 'constraint_0']), 500, unit,
-                                    'generic'),                                                    # examples 81-88
+                                    'fused'),                                                      # examples 81-88
+        'trainable_initial_value_equation_only': (plain_ode, dict(ndims=1, initial_condition=initial),
+                                                  dict(lr=0.05), 500, unit, 'fused'),              # examples 81-83
     }
 
 
