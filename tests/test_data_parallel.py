@@ -34,17 +34,45 @@ def _worker(rank, world, port, out_dir, path):
     os.environ['MASTER_PORT'] = str(port)
     dist.init_process_group('gloo', rank=rank, world_size=world)
     lib = engine.bind(ctypes.CDLL(build_emu.build()))
-    g = Golden('cfg1')
-    _, solver = make_solver('cfg1', pa, lib=lib, device='cpu')
+    solver, points, fit_kw, start = _problem(path, pa, lib)
     if rank == 0:
-        load_params(solver, g.params)               # the other rank starts elsewhere: fit must broadcast from rank 0
-    shard = g.points[:3, rank::world]               # rank r owns points r, r+world, ... of every batch
-    if path == 'generic':
-        solver.program = None
-    solver.fit(niters=3, batch_size=shard.shape[1], sampler=FixedBatches(shard), lr=g.lr)
+        load_params(solver, start)                  # the other rank starts elsewhere: fit must broadcast from rank 0
+    shard = points[:, rank::world]                  # rank r owns points r, r+world, ... of every batch
+    solver.fit(niters=points.shape[0], batch_size=shard.shape[1], sampler=FixedBatches(shard), **fit_kw)
     np.savez(os.path.join(out_dir, f'rank{rank}.npz'), losses=np.array([float(v) for v in solver.losses]),
-             **{f'p{i}': p for i, p in enumerate(export_params(solver))})
+             variables=_variables(solver), **{f'p{i}': p for i, p in enumerate(export_params(solver))})
     dist.destroy_process_group()
+
+
+def _variables(solver):
+    return np.array([float(getattr(solver.model, name).detach()) for name in sorted(solver.model.variables)])
+
+
+def _problem(path, pa, lib):
+    """ -> (solver, batches [steps, N, d], fit kwargs, start parameters) """
+    from helpers import make_solver
+    if path in ('fused', 'generic'):
+        g = Golden('cfg1')
+        _, solver = make_solver('cfg1', pa, lib=lib, device='cpu')
+        if path == 'generic':
+            solver.program = None
+        return solver, g.points[:3], dict(lr=g.lr), g.params
+    # tutorial cells 50-60: trainable variable in the equation + a constraint term; every rank evaluates the constraint,
+    # the all-reduce sums the copies, hence its 1 / world scale
+    from test_emu_engine import _variable_problem
+    torch.manual_seed(21)
+    eq, con = _variable_problem(pa.D, pa.V, torch)
+    solver = pa.Solver(eq, constraints=con, ndims=1, initial_condition=1, layout='fafaf', features=[12, 10, 1],
+                       activation='Tanh', lib=lib, device='cpu')
+    solver.use_fused = path == 'constraint_fused'
+    rng = np.random.RandomState(3)
+    start = [np.asarray(rng.randn(*p.shape) * 0.5, dtype=np.float32) for p in export_params_of(solver)]
+    return solver, rng.rand(4, 32, 1).astype(np.float32), dict(lr=0.05, loss_terms=['equation', 'constraint_0']), start
+
+
+def export_params_of(solver):
+    from helpers import export_params
+    return export_params(solver)
 
 
 def _run(path):
@@ -53,21 +81,20 @@ def _run(path):
     import build_emu
     import pydens_amd as pa
     from pydens_amd import engine
-    from helpers import FixedBatches, export_params, load_params, make_solver
+    from helpers import FixedBatches, export_params, load_params
     lib = engine.bind(ctypes.CDLL(build_emu.build()))
-    g = Golden('cfg1')
-    _, single = make_solver('cfg1', pa, lib=lib, device='cpu')
-    load_params(single, g.params)
-    if path == 'generic':
-        single.program = None
-    single.fit(niters=3, batch_size=g.points.shape[1], sampler=FixedBatches(g.points[:3]), lr=g.lr)
+    single, points, fit_kw, start = _problem(path, pa, lib)
+    load_params(single, start)
+    single.fit(niters=points.shape[0], batch_size=points.shape[1], sampler=FixedBatches(points), **fit_kw)
+    assert single.last_fit_path == ('generic' if path in ('generic', 'constraint_generic') else 'fused')
     want_losses = np.array([float(v) for v in single.losses])
-    want = export_params(single)
+    want, want_vars = export_params(single), _variables(single)
     with tempfile.TemporaryDirectory() as tmp:
         mp.spawn(_worker, args=(2, _free_port(), tmp, path), nprocs=2, join=True)
         for rank in range(2):
             z = np.load(os.path.join(tmp, f'rank{rank}.npz'))
             np.testing.assert_allclose(z['losses'], want_losses, rtol=1e-5)      # loss slot is all-reduced too
+            np.testing.assert_allclose(z['variables'], want_vars, rtol=1e-5, atol=1e-6)
             for i, w in enumerate(want):
                 assert rel_l2(z[f'p{i}'], w) < 1e-5, (rank, i)
 
@@ -78,3 +105,11 @@ def test_two_ranks_fused_path_equals_single_process():
 
 def test_two_ranks_generic_path_equals_single_process():
     _run('generic')
+
+
+def test_two_ranks_constraint_term_and_variable_fused():
+    _run('constraint_fused')
+
+
+def test_two_ranks_constraint_term_and_variable_generic():
+    _run('constraint_generic')
