@@ -1,5 +1,6 @@
-""" Solver.fit rate of the generic step path (constraint term + trainable variable: tutorial cells 50-60) next to the
-fused path of the same problem. """
+""" Solver.fit rate of the tutorial's variable + constraint problem (cells 50-60): equation only and with the constraint
+term, on the fused path (residual programs; default) and on the generic path (use_fused = False: kernel streams + the
+user's torch code + autograd). """
 import os, sys, time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
@@ -12,7 +13,8 @@ def odevar(f, x):
 
 for batch in (500, 65536):
     solver = pa.Solver(odevar, ndims=1, initial_condition=1, constraints=lambda f, x: f(torch.tensor([0.5])))
-    for terms in ('equation', ['equation', 'constraint_0']):
+    for terms, fused in (('equation', True), (['equation', 'constraint_0'], True), (['equation', 'constraint_0'], False)):
+        solver.use_fused = fused
         solver.fit(niters=20, batch_size=batch, lr=0.01, loss_terms=terms)
         torch.cuda.synchronize()
         t0 = time.perf_counter()

@@ -1,5 +1,8 @@
+""" Host-side profile (cProfile) of a small-batch Solver.fit (BASELINE cfg1, 100 points): where the Python time of the
+latency-bound regime goes. """
 import sys, time, cProfile, pstats
-sys.path.insert(0, '/root/repo')
+import os
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch, pinn_configs as pc, pydens_amd as pa
 torch.manual_seed(0)
 cfg = pc.make_config('cfg1', pa.D, torch)
