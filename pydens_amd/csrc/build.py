@@ -16,10 +16,16 @@ OUT = os.path.join(PKG, 'libpinn_hip.so')
 OBJ = os.path.join(HERE, '_obj')
 WIDTHS = (16, 32, 64, 128, 256)
 FLAGS = ['--offload-arch=gfx950', '-O3', '-std=c++17', '-fPIC', '-x', 'hip', '-Wno-unused-result']
+# per-width scheduler choice (same-box A/B of hipcc's -amdgpu-sched-strategy values on the BASELINE kernels, DESIGN.md
+# section 6): the width-256 kernels (256 VGPRs, spilling) run 4.9 % faster under `iterative-maxocc` (4.1 % under
+# `iterative-ilp`, 10 % slower under `iterative-minreg` / `max-memory-clause`); the other widths are within 1 % of the
+# default either way and keep it
+WIDTH_FLAGS = {256: ['-mllvm', '-amdgpu-sched-strategy=iterative-maxocc']}
 
 
 def _sources():
     deps = [os.path.join(HERE, f) for f in os.listdir(HERE) if f.endswith(('.h', '.inc', '.cpp'))]
+    deps.append(os.path.abspath(__file__))                    # compile flags live here
     deps.append(os.path.join(os.path.dirname(PKG), 'include', 'pinn.h'))
     return deps
 
@@ -59,7 +65,8 @@ def _build(force, verbose, extra_flags, widths):
             extra = ['-DPINN_INST_STUB']
         else:
             extra = []
-        jobs.append((obj, [hipcc, *FLAGS, *extra_flags, *extra, f'-DPINN_INST_HP={hp}', '-c', os.path.join(HERE, 'pinn_inst.inc'), '-o', obj]))
+        jobs.append((obj, [hipcc, *FLAGS, *WIDTH_FLAGS.get(hp, []), *extra_flags, *extra, f'-DPINN_INST_HP={hp}', '-c',
+                           os.path.join(HERE, 'pinn_inst.inc'), '-o', obj]))
     obj = os.path.join(OBJ, 'abi.o')
     jobs.append((obj, [hipcc, *FLAGS, *extra_flags, '-c', os.path.join(HERE, 'pinn_abi.cpp'), '-o', obj]))
 
