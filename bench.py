@@ -175,6 +175,7 @@ def main():
     if world > 1:
         dist.barrier()
 
+    out = None
     if rank == 0:
         print(f'[bench] gpu: {dt / args.steps * 1e3:.3f} ms/step, tile kernel {tile_ms:.3f} ms', file=sys.stderr)
         # algorithmic FLOPs: the reference's formulation (one stream per derivative D(...) asks for, S = 5 here;
@@ -216,9 +217,15 @@ def main():
         }
         if not args.no_cpu_baseline and world == 1:      # reported at N = 1 only (the other ranks would wait on it)
             out['cpu_baseline'] = cpu_baseline()
-        print(json.dumps(out))
     if world > 1 or args.unfused:
         dist.destroy_process_group()
+    if rank == 0:
+        # the JSON line goes out LAST: RCCL writes its version banner through C stdio, which (piped) is flushed only at
+        # exit and would otherwise land behind it
+        import ctypes
+        sys.stdout.flush()
+        ctypes.CDLL(None).fflush(None)
+        print(json.dumps(out), flush=True)
 
 
 if __name__ == '__main__':
