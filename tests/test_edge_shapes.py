@@ -1,0 +1,79 @@
+""" Problem shapes at the edges of what the kernels instantiate -- no derivative at all, three second derivatives, a
+variable coefficient that blocks the combined second-order stream, five input columns, a single hidden layer, a padded
+width with six layers, another torch optimizer, a shifted domain -- each stepped a few times on the product and on the
+oracle from the same weights and points (emulated kernels on CPU; -m gpu: the HIP library). """
+import numpy as np
+import pytest
+import torch
+
+from conftest import rel_l2
+from helpers import FixedBatches, export_params, load_params
+
+CASES = {
+    'algebraic_no_derivative': (lambda D: (lambda u, x: u - torch.sin(3 * x)),
+                                dict(ndims=1, layout='fafaf', features=[8, 8, 1], activation='Tanh'), 1, {}),
+    'laplace_3d_three_second_derivatives': (
+        lambda D: (lambda u, x, y, z: D(D(u, x), x) + D(D(u, y), y) + D(D(u, z), z) - 1.0),
+        dict(ndims=3, boundary_condition=0.5, layout='fafaf', features=[16, 16, 1], activation='Tanh'), 3, {}),
+    'anisotropic_3d_nonlinear': (
+        lambda D: (lambda u, x, y, z: D(D(u, x), x) + x * D(D(u, y), y) + D(D(u, z), z) - u * u),
+        dict(ndims=3, boundary_condition=0.5, layout='fafaf', features=[16, 16, 1], activation='Tanh'), 3, {}),
+    'two_dims_three_parameters': (
+        lambda D: (lambda u, x, t, a, b, c: D(u, t) - a * D(D(u, x), x) + b * u - c),
+        dict(ndims=2, nparams=3, initial_condition=lambda x: x * (1 - x), boundary_condition=0.0, layout='fafaf',
+             features=[16, 16, 1], activation='Sigmoid'), 5, {}),
+    'single_hidden_layer': (lambda D: (lambda u, x, y: D(D(u, x), x) + D(D(u, y), y) - 1.0),
+                            dict(ndims=2, boundary_condition=1, layout='faf', features=[24, 1], activation='Tanh'), 2, {}),
+    'width_100_six_layers_wave': (
+        lambda D: (lambda u, x, t: D(D(u, t), t) - D(D(u, x), x)),
+        dict(ndims=2, initial_condition=lambda x: x * (1 - x), boundary_condition=0.0, layout='fa' * 6 + 'f',
+             features=[100] * 6 + [1], activation='Tanh'), 2, {}),
+    'sgd_by_name': (lambda D: (lambda u, x: D(u, x) - u),
+                    dict(ndims=1, initial_condition=1.0, layout='fafaf', features=[8, 8, 1], activation='Tanh'), 1,
+                    dict(optimizer='SGD')),
+    'shifted_domain': (lambda D: (lambda u, x, y: D(D(u, x), x) + D(D(u, y), y) - torch.exp(x)),
+                       dict(ndims=2, boundary_condition=1, domain=(-1, 2), layout='fafaf', features=[16, 16, 1],
+                            activation='Tanh'), 2, {}),
+}
+
+
+def _run(pa, name, extra, batch):
+    from oracle import pinn_oracle as po
+    make, kw, d, fit_kw = CASES[name]
+    torch.manual_seed(1)
+    oracle = po.OracleSolver(make(po.D), **kw)
+    solver = pa.Solver(make(pa.D), **kw, **extra)
+    load_params(solver, oracle.export_params())
+    pts = np.random.RandomState(2).rand(3, batch, d).astype(np.float32)
+    oracle.fit(niters=3, batch_size=batch, points=pts, lr=0.01, **fit_kw)
+    solver.fit(niters=3, batch_size=batch, sampler=FixedBatches(pts), lr=0.01, **fit_kw)
+    assert solver.last_fit_path == 'fused', solver.program_error
+    np.testing.assert_allclose([float(v) for v in solver.losses], [float(v) for v in oracle.losses], rtol=2e-5)
+    for got, want in zip(export_params(solver), oracle.export_params()):
+        assert rel_l2(got, want) < 5e-5
+    grid = [np.linspace(0.1, 0.9, 5).astype(np.float32)] * d
+    assert np.abs(solver.predict(*grid) - oracle.predict(*grid)).max() < 2e-5
+
+
+@pytest.fixture(scope='module')
+def emu_lib():
+    import ctypes
+    import os
+    import sys
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), 'emu'))
+    import build_emu
+    from pydens_amd import engine
+    return engine.bind(ctypes.CDLL(build_emu.build()))
+
+
+@pytest.mark.parametrize('name', sorted(CASES))
+def test_edge_shape_on_the_emulated_kernels(name, emu_lib):
+    import pydens_amd as pa
+    _run(pa, name, dict(lib=emu_lib, device='cpu'), batch=37 if 'width_100' not in name else 19)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('name', sorted(CASES))
+def test_edge_shape_on_the_gpu(name):
+    import pydens_amd as pa
+    _run(pa, name, {}, batch=1000)
