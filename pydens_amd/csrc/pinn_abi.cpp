@@ -71,6 +71,7 @@ struct Plan {
     launch_fn fn;
     int n2k, grid, threads;
     size_t smem, slab_vec4_per_wg;
+    size_t wt_floats_per_wg;        // slab-in-LDS kernels: W^T scratch of every workgroup (PinnKArgs::wt)
 };
 
 int make_plan(const pinn_net* net, int64_t n_points, int nd, int n2, Plan* plan, int mode = PINN_MODE_FORWARD,
@@ -89,12 +90,13 @@ int make_plan(const pinn_net* net, int64_t n_points, int nd, int n2, Plan* plan,
     probe.mode = mode;
     probe.res_kind = res_kind;
     probe.comb = comb;
-    long long info[5] = {0, 0, 0, 1, 1};
+    long long info[6] = {0, 0, 0, 1, 1, 0};
     if (plan->fn(nd, plan->n2k, &probe, 0, nullptr, 1, info))
         return fail("no kernel instantiation for width %d with nd=%d n2=%d%s", net->lay.hp, nd, plan->n2k, comb ? " (combined)" : "");
     plan->smem = (size_t)info[0];
     plan->threads = (int)info[1];
     plan->slab_vec4_per_wg = (size_t)info[2];
+    plan->wt_floats_per_wg = (size_t)info[5];
     const int64_t ntiles = (n_points + 15) / 16;
     const int64_t wg_tiles = (ntiles + info[4] - 1) / info[4];       // a two-team workgroup streams two tiles at a time
     int64_t grid = (int64_t)net->n_cu * info[3];
@@ -357,7 +359,8 @@ size_t pinn_workspace_bytes(const pinn_t* net, int64_t n_points, int nd, int n2)
             return 0;
         }
         const size_t v = align256((size_t)plan.grid * net->lay.p_total * sizeof(float)) +
-                         align256((size_t)plan.grid * plan.slab_vec4_per_wg * 16);
+                         align256((size_t)plan.grid * plan.slab_vec4_per_wg * 16) +
+                         align256((size_t)plan.grid * plan.wt_floats_per_wg * sizeof(float));
         if (v > need) need = v;
     }
     return need + align256((size_t)PINN_MAX_AUX * (size_t)n_points * sizeof(float)) + wt_workspace_bytes(net) + 256;
@@ -384,7 +387,10 @@ static int run_train(pinn_t* net, PinnKArgs* a, const Plan& plan, int nd, float*
     const size_t part_bytes = align256((size_t)plan.grid * net->lay.p_total * sizeof(float));
     const size_t slab_bytes = align256((size_t)plan.grid * plan.slab_vec4_per_wg * 16);
     const size_t aux_bytes = (pre && a->n_aux > 0) ? align256((size_t)a->n_aux * (size_t)a->n_points * sizeof(float)) : 0;
-    const size_t wt_bytes = wt_workspace_bytes(net);
+    // transposed hidden weights: one copy written by pinn_transpose_kernel (widths >= 128) or one scratch per workgroup
+    // filled by the tile kernel itself (slab-in-LDS kernels)
+    const size_t wt_bytes = plan.wt_floats_per_wg ? align256((size_t)plan.grid * plan.wt_floats_per_wg * sizeof(float))
+                                                  : wt_workspace_bytes(net);
     if (!workspace || workspace_bytes < part_bytes + slab_bytes + aux_bytes + wt_bytes)
         return fail("workspace too small: need %zu bytes, got %zu", part_bytes + slab_bytes + aux_bytes + wt_bytes, workspace_bytes);
     if (((uintptr_t)workspace & 15) != 0) return fail("workspace must be 16-byte aligned");
@@ -408,7 +414,9 @@ static int run_train(pinn_t* net, PinnKArgs* a, const Plan& plan, int nd, float*
 #endif
         }
     }
-    if (wt_bytes) {
+    if (plan.wt_floats_per_wg)
+        a->wt = reinterpret_cast<float*>(reinterpret_cast<char*>(workspace) + part_bytes + slab_bytes + aux_bytes);
+    else if (wt_bytes) {
         // widths >= 128: transposed copy of the hidden weights for the data-gradient GEMM (the weights change every step)
         float* wt = reinterpret_cast<float*>(reinterpret_cast<char*>(workspace) + part_bytes + slab_bytes + aux_bytes);
         a->wt = wt;

@@ -110,6 +110,14 @@ struct PinnCfg {
     PINN_HOST_DEVICE static constexpr int smem_floats(int lh_static) {
         return SMEM_FLOATS + (wt_fits(lh_static) ? lh_static * HP * WT_LD : 0);
     }
+    // "slab in LDS" kernels (shape-specialised, affine residual: no program registers): the saved jets take the LDS
+    // from O_PREG on -- one value per layer-0 unit, S jets per further activation below the top one (which stays in
+    // registers) -- instead of a global slab, and W^T moves from LDS to a per-workgroup global scratch (A.wt)
+    PINN_HOST_DEVICE static constexpr int slabl_vec4(int lh) { return (1 + (lh > 1 ? (lh - 1) * S : 0)) * NTW * MT * NTHREADS; }
+    PINN_HOST_DEVICE static constexpr int slabl_smem_floats(int lh) { return O_PREG + 4 * slabl_vec4(lh); }
+    PINN_HOST_DEVICE static constexpr bool slabl_fits(int lh) {
+        return lh >= 1 && HP <= 64 && slabl_smem_floats(lh) * 4 <= 160 * 1024;
+    }
     // one slot of S jets per activation (+ one per skip connection: the skipped activations, later their gradient)
     PINN_HOST_DEVICE static constexpr size_t slab_vec4_per_wg(int lh, int n_skips = 0) {
         return (size_t)(lh + 1 + n_skips) * S * NTW * MT * NTHREADS;
@@ -682,10 +690,15 @@ pinn_tile_kernel(const PinnKArgs A) {
     constexpr int S = C::S, NT = C::NT, NTW = C::NTW, NW = C::NW, T = C::T, LDA = C::LDA, NTHREADS = C::NTHREADS;
     constexpr bool DWG = (LHC < 0) || (VAR & 1), ONEBUF = C::ONEBUF, SKIPS = (VAR & 8) != 0;
     constexpr int LHREG = DWG ? 1 : PINN_LHMAX;            // layers with register-resident dW accumulators
-    constexpr bool WTL = C::wt_fits(LHC);                  // transposed hidden weights staged in LDS
+    // VAR 64: saved jets in LDS instead of the global slab (no slab traffic at all); W^T then lives in the workgroup's own
+    // global scratch, written in the prologue (the LDS it used to occupy is what the jets need)
+    constexpr bool SLABL = (VAR & 64) != 0;
+    static_assert(!SLABL || (((VAR >> 4) & 3) != 0 && LHC >= 1 && !(VAR & 8) && !(VAR & 1) && C::slabl_fits(LHC)),
+                  "slab-in-LDS kernels: shape-specialised, static depth, no skips, and the jets must fit");
+    constexpr bool WTL = C::wt_fits(LHC) && !SLABL;        // transposed hidden weights staged in LDS
     // widths >= 128: the data-gradient A operand comes from a transposed copy of the weights in global memory (one b128 per
     // K quad like the forward GEMM) instead of four strided global_load_dword per quad
-    constexpr bool WTG = C::WTG;
+    constexpr bool WTG = C::WTG || SLABL;
     constexpr int SPEC = (VAR >> 4) & 3;                   // VAR 16/32/48: training shape 1/2/3 fixed at compile time
     using SH = PinnShape<SPEC, ND>;
     const int tid = PINN_TID, lane = tid & 63, wave = tid >> 6;
@@ -736,6 +749,16 @@ pinn_tile_kernel(const PinnKArgs A) {
     for (int i = tid; i < HP; i += NTHREADS) { b1s[i] = A.params[A.off_b1 + i]; WLs[i] = A.params[A.off_wl + i]; }
     for (int i = tid; i < PINN_MAX_LAYERS * HP; i += NTHREADS) accB[i] = 0.0f;
     float* WTs = smem + C::O_WT;
+    const float* wtg = A.wt + (SLABL ? (size_t)PINN_BID * (size_t)lh * HP * HP : (size_t)0);
+    if (SLABL && train) {
+        // wt[l][k][n] = W_l[n][k] in this workgroup's scratch: coalesced reads along k, strided fire-and-forget writes;
+        // first read long after the barriers of the first tile's forward half
+        float* wtw = const_cast<float*>(wtg);
+        for (int i = tid; i < lh * HP * HP; i += NTHREADS) {
+            const int l = i / (HP * HP), n = (i / HP) % HP, k = i % HP;
+            wtw[((size_t)l * HP + k) * HP + n] = A.params[A.off_wh + (size_t)l * A.hidden_stride + n * HP + k];
+        }
+    }
     if (WTL && train) {
         // WTs[l][k][n] = W_l[n][k]: coalesced global reads along k, one-time strided LDS writes
         for (int i = tid; i < (LHC > 0 ? LHC : 0) * HP * HP; i += NTHREADS) {
@@ -743,7 +766,7 @@ pinn_tile_kernel(const PinnKArgs A) {
             WTs[(l * HP + k) * C::WT_LD + n] = A.params[A.off_wh + (size_t)l * A.hidden_stride + n * HP + k];
         }
     }
-    for (int i = tid; i < PINN_MAX_REGS * T; i += NTHREADS) padj[i] = 0.0f;
+    if (!SLABL) for (int i = tid; i < PINN_MAX_REGS * T; i += NTHREADS) padj[i] = 0.0f;
     const float bL = A.params[A.off_bl];
 
     // persistent per-lane accumulators
@@ -793,9 +816,12 @@ pinn_tile_kernel(const PinnKArgs A) {
     }
     float sum_loss = 0.0f, sum_ls = 0.0f, sum_bl = 0.0f, sum_ic = 0.0f;
 
-    f32x4* slab = A.slab ? A.slab + (size_t)PINN_BID * C::slab_vec4_per_wg(lh, SKIPS ? A.n_skips : 0) : nullptr;
+    f32x4* slab = SLABL ? reinterpret_cast<f32x4*>(smem + C::O_PREG)
+                        : (A.slab ? A.slab + (size_t)PINN_BID * C::slab_vec4_per_wg(lh, SKIPS ? A.n_skips : 0) : nullptr);
     auto slab_at = [&](int a, int s, int j, int mt) -> f32x4* {
-        return slab + ((((size_t)a * S + s) * NTW + j) * MT + mt) * NTHREADS + tid;
+        // SLABL: compact slots -- activation 0 keeps its value only, the top activation never comes here
+        const size_t slot = SLABL ? (size_t)(a == 0 ? 0 : 1 + (a - 1) * S + s) : (size_t)a * S + s;
+        return slab + ((slot * NTW + j) * MT + mt) * NTHREADS + tid;
     };
     auto unit0 = [&](int j) { return (wave * NTW + j) * 16 + 4 * lq; };     // first of this lane's 4 units
     // weight-gradient GEMM: MFMA k-slot (lq, m) -> point of the tile. Any bijection works (K is a sum index); this one
@@ -1424,7 +1450,7 @@ pinn_tile_kernel(const PinnKArgs A) {
                         for (int m = 0; m < 4; ++m) {
                             if (WTG) {
                                 if (m == 0) {
-                                    const f32x4 wv = pinn_ld4(A.wt + ((size_t)li * HP + (wave * NTW + j) * 16 + lr) * HP + 16 * q + 4 * lq);
+                                    const f32x4 wv = pinn_ld4(wtg + ((size_t)li * HP + (wave * NTW + j) * 16 + lr) * HP + 16 * q + 4 * lq);
                                     w[j][0] = wv[0]; w[j][1] = wv[1]; w[j][2] = wv[2]; w[j][3] = wv[3];
                                 }
                             } else if (WTL) {
