@@ -77,7 +77,10 @@ struct PinnCfg {
     static constexpr int NW = (NT <= 4) ? NT : PINN_NW_MAX;  // waves per workgroup
     static constexpr int NTW = NT / NW;                      // unit tiles per wave
     static constexpr int T = 16 * MT;                        // points per tile
-    static constexpr int LDA = HP + 8;                       // row stride of point-major activation buffers (bank spread)
+#ifndef PINN_LDA_PAD
+#define PINN_LDA_PAD 8
+#endif
+    static constexpr int LDA = HP + PINN_LDA_PAD;            // row stride of point-major activation buffers (bank spread)
     static constexpr int NTHREADS = NW * 64;
     // widths above 128: ONE activation buffer (two would not fit the 160 KB of LDS): the forward pass works in place and
     // the reverse pass keeps the weight-gradient B fragments of h_{a-1} in registers while gz_a replaces it in LDS
