@@ -7,7 +7,6 @@ pointers (`Tensor.data_ptr()`) and torch's current HIP stream, allocates nothing
 import ctypes
 import os
 
-import numpy as np
 import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))

@@ -4,7 +4,6 @@ buffer laid out for the HIP kernels (include/pinn.h); `nn.Parameter`s are views 
 `state_dict()`, `freeze_trainable` and user code that pokes weights keep working. """
 from abc import ABC, abstractmethod
 
-import numpy as np
 import torch
 from torch import nn
 

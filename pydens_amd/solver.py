@@ -20,7 +20,7 @@ from torch import nn
 from tqdm import tqdm
 
 from . import engine, trace
-from .model import ConvBlockModel, TorchModel
+from .model import ConvBlockModel
 from .tokens import current_model
 
 
