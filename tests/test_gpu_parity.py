@@ -168,6 +168,50 @@ def test_baseline_full_sizes_through_size_independent_properties(pa, name, n_ful
             assert rel_l2(got, want) < 1e-4
 
 
+@pytest.mark.parametrize('name,iters,batch', [('cfg2', 600, 4096), ('cfg4', 400, 4096), ('cfg3', 150, 2048)])
+def test_trained_models_against_the_fp64_arbiter(pa, name, iters, batch):
+    """ on a TRAINED model the residual is a small difference of large terms and the reference's own
+    fp32 result is only good to 1e-5 .. 1e-2 (gradients of cfg3!) of the fp64 value, so neither engine can be held to 1e-5
+    of the other; the fp64 oracle arbitrates: |ours - f64| <= max(k |ref32 - f64|, 1e-5 |f64|) with k = 2 for the loss and
+    the predicted field and k = 3 for the gradient (all tensors as one vector; tools/arbiter.py measures 0.8x on cfg2,
+    2.4x on cfg4, 1.0x on cfg3 -- the fast tanh is the difference) after `iters` Adam iterations of
+    Solver.fit on the device. """
+    from oracle import pinn_oracle as po
+    torch.manual_seed(13)
+    cfg, solver = make_solver(name, pa)
+    sampler = pa.NumpySampler('uniform') & pa.NumpySampler('uniform', low=1, high=5) if name == 'cfg4' else None
+    solver.fit(niters=iters, batch_size=batch, sampler=sampler, lr=0.005)
+    losses = solver.losses
+    assert float(losses[-1]) < 0.25 * float(losses[0])              # it did train
+    params = export_params(solver)
+    ocfg = pc.make_config(name, po.D, torch)
+    evals = {}
+    pts = pc.sample_points(cfg, 4096, seed=17)
+    for dtype in (torch.float32, torch.float64):
+        oracle = po.OracleSolver(ocfg['equation'], **ocfg['solver_kwargs'], dtype=dtype)
+        oracle.import_params(params)
+        ev = oracle.evaluate(pts, chunk=2048)
+        evals[dtype] = (ev['loss'], oracle.export_grads(), ev['u'])
+    solver._fused_step(torch.from_numpy(pts).cuda(), 1)
+    lay = solver.model.net.layout
+    (l32, g32, u32), (l64, g64, u64) = evals[torch.float32], evals[torch.float64]
+
+    def flat(tensors, mask):
+        return np.concatenate([np.asarray(t, dtype=np.float64).ravel() for t, m in zip(tensors, mask) if m is not None])
+
+    def within(ours, ref32, ref64, k):
+        ours, ref32, ref64 = (np.asarray(v, dtype=np.float64).ravel() for v in (ours, ref32, ref64))
+        err, ref_err, scale = (float(np.linalg.norm(v)) for v in (ours - ref64, ref32 - ref64, ref64))
+        return err <= max(k * ref_err, 1e-5 * scale), (err, ref_err, scale)
+    ok, detail = within(float(solver.grads[lay.off_loss]), l32, l64, 2.0)
+    assert ok, ('loss', detail)
+    ok, detail = within(flat(export_grads(solver), g64), flat(g32, g64), flat(g64, g64), 3.0)
+    assert ok, ('gradient', detail)
+    u = solver.predict(*[pts[:, c] for c in range(pts.shape[1])])
+    ok, detail = within(u, u32, u64, 2.0)
+    assert ok, ('field', detail)
+
+
 def test_adam_matches_torch(pa):
     from pydens_amd import engine
     torch.manual_seed(0)
