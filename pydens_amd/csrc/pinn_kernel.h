@@ -139,6 +139,7 @@ PINN_DEVICE float pinn_act(float z, int act) {
         //   0  1 - 2/(1 + e^{2z})                  2.95x   baseline      absolute error 1.5e-7 everywhere: poor RELATIVE
         //                                                                accuracy for |z| < 1, where most units live
         //   1  sign(z) (1 - t)/(1 + t), t = e^{-2|z|}   2.42x   +0 %, +1 %   (default) symmetric, no overflow
+        //   4  form 1, but 1 - 2t/(1 + t) for t < 1/2    1.4x (1.9x for form 1 at that state)   +0.5 %, +1.9 %
         //   3  form 1 + odd polynomial for |z| < 0.35   1.82x   +1.1 %, +3.9 %
         //   2  ocml tanhf                               1.29x   +5 %, +8.5 %
 #ifndef PINN_TANH_FORM
@@ -150,6 +151,13 @@ PINN_DEVICE float pinn_act(float z, int act) {
 #elif PINN_TANH_FORM == 1
         const float t = pinn_exp2(fabsf(z) * -2.8853900817779268f);   // e^{-2|z|} in (0, 1]: no overflow
         return copysignf((1.0f - t) * pinn_rcp(1.0f + t), z);
+#elif PINN_TANH_FORM == 4
+        // form 1 for small |z|; 1 - 2t/(1 + t) where the unit saturates (t < 1/2): the subtraction from 1 is then exact and
+        // the error of the small second term does not matter, which is what 1 - v^2 downstream needs
+        const float t = pinn_exp2(fabsf(z) * -2.8853900817779268f);
+        const float r = pinn_rcp(1.0f + t);
+        const float lo = (1.0f - t) * r, hi = 1.0f - (t + t) * r;
+        return copysignf(t < 0.5f ? hi : lo, z);
 #elif PINN_TANH_FORM == 3
         const float a = fabsf(z);
         const float t = pinn_exp2(a * -2.8853900817779268f);
