@@ -403,6 +403,13 @@ static int run_train(pinn_t* net, PinnKArgs* a, const Plan& plan, int nd, float*
         a->aux = aux;
         if (g_pinn_prepass_in_kernel && g_pinn_disable_duo) {
             a->pre = *pre;          // evaluated in the prologue of the tile kernel: one launch (and one dependent-launch gap) less
+            int nregs = a->d;
+            for (int i = 0; i < pre->n_ops; ++i) {
+                const uint32_t w = pre->code[i];
+                const int op = w & 255, dst = (w >> 8) & 255;
+                if (op != PINN_OP_STORE && dst + 1 > nregs) nregs = dst + 1;
+            }
+            a->pre_nregs = nregs;
         } else {
             const int blocks = (int)((a->n_points + 255) / 256);
 #ifdef PINN_EMU

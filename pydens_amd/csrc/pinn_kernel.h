@@ -62,6 +62,7 @@ struct PinnKArgs {
     int coef_row[PINN_MAX_STREAMS];
     float* aux;                  // [n_aux][N] rows of the x-only pre-pass
     pinn_program_t prog;
+    int pre_nregs;               // registers the pre-pass program touches (inputs included)
     pinn_program_t pre;          // n_ops > 0: the tile kernel evaluates the pre-pass itself for the points of its own tiles
                                  // (kernel prologue) instead of a separate launch in front of it
 };
@@ -319,9 +320,12 @@ PINN_DEVICE float pinn_prog_forward(const pinn_program_t& pg, float* regs, int T
 
 // x-only pre-pass of ONE point inside the tile kernel: registers 0..d-1 = the input columns, PINN_OP_STORE writes a
 // register to aux row b (read back by the same thread in pinn_point_prefetch). Same arithmetic as pinn_aux_kernel.
-PINN_DEVICE void pinn_prepass_point(const pinn_program_t& pg, const float* x, int d, float* aux, long long n, long long gi) {
-    constexpr int T = 1;
-    float regs[PINN_MAX_REGS];                 // private (scratch): the program indexes it at run time
+// `regs` / T: the register file -- LDS of the workgroup (register r of this thread at regs[r * T], T = threads) when the
+// program's registers fit the free activation buffers, else null: private memory (scratch; 10x the latency per access).
+PINN_DEVICE void pinn_prepass_point(const pinn_program_t& pg, const float* x, int d, float* aux, long long n, long long gi,
+                                    float* regs, int T) {
+    float priv[PINN_MAX_REGS];                 // private (scratch): the program indexes it at run time
+    if (!regs) { regs = priv; T = 1; }
     for (int c = 0; c < d; ++c) regs[c * T] = x[c];
     for (int i = 0; i < pg.n_ops; ++i) {
         const unsigned w = pg.code[i];
@@ -795,10 +799,30 @@ pinn_tile_kernel(const PinnKArgs A) {
         }
     }
     if (WTL && train) {
-        // WTs[l][k][n] = W_l[n][k]: coalesced global reads along k, one-time strided LDS writes
-        for (int i = tid; i < (LHC > 0 ? LHC : 0) * HP * HP; i += NTHREADS) {
-            const int l = i / (HP * HP), n = (i / HP) % HP, k = i % HP;
-            WTs[(l * HP + k) * C::WT_LD + n] = A.params[A.off_wh + (size_t)l * A.hidden_stride + n * HP + k];
+        // WTs[l][k][n] = W_l[n][k]: coalesced global reads along k, one-time strided LDS writes. ALL loads of a thread are
+        // issued before the first LDS write (the registers are free here): the weights were last written by another
+        // launch's Adam on other XCDs, so every batch of loads pays a full L2-miss round trip -- one instead of six or more
+        // (prologue phase counters: 9.4 K -> cycles of one round trip on cfg2)
+        constexpr int WT_TOTAL = (LHC > 0 ? LHC : 0) * HP * HP;
+        constexpr int WT_PER = (WT_TOTAL + NTHREADS - 1) / NTHREADS;
+#ifndef PINN_WT_STAGE_BATCH
+#define PINN_WT_STAGE_BATCH 64
+#endif
+        constexpr int WT_B = WT_PER < 1 ? 1 : (WT_PER < PINN_WT_STAGE_BATCH ? WT_PER : PINN_WT_STAGE_BATCH);
+        for (int e0 = 0; e0 < WT_PER; e0 += WT_B) {
+            float wreg[WT_B];
+#pragma unroll
+            for (int e = 0; e < WT_B; ++e) {
+                const int i = tid + (e0 + e) * NTHREADS;
+                const int l = i / (HP * HP), n = (i / HP) % HP, k = i % HP;
+                wreg[e] = (i < WT_TOTAL) ? A.params[A.off_wh + (size_t)l * A.hidden_stride + n * HP + k] : 0.0f;
+            }
+#pragma unroll
+            for (int e = 0; e < WT_B; ++e) {
+                const int i = tid + (e0 + e) * NTHREADS;
+                const int l = i / (HP * HP), n = (i / HP) % HP, k = i % HP;
+                if (i < WT_TOTAL) WTs[(l * HP + k) * C::WT_LD + n] = wreg[e];
+            }
         }
     }
     if (!SLABL) for (int i = tid; i < PINN_MAX_REGS * T; i += NTHREADS) padj[i] = 0.0f;
@@ -890,9 +914,15 @@ pinn_tile_kernel(const PinnKArgs A) {
         // x-only pre-pass (source terms, variable coefficients) for the points of this workgroup's own tiles, all threads,
         // NTHREADS / T tiles per sweep; the rows land in A.aux and are read back (by the point-stage threads of the same
         // workgroup, hence the fence + the barrier below) at the top of each tile
+        // (its registers live in the activation buffers, which nothing uses before the first tile, whenever they fit)
+#ifdef PINN_PREPASS_PRIVATE
+        float* pp_regs = nullptr;               // A/B builds: registers in private memory as before
+#else
+        float* pp_regs = (A.pre_nregs * NTHREADS <= C::O_NET - C::O_BUFA) ? smem + C::O_BUFA + tid : nullptr;
+#endif
         for (long long tile = PINN_BID + (long long)(tid / T) * PINN_NBLK; tile < ntiles; tile += (long long)(NTHREADS / T) * PINN_NBLK) {
             const long long gi = tile * T + tid % T;
-            if (gi < A.n_points) pinn_prepass_point(A.pre, A.xs + gi * d, d, A.aux, A.n_points, gi);
+            if (gi < A.n_points) pinn_prepass_point(A.pre, A.xs + gi * d, d, A.aux, A.n_points, gi, pp_regs, NTHREADS);
         }
         PINN_FENCE_BLOCK();
     }
