@@ -11,6 +11,21 @@
 // evaluated on the MFMA accumulators in registers (all S streams of one (point, unit) live in one lane).
 // Weight gradients are accumulated in MFMA accumulators that persist across all tiles of the (persistent)
 // workgroup; per-workgroup partials are summed by pinn_reduce_kernel.  See DESIGN.md sections 3-5.
+//
+// Build knobs (all have the product's value as default; `tools/variant.sh <name> -D...` builds an A/B library, the
+// measurements behind each default are in DESIGN.md section 6):
+//   PINN_TANH_FORM (1)            tanh formula: 0 / 1 / 4 / 3 / 2 = increasingly accurate and expensive
+//   PINN_LDA_PAD (8)              padding of the LDS activation rows (bank spread)
+//   PINN_WT_STAGE_BATCH (64)      W^T staging loads issued before the first LDS write
+//   PINN_PREPASS_PRIVATE          pre-pass registers in private memory instead of LDS
+//   PINN_WTG_MIN_HP (128)         from this width on W^T comes from a transposed global copy instead of LDS
+//   PINN_CFG2_SLABL (0)           64: saved jets of the cfg2 kernel in LDS instead of the global slab (pinn_inst.inc)
+//   PINN_EXP_WGRAD (0)            width-256 weight-gradient traffic experiments (1 / 2: timing only, 3: atomics)
+//   PINN_OB_CHAINS (4), PINN_SVPF_MAX (8), PINN_REGB_MAX (6), PINN_REGB_MAX_SPEC (8), PINN_NW_MAX (8),
+//   PINN_WAVES_PER_SIMD (1), PINN_SCHED_IL (1, pinn_port.h)   blocking / prefetch / occupancy / scheduling thresholds
+//   PINN_FAST_MT_S5 / _S2 / _COMB, PINN_FAST_VAR_COMB, PINN_WIDE_MT (pinn_inst.inc)   tile heights of the fast kernels
+//   PINN_ONLY_BASELINE            experiment builds: only the BASELINE kernels (seconds to compile)
+//   PINN_PROFILE_PHASES           per-phase cycle counters (tools/phases.py)
 #pragma once
 #include "pinn_port.h"
 
