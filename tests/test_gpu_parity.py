@@ -199,11 +199,13 @@ def test_trained_models_against_the_fp64_arbiter(pa, name, iters, batch):
     def flat(tensors, mask):
         return np.concatenate([np.asarray(t, dtype=np.float64).ravel() for t, m in zip(tensors, mask) if m is not None])
 
-    def within(ours, ref32, ref64, k):
+    def within(ours, ref32, ref64, k, floor=1e-5):
         ours, ref32, ref64 = (np.asarray(v, dtype=np.float64).ravel() for v in (ours, ref32, ref64))
         err, ref_err, scale = (float(np.linalg.norm(v)) for v in (ours - ref64, ref32 - ref64, ref64))
-        return err <= max(k * ref_err, 1e-5 * scale), (err, ref_err, scale)
-    ok, detail = within(float(solver.grads[lay.off_loss]), l32, l64, 2.0)
+        return err <= max(k * ref_err, floor * scale), (err, ref_err, scale)
+    # (loss of a trained model = a mean of 4096 squared residuals of size 1e-2: measured 7e-6 / 2e-6 / 5e-8 relative on
+    #  cfg2 / cfg4 / cfg3; the floor leaves the margin a different summation order may need)
+    ok, detail = within(float(solver.grads[lay.off_loss]), l32, l64, 2.0, floor=2e-5)
     assert ok, ('loss', detail)
     ok, detail = within(flat(export_grads(solver), g64), flat(g32, g64), flat(g64, g64), 3.0)
     assert ok, ('gradient', detail)
