@@ -116,3 +116,24 @@ def test_types_of_losses_and_predictions(kw):
     b = two.predict(np.linspace(0, 1, 4), np.full(4, 0.25))
     c = two.predict(np.linspace(0, 1, 4), np.array([0.25, 0.9]))             # wrong size: first element, tiled (:355-356)
     assert a.shape == (4, 1) and np.array_equal(a, b) and np.array_equal(a, c)
+
+
+def test_state_dict_round_trip_through_the_flat_buffer(kw):
+    """ checkpoint / resume the torch way: the nn.Parameter views of the flat kernel buffer (layers, log_scale, trainable
+    variables) survive model.state_dict() -> load_state_dict() into a fresh Solver bit for bit """
+    import pydens_amd as pa
+
+    def make():
+        return pa.Solver(lambda u, x: pa.D(u, x) - 2 * np.pi * torch.cos(2 * np.pi * x) + pa.V('new_var', data=torch.Tensor([1.0])),
+                         ndims=1, initial_condition=1, layout='fafaf', features=[12, 10, 1], activation='Tanh', **kw)
+    first = make()
+    first.fit(niters=5, batch_size=32, lr=0.05)
+    state = first.model.state_dict()
+    assert set(state) == {'log_scale', 'new_var', 'conv_block.fc1.weight', 'conv_block.fc1.bias', 'conv_block.fc2.weight',
+                          'conv_block.fc2.bias', 'conv_block.fc3.weight', 'conv_block.fc3.bias'}
+    second = make()
+    second.model.load_state_dict(state)
+    assert torch.equal(first.model.flat, second.model.flat)
+    xs = np.linspace(0, 1, 9).astype(np.float32)
+    assert np.array_equal(first.predict(xs), second.predict(xs))
+    assert float(second.model.new_var.detach()) == float(first.model.new_var.detach()) != 1.0
