@@ -205,3 +205,91 @@ def test_D_of_composite_expressions_is_differentiated_symbolically():
     np.testing.assert_allclose(got, want, rtol=1e-12)
     with pytest.raises(trace.TraceUnsupported, match='third order'):
         trace.symbolic(lambda f, x: D(x * D(D(f, x), x), x), run, 1)
+
+
+def test_random_expression_trees_survive_the_lowering():
+    """ fuzz: 600 random residual expressions over u, u_x, u_t, u_xx, the coordinates and constants (arithmetic, sin / cos /
+    exp / tanh / sigmoid / abs, squares and cubes) -- affine ones with x-dependent coefficients and source terms included --
+    traced, lowered (pre-pass + affine form or program) and run by the fp64 host interpreter: same values as evaluating
+    the tree directly (program constants are fp32, hence 3e-6) """
+    rng = np.random.RandomState(0)
+    leaves = ['u', 'ux', 'ut', 'uxx', 'x', 't', 'c']
+    unary = ['sin', 'cos', 'exp', 'tanh', 'neg', 'sq', 'cube', 'sigmoid', 'abs']
+    binary = ['add', 'sub', 'mul', 'divc', 'mulc']
+
+    def gen(depth):
+        if depth == 0 or rng.rand() < 0.25:
+            leaf = leaves[rng.randint(len(leaves))]
+            return ('c', float(np.round(rng.uniform(-2, 2), 3))) if leaf == 'c' else (leaf,)
+        if rng.rand() < 0.4:
+            return (unary[rng.randint(len(unary))], gen(depth - 1))
+        op = binary[rng.randint(len(binary))]
+        if op in ('divc', 'mulc'):
+            return (op, gen(depth - 1), float(np.round(rng.uniform(0.5, 3), 3)))
+        return (op, gen(depth - 1), gen(depth - 1))
+
+    def ev(tree, env, lib):
+        kind = tree[0]
+        if kind == 'c':
+            return tree[1]
+        if kind in env:
+            return env[kind]
+        a = ev(tree[1], env, lib)
+        if kind in unary:
+            if kind == 'neg':
+                return -a
+            if kind == 'sq':
+                return a ** 2
+            if kind == 'cube':
+                return a * a * a
+            if kind == 'sigmoid':
+                return torch.sigmoid(a) if lib is torch else 1 / (1 + np.exp(-a))
+            return getattr(lib, kind)(a)
+        if kind == 'divc':
+            return a / tree[2]
+        if kind == 'mulc':
+            return tree[2] * a
+        b = ev(tree[2], env, lib)
+        return {'add': a + b, 'sub': a - b, 'mul': a * b}[kind]
+
+    def uses(tree, name):
+        return tree[0] == name or any(isinstance(c, tuple) and uses(c, name) for c in tree[1:])
+
+    lowered = {0: 0, 1: 0}
+    for _ in range(600):
+        tree = gen(4)
+
+        def eq(u, x, t, tree=tree):
+            env = {'u': u, 'x': x, 't': t}
+            if uses(tree, 'ux') or uses(tree, 'uxx'):
+                env['ux'] = D(u, x)
+            if uses(tree, 'uxx'):
+                env['uxx'] = D(env['ux'], x)
+            if uses(tree, 'ut'):
+                env['ut'] = D(u, t)
+            return ev(tree, env, torch)
+        requested = set()
+        if uses(tree, 'ux') or uses(tree, 'uxx'):
+            requested.add((0,))
+        if uses(tree, 'uxx'):
+            requested.add((0, 0))
+        if uses(tree, 'ut'):
+            requested.add((1,))
+        spec = trace.StreamSpec(requested)
+        try:
+            plan = trace.lower_residual(trace.symbolic(eq, lambda f, *a: f(*a), 2), spec, 2)
+        except trace.TraceUnsupported:
+            continue                                            # too many constants / registers: generic path, fine
+        n = 9
+        streams, xs = rng.uniform(-1, 1, size=(spec.n_streams, n)), rng.uniform(0.2, 1.2, size=(n, 2))
+        env = {'u': streams[0], 'x': xs[:, 0], 't': xs[:, 1]}
+        for name, alpha in (('ux', (0,)), ('uxx', (0, 0)), ('ut', (1,))):
+            if alpha in spec.index:
+                env[name] = streams[spec.index[alpha]]
+        want = ev(tree, env, np) * np.ones(n)
+        if not np.all(np.isfinite(want)) or np.abs(want).max() > 1e6:
+            continue
+        got = trace.run_residual_numpy(plan, streams, xs)
+        np.testing.assert_allclose(got, want, rtol=3e-6, atol=3e-6, err_msg=str(tree))
+        lowered[plan.kind] += 1
+    assert lowered[0] > 150 and lowered[1] > 150                  # both residual kinds were exercised
