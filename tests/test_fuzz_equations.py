@@ -114,3 +114,72 @@ def test_random_equations_on_the_emulated_kernels():
 def test_random_equations_on_the_gpu():
     import pydens_amd as pa
     _run(pa, {}, n_trees=40, batch=523)
+
+
+def _random_net(rng):
+    """ a random fully connected layout of the reference's Block vocabulary: 1-5 hidden layers of 5-40 units (padded to
+    16 / 32 / 64 inside), Tanh / Sigmoid / Sin per layer (or one name), sometimes a hidden layer without activation,
+    sometimes one skip connection 'R ... +' over layers of equal width """
+    depth = rng.randint(1, 6)
+    widths = [int(rng.randint(5, 41)) for _ in range(depth)]
+    acts = [['Tanh', 'Sigmoid', 'Sin'][rng.randint(3)] for _ in range(depth)]
+    letters = ['fa'] * depth
+    no_act = depth >= 3 and rng.rand() < 0.3
+    skip = depth >= 3 and not no_act and rng.rand() < 0.5
+    if no_act:
+        k = rng.randint(1, depth - 1)
+        letters[k] = 'f'
+        del acts[k]
+    if skip:
+        a = rng.randint(0, depth - 2)
+        b = rng.randint(a + 1, depth - 1) if a + 1 < depth - 1 else a + 1
+        for i in range(a, b + 1):
+            widths[i] = widths[a]
+        letters[a] = 'faR'
+        letters[b] = 'fa+'
+    activation = acts[0] if rng.rand() < 0.4 and not no_act else acts
+    if isinstance(activation, str):
+        acts = [activation] * len(acts)
+    return dict(layout=' '.join(letters) + ' f', features=widths + [1], activation=activation if isinstance(activation, str) else acts)
+
+
+def test_random_layouts_on_the_emulated_kernels():
+    import ctypes
+    import os
+    import sys
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), 'emu'))
+    import build_emu
+    import pydens_amd as pa
+    from pydens_amd import engine
+    from oracle import pinn_oracle as po
+    extra = dict(lib=engine.bind(ctypes.CDLL(build_emu.build())), device='cpu')
+    rng = np.random.RandomState(4)
+
+    def problems(D):
+        return [
+            (lambda u, x, y: D(D(u, x), x) + D(D(u, y), y) - 5 * torch.sin(np.pi * (x + y)), dict(ndims=2, boundary_condition=1)),
+            (lambda u, x, t: D(u, t) + u * D(u, x) - 0.05 * D(D(u, x), x),
+             dict(ndims=2, boundary_condition=0, initial_condition=lambda x: torch.sin(np.pi * x))),
+            (lambda u, x, e: D(u, x) - e * torch.cos(e * x), dict(ndims=1, nparams=1, initial_condition=1.0)),
+        ]
+    seen = set()
+    for trial in range(14):
+        net = _random_net(rng)
+        which = trial % 3
+        eq_o, kw = problems(po.D)[which]
+        eq_p, _ = problems(pa.D)[which]
+        torch.manual_seed(trial)
+        oracle = po.OracleSolver(eq_o, **kw, **net)
+        solver = pa.Solver(eq_p, **kw, **net, **extra)
+        load_params(solver, oracle.export_params())
+        pts = np.random.RandomState(trial).rand(2, 21, 2).astype(np.float32)
+        oracle.fit(niters=2, batch_size=21, points=pts, lr=0.01)
+        solver.fit(niters=2, batch_size=21, sampler=FixedBatches(pts), lr=0.01)
+        assert solver.last_fit_path == 'fused', (net, solver.program_error)
+        np.testing.assert_allclose([float(v) for v in solver.losses], [float(v) for v in oracle.losses], rtol=5e-5, err_msg=str(net))
+        for got, ref in zip(export_params(solver), oracle.export_params()):
+            assert rel_l2(got, ref) < 2e-4, net
+        grid = [np.linspace(0.1, 0.9, 5).astype(np.float32)] * 2
+        assert np.abs(solver.predict(*grid) - oracle.predict(*grid)).max() < 2e-5, net
+        seen.add(('R' in net['layout'], isinstance(net['activation'], list)))
+    assert len(seen) >= 3                                          # with / without skips, one name / per-layer lists
