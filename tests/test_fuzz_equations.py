@@ -2,7 +2,8 @@
 (arithmetic, sin / cos / tanh / sigmoid / abs / exp, squares and cubes), each handed to the product and to the oracle as a
 pydens equation callable under an IC + BC ansatz; two Adam iterations must agree (losses, every parameter). Exercises the
 tracer, both residual kinds, the in-kernel interpreter with its reverse sweep and the pre-pass on shapes nobody wrote by
-hand. CPU: emulated kernels; -m gpu: the HIP library. """
+hand -- and, with use_fused = False, the generic path (kernel streams, the user's torch code, D's stream chain rule).
+CPU: emulated kernels; -m gpu: the HIP library. """
 import numpy as np
 import pytest
 import torch
@@ -71,7 +72,7 @@ def _equation(tree, D):
     return equation
 
 
-def _run(pa, extra, n_trees, batch):
+def _run(pa, extra, n_trees, batch, fused=True):
     from oracle import pinn_oracle as po
     rng = np.random.RandomState(1)
     kw = dict(ndims=2, initial_condition=lambda x: torch.sin(np.pi * x), boundary_condition=0.0, layout='fafaf',
@@ -84,6 +85,7 @@ def _run(pa, extra, n_trees, batch):
         torch.manual_seed(trial)
         oracle = po.OracleSolver(_equation(tree, po.D), **kw)
         solver = pa.Solver(_equation(tree, pa.D), **kw, **extra)
+        solver.use_fused = fused
         load_params(solver, oracle.export_params())
         pts = np.random.RandomState(trial).rand(2, batch, 2).astype(np.float32)
         oracle.fit(niters=2, batch_size=batch, points=pts, lr=0.01)
@@ -91,7 +93,7 @@ def _run(pa, extra, n_trees, batch):
         want = np.array([float(v) for v in oracle.losses])
         if not np.all(np.isfinite(want)):
             continue
-        assert solver.last_fit_path == 'fused', (tree, solver.program_error)
+        assert solver.last_fit_path == ('fused' if fused else 'generic'), (tree, solver.program_error)
         np.testing.assert_allclose([float(v) for v in solver.losses], want, rtol=5e-5, err_msg=str(tree))
         for got, ref in zip(export_params(solver), oracle.export_params()):
             assert rel_l2(got, ref) < 2e-4, tree
@@ -99,7 +101,8 @@ def _run(pa, extra, n_trees, batch):
     assert kinds['program'] >= 5 and kinds['affine'] >= 5, kinds
 
 
-def test_random_equations_on_the_emulated_kernels():
+@pytest.mark.parametrize('path', ['fused', 'generic'])
+def test_random_equations_on_the_emulated_kernels(path):
     import ctypes
     import os
     import sys
@@ -107,7 +110,7 @@ def test_random_equations_on_the_emulated_kernels():
     import build_emu
     import pydens_amd as pa
     from pydens_amd import engine
-    _run(pa, dict(lib=engine.bind(ctypes.CDLL(build_emu.build())), device='cpu'), n_trees=40, batch=23)
+    _run(pa, dict(lib=engine.bind(ctypes.CDLL(build_emu.build())), device='cpu'), n_trees=40, batch=23, fused=path == 'fused')
 
 
 @pytest.mark.gpu
