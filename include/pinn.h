@@ -143,7 +143,10 @@ int pinn_destroy(pinn_t* net);
 int pinn_layout(const pinn_t* net, pinn_layout_t* out);
 
 /* Bytes of scratch the step/backward entry points need for n_points (per-workgroup partial gradients +
- * activation slab + PINN_MAX_AUX pre-pass rows).  Caller allocates once (torch tensor) and reuses it. */
+ * activation slab + PINN_MAX_AUX pre-pass rows).  Caller allocates once (torch tensor) and reuses it.
+ * Widths >= 128 keep the saved jets and pre-activation gradients of every tile of a pass in HBM for the streamed
+ * weight-gradient kernel (44 B per point, hidden layer and unit at 4 streams: 5.9 GB for 131 072 points of a 6 x 256 net);
+ * batches beyond a 6.5 GB slab budget run chunk by chunk inside the call. */
 size_t pinn_workspace_bytes(const pinn_t* net, int64_t n_points, int nd, int n2);
 
 /* Value + derivative streams of the ansatz-transformed network on given points.
@@ -200,16 +203,35 @@ int pinn_adam_step(float* params, const float* grads, float* exp_avg, float* exp
                    int64_t n, int32_t* step_ptr, float lr, float beta1, float beta2, float eps, void* stream);
 /* Same update with the 1-based step passed by value (the host counts, as torch.optim does): ONE launch instead of
  * two; the value is also stored to step_ptr[0] so that the forms can be mixed. Data-parallel ranks call this after the
- * gradient all-reduce. */
+ * gradient all-reduce; loss_out (nullable) then receives grads[off_loss] -- the all-reduced loss of the iteration goes
+ * straight into entry i of the host's loss history (`self.losses.append(...)`, model_torch.py:464) in the same launch. */
 int pinn_adam_step_at(float* params, const float* grads, float* exp_avg, float* exp_avg_sq, const uint8_t* mask,
                       int64_t n, int32_t* step_ptr, int32_t step, float lr, float beta1, float beta2, float eps,
-                      void* stream);
+                      float* loss_out, int32_t off_loss, void* stream);
 
 /* Measurement hook (bench.py `roofline`): with enable != 0 the step/backward entry points bracket their TILE
  * kernel launch with hipEvents on the launch stream; pinn_last_tile_ms() waits for the last bracket and returns
  * its duration in milliseconds (negative if none). Off by default; never used on the training path. */
 int pinn_profile_tile(int enable);
 float pinn_last_tile_ms(void);
+/* same bracket around the streamed weight-gradient kernel of widths >= 128 (negative if the last step had none) */
+float pinn_last_wgrad_ms(void);
+/* Instantiation of the tile kernel the last step / forward / backward call launched on this thread's library, e.g.
+ * "pinn_tile_kernel<64,2,1,2,3,0,true,16>" (the symbol rocprofv3 shows): bench.py names the kernel it prices with it. */
+const char* pinn_last_kernel_name(void);
+
+/* Diagnostics (tests, tools/): never used on the training path, no effect on results.
+ *   pinn_debug_last_kernel        0 = general tile kernel, 2 = shape-specialised tile kernel took the last launch
+ *   pinn_debug_set_flags          experiment bits handed to the kernels (PinnKArgs::debug_flags)
+ *   pinn_debug_prepass_in_kernel  0: x-only pre-pass as its own launch (pinn_aux_kernel) instead of the tile kernel's prologue
+ *   pinn_debug_phase_buffer       device buffer for per-phase cycle counters (-DPINN_PROFILE_PHASES builds, tools/phases.py)
+ *   pinn_debug_wgx_chunk_bytes    slab budget per pass of the widths >= 128 (default 6.5 GB; <= 0 restores it): tests force
+ *                                 multi-chunk steps with a tiny budget; affects pinn_workspace_bytes, so set it first */
+int pinn_debug_last_kernel(void);
+int pinn_debug_set_flags(int flags);
+int pinn_debug_prepass_in_kernel(int enable);
+int pinn_debug_phase_buffer(void* buf);
+int pinn_debug_wgx_chunk_bytes(long long bytes);
 
 /* Collocation points drawn on the device: replaces the host-side sampling of model_torch.py:430-434 (d independent
  * `torch.rand((N,1))` columns, or `sampler.sample(N)` of a NumpySampler product `a & b & ...`, README.md:82) with ONE

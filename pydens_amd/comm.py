@@ -1,0 +1,102 @@
+""" Data-parallel gradient exchange: ONE all-reduce(sum) of the flat [p_total] gradient buffer per iteration.
+
+On HIP devices the collective is RCCL's `ncclAllReduce`, called directly (ctypes on the librccl.so torch itself links)
+with the COMPUTE stream: the kernels of an iteration -- tile kernel, reduction, all-reduce, Adam -- then sit on one stream
+in program order, with no side stream and no event hops in between (torch.distributed's ProcessGroupNCCL runs its
+collectives on an internal stream and synchronises it with the caller's through events, two extra dependent hops per
+iteration; at 0.2 ms per iteration of BASELINE config 4 that is what SURVEY 7.3 warns about). The communicator is
+bootstrapped over the existing torch.distributed group (the 128-byte ncclUniqueId is broadcast from rank 0), one rank per
+GPU as torchrun launched them. xGMI is point-to-point: for 51 KB (cfg4) .. 1.3 MB (cfg5) messages the exchange is
+latency-bound, so the buffer is sent whole, never bucketed.
+
+On CPU tensors (the emulator-backed tests, gloo) the same interface falls through to torch.distributed.all_reduce.
+`PYDENS_AMD_COMM=torch` forces that path on HIP devices too (debug switch).
+"""
+import ctypes
+import os
+
+import torch
+import torch.distributed as dist
+
+NCCL_UNIQUE_ID_BYTES = 128
+NCCL_FLOAT32, NCCL_SUM = 7, 0
+
+
+class _UniqueId(ctypes.Structure):
+    _fields_ = [('internal', ctypes.c_char * NCCL_UNIQUE_ID_BYTES)]
+
+
+_RCCL = None
+
+
+def _rccl():
+    """ the librccl torch loaded (same library instance as ProcessGroupNCCL: one RCCL runtime per process) """
+    global _RCCL
+    if _RCCL is None:
+        path = os.path.join(os.path.dirname(torch.__file__), 'lib', 'librccl.so')
+        lib = ctypes.CDLL(path if os.path.exists(path) else 'librccl.so')
+        lib.ncclGetUniqueId.argtypes = [ctypes.POINTER(_UniqueId)]
+        lib.ncclCommInitRank.argtypes = [ctypes.POINTER(ctypes.c_void_p), ctypes.c_int, _UniqueId, ctypes.c_int]
+        lib.ncclAllReduce.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_size_t, ctypes.c_int, ctypes.c_int,
+                                      ctypes.c_void_p, ctypes.c_void_p]
+        lib.ncclCommDestroy.argtypes = [ctypes.c_void_p]
+        lib.ncclGetErrorString.argtypes = [ctypes.c_int]
+        lib.ncclGetErrorString.restype = ctypes.c_char_p
+        for name in ('ncclGetUniqueId', 'ncclCommInitRank', 'ncclAllReduce', 'ncclCommDestroy'):
+            getattr(lib, name).restype = ctypes.c_int
+        _RCCL = lib
+    return _RCCL
+
+
+def _check(lib, rc, what):
+    if rc != 0:
+        raise RuntimeError(f'RCCL {what} failed: {lib.ncclGetErrorString(rc).decode()}')
+
+
+class Communicator:
+    """ all_reduce_(tensor, stream): in-place sum over the ranks of the default torch.distributed group. """
+    def __init__(self, device):
+        self.device = torch.device(device)
+        self.rank, self.world = dist.get_rank(), dist.get_world_size()
+        self.comm = None
+        self.direct = (self.device.type == 'cuda' and dist.get_backend() == 'nccl'
+                       and os.environ.get('PYDENS_AMD_COMM', 'rccl') != 'torch')
+        if self.direct:
+            lib = _rccl()
+            uid = _UniqueId()
+            if self.rank == 0:
+                _check(lib, lib.ncclGetUniqueId(ctypes.byref(uid)), 'ncclGetUniqueId')
+            box = torch.tensor(list(bytes(uid.internal)) if self.rank == 0 else [0] * NCCL_UNIQUE_ID_BYTES,
+                               dtype=torch.uint8, device=self.device)
+            dist.broadcast(box, src=0)
+            raw = bytes(box.cpu().tolist())
+            ctypes.memmove(ctypes.byref(uid), raw, NCCL_UNIQUE_ID_BYTES)
+            comm = ctypes.c_void_p()
+            with torch.cuda.device(self.device):
+                _check(lib, lib.ncclCommInitRank(ctypes.byref(comm), self.world, uid, self.rank), 'ncclCommInitRank')
+            self.comm = comm
+
+    def all_reduce_(self, tensor, stream=None):
+        if not self.direct:
+            dist.all_reduce(tensor)
+            return tensor
+        if not tensor.is_contiguous() or tensor.dtype != torch.float32:
+            raise ValueError('all_reduce_ needs a contiguous float32 tensor')
+        if stream is None:
+            stream = ctypes.c_void_p(torch.cuda.current_stream(tensor.device).cuda_stream)
+        lib = _rccl()
+        ptr = ctypes.c_void_p(tensor.data_ptr())
+        _check(lib, lib.ncclAllReduce(ptr, ptr, tensor.numel(), NCCL_FLOAT32, NCCL_SUM, self.comm, stream), 'ncclAllReduce')
+        return tensor
+
+    def close(self):
+        if self.comm is not None:
+            torch.cuda.synchronize(self.device)
+            _rccl().ncclCommDestroy(self.comm)
+            self.comm = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:       # interpreter shutdown: the process group may be gone already
+            pass

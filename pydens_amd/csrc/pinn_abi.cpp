@@ -23,14 +23,34 @@ int round16(int v) { return (v + 15) / 16 * 16; }
 
 int g_profile = 0;
 long long* g_phase_prof = nullptr;
-bool g_have_bracket = false;
 #ifndef PINN_EMU
-hipEvent_t g_ev0 = nullptr, g_ev1 = nullptr;
+// measurement hook (pinn_profile_tile): one pair of events per kernel and DEVICE -- an event belongs to the device it was
+// created on, and a process may drive several
+struct ProfEvents {
+    hipEvent_t tile0 = nullptr, tile1 = nullptr, wg0 = nullptr, wg1 = nullptr;
+    bool have_tile = false, have_wgrad = false;
+};
+ProfEvents g_prof[64];
+int g_prof_dev = 0;                 // device of the last bracket (what pinn_last_*_ms reads)
+ProfEvents* prof_events() {
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return nullptr;
+    ProfEvents& e = g_prof[dev];
+    if (!e.tile0 && (hipEventCreate(&e.tile0) != hipSuccess || hipEventCreate(&e.tile1) != hipSuccess ||
+                     hipEventCreate(&e.wg0) != hipSuccess || hipEventCreate(&e.wg1) != hipSuccess)) return nullptr;
+    g_prof_dev = dev;
+    return &e;
+}
+float prof_elapsed(hipEvent_t a, hipEvent_t b) {
+    float ms = -1.0f;
+    if (hipEventSynchronize(b) != hipSuccess || hipEventElapsedTime(&ms, a, b) != hipSuccess) return -1.0f;
+    return ms;
+}
 #endif
 }  // namespace
 
-int g_pinn_disable_duo = 1;      // the two-team kernel is an experiment; off by default
 int g_pinn_last_kernel = -1;
+char g_pinn_last_kernel_name[96] = "";
 int g_pinn_prepass_in_kernel = 1;   // debug switch: 0 = x-only pre-pass as its own launch (pinn_aux_kernel)
 int g_pinn_debug_flags = 0;
 
@@ -46,6 +66,19 @@ struct pinn_net {
 
 namespace {
 typedef int (*launch_fn)(int, int, const PinnKArgs*, int, void*, int, long long*);
+typedef int (*wgrad_fn)(int, int, int, int, const PinnKArgs*, int, void*, int, long long*);
+
+wgrad_fn wgrad_launcher_for(int hp) {
+    switch (hp) {
+        case 128: return pinn_launch_wgrad_hp128;
+        case 256: return pinn_launch_wgrad_hp256;
+        default: return nullptr;
+    }
+}
+
+// WGX kernels keep the saved jets and gz of EVERY tile of a launch in HBM (44 B per point, layer and unit at S = 4): a
+// batch larger than this many bytes of slab goes through the kernels chunk by chunk (gradients accumulate in the reduction)
+size_t g_wgx_chunk_bytes = (size_t)6656 << 20;
 
 launch_fn launcher_for(int hp) {
     switch (hp) {
@@ -67,11 +100,38 @@ int pick_n2(int nd, int n2) {
     return -1;
 }
 
+// compute units of the device the CALL runs on (the current device of the calling thread; cached per device): a net
+// created while another device was current still gets the right grid
+int device_cus(const pinn_net* net) {
+#ifndef PINN_EMU
+    static int cus[64] = {0};
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return net->n_cu;
+    if (cus[dev] == 0) {
+        hipDeviceProp_t prop;
+        cus[dev] = (hipGetDeviceProperties(&prop, dev) == hipSuccess && prop.multiProcessorCount > 0) ? prop.multiProcessorCount : -1;
+    }
+    return cus[dev] > 0 ? cus[dev] : net->n_cu;
+#else
+    return net->n_cu;
+#endif
+}
+
 struct Plan {
     launch_fn fn;
     int n2k, grid, threads;
-    size_t smem, slab_vec4_per_wg;
+    size_t smem, slab_vec4_per_wg;  // saved-jet slab per workgroup (per TILE for WGX kernels)
     size_t wt_floats_per_wg;        // slab-in-LDS kernels: W^T scratch of every workgroup (PinnKArgs::wt)
+    int64_t ntiles;                 // tiles of T = 16 * mt points in the batch
+    int mt, comb;
+    // WGX (widths >= 128): hidden->hidden weight gradients by pinn_wgrad_kernel from per-tile slabs in HBM
+    int wgx, grid2;                 // grid2: workgroups of the weight-gradient kernel
+    wgrad_fn wfn;
+    size_t gz_vec4_per_tile;
+    int64_t chunk_tiles;            // tiles per pass through the two kernels
+    int rows() const { return wgx && grid2 > grid ? grid2 : grid; }       // partial-gradient rows the reduction sums
+    size_t slab_bytes() const { return (size_t)(wgx ? chunk_tiles : grid) * slab_vec4_per_wg * 16; }
+    size_t gz_bytes() const { return wgx ? (size_t)chunk_tiles * gz_vec4_per_tile * 16 : 0; }
 };
 
 int make_plan(const pinn_net* net, int64_t n_points, int nd, int n2, Plan* plan, int mode = PINN_MODE_FORWARD,
@@ -90,7 +150,7 @@ int make_plan(const pinn_net* net, int64_t n_points, int nd, int n2, Plan* plan,
     probe.mode = mode;
     probe.res_kind = res_kind;
     probe.comb = comb;
-    long long info[6] = {0, 0, 0, 1, 1, 0};
+    long long info[9] = {0, 0, 0, 1, 1, 0, 0, 0, 0};
     if (plan->fn(nd, plan->n2k, &probe, 0, nullptr, 1, info))
         return fail("no kernel instantiation for width %d with nd=%d n2=%d%s", net->lay.hp, nd, plan->n2k, comb ? " (combined)" : "");
     plan->smem = (size_t)info[0];
@@ -99,10 +159,31 @@ int make_plan(const pinn_net* net, int64_t n_points, int nd, int n2, Plan* plan,
     plan->wt_floats_per_wg = (size_t)info[5];
     const int64_t ntiles = (n_points + 15) / 16;
     const int64_t wg_tiles = (ntiles + info[4] - 1) / info[4];       // a two-team workgroup streams two tiles at a time
-    int64_t grid = (int64_t)net->n_cu * info[3];
+    int64_t grid = (int64_t)device_cus(net) * info[3];
     if (grid > wg_tiles) grid = wg_tiles;
     if (grid < 1) grid = 1;
     plan->grid = (int)grid;
+    plan->ntiles = wg_tiles;
+    plan->mt = (int)info[4];
+    plan->comb = comb;
+    plan->wgx = (mode != PINN_MODE_FORWARD && info[6]) ? 1 : 0;
+    plan->grid2 = 0; plan->wfn = nullptr; plan->gz_vec4_per_tile = 0; plan->chunk_tiles = wg_tiles;
+    if (plan->wgx) {
+        plan->wfn = wgrad_launcher_for(net->lay.hp);
+        long long winfo[9] = {0, 0, 0, 1, 1, 0, 0, 0, 0};
+        if (!plan->wfn || plan->wfn(nd, plan->n2k, comb, plan->mt, &probe, 0, nullptr, 1, winfo))
+            return fail("no weight-gradient kernel for width %d with nd=%d n2=%d%s", net->lay.hp, nd, plan->n2k, comb ? " (combined)" : "");
+        int64_t grid2 = (int64_t)device_cus(net) * winfo[3];
+        if (grid2 > wg_tiles) grid2 = wg_tiles;
+        plan->grid2 = (int)(grid2 < 1 ? 1 : grid2);
+        plan->gz_vec4_per_tile = (size_t)info[7];
+        // whole sweeps of the persistent workgroups per chunk
+        const size_t per_tile = (plan->slab_vec4_per_wg + plan->gz_vec4_per_tile) * 16;
+        const int64_t sweep = plan->grid2 > plan->grid ? plan->grid2 : plan->grid;
+        int64_t chunk = (int64_t)(g_wgx_chunk_bytes / (per_tile ? per_tile : 1)) / sweep * sweep;
+        if (chunk < sweep) chunk = sweep;
+        plan->chunk_tiles = chunk < wg_tiles ? chunk : wg_tiles;
+    }
     return 0;
 }
 
@@ -126,6 +207,13 @@ void fill_args(const pinn_net* net, PinnKArgs* a, const float* params, const flo
     }
     for (int k = 0; k < PINN_MAX_DIRS; ++k) a->dir_cols[k] = (k < nd) ? dir_cols[k] : 0;
     a->s_user = 1 + nd + n2;
+    a->tile_begin = 0;
+    a->tile_end = 0;                // set from the plan (set_tile_range) before every launch
+}
+
+void set_tile_range(PinnKArgs* a, const Plan& plan, int64_t begin, int64_t end) {
+    a->tile_begin = begin;
+    a->tile_end = end < plan.ntiles ? end : plan.ntiles;
 }
 
 int check_dirs(const pinn_net* net, const int* dir_cols, int nd, int n2) {
@@ -209,13 +297,15 @@ int pinn_debug_set_flags(int flags) { g_pinn_debug_flags = flags; return 0; }
 
 int pinn_debug_last_kernel(void) { return g_pinn_last_kernel; }
 
+const char* pinn_last_kernel_name(void) { return g_pinn_last_kernel_name; }
+
 int pinn_debug_prepass_in_kernel(int enable) {
     g_pinn_prepass_in_kernel = enable ? 1 : 0;
     return 0;
 }
 
-int pinn_debug_disable_duo(int disable) {
-    g_pinn_disable_duo = disable ? 1 : 0;
+int pinn_debug_wgx_chunk_bytes(long long bytes) {
+    g_wgx_chunk_bytes = bytes > 0 ? (size_t)bytes : ((size_t)6656 << 20);
     return 0;
 }
 
@@ -226,16 +316,25 @@ int pinn_debug_phase_buffer(void* buf) {
 
 int pinn_profile_tile(int enable) {
     g_profile = enable ? 1 : 0;
-    g_have_bracket = false;
+#ifndef PINN_EMU
+    for (ProfEvents& e : g_prof) e.have_tile = e.have_wgrad = false;
+#endif
     return 0;
 }
 
 float pinn_last_tile_ms(void) {
 #ifndef PINN_EMU
-    if (!g_have_bracket) return -1.0f;
-    float ms = -1.0f;
-    if (hipEventSynchronize(g_ev1) != hipSuccess || hipEventElapsedTime(&ms, g_ev0, g_ev1) != hipSuccess) return -1.0f;
-    return ms;
+    const ProfEvents& e = g_prof[g_prof_dev];
+    return e.have_tile ? prof_elapsed(e.tile0, e.tile1) : -1.0f;
+#else
+    return -1.0f;
+#endif
+}
+
+float pinn_last_wgrad_ms(void) {
+#ifndef PINN_EMU
+    const ProfEvents& e = g_prof[g_prof_dev];
+    return e.have_wgrad ? prof_elapsed(e.wg0, e.wg1) : -1.0f;
 #else
     return -1.0f;
 #endif
@@ -358,8 +457,8 @@ size_t pinn_workspace_bytes(const pinn_t* net, int64_t n_points, int nd, int n2)
             if (comb) continue;
             return 0;
         }
-        const size_t v = align256((size_t)plan.grid * net->lay.p_total * sizeof(float)) +
-                         align256((size_t)plan.grid * plan.slab_vec4_per_wg * 16) +
+        const size_t v = align256((size_t)plan.rows() * net->lay.p_total * sizeof(float)) +
+                         align256(plan.slab_bytes()) + align256(plan.gz_bytes()) +
                          align256((size_t)plan.grid * plan.wt_floats_per_wg * sizeof(float));
         if (v > need) need = v;
     }
@@ -377,6 +476,7 @@ int pinn_jet_forward(pinn_t* net, const float* params, const float* xs, int64_t 
     fill_args(net, &a, params, xs, n_points, dir_cols, nd, n2, ic_streams, ic_const);
     a.mode = PINN_MODE_FORWARD;
     a.out_streams = streams_out;
+    set_tile_range(&a, plan, 0, plan.ntiles);
     const int rc = plan.fn(nd, plan.n2k, &a, plan.grid, stream, 0, nullptr);
     return rc ? fail("tile kernel launch failed (%d)", rc) : 0;
 }
@@ -384,24 +484,29 @@ int pinn_jet_forward(pinn_t* net, const float* params, const float* xs, int64_t 
 static int run_train(pinn_t* net, PinnKArgs* a, const Plan& plan, int nd, float* grads, int accumulate, void* workspace,
                      size_t workspace_bytes, void* stream, const pinn_program_t* pre = nullptr,
                      const AdamArgs* adam = nullptr) {
-    const size_t part_bytes = align256((size_t)plan.grid * net->lay.p_total * sizeof(float));
-    const size_t slab_bytes = align256((size_t)plan.grid * plan.slab_vec4_per_wg * 16);
+    const size_t part_bytes = align256((size_t)plan.rows() * net->lay.p_total * sizeof(float));
+    const size_t slab_bytes = align256(plan.slab_bytes());
     const size_t aux_bytes = (pre && a->n_aux > 0) ? align256((size_t)a->n_aux * (size_t)a->n_points * sizeof(float)) : 0;
     // transposed hidden weights: one copy written by pinn_transpose_kernel (widths >= 128) or one scratch per workgroup
     // filled by the tile kernel itself (slab-in-LDS kernels)
     const size_t wt_bytes = plan.wt_floats_per_wg ? align256((size_t)plan.grid * plan.wt_floats_per_wg * sizeof(float))
                                                   : wt_workspace_bytes(net);
-    if (!workspace || workspace_bytes < part_bytes + slab_bytes + aux_bytes + wt_bytes)
-        return fail("workspace too small: need %zu bytes, got %zu", part_bytes + slab_bytes + aux_bytes + wt_bytes, workspace_bytes);
+    const size_t gz_bytes = align256(plan.gz_bytes());
+    const size_t need = part_bytes + slab_bytes + aux_bytes + wt_bytes + gz_bytes;
+    if (!workspace || workspace_bytes < need)
+        return fail("workspace too small: need %zu bytes, got %zu", need, workspace_bytes);
     if (((uintptr_t)workspace & 15) != 0) return fail("workspace must be 16-byte aligned");
+    char* ws = reinterpret_cast<char*>(workspace);
     a->prof = g_phase_prof;
     a->debug_flags = g_pinn_debug_flags;
-    a->partials = reinterpret_cast<float*>(workspace);
-    a->slab = reinterpret_cast<f32x4*>(reinterpret_cast<char*>(workspace) + part_bytes);
+    a->partials = reinterpret_cast<float*>(ws);
+    a->slab = reinterpret_cast<f32x4*>(ws + part_bytes);
+    a->gzslab = gz_bytes ? reinterpret_cast<f32x4*>(ws + part_bytes + slab_bytes + aux_bytes + wt_bytes) : nullptr;
+    a->partial_row0 = plan.grid;
     if (aux_bytes) {
-        float* aux = reinterpret_cast<float*>(reinterpret_cast<char*>(workspace) + part_bytes + slab_bytes);
+        float* aux = reinterpret_cast<float*>(ws + part_bytes + slab_bytes);
         a->aux = aux;
-        if (g_pinn_prepass_in_kernel && g_pinn_disable_duo) {
+        if (g_pinn_prepass_in_kernel) {
             a->pre = *pre;          // evaluated in the prologue of the tile kernel: one launch (and one dependent-launch gap) less
             int nregs = a->d;
             for (int i = 0; i < pre->n_ops; ++i) {
@@ -422,10 +527,10 @@ static int run_train(pinn_t* net, PinnKArgs* a, const Plan& plan, int nd, float*
         }
     }
     if (plan.wt_floats_per_wg)
-        a->wt = reinterpret_cast<float*>(reinterpret_cast<char*>(workspace) + part_bytes + slab_bytes + aux_bytes);
+        a->wt = reinterpret_cast<float*>(ws + part_bytes + slab_bytes + aux_bytes);
     else if (wt_bytes) {
         // widths >= 128: transposed copy of the hidden weights for the data-gradient GEMM (the weights change every step)
-        float* wt = reinterpret_cast<float*>(reinterpret_cast<char*>(workspace) + part_bytes + slab_bytes + aux_bytes);
+        float* wt = reinterpret_cast<float*>(ws + part_bytes + slab_bytes + aux_bytes);
         a->wt = wt;
         const int hp = net->lay.hp, blocks = (hp / 32) * (hp / 32) * net->lay.lh;
         const float* wh = a->params + net->lay.off_wh;
@@ -439,18 +544,39 @@ static int run_train(pinn_t* net, PinnKArgs* a, const Plan& plan, int nd, float*
 #endif
     }
 #ifndef PINN_EMU
-    if (g_profile) {
-        if (!g_ev0 && (hipEventCreate(&g_ev0) != hipSuccess || hipEventCreate(&g_ev1) != hipSuccess))
-            return fail("hipEventCreate failed");
-        hipEventRecord(g_ev0, (hipStream_t)stream);
-    }
+    ProfEvents* pe = g_profile ? prof_events() : nullptr;
+    if (g_profile && !pe) return fail("hipEventCreate failed");
+    if (pe) pe->have_wgrad = false;
 #endif
-    const int rc = plan.fn(nd, plan.n2k, a, plan.grid, stream, 0, nullptr);
-    if (rc) return fail("tile kernel launch failed (%d)", rc);
+    // one pass (any non-WGX kernel; a WGX batch whose slabs fit g_wgx_chunk_bytes) or chunk by chunk: tile kernel ->
+    // weight-gradient kernel -> reduction of the partial rows, later chunks ADD into `grads`, Adam rides in the last reduction
+    for (int64_t t0 = 0; t0 < plan.ntiles || t0 == 0; t0 += plan.chunk_tiles) {
+        const bool last = t0 + plan.chunk_tiles >= plan.ntiles;
+        set_tile_range(a, plan, t0, t0 + plan.chunk_tiles);
 #ifndef PINN_EMU
-    if (g_profile) { hipEventRecord(g_ev1, (hipStream_t)stream); g_have_bracket = true; }
+        if (pe) hipEventRecord(pe->tile0, (hipStream_t)stream);
 #endif
-    return launch_reduce(a->partials, plan.grid, net->lay.p_total, grads, accumulate, stream, adam);
+        const int rc = plan.fn(nd, plan.n2k, a, plan.grid, stream, 0, nullptr);
+        if (rc) return fail("tile kernel launch failed (%d)", rc);
+#ifndef PINN_EMU
+        if (pe) { hipEventRecord(pe->tile1, (hipStream_t)stream); pe->have_tile = true; }
+#endif
+        if (plan.wgx && net->lay.lh > 0) {
+#ifndef PINN_EMU
+            if (pe) hipEventRecord(pe->wg0, (hipStream_t)stream);
+#endif
+            const int rw = plan.wfn(nd, plan.n2k, plan.comb, plan.mt, a, plan.grid2, stream, 0, nullptr);
+            if (rw) return fail("weight-gradient kernel launch failed (%d)", rw);
+#ifndef PINN_EMU
+            if (pe) { hipEventRecord(pe->wg1, (hipStream_t)stream); pe->have_wgrad = true; }
+#endif
+        }
+        const int rows = (plan.wgx && net->lay.lh > 0) ? plan.rows() : plan.grid;
+        if (launch_reduce(a->partials, rows, net->lay.p_total, grads, (accumulate || t0 > 0) ? 1 : 0, stream, last ? adam : nullptr))
+            return 1;
+        if (last) break;
+    }
+    return 0;
 }
 
 int pinn_jet_backward(pinn_t* net, const float* params, const float* xs, int64_t n_points, const int* dir_cols, int nd,
@@ -579,7 +705,8 @@ int pinn_residual_adam_step(pinn_t* net, const pinn_residual_t* residual, float*
 }
 
 static int adam_launch(float* params, const float* grads, float* exp_avg, float* exp_avg_sq, const uint8_t* mask, int64_t n,
-                       int32_t* step_ptr, int32_t step, float lr, float beta1, float beta2, float eps, void* stream) {
+                       int32_t* step_ptr, int32_t step, float lr, float beta1, float beta2, float eps, void* stream,
+                       float* loss_out = nullptr, int off_loss = -1) {
     if (!params || !grads || !exp_avg || !exp_avg_sq || !step_ptr) return fail("null argument");
     if (n <= 0) return 0;
     const int blocks = (int)((n + 255) / 256);
@@ -587,11 +714,12 @@ static int adam_launch(float* params, const float* grads, float* exp_avg, float*
     if (step > 0) pinn_adam_scalars((double)step, lr, beta1, beta2, &step_size, &bc2_sqrt);
 #ifdef PINN_EMU
     if (step <= 0) emu::launch(1, 64, 0, [&] { pinn_tick_kernel(step_ptr); });
-    emu::launch(blocks, 256, 0, [&] { pinn_adam_kernel(params, grads, exp_avg, exp_avg_sq, mask, n, step_ptr, step, lr, step_size, bc2_sqrt, beta1, beta2, eps); });
+    emu::launch(blocks, 256, 0, [&] { pinn_adam_kernel(params, grads, exp_avg, exp_avg_sq, mask, n, step_ptr, step, lr, step_size, bc2_sqrt, beta1, beta2, eps, loss_out, off_loss); });
 #else
     if (step <= 0) hipLaunchKernelGGL(pinn_tick_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, step_ptr);
     hipLaunchKernelGGL(pinn_adam_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, params, grads, exp_avg,
-                       exp_avg_sq, mask, (long long)n, (int*)step_ptr, (int)step, lr, step_size, bc2_sqrt, beta1, beta2, eps);
+                       exp_avg_sq, mask, (long long)n, (int*)step_ptr, (int)step, lr, step_size, bc2_sqrt, beta1, beta2, eps,
+                       loss_out, off_loss);
     if (hipGetLastError() != hipSuccess) return fail("adam kernel launch failed");
 #endif
     return 0;
@@ -603,9 +731,12 @@ int pinn_adam_step(float* params, const float* grads, float* exp_avg, float* exp
 }
 
 int pinn_adam_step_at(float* params, const float* grads, float* exp_avg, float* exp_avg_sq, const uint8_t* mask, int64_t n,
-                      int32_t* step_ptr, int32_t step, float lr, float beta1, float beta2, float eps, void* stream) {
+                      int32_t* step_ptr, int32_t step, float lr, float beta1, float beta2, float eps, float* loss_out,
+                      int32_t off_loss, void* stream) {
     if (step < 1) return fail("step must be >= 1");
-    return adam_launch(params, grads, exp_avg, exp_avg_sq, mask, n, step_ptr, step, lr, beta1, beta2, eps, stream);
+    if (loss_out && (off_loss < 0 || off_loss >= n)) return fail("off_loss=%d outside the gradient buffer", off_loss);
+    return adam_launch(params, grads, exp_avg, exp_avg_sq, mask, n, step_ptr, step, lr, beta1, beta2, eps, stream, loss_out,
+                       off_loss);
 }
 
 }  // extern "C"

@@ -116,11 +116,15 @@ PINN_GLOBAL void PINN_LAUNCH_BOUNDS(64) pinn_tick_kernel(int* step_ptr) {
 
 PINN_GLOBAL void PINN_LAUNCH_BOUNDS(256)
 pinn_adam_kernel(float* params, const float* grads, float* m, float* v, const unsigned char* mask, long long n,
-                 int* step_ptr, int step_value, float lr, float step_size, float bc2_sqrt, float b1, float b2, float eps) {
+                 int* step_ptr, int step_value, float lr, float step_size, float bc2_sqrt, float b1, float b2, float eps,
+                 float* loss_out, int off_loss) {
     // step_value > 0: the host counts (step_size / bc2_sqrt come with it, the count is mirrored to step_ptr); otherwise
     // the count lives on the device and the bias corrections are computed here
+    // loss_out: the loss slot of the (all-reduced) gradient buffer is copied to one more address -- entry i of the host's
+    // loss history (model_torch.py:464) -- so that recording an iteration costs no launch of its own
     const long long i = (long long)PINN_BID * 256 + PINN_TID;
     if (step_value > 0 && i == 0) step_ptr[0] = step_value;
+    if (loss_out && i == 0) loss_out[0] = grads[off_loss];
     if (i >= n) return;
     if (mask && !mask[i]) return;
     if (step_value <= 0) pinn_adam_scalars((double)step_ptr[0], lr, b1, b2, &step_size, &bc2_sqrt);

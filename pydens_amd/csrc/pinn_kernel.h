@@ -14,7 +14,7 @@
 //
 // Build knobs (all have the product's value as default; `tools/variant.sh <name> -D...` builds an A/B library, the
 // measurements behind each default are in DESIGN.md section 6):
-//   PINN_TANH_FORM (1)            tanh formula: 0 / 1 / 4 / 3 / 2 = increasingly accurate and expensive
+//   PINN_TANH_FORM (4)            tanh formula: 0 / 1 / 4 / 3 / 5 / 2 = increasingly accurate and expensive
 //   PINN_LDA_PAD (8)              padding of the LDS activation rows (bank spread)
 //   PINN_WT_STAGE_BATCH (64)      W^T staging loads issued before the first LDS write
 //   PINN_PREPASS_PRIVATE          pre-pass registers in private memory instead of LDS
@@ -49,7 +49,10 @@ struct PinnKArgs {
     const float* gin;            // MODE_BACKWARD: [S_user][N]
     float* out_streams;          // MODE_FORWARD: [S_user][N]
     float* partials;             // [nWG][p_core]
-    f32x4* slab;                 // saved activations, lane private
+    f32x4* slab;                 // saved activations, lane private (per workgroup; per TILE of the launch for WGX kernels)
+    f32x4* gzslab;               // WGX kernels: pre-activation gradients gz_a of every tile, the A operand of pinn_wgrad_kernel
+    long long tile_begin, tile_end;   // tiles [tile_begin, tile_end) of the batch belong to this launch (WGX launches go chunk by chunk)
+    int partial_row0;            // pinn_wgrad_kernel: partial rows >= this one belong to no tile-kernel workgroup (zeroed there)
     const float* wt;             // widths >= 128: transposed copy of the hidden weights, [lh][in][out] (pinn_transpose_kernel)
     long long* prof;             // optional per-phase cycle counters (PINN_PROFILE_PHASES builds only)
     int debug_flags;             // bit 0: two-team kernel runs team 0 only (experiments)
@@ -137,6 +140,8 @@ struct PinnCfg {
     PINN_HOST_DEVICE static constexpr bool slabl_fits(int lh) {
         return lh >= 1 && HP <= 64 && slabl_smem_floats(lh) * 4 <= 160 * 1024;
     }
+    // WGX kernels: gz_a, a = 1 .. lh, of one tile (S jets per hidden->hidden layer)
+    PINN_HOST_DEVICE static constexpr size_t gz_vec4_per_tile(int lh) { return (size_t)lh * S * NTW * MT * NTHREADS; }
     // one slot of S jets per activation (+ one per skip connection: the skipped activations, later their gradient)
     PINN_HOST_DEVICE static constexpr size_t slab_vec4_per_wg(int lh, int n_skips = 0) {
         return (size_t)(lh + 1 + n_skips) * S * NTW * MT * NTHREADS;
@@ -154,12 +159,13 @@ PINN_DEVICE float pinn_act(float z, int act) {
         // relative to the fp32 reference's own, cfg4 / time on cfg2, cfg4):
         //   0  1 - 2/(1 + e^{2z})                  2.95x   baseline      absolute error 1.5e-7 everywhere: poor RELATIVE
         //                                                                accuracy for |z| < 1, where most units live
-        //   1  sign(z) (1 - t)/(1 + t), t = e^{-2|z|}   2.42x   +0 %, +1 %   (default) symmetric, no overflow
-        //   4  form 1, but 1 - 2t/(1 + t) for t < 1/2    1.4x (1.9x for form 1 at that state)   +0.5 %, +1.9 %
+        //   1  sign(z) (1 - t)/(1 + t), t = e^{-2|z|}   2.42x   +0 %, +1 %   symmetric, no overflow
+        //   4  form 1, but 1 - 2t/(1 + t) for t < 1/2    1.4x (1.9x for form 1 at that state)   +0.5 %, +1.9 %   (default)
         //   3  form 1 + odd polynomial for |z| < 0.35   1.82x   +1.1 %, +3.9 %
         //   2  ocml tanhf                               1.29x   +5 %, +8.5 %
+        //   5  minimax odd polynomial (degree 9, rel. error 9e-8) for |z| < 0.45, 1 - 2t/(1 + t) above
 #ifndef PINN_TANH_FORM
-#define PINN_TANH_FORM 1
+#define PINN_TANH_FORM 4
 #endif
 #if PINN_TANH_FORM == 0
         const float e = pinn_exp2(z * 2.8853900817779268f);       // 2 log2(e)
@@ -174,6 +180,15 @@ PINN_DEVICE float pinn_act(float z, int act) {
         const float r = pinn_rcp(1.0f + t);
         const float lo = (1.0f - t) * r, hi = 1.0f - (t + t) * r;
         return copysignf(t < 0.5f ? hi : lo, z);
+#elif PINN_TANH_FORM == 5
+        // |z| < 0.45: z (1 + w P(w)), w = z^2, P = minimax fit of (tanh(z)/z - 1)/w (no cancellation, no exp error
+        // amplified by 1 - t); above: t < 0.41, so 1 - 2t/(1 + t) subtracts from 1 exactly
+        const float a = fabsf(z);
+        const float t = pinn_exp2(a * -2.8853900817779268f);
+        const float hi = copysignf(1.0f - (t + t) * pinn_rcp(1.0f + t), z);
+        const float w = z * z;
+        const float q = w * (-0.3333321511745453f + w * (0.1332860141992569f + w * (-0.053299661725759506f + w * 0.017926184460520744f)));
+        return a < 0.45f ? fmaf(z, q, z) : hi;
 #elif PINN_TANH_FORM == 3
         const float a = fabsf(z);
         const float t = pinn_exp2(a * -2.8853900817779268f);
@@ -730,7 +745,10 @@ PINN_DEVICE void pinn_st4(float* p, f32x4 v) { *reinterpret_cast<f32x4*>(p) = v;
 // VAR (experiment bits): 1 = accumulate dW in the partial buffer although the layer count is static, 2 = two waves per
 // SIMD (two workgroups per CU), 4 = no whole-layer weight prefetch; 8 = layout breadth: Sin / identity activations and
 // skip connections ('R ... +' layouts; the skipped activations ride in registers through the forward half and in extra
-// slab slots through the reverse half); 16, 32, 48 = shape facts of a common training step (PinnShape 1, 2, 3) fixed at compile time.
+// slab slots through the reverse half); 16, 32, 48 = shape facts of a common training step (PinnShape 1, 2, 3) fixed at compile time;
+// 128 = WGX: the weight gradients of the hidden->hidden layers are NOT accumulated here -- the kernel streams gz_a and the
+// saved jets of every tile to HBM (lane-private, coalesced) and pinn_wgrad_kernel (pinn_wgrad_kernel.h) turns them into dW
+// with the whole HP x HP accumulator in registers (widths >= 128, where a workgroup's dW does not fit on chip).
 template <int HP, int ND, int N2, int MT, int LHC, int ACTC, bool COMB = false, int VAR = 0>
 // occupancy hint: the fused kernel of a 64/128-wide net wants the whole register file of a SIMD (one wave per SIMD,
 // no spills); narrower nets (1-2 waves per workgroup) run several workgroups per CU
@@ -747,6 +765,8 @@ pinn_tile_kernel(const PinnKArgs A) {
     // VAR 64: saved jets in LDS instead of the global slab (no slab traffic at all); W^T then lives in the workgroup's own
     // global scratch, written in the prologue (the LDS it used to occupy is what the jets need)
     constexpr bool SLABL = (VAR & 64) != 0;
+    constexpr bool WGX = (VAR & 128) != 0;
+    static_assert(!WGX || (DWG && !SKIPS && !SLABL), "WGX kernels: generic depth, no skips, global slab");
     static_assert(!SLABL || (((VAR >> 4) & 3) != 0 && LHC >= 1 && !(VAR & 8) && !(VAR & 1) && C::slabl_fits(LHC)),
                   "slab-in-LDS kernels: shape-specialised, static depth, no skips, and the jets must fit");
     constexpr bool WTL = C::wt_fits(LHC) && !SLABL;        // transposed hidden weights staged in LDS
@@ -856,7 +876,7 @@ pinn_tile_kernel(const PinnKArgs A) {
         return A.partials + (size_t)PINN_BID * A.p_core + A.off_wh + (size_t)li * A.hidden_stride +
                (o * 16 + lq * 4 + r) * HP + (wave * NTW + j) * 16 + lr;
     };
-    if (DWG && train) {
+    if (DWG && !WGX && train) {
         for (int li = 0; li < lh; ++li)
             for (int o = 0; o < NT; ++o)
 #pragma unroll
@@ -892,6 +912,10 @@ pinn_tile_kernel(const PinnKArgs A) {
 
     f32x4* slab = SLABL ? reinterpret_cast<f32x4*>(smem + C::O_PREG)
                         : (A.slab ? A.slab + (size_t)PINN_BID * C::slab_vec4_per_wg(lh, SKIPS ? A.n_skips : 0) : nullptr);
+    f32x4* gzs = nullptr;            // WGX: this tile's block of A.gzslab (set per tile, like `slab`)
+    auto gz_at = [&](int a, int s, int j, int mt) -> f32x4* {      // a = 1 .. lh
+        return gzs + (((size_t)((a - 1) * S + s) * NTW + j) * MT + mt) * NTHREADS + tid;
+    };
     auto slab_at = [&](int a, int s, int j, int mt) -> f32x4* {
         // SLABL: compact slots -- activation 0 keeps its value only, the top activation never comes here
         const size_t slot = SLABL ? (size_t)(a == 0 ? 0 : 1 + (a - 1) * S + s) : (size_t)a * S + s;
@@ -902,7 +926,7 @@ pinn_tile_kernel(const PinnKArgs A) {
     // puts lanes lq and lq+1 two rows (2*LDA = 16 mod 32 banks) apart, so the ds_read_b32 column reads are conflict-free.
     auto wg_pt = [&](int m) { return 2 * lq + (m & 1) + 8 * (m >> 1); };
 
-    const long long ntiles = (A.n_points + T - 1) / T;
+    const long long ntiles = A.tile_end;             // tiles [A.tile_begin, A.tile_end) of the batch belong to this launch
     // the points of a tile are fetched one tile ahead into registers (HBM latency hidden behind a whole tile)
     constexpr int NPRE = (T * PINN_XS_LD + NTHREADS - 1) / NTHREADS;
     float xpre[NPRE];
@@ -935,21 +959,26 @@ pinn_tile_kernel(const PinnKArgs A) {
 #else
         float* pp_regs = (A.pre_nregs * NTHREADS <= C::O_NET - C::O_BUFA) ? smem + C::O_BUFA + tid : nullptr;
 #endif
-        for (long long tile = PINN_BID + (long long)(tid / T) * PINN_NBLK; tile < ntiles; tile += (long long)(NTHREADS / T) * PINN_NBLK) {
+        for (long long tile = A.tile_begin + PINN_BID + (long long)(tid / T) * PINN_NBLK; tile < ntiles; tile += (long long)(NTHREADS / T) * PINN_NBLK) {
             const long long gi = tile * T + tid % T;
             if (gi < A.n_points) pinn_prepass_point(A.pre, A.xs + gi * d, d, A.aux, A.n_points, gi, pp_regs, NTHREADS);
         }
         PINN_FENCE_BLOCK();
     }
-    fetch_points(PINN_BID);
+    fetch_points(A.tile_begin + PINN_BID);
     store_points(xs_base);
-    fetch_points((long long)PINN_BID + PINN_NBLK);
+    fetch_points(A.tile_begin + PINN_BID + PINN_NBLK);
     PINN_SYNC();
     PH_DECL
 
     int tile_parity = 0;
-    for (long long tile = PINN_BID; tile < ntiles; tile += PINN_NBLK, tile_parity ^= 1) {
+    for (long long tile = A.tile_begin + PINN_BID; tile < ntiles; tile += PINN_NBLK, tile_parity ^= 1) {
         const long long base = tile * T;
+        if (WGX && train) {
+            const size_t tl = (size_t)(tile - A.tile_begin);
+            slab = A.slab + tl * C::slab_vec4_per_wg(lh);
+            gzs = A.gzslab + tl * C::gz_vec4_per_tile(lh);
+        }
         float* xs_t = xs_base + tile_parity * T * PINN_XS_LD;
         float* xs_next = xs_base + (tile_parity ^ 1) * T * PINN_XS_LD;
         PinnPointPre<ND, N2> ppre;
@@ -1317,28 +1346,31 @@ pinn_tile_kernel(const PinnKArgs A) {
             const bool top = (a == lh);
             if (top && !ONEBUF) { float* tmp = cur; cur = nxt; nxt = tmp; }   // cur = h_{a-1}, nxt = free (receives gz)
             // recompute h_{a-1} from its saved jets (kept in sv for the next step); stage h_{a-1} and gz_a for the GEMMs
-            f32x4 hv[NTW][MT][S];
+            // (WGX: the weight gradient is pinn_wgrad_kernel's job -- nothing of h_{a-1} is needed here, gz_a goes to LDS for
+            //  the data-gradient GEMM and to HBM for that kernel)
+            f32x4 hv[NTW][MT][S];               // (WGX: never touched)
             if (!SVPF) load_saved(a - 1, svn);
             const int act = act_at(a - 1), sk_prev = skip_into(a - 1);
 #pragma unroll
             for (int j = 0; j < NTW; ++j) {
-                const int n0 = unit0(j);
 #pragma unroll
                 for (int mt = 0; mt < MT; ++mt) {
 #pragma unroll
                     for (int s = 0; s < S; ++s) sv[j][mt][s] = svn[j][mt][s];     // fetched one phase ago (or just now)
+                    if constexpr (!WGX) {
 #pragma unroll
-                    for (int r = 0; r < 4; ++r) {
-                        float sv1[S], h[S];
+                        for (int r = 0; r < 4; ++r) {
+                            float sv1[S], h[S];
 #pragma unroll
-                        for (int s = 0; s < S; ++s) sv1[s] = sv[j][mt][s][r];
-                        pinn_jet_recompute<ND, N2, COMB>(sv1, act, h, cw);
+                            for (int s = 0; s < S; ++s) sv1[s] = sv[j][mt][s][r];
+                            pinn_jet_recompute<ND, N2, COMB>(sv1, act, h, cw);
 #pragma unroll
-                        for (int s = 0; s < S; ++s) hv[j][mt][s][r] = h[s];
-                    }
-                    if (SKIPS && sk_prev >= 0) {
+                            for (int s = 0; s < S; ++s) hv[j][mt][s][r] = h[s];
+                        }
+                        if (SKIPS && sk_prev >= 0) {
 #pragma unroll
-                        for (int s = 0; s < S; ++s) hv[j][mt][s] += *slab_at(lh + 1 + sk_prev, s, j, mt);
+                            for (int s = 0; s < S; ++s) hv[j][mt][s] += *slab_at(lh + 1 + sk_prev, s, j, mt);
+                        }
                     }
                 }
             }
@@ -1351,8 +1383,16 @@ pinn_tile_kernel(const PinnKArgs A) {
                         for (int s = 0; s < S; ++s) pinn_st4(buf + (s * T + mt * 16 + lr) * LDA + unit0(j), v[j][mt][s]);
             };
             // B fragments of the weight-gradient GEMM (h_{a-1}): lane (lr, lq) needs h[pt = wg_pt(m)][its unit column]
-            float hfrag[ONEBUF ? MT * S : 1][NTW][4];
-            if (ONEBUF) {
+            float hfrag[(ONEBUF && !WGX) ? MT * S : 1][NTW][4];
+            if constexpr (WGX) {
+                stage(nxt, gz);
+#pragma unroll
+                for (int j = 0; j < NTW; ++j)
+#pragma unroll
+                    for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+                        for (int s = 0; s < S; ++s) *gz_at(a, s, j, mt) = gz[j][mt][s];
+            } else if constexpr (ONEBUF) {
                 // one LDS buffer: h_{a-1} -> LDS -> fragments in registers, then gz_a takes its place
                 if (!top) { stage(cur, hv); PINN_SYNC(); }
 #pragma unroll
@@ -1386,7 +1426,9 @@ pinn_tile_kernel(const PinnKArgs A) {
                             wqall[WPF ? q : 0][j][m] = Wl[(16 * q + 4 * lq + m) * HP + (wave * NTW + j) * 16 + lr];
             }
             // weight gradient: dW_li[out][in] += sum_{s,pt} gz_s[pt][out] * h_s[pt][in]   (A = gz^T, B = h)
-            if constexpr (!DWG) {
+            if constexpr (WGX) {
+                // pinn_wgrad_kernel
+            } else if constexpr (!DWG) {
                 // register accumulators, software pipeline over the (mt, s) row tiles, NT*NTW accumulators interleaved
                 float bq[2][NTW][4], aq[2][NT][4];
                 auto load_ms = [&](int ms, float (&b)[NTW][4], float (&a_)[NT][4]) {

@@ -1,0 +1,192 @@
+// pinn_wgrad_kernel.h -- streamed weight-gradient GEMMs of the hidden->hidden layers for widths >= 128.
+//
+// Replaces, for those widths, the dW part of `loss.backward()` (pydens/model_torch.py:460):
+//     dW_a[out][in] = sum over points and streams of  gz_a,s[pt][out] * h_{a-1},s[pt][in],     a = 1 .. LH.
+// Why its own launch: a workgroup's dW (LH x HP x HP floats: 1.3 MB at 5 x 256 x 256) fits neither the register file
+// (512 KB per CU) nor the LDS, so the fused tile kernel used to read-modify-write one 16 x HP tile row of it per 16-point
+// tile in its partial-gradient buffer -- 21 GB of traffic per 131 072-point launch of BASELINE config 5 from a 335 MB working
+// set, 44 % of the kernel. Here ONE layer's whole HP x HP accumulator lives in registers
+// (8 waves x 128 x 64 outputs = 128 registers per lane at HP = 256) for ALL the tiles of the workgroup and is written once
+// per layer; the operands stream in from HBM exactly once: the tile kernel (VAR 128, "WGX") leaves gz_a and the saved jets
+// of every tile there, lane-private and coalesced (16 B per lane, 1 KB per wave instruction), 44 B per point, layer and
+// unit instead of the 512 KB-per-tile-row read-modify-write.  h_{a-1} is rebuilt from the saved jets on the fly
+// (a handful of VALU instructions per element against 2 x HP MFMA flops).
+//
+// Work split: workgroup b takes tiles b, b + grid, ... of the launch's tile range for every layer in turn.  Per
+// (tile, row tile mt, stream s) -- one "stage", K = 16 points -- the 512 threads drop gz and h as unit-major rows
+// [HP][16 + 4] into LDS (ds_write_b32, conflict-free), double-buffered, one barrier per stage; every wave then reads its
+// A / B fragments as ds_read_b128 along K (the MFMA k-slot -> point map is a free bijection, shared by both operands) and
+// issues AM x BN x 4 v_mfma_f32_16x16x4_f32 (exact fp32).  Wave grid 2 x 4 over the HP x HP output.
+#pragma once
+#include "pinn_kernel.h"
+
+template <int HP, int ND, int N2, int MT = 1>
+struct PinnWgCfg {
+    using C = PinnCfg<HP, ND, N2, MT>;
+    static constexpr int S = C::S, NW = C::NW, NTW = C::NTW, NTHREADS = C::NTHREADS;
+    static_assert(NW == 8, "the streamed weight-gradient kernel is built for the 8-wave widths (HP >= 128)");
+    static constexpr int KC = 16;                    // K rows per stage: the 16 points of one (tile, mt, stream)
+    static constexpr int LDK = KC + 4;               // row stride of the unit-major operand buffers: rows 4 units apart land
+                                                     // 16 banks apart (ds_write_b32 of lanes lq, lq + 1), b128 rows stay aligned
+    static constexpr int WM = 2, WN = 4;             // wave grid over the output
+    static constexpr int AM = HP / 16 / WM, BN = HP / 16 / WN;    // 16 x 16 output tiles per wave (8 x 4 at 256, 4 x 2 at 128)
+    static constexpr int OPER = HP * LDK;            // one operand buffer (floats)
+    static constexpr int O_W1 = 4 * OPER;            // [2 buffers][gz, h], then the first-layer weights
+    static constexpr int SMEM_FLOATS = O_W1 + HP * PINN_XS_LD;
+    static constexpr int WGS_PER_CU = (SMEM_FLOATS * 4 <= 75 * 1024 && AM * BN * 4 <= 64) ? 2 : 1;
+};
+
+template <int HP, int ND, int N2, bool COMB, int MT>
+PINN_GLOBAL void PINN_LAUNCH_BOUNDS2((PinnWgCfg<HP, ND, N2, MT>::NTHREADS), (2 * PinnWgCfg<HP, ND, N2, MT>::WGS_PER_CU))
+pinn_wgrad_kernel(const PinnKArgs A) {
+    using W = PinnWgCfg<HP, ND, N2, MT>;
+    using C = typename W::C;
+    using J = PinnJet<ND, N2, COMB>;
+    constexpr int S = W::S, NTW = W::NTW, NTHREADS = W::NTHREADS, LDK = W::LDK, AM = W::AM, BN = W::BN, OPER = W::OPER;
+    const int tid = PINN_TID, lane = tid & 63, wave = tid >> 6;
+    const int lr = lane & 15, lq = lane >> 4;
+    const int lh = A.lh;
+    const float* cw = A.comb_w;
+    PINN_SMEM(smem);
+    float* W1s = smem + W::O_W1;
+    for (int i = tid; i < HP * PINN_XS_LD; i += NTHREADS) {
+        const int n = i / PINN_XS_LD, c = i % PINN_XS_LD;
+        W1s[i] = (c < A.d) ? A.params[n * A.d + c] : 0.0f;
+    }
+    float* part = A.partials + (size_t)PINN_BID * A.p_core;
+    if (PINN_BID >= A.partial_row0) {
+        // this row belongs to no workgroup of the tile kernel (two of these workgroups share a CU at width 128): everything
+        // outside the hidden->hidden matrices is zero
+        for (int i = tid; i < A.p_core; i += NTHREADS) {
+            const int rel = i - A.off_wh;
+            const bool in_w = rel >= 0 && rel < lh * A.hidden_stride && (rel % A.hidden_stride) < HP * HP;
+            if (!in_w) part[i] = 0.0f;
+        }
+    }
+    PINN_SYNC();
+    const int m0 = (wave / W::WN) * AM * 16, n0 = (wave % W::WN) * BN * 16;
+    const size_t sv_tile = C::slab_vec4_per_wg(lh), gz_tile = C::gz_vec4_per_tile(lh);
+    const long long t_first = A.tile_begin + PINN_BID, t_step = PINN_NBLK;
+    auto unit0 = [&](int j) { return (wave * NTW + j) * 16 + 4 * lq; };
+
+    for (int li = 0; li < lh; ++li) {
+        // layer a = li + 1: A operand gz_a, B operand h_{a-1} = h of activation index li
+        const int act = (int)((A.act_codes >> (2 * li)) & 1u);
+        f32x4 acc[AM][BN];
+#pragma unroll
+        for (int i = 0; i < AM; ++i)
+#pragma unroll
+            for (int jn = 0; jn < BN; ++jn) acc[i][jn] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+        // raw operands of a stage, straight from HBM (the tile kernel's lane-private layout: this thread reads what the
+        // thread with the same id stored)
+        auto load_raw = [&](long long tile, int mt, int s, f32x4 (&gzr)[NTW], f32x4 (&svr)[NTW]) {
+            const size_t tl = (size_t)(tile - A.tile_begin);
+            const f32x4* gzp = A.gzslab + tl * gz_tile + (((size_t)(li * S + s) * NTW) * MT + mt) * NTHREADS + tid;
+            const f32x4* svp = A.slab + tl * sv_tile + (((size_t)(li * S + s) * NTW) * MT + mt) * NTHREADS + tid;
+#pragma unroll
+            for (int j = 0; j < NTW; ++j) {
+                gzr[j] = gzp[(size_t)j * MT * NTHREADS];
+                if (li > 0 || s == 0) {
+                    svr[j] = svp[(size_t)j * MT * NTHREADS];
+                } else {
+                    // first layer: only tanh(z) was saved; z_k = W1[:, col_k] (+ the diagonal partner), z_kk = 0
+#pragma unroll
+                    for (int r = 0; r < 4; ++r)
+                        svr[j][r] = (s <= ND) ? pinn_dir_weight(W1s + (unit0(j) + r) * PINN_XS_LD, A.dir_cols[s - 1 < 0 ? 0 : s - 1]) : 0.0f;
+                }
+            }
+        };
+        // h_s of the saved jets, stream by stream in ascending s (d1, d2 and the z_k^2 terms ride along in registers)
+        f32x4 d1v[NTW], d2v[NTW], zz[ND > 0 ? ND : 1][NTW];
+        auto transform = [&](int s, const f32x4 (&svr)[NTW], f32x4 (&hv)[NTW]) {
+#pragma unroll
+            for (int j = 0; j < NTW; ++j) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    if (s == 0) {
+                        float d1, d2;
+                        pinn_act_d12(svr[j][r], act, d1, d2);
+                        d1v[j][r] = d1; d2v[j][r] = d2;
+                        hv[j][r] = pinn_act_value(svr[j][r], act);
+                    } else if (s <= ND) {
+                        hv[j][r] = d1v[j][r] * svr[j][r];
+                        zz[ND > 0 ? s - 1 : 0][j][r] = svr[j][r] * svr[j][r];
+                    } else {
+                        float q = 0.0f;
+                        if (COMB) {
+#pragma unroll
+                            for (int k = 0; k < ND; ++k) q = fmaf(cw[k], zz[k][j][r], q);
+                        } else {
+                            q = zz[ND > 0 ? s - 1 - ND : 0][j][r];
+                        }
+                        hv[j][r] = fmaf(d2v[j][r], q, d1v[j][r] * svr[j][r]);
+                    }
+                }
+            }
+        };
+        auto write_stage = [&](float* buf, const f32x4 (&gzr)[NTW], const f32x4 (&hv)[NTW]) {
+#pragma unroll
+            for (int j = 0; j < NTW; ++j)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    buf[(unit0(j) + r) * LDK + lr] = gzr[j][r];
+                    buf[OPER + (unit0(j) + r) * LDK + lr] = hv[j][r];
+                }
+        };
+
+        // stages of this workgroup in order: (tile, mt, s), s fastest and unrolled (the jet formulas branch on s). Stage i
+        // computes from LDS buffer p while the raw operands of stage i + 1 are in flight from HBM; they are turned into
+        // buffer p ^ 1 right behind the MFMAs, one barrier per stage.
+        auto mfma_stage = [&](const float* bg) {
+            const float* bh = bg + OPER;
+            f32x4 bf[BN];
+#pragma unroll
+            for (int jn = 0; jn < BN; ++jn) bf[jn] = pinn_ld4(bh + (n0 + 16 * jn + lr) * LDK + 4 * lq);
+#pragma unroll
+            for (int i = 0; i < AM; ++i) {
+                const f32x4 af = pinn_ld4(bg + (m0 + 16 * i + lr) * LDK + 4 * lq);
+#pragma unroll
+                for (int kk = 0; kk < 4; ++kk)
+#pragma unroll
+                    for (int jn = 0; jn < BN; ++jn) acc[i][jn] = pinn_mfma16(af[kk], bf[jn][kk], acc[i][jn]);
+            }
+        };
+        f32x4 gzr[NTW], svr[NTW], hv[NTW];
+        int p = 0;
+        if (t_first < A.tile_end) {
+            load_raw(t_first, 0, 0, gzr, svr);
+            transform(0, svr, hv);
+            write_stage(smem, gzr, hv);
+        }
+        PINN_SYNC();
+        for (long long tile = t_first; tile < A.tile_end; tile += t_step) {
+            for (int mt = 0; mt < MT; ++mt) {
+                const bool last_group = (mt + 1 == MT) && (tile + t_step >= A.tile_end);
+#pragma unroll
+                for (int k = 0; k < S; ++k) {
+                    const int ns = (k + 1) % S;                          // stream of the next stage (compile time)
+                    const bool has_next = !(last_group && k + 1 == S);
+                    const int nmt = (k + 1 == S) ? (mt + 1) % MT : mt;
+                    const long long ntile = (k + 1 == S && mt + 1 == MT) ? tile + t_step : tile;
+                    if (has_next) load_raw(ntile, nmt, ns, gzr, svr);
+                    mfma_stage(smem + p * 2 * OPER);
+                    if (has_next) {
+                        transform(ns, svr, hv);
+                        write_stage(smem + (p ^ 1) * 2 * OPER, gzr, hv);
+                    }
+                    PINN_SYNC();
+                    p ^= 1;
+                }
+            }
+        }
+        // this workgroup's dW_li: D[(l >> 4) * 4 + r][l & 15] of tile (i, jn) -> row (out) m0 + 16 i + 4 lq + r, column (in) n0 + 16 jn + lr
+        float* dst = part + A.off_wh + (size_t)li * A.hidden_stride;
+#pragma unroll
+        for (int i = 0; i < AM; ++i)
+#pragma unroll
+            for (int jn = 0; jn < BN; ++jn)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) dst[(m0 + 16 * i + 4 * lq + r) * HP + n0 + 16 * jn + lr] = acc[i][jn][r];
+    }
+}

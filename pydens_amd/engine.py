@@ -4,6 +4,7 @@ This is the only place where Python meets the kernels. There is NO fallback: if 
 import of the product fails loudly (`load_library`). Buffers are torch tensors; the library receives raw device
 pointers (`Tensor.data_ptr()`) and torch's current HIP stream, allocates nothing and never synchronises.
 """
+import contextlib
 import ctypes
 import os
 
@@ -90,7 +91,7 @@ def bind(lib):
                                        ctypes.c_size_t, vp]
     lib.pinn_residual_step_add.argtypes = lib.pinn_residual_step.argtypes
     lib.pinn_adam_step.argtypes = [vp, vp, vp, vp, vp, i64, vp, f32, f32, f32, f32, vp]
-    lib.pinn_adam_step_at.argtypes = [vp, vp, vp, vp, vp, i64, vp, i32, f32, f32, f32, f32, vp]
+    lib.pinn_adam_step_at.argtypes = [vp, vp, vp, vp, vp, i64, vp, i32, f32, f32, f32, f32, vp, i32, vp]
     lib.pinn_residual_adam_step.argtypes = [vp, ctypes.POINTER(Residual), vp, vp, i64, ip, i32, i32, vp, f32, vp, vp, vp, vp,
                                             vp, i32, f32, f32, f32, f32, vp, vp, ctypes.c_size_t, vp]
     lib.pinn_sample_points.argtypes = [vp, i64, i32, ip, ctypes.POINTER(f32), ctypes.POINTER(f32), ctypes.c_uint64,
@@ -98,6 +99,10 @@ def bind(lib):
     lib.pinn_profile_tile.argtypes = [i32]
     lib.pinn_profile_tile.restype = i32
     lib.pinn_last_tile_ms.restype = f32
+    lib.pinn_last_wgrad_ms.restype = f32
+    lib.pinn_last_kernel_name.restype = ctypes.c_char_p
+    lib.pinn_debug_phase_buffer.argtypes = [vp]
+    lib.pinn_debug_wgx_chunk_bytes.argtypes = [ctypes.c_longlong]
     for name in ('pinn_create', 'pinn_create_ex', 'pinn_destroy', 'pinn_layout', 'pinn_jet_forward', 'pinn_jet_backward',
                  'pinn_residual_step', 'pinn_residual_adam_step', 'pinn_adam_step', 'pinn_adam_step_at'):
         getattr(lib, name).restype = i32
@@ -106,7 +111,8 @@ def bind(lib):
 
 ABI_SYMBOLS = ('pinn_create', 'pinn_create_ex', 'pinn_destroy', 'pinn_layout', 'pinn_workspace_bytes', 'pinn_jet_forward',
                'pinn_jet_backward', 'pinn_residual_step', 'pinn_residual_step_add', 'pinn_residual_adam_step', 'pinn_adam_step', 'pinn_adam_step_at', 'pinn_sample_points', 'pinn_profile_tile',
-               'pinn_last_tile_ms',
+               'pinn_last_tile_ms', 'pinn_last_wgrad_ms', 'pinn_last_kernel_name', 'pinn_debug_last_kernel', 'pinn_debug_set_flags',
+               'pinn_debug_prepass_in_kernel', 'pinn_debug_phase_buffer', 'pinn_debug_wgx_chunk_bytes',
                'pinn_last_error', 'pinn_backend')
 
 _LIB = None
@@ -142,6 +148,16 @@ def _stream(t):
 
 
 stream_of = _stream
+
+_NO_GUARD = contextlib.nullcontext()
+
+
+def _on_device(t):
+    """ the library launches on the CURRENT HIP device (grid sizing, kernel attributes, the stream's owner): make the
+    tensor's device current for the call when it is not (`Solver(device='cuda:1')` while cuda:0 is current) """
+    if t.is_cuda and torch.cuda.current_device() != t.device.index:
+        return torch.cuda.device(t.device)
+    return _NO_GUARD
 
 
 def _check(t, name, dtype=torch.float32):
@@ -231,8 +247,9 @@ class Net:
         if out is None:
             out = torch.empty((s, n), dtype=torch.float32, device=xs.device)
         _check(out, 'out')
-        self._raise(self.lib.pinn_jet_forward(self.handle, _ptr(params), _ptr(xs), n, dirs, nd, n2, _ptr(ic_streams),
-                                              float(ic_const), _ptr(out), _stream(xs)))
+        with _on_device(params):
+            self._raise(self.lib.pinn_jet_forward(self.handle, _ptr(params), _ptr(xs), n, dirs, nd, n2, _ptr(ic_streams),
+                                                  float(ic_const), _ptr(out), _stream(xs)))
         return out
 
     def jet_backward(self, params, xs, grad_streams, grads, workspace, dir_cols=(), n2=0, ic_streams=None,
@@ -241,23 +258,25 @@ class Net:
                         (ic_streams, 'ic_streams')):
             _check(t, name)
         dirs, nd = self._dirs(dir_cols)
-        self._raise(self.lib.pinn_jet_backward(self.handle, _ptr(params), _ptr(xs), xs.shape[0], dirs, nd, n2,
-                                               _ptr(ic_streams), float(ic_const), _ptr(grad_streams), _ptr(grads),
-                                               int(accumulate), _ptr(workspace), workspace.numel() * workspace.element_size(),
-                                               _stream(xs)))
+        with _on_device(params):
+            self._raise(self.lib.pinn_jet_backward(self.handle, _ptr(params), _ptr(xs), xs.shape[0], dirs, nd, n2,
+                                                   _ptr(ic_streams), float(ic_const), _ptr(grad_streams), _ptr(grads),
+                                                   int(accumulate), _ptr(workspace), workspace.numel() * workspace.element_size(),
+                                                   _stream(xs)))
 
     def residual_step(self, residual, params, xs, grads, workspace, dir_cols=(), n2=0, ic_streams=None, ic_const=0.0,
-                      inv_n_global=None, accumulate=False):
+                      inv_n_global=None, accumulate=False, stream=None):
         for t, name in ((params, 'params'), (xs, 'xs'), (grads, 'grads'), (ic_streams, 'ic_streams')):
             _check(t, name)
         dirs, nd = self._dirs(dir_cols)
         n = xs.shape[0]
         inv_n = 1.0 / n if inv_n_global is None else inv_n_global
         fn = self.lib.pinn_residual_step_add if accumulate else self.lib.pinn_residual_step
-        self._raise(fn(self.handle, ctypes.byref(residual), _ptr(params), _ptr(xs), n, dirs, nd,
-                                                n2, _ptr(ic_streams), float(ic_const), float(inv_n), _ptr(grads),
-                                                _ptr(workspace), workspace.numel() * workspace.element_size(),
-                                                _stream(xs)))
+        with _on_device(params):
+            self._raise(fn(self.handle, ctypes.byref(residual), _ptr(params), _ptr(xs), n, dirs, nd,
+                                                    n2, _ptr(ic_streams), float(ic_const), float(inv_n), _ptr(grads),
+                                                    _ptr(workspace), workspace.numel() * workspace.element_size(),
+                                                    _stream(xs) if stream is None else stream))
 
     def residual_adam_step(self, residual, params, xs, grads, workspace, exp_avg, exp_avg_sq, mask, step_tensor, step,
                            lr, betas=(0.9, 0.999), eps=1e-8, dir_cols=(), n2=0, ic_streams=None, ic_const=0.0,
@@ -270,12 +289,13 @@ class Net:
         _check(mask, 'mask', torch.uint8)
         _check(step_tensor, 'step', torch.int32)
         dirs, nd = self._dirs(dir_cols)
-        self._raise(self.lib.pinn_residual_adam_step(
-            self.handle, ctypes.byref(residual), _ptr(params), _ptr(xs), xs.shape[0], dirs, nd, n2, _ptr(ic_streams),
-            float(ic_const), _ptr(grads), _ptr(exp_avg), _ptr(exp_avg_sq), _ptr(mask), _ptr(step_tensor), int(step),
-            float(lr), float(betas[0]), float(betas[1]), float(eps),
-            None if loss_out is None else ctypes.c_void_p(loss_out), _ptr(workspace),
-            workspace.numel() * workspace.element_size(), _stream(xs) if stream is None else stream))
+        with _on_device(params):
+            self._raise(self.lib.pinn_residual_adam_step(
+                self.handle, ctypes.byref(residual), _ptr(params), _ptr(xs), xs.shape[0], dirs, nd, n2, _ptr(ic_streams),
+                float(ic_const), _ptr(grads), _ptr(exp_avg), _ptr(exp_avg_sq), _ptr(mask), _ptr(step_tensor), int(step),
+                float(lr), float(betas[0]), float(betas[1]), float(eps),
+                None if loss_out is None else ctypes.c_void_p(loss_out), _ptr(workspace),
+                workspace.numel() * workspace.element_size(), _stream(xs) if stream is None else stream))
 
     def sample_points(self, xs, columns, seed, call_index, stream=None):
         """ fill xs [N, d] on the device: columns = [(kind, a, b), ...] with kind SAMPLE_UNIFORM (a + (b - a) u),
@@ -287,21 +307,28 @@ class Net:
         kind = (ctypes.c_int * d)(*[int(c[0]) for c in columns])
         a = (ctypes.c_float * d)(*[float(c[1]) for c in columns])
         b = (ctypes.c_float * d)(*[float(c[2]) for c in columns])
-        self._raise(self.lib.pinn_sample_points(_ptr(xs), xs.shape[0], d, kind, a, b, int(seed) & (2 ** 64 - 1),
-                                                int(call_index), _stream(xs) if stream is None else stream))
+        with _on_device(xs):
+            self._raise(self.lib.pinn_sample_points(_ptr(xs), xs.shape[0], d, kind, a, b, int(seed) & (2 ** 64 - 1),
+                                                    int(call_index), _stream(xs) if stream is None else stream))
         return xs
 
-    def adam_step(self, params, grads, exp_avg, exp_avg_sq, mask, step, lr, betas=(0.9, 0.999), eps=1e-8, at=0):
-        """ `step`: int32 device counter; at > 0: the host's 1-based step count (one launch, counter mirrored) """
+    def adam_step(self, params, grads, exp_avg, exp_avg_sq, mask, step, lr, betas=(0.9, 0.999), eps=1e-8, at=0,
+                  loss_out=None, stream=None):
+        """ `step`: int32 device counter; at > 0: the host's 1-based step count (one launch, counter mirrored);
+        loss_out: device ADDRESS (int) that receives grads[off_loss] in the same launch (at > 0 only) """
         for t, name in ((params, 'params'), (grads, 'grads'), (exp_avg, 'exp_avg'), (exp_avg_sq, 'exp_avg_sq')):
             _check(t, name)
         _check(mask, 'mask', torch.uint8)
         _check(step, 'step', torch.int32)
         if at > 0:
-            self._raise(self.lib.pinn_adam_step_at(_ptr(params), _ptr(grads), _ptr(exp_avg), _ptr(exp_avg_sq), _ptr(mask),
-                                                   params.numel(), _ptr(step), int(at), float(lr), float(betas[0]),
-                                                   float(betas[1]), float(eps), _stream(params)))
+            with _on_device(params):
+                self._raise(self.lib.pinn_adam_step_at(_ptr(params), _ptr(grads), _ptr(exp_avg), _ptr(exp_avg_sq), _ptr(mask),
+                                                       params.numel(), _ptr(step), int(at), float(lr), float(betas[0]),
+                                                       float(betas[1]), float(eps),
+                                                       None if loss_out is None else ctypes.c_void_p(loss_out),
+                                                       int(self.layout.off_loss), _stream(params) if stream is None else stream))
             return
-        self._raise(self.lib.pinn_adam_step(_ptr(params), _ptr(grads), _ptr(exp_avg), _ptr(exp_avg_sq), _ptr(mask),
-                                            params.numel(), _ptr(step), float(lr), float(betas[0]), float(betas[1]),
-                                            float(eps), _stream(params)))
+        with _on_device(params):
+            self._raise(self.lib.pinn_adam_step(_ptr(params), _ptr(grads), _ptr(exp_avg), _ptr(exp_avg_sq), _ptr(mask),
+                                                params.numel(), _ptr(step), float(lr), float(betas[0]), float(betas[1]),
+                                                float(eps), _stream(params)))

@@ -32,6 +32,29 @@ class Sampler:
         or None when the sampler is not such a product (then `sample_device` / `sample` are used). """
         return None
 
+    def seeds(self):
+        """ seeds of the random leaves of this sampler, None for an unseeded leaf (constants contribute nothing) """
+        return []
+
+    def device_key(self):
+        """ Philox key for the device sampler when EVERY random leaf was given a seed (`NumpySampler(..., seed=k)`: the
+        reference then draws a sequence that depends on those seeds alone, model_torch.py:433), else None: the solver
+        keys the stream by torch's generator instead. """
+        seeds = self.seeds()
+        if not seeds or any(s is None for s in seeds):
+            return None
+        key = 0x9E3779B97F4A7C15
+        for s in seeds:                       # splitmix64-style fold
+            key = (key ^ (int(s) & (2 ** 64 - 1))) * 0xBF58476D1CE4E5B9 & (2 ** 64 - 1)
+            key ^= key >> 31
+        return key
+
+    def next_device_call(self):
+        """ batches this sampler object has drawn on the device so far (its own call counter, like its own numpy state) """
+        n = getattr(self, '_device_calls', 0)
+        self._device_calls = n + 1
+        return n
+
     def __and__(self, other):
         if isinstance(other, (int, float)):
             other = ConstantSampler(other)
@@ -54,6 +77,9 @@ class _ConcatSampler(Sampler):
         left, right = self.left.columns(), self.right.columns()
         return None if left is None or right is None else left + right
 
+    def seeds(self):
+        return self.left.seeds() + self.right.seeds()
+
 
 class ConstantSampler(Sampler):
     def __init__(self, value, dim=1):
@@ -75,9 +101,13 @@ class NumpySampler(Sampler):
         self.name = _ALIASES.get(name, name)
         self.dim = dim
         self.kwargs = kwargs
+        self.seed = seed
         self.rng = np.random.RandomState(seed)
         if not hasattr(self.rng, self.name):
             raise ValueError(f'unknown numpy distribution {name!r}')
+
+    def seeds(self):
+        return [self.seed] * self.dim
 
     def sample(self, size):
         draw = getattr(self.rng, self.name)

@@ -12,6 +12,7 @@ Two step paths share every kernel:
 Data parallelism: if torch.distributed is initialised, every rank steps on its own `batch_size` points and the flat
 gradient buffer (loss slot included) is summed with one all-reduce (RCCL) per iteration.
 """
+import contextlib
 from contextvars import copy_context
 
 import numpy as np
@@ -40,10 +41,11 @@ class FlatAdam:
     def refresh(self):
         self.mask = self.model.trainable_mask()
 
-    def step(self, grads):
+    def step(self, grads, loss_out=None, stream=None):
+        """ loss_out: device address that receives grads[off_loss] in the same launch (the fit's loss history) """
         self.t += 1
         self.model.net.adam_step(self.model.flat, grads, self.exp_avg, self.exp_avg_sq, self.mask, self.step_count,
-                                 self.lr, self.betas, self.eps, at=self.t)
+                                 self.lr, self.betas, self.eps, at=self.t, loss_out=loss_out, stream=stream)
 
 
 class TorchOptimizerAdapter:
@@ -57,7 +59,7 @@ class TorchOptimizerAdapter:
     def refresh(self):
         pass
 
-    def step(self, grads):
+    def step(self, grads, loss_out=None, stream=None):
         for p in self.params:
             p.grad = grads.as_strided(tuple(p.shape), tuple(p.stride()), p.storage_offset())
         self.opt.step()
@@ -83,9 +85,13 @@ class Solver:
 
         self.model = model(**kwargs, ndims=ndims, initial_condition=initial_condition,
                            boundary_condition=boundary_condition, domain=domain, nparams=nparams)
-        if not isinstance(self.model, ConvBlockModel):
-            raise NotImplementedError('custom TorchModel subclasses run arbitrary torch code in forward(); only '
-                                      'ConvBlockModel (fully connected layouts) is backed by the HIP kernels')
+        # the reference's plug-in seam (`Solver(model=...)`, model_torch.py:299-313): subclasses of ConvBlockModel that
+        # change how the fully connected net / the ansatz parameters are set up run on the HIP kernels; a subclass that
+        # replaces `forward` runs arbitrary torch code, which the kernels cannot see -- refused loudly
+        if not isinstance(self.model, ConvBlockModel) or type(self.model).forward is not ConvBlockModel.forward:
+            raise NotImplementedError('Solver(model=...): only ConvBlockModel and subclasses that keep its forward() (fully '
+                                      'connected layouts + the hard-binding ansatz) are backed by the HIP kernels; a custom '
+                                      'forward() is arbitrary torch code')
         current_model.set(self.model)                                     # :316-317
         self.ctx = copy_context()
         self.device = self.model.flat.device
@@ -94,19 +100,13 @@ class Solver:
         self._generator = None
         self._sample_seed, self._sample_calls = None, 0      # Philox key / batch counter of the device sampler
         self._broadcast_done = False
+        self._comm = None                                    # data-parallel communicator (comm.Communicator)
 
         # "fake run" (:319-325): materialises V-variables and, here, tells which derivative streams D(...) needs
         if self.model.initial_condition is not None and self.model.ic_constant is None:
             fake = torch.rand((3, self.model.total), device=self.device)
             self.ctx.run(self.model.ic_values, fake)
-        self.spec, self.needs_x_grad = trace.discover(self.equation, self.ctx.run, self.model.total, self.device)
-        # a callable initial condition that IS one scalar trainable variable (`lambda *a: V('init', ...)`, reference
-        # examples notebook cells 80-88) stays on the fused path: the kernels read it from its user slot and return its
-        # gradient there (pinn_residual_t::ic_var1); any other dependence on variables needs torch autograd (generic path)
-        self.ic_var_slot = self._ic_variable_slot()
-        self.ic_trainable = self.ic_var_slot is None and self._ic_depends_on_variables()
-        self.residual_plan = None
-        self.program, self.program_error = self._try_compile()
+        self._trace_equation()
         # constraint terms (:451-457) the tracer can lower run as further residual programs over the value stream on
         # their own few points; the others keep the generic path (entry None, reason in constraint_errors)
         self.constraint_plans, self.constraint_errors = [], []
@@ -119,6 +119,46 @@ class Solver:
             self.constraint_errors.append(err)
             self._born_in_constraint[num] = set(self.model.variables) - before
             self.model.dormant_variables |= self._born_in_constraint[num]
+        self._traced_constraints = tuple(self.constraints)
+
+    def _trace_equation(self):
+        """ which streams does the equation need, and can it be lowered to a residual program? (construction, and again at
+        the start of a fit call whenever the cached lowering no longer reproduces the live callable) """
+        self.spec, self.needs_x_grad = trace.discover(self.equation, self.ctx.run, self.model.total, self.device)
+        # a callable initial condition that IS one scalar trainable variable (`lambda *a: V('init', ...)`, reference
+        # examples notebook cells 80-88) stays on the fused path: the kernels read it from its user slot and return its
+        # gradient there (pinn_residual_t::ic_var1); any other dependence on variables needs torch autograd (generic path)
+        self.ic_var_slot = self._ic_variable_slot()
+        self.ic_trainable = self.ic_var_slot is None and self._ic_depends_on_variables()
+        self.residual_plan = None
+        self.program, self.program_error = self._try_compile()
+        self._traced_equation = self.equation
+
+    def _refresh_traces(self, nums_constraints):
+        """ The reference calls `equation(u_hat, *xs)` and the constraints in EVERY iteration (model_torch.py:448, :457), so
+        a closure constant changed between two fit calls, a re-assigned `solver.equation` or new constraint points take
+        effect there. Here they were lowered once: re-check the cached lowering against the live callables at the start of
+        every fit call (17 random points, a few torch ops) and lower again on any mismatch. """
+        if self.equation is not self._traced_equation:
+            self._trace_equation()
+        elif self.program is not None and self.residual_plan is not None:
+            try:
+                ok = self._plan_matches(self.residual_plan)
+            except (trace.TraceUnsupported, NotImplementedError, RuntimeError, TypeError, ValueError):
+                ok = False
+            if not ok:
+                self._trace_equation()
+        if tuple(self.constraints) != self._traced_constraints or nums_constraints:
+            for num, constraint in enumerate(self.constraints):
+                if num < len(self.constraint_plans) and num not in nums_constraints and \
+                        num < len(self._traced_constraints) and constraint is self._traced_constraints[num]:
+                    continue
+                plan, err = self._try_compile_constraint(constraint)
+                if num < len(self.constraint_plans):
+                    self.constraint_plans[num], self.constraint_errors[num] = plan, err
+                else:
+                    self.constraint_plans.append(plan); self.constraint_errors.append(err)
+            self._traced_constraints = tuple(self.constraints)
 
     # ---- tracing ---------------------------------------------------------------------------------------------------
     def _ic_variable_slot(self):
@@ -138,6 +178,20 @@ class Solver:
         fake = torch.rand((3, m.total), device=self.device)
         return bool(self.ctx.run(m.ic_values, fake).requires_grad)
 
+    def _plan_matches(self, plan):
+        """ validation on random data: lowered residual (fp64 host interpreter) vs the user's callable on tagged tensors """
+        total, n = self.model.total, 17
+        streams = torch.rand((self.spec.n_streams, n), device=self.device) * 2 - 1
+        pts = torch.rand((n, total), device=self.device) + 0.25
+        # (an equation that differentiates composite expressions needs autograd over its own pointwise ops)
+        probe = streams.clone().requires_grad_() if self.needs_x_grad else streams
+        want = self._eval_equation(probe, pts, requires_grad=self.needs_x_grad)
+        want = want.detach().reshape(-1).double().cpu().numpy()
+        lay = self.model.net.layout
+        var_values = self.model.flat[lay.off_extra:lay.off_extra + plan.n_vars].detach().cpu().numpy()
+        got = trace.run_residual_numpy(plan, streams.cpu().numpy(), pts.cpu().numpy(), var_values)
+        return bool(np.allclose(got, want, rtol=1e-4, atol=1e-5))
+
     def _try_compile(self):
         """ lower the equation to a residual program and cross-check it numerically against the callable. """
         total = self.model.total
@@ -145,18 +199,7 @@ class Solver:
             root = trace.symbolic(self.equation, self.ctx.run, total, variable_slot=self._variable_slot)
             plan = trace.lower_residual(root, self.spec, total)
             trace.combine_second_order(plan, self.spec)
-            # validation on random data: program (fp64 host interpreter) vs the user's callable on tagged tensors
-            n = 17
-            streams = torch.rand((self.spec.n_streams, n), device=self.device) * 2 - 1
-            pts = torch.rand((n, total), device=self.device) + 0.25
-            # (an equation that differentiates composite expressions needs autograd over its own pointwise ops)
-            probe = streams.clone().requires_grad_() if self.needs_x_grad else streams
-            want = self._eval_equation(probe, pts, requires_grad=self.needs_x_grad)
-            want = want.detach().reshape(-1).double().cpu().numpy()
-            lay = self.model.net.layout
-            var_values = self.model.flat[lay.off_extra:lay.off_extra + plan.n_vars].detach().cpu().numpy()
-            got = trace.run_residual_numpy(plan, streams.cpu().numpy(), pts.cpu().numpy(), var_values)
-            if not np.allclose(got, want, rtol=1e-4, atol=1e-5):
+            if not self._plan_matches(plan):
                 raise trace.TraceUnsupported('traced program disagrees with the callable (data-dependent control flow?)')
             self.residual_plan = plan
             return self._with_ic_variable(plan.to_struct()), None
@@ -281,8 +324,8 @@ class Solver:
         """ list of 0-d numpy arrays, one per iteration (reference model_torch.py:308, :464); device-side history is
         fetched lazily so that `fit` itself never synchronises. """
         if self._pending:
-            for chunk in self._pending:
-                self._losses.extend(np.float32(v) for v in chunk.detach().cpu().numpy().reshape(-1))
+            for chunk, done in self._pending:       # `done`: iterations the fit call completed (all, unless interrupted)
+                self._losses.extend(np.float32(v) for v in chunk.detach().cpu().numpy().reshape(-1)[:done[0]])
             self._pending = []
             self._losses = [np.asarray(v) for v in self._losses]
         return self._losses
@@ -320,6 +363,19 @@ class Solver:
             return dist.get_rank(), dist.get_world_size()
         return 0, 1
 
+    def _device_guard(self):
+        """ the library launches on the CURRENT device: make the model's device current where it is not """
+        if self.device.type == 'cuda' and torch.cuda.current_device() != self.device.index:
+            return torch.cuda.device(self.device)
+        return contextlib.nullcontext()
+
+    def _new_sample_seed(self):
+        """ Philox key of the device sampler: drawn from torch's default generator, like the `torch.rand` calls of the
+        reference's default sampler (model_torch.py:431) follow `torch.manual_seed`; per-rank offset under data parallelism """
+        rank, _ = self._world()
+        base = int(torch.randint(0, 2 ** 62, (1,), dtype=torch.int64).item())
+        self._sample_seed = (base + 7919 * rank) & (2 ** 64 - 1)
+
     def _sample(self, batch_size, sampler, stream=None):
         """ reference model_torch.py:430-434: default U[0,1) columns (domain is ignored, trap 3 of SURVEY 8a),
         or `sampler.sample(batch_size)`. Products of independent uniform / normal / constant columns -- the default
@@ -330,10 +386,16 @@ class Solver:
             (sampler.columns() if hasattr(sampler, 'columns') else None)
         if columns is not None and len(columns) == total and total <= engine.MAX_INPUTS:
             if self._sample_seed is None:
+                self._new_sample_seed()
+            seed, call = self._sample_seed, self._sample_calls
+            own = sampler.device_key() if hasattr(sampler, 'device_key') else None
+            if own is not None:
+                # `NumpySampler(..., seed=k)`: the reference draws from THAT seeded generator (model_torch.py:433), whatever
+                # torch's seed is -- the sampler's seed keys the Philox stream and the sampler counts its own batches
                 rank, _ = self._world()
-                self._sample_seed = (torch.initial_seed() + 7919 * rank) & (2 ** 64 - 1)
+                seed, call = (own + 7919 * rank) & (2 ** 64 - 1), sampler.next_device_call()
             xs = torch.empty((batch_size, total), dtype=torch.float32, device=self.device)
-            self.model.net.sample_points(xs, columns, self._sample_seed, self._sample_calls, stream=stream)
+            self.model.net.sample_points(xs, columns, seed, call, stream=stream)
             self._sample_calls += 1
             return xs
         if self._generator is None:
@@ -348,14 +410,54 @@ class Solver:
             raise ValueError(f'sampler produced {xs.shape[1]} columns, the problem has {total}')
         return xs.contiguous()
 
+    # ---- data parallelism ---------------------------------------------------------------------------------
+    def begin_data_parallel(self):
+        """ once per process group: parameters of rank 0 everywhere, and a communicator whose all-reduce is enqueued on the
+        COMPUTE stream (RCCL called directly -- no side stream, no event hops between the kernels of an iteration) """
+        _, world = self._world()
+        dist = torch.distributed
+        if not (dist.is_available() and dist.is_initialized()):
+            return
+        if not self._broadcast_done:
+            dist.broadcast(self.model.flat, src=0)
+            self._broadcast_done = True
+        if self._comm is None:
+            from . import comm
+            self._comm = comm.Communicator(self.device)
+
+    def end_data_parallel(self):
+        if self._comm is not None:
+            self._comm.close()
+            self._comm = None
+
+    def _all_reduce(self, stream=None):
+        if self._comm is None:
+            self.begin_data_parallel()
+        if self._comm is not None:              # (no process group: single process, nothing to exchange)
+            self._comm.all_reduce_(self.grads, stream)
+
+    def _dp_step(self, xs, world, stream=None, loss_out=None):
+        """ one data-parallel iteration on this rank's shard `xs`: tile kernel + reduction, all-reduce of the flat gradient
+        buffer (network, log_scale, loss slot, V slots) on the same stream, ONE Adam launch that also records the loss """
+        self._fused_step(xs, world, stream=stream)
+        self._all_reduce(stream)
+        self.optimizer.step(self.grads, loss_out=loss_out, stream=stream)
+
     def fit(self, niters, batch_size, sampler=None, loss_terms='equation', optimizer='Adam',
             criterion=nn.MSELoss(), lr=0.005, **kwargs):
-        """ reference model_torch.py:364-464. `batch_size` is per rank under torch.distributed. """
+        """ reference model_torch.py:364-464. Under torch.distributed `batch_size` stays the GLOBAL number of points per
+        iteration (the reference's meaning); rank r steps on its share of it. """
+        with self._device_guard():
+            return self._fit(niters, batch_size, sampler, loss_terms, optimizer, criterion, lr, **kwargs)
+
+    def _fit(self, niters, batch_size, sampler, loss_terms, optimizer, criterion, lr, **kwargs):
         model = self.model
         for num in self._constraints_seen:          # variables an earlier fit call brought to life are trainable now
             model.dormant_variables -= self._born_in_constraint.get(num, set())
         if optimizer is not None:                                                          # :419-422
-            self.optimizer = (FlatAdam(model, lr=lr, **kwargs) if optimizer == 'Adam'
+            plain_adam = optimizer == 'Adam' and not kwargs.get('weight_decay') and not kwargs.get('amsgrad') and \
+                not (set(kwargs) - {'betas', 'eps', 'weight_decay', 'amsgrad'})
+            self.optimizer = (FlatAdam(model, lr=lr, **kwargs) if plain_adam
                               else TorchOptimizerAdapter(model, optimizer, lr, **kwargs))
         elif self.optimizer is None:
             raise ValueError('optimizer=None reuses the optimizer of a previous fit call; there is none yet')
@@ -364,6 +466,7 @@ class Solver:
         loss_terms = loss_terms if isinstance(loss_terms, (tuple, list)) else (loss_terms, )
         nums_constraints = [int(term.replace('constraint', '').replace('_', ''))
                             for term in loss_terms if 'constraint' in term]
+        self._refresh_traces(set(nums_constraints))
         self._constraints_seen |= {num for num in nums_constraints if num < len(self.constraints)}
         mse_mean = isinstance(criterion, nn.MSELoss) and criterion.reduction == 'mean'
         lowered = all(num < len(self.constraint_plans) and self.constraint_plans[num] is not None
@@ -372,26 +475,41 @@ class Solver:
         fused = (self.use_fused and mse_mean and not self.ic_trainable and only_known_terms and lowered
                  and len(loss_terms) > 0 and (self.program is not None or 'equation' not in loss_terms))
         rank, world = self._world()
-        if world > 1 and not self._broadcast_done:
-            torch.distributed.broadcast(model.flat, src=0)
-            self._broadcast_done = True
+        if world > 1:
+            self.begin_data_parallel()
+        local_batch = batch_size // world + (1 if rank < batch_size % world else 0)
+        self._global_batch = batch_size
+        self._new_sample_seed()
         lay = model.net.layout
         history = torch.zeros(niters, dtype=torch.float32, device=self.device)
+        done = [0]
+        self._pending.append((history, done))       # registered up front: an interrupted fit keeps the losses it reached
         self.last_fit_path = 'fused' if fused else 'generic'
-        one_launch = fused and world == 1 and isinstance(self.optimizer, FlatAdam) and tuple(loss_terms) == ('equation',)
+        flat_adam = isinstance(self.optimizer, FlatAdam)
+        one_launch = fused and world == 1 and flat_adam and tuple(loss_terms) == ('equation',)
         stream = engine.stream_of(model.flat)           # looked up once per call, not per iteration
         history_ptr = history.data_ptr()
+        try:
+            self._fit_loop(niters, local_batch, sampler, loss_terms, nums_constraints, criterion, world, fused, one_launch,
+                           flat_adam, stream, history, history_ptr, done)
+        finally:
+            self._global_batch = None
+
+    def _fit_loop(self, niters, local_batch, sampler, loss_terms, nums_constraints, criterion, world, fused, one_launch,
+                  flat_adam, stream, history, history_ptr, done):
+        lay = self.model.net.layout
         for it in tqdm(range(niters), disable=None):
-            xs = self._sample(batch_size, sampler, stream)
+            xs = self._sample(local_batch, sampler, stream)
             if one_launch:
                 # Adam rides in the gradient-reduction launch, which also drops the loss into history[it]
                 self._fused_step(xs, 1, adam=self.optimizer, loss_out=history_ptr + 4 * it, stream=stream)
+                done[0] = it + 1
                 continue
             if fused:
                 # summed loss (:441-457): the equation term stores gradient + loss, every constraint term adds its own
                 first = True
                 if 'equation' in loss_terms:
-                    self._fused_step(xs, world)
+                    self._fused_step(xs, world, stream=stream)
                     first = False
                 for num in nums_constraints:
                     self._constraint_step(num, world, accumulate=not first)
@@ -399,10 +517,13 @@ class Solver:
             else:
                 self._generic_step(xs, loss_terms, nums_constraints, criterion, world)
             if world > 1:
-                torch.distributed.all_reduce(self.grads)  # flat [p_total]: network, log_scale, loss slot, V slots
-            self.optimizer.step(self.grads)
-            history[it:it + 1].copy_(self.grads[lay.off_loss:lay.off_loss + 1])
-        self._pending.append(history)
+                self._all_reduce(stream)                # flat [p_total]: network, log_scale, loss slot, V slots
+            if flat_adam:
+                self.optimizer.step(self.grads, loss_out=history_ptr + 4 * it, stream=stream)
+            else:
+                self.optimizer.step(self.grads)
+                history[it:it + 1].copy_(self.grads[lay.off_loss:lay.off_loss + 1])
+            done[0] = it + 1
 
     def _fused_step(self, xs, world, adam=None, loss_out=None, stream=None):
         model, spec = self.model, self.spec
@@ -427,9 +548,11 @@ class Solver:
                                          dir_cols=spec.dir_cols, n2=n2, ic_streams=ic_streams,
                                          ic_const=model.kernel_ic_const(), loss_out=loss_out, stream=stream)
             return
+        # data parallel: this rank's share of a GLOBAL batch (shares may differ by one point: the true global count divides)
+        n_global = self._global_batch if (world > 1 and getattr(self, '_global_batch', None)) else xs.shape[0] * world
         model.net.residual_step(self.program, model.flat, xs, self.grads, ws, spec.dir_cols, n2,
                                 ic_streams=ic_streams, ic_const=model.kernel_ic_const(),
-                                inv_n_global=1.0 / (xs.shape[0] * world))
+                                inv_n_global=1.0 / n_global, stream=stream)
 
     def _generic_step(self, xs, loss_terms, nums_constraints, criterion, world):
         model, spec = self.model, self.spec
@@ -441,6 +564,10 @@ class Solver:
         try:
             loss = 0
             leaf = None
+            # data parallel: the all-reduce SUMS the ranks' buffers, so the equation term (a mean over this rank's share of
+            # the global batch) is weighted by that share and the constraint terms, which every rank evaluates, by 1 / world
+            n_global = self._global_batch if (world > 1 and getattr(self, '_global_batch', None)) else xs.shape[0] * world
+            w_eq, w_con = xs.shape[0] / n_global, 1.0 / world
             if 'equation' in loss_terms:
                 leaf = model.net.jet_forward(model.flat, xs, spec.dir_cols, spec.n2,
                                              ic_const=model.kernel_ic_const()).requires_grad_()
@@ -448,15 +575,16 @@ class Solver:
                 if model.initial_condition is not None and model.ic_constant is None:
                     ic_streams = self._ic_streams(xs, create_graph=True)
                 r = self._eval_equation(leaf, xs, ic_streams)
-                loss = loss + criterion(r, torch.zeros_like(xs[:, :1]))                 # :448
+                term = criterion(r, torch.zeros_like(xs[:, :1]))                        # :448
+                loss = loss + (term if world == 1 else term * w_eq)
 
             def _forward(*pts):                                                          # :451-454
                 return model(self.reshape_and_concat(pts, device=self.device))
 
             cols = [xs[:, c:c + 1] for c in range(model.total)]
             for num in nums_constraints:                                                  # :456-457
-                loss = loss + criterion(self.ctx.run(self.constraints[num], _forward, *cols),
-                                        torch.zeros(1, device=self.device))
+                term = criterion(self.ctx.run(self.constraints[num], _forward, *cols), torch.zeros(1, device=self.device))
+                loss = loss + (term if world == 1 else term * w_con)
             loss.backward()
             if leaf is not None and leaf.grad is not None:
                 ws = model.workspace(xs.shape[0], spec.nd, spec.n2)
@@ -467,16 +595,16 @@ class Solver:
                 if p.grad is not None:
                     self.grads[off:off + n] += p.grad.reshape(-1)
                     p.grad = None
-            if world > 1:
-                self.grads[:lay.p_core] /= world
-                self.grads[lay.off_extra:] /= world
-                loss = loss / world
             self.grads[lay.off_loss] = loss.detach()
         finally:
             model.grad_sink = None
 
     def predict(self, *xs):
         """ reference model_torch.py:466-487 -> ndarray [N,1]. """
+        with self._device_guard():
+            return self._predict(*xs)
+
+    def _predict(self, *xs):
         model = self.model
         pts = self.reshape_and_concat(xs, device=self.device).contiguous()
         model.eval()

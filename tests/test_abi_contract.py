@@ -145,6 +145,6 @@ def test_sampler_and_adam_argument_checks(lib):
     p, g, m, v = (torch.zeros(16) for _ in range(4))
     step = torch.zeros(1, dtype=torch.int32)
     assert lib.pinn_adam_step(_ptr(p), None, _ptr(m), _ptr(v), None, 16, _ptr(step), 0.1, 0.9, 0.999, 1e-8, None) != 0
-    assert lib.pinn_adam_step_at(_ptr(p), _ptr(g), _ptr(m), _ptr(v), None, 16, _ptr(step), 0, 0.1, 0.9, 0.999, 1e-8, None) != 0
+    assert lib.pinn_adam_step_at(_ptr(p), _ptr(g), _ptr(m), _ptr(v), None, 16, _ptr(step), 0, 0.1, 0.9, 0.999, 1e-8, None, 0, None) != 0
     assert lib.pinn_adam_step(_ptr(p), _ptr(g), _ptr(m), _ptr(v), None, 0, _ptr(step), 0.1, 0.9, 0.999, 1e-8, None) == 0
     assert np.all(p.numpy() == 0)

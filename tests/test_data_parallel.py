@@ -38,7 +38,8 @@ def _worker(rank, world, port, out_dir, path):
     if rank == 0:
         load_params(solver, start)                  # the other rank starts elsewhere: fit must broadcast from rank 0
     shard = points[:, rank::world]                  # rank r owns points r, r+world, ... of every batch
-    solver.fit(niters=points.shape[0], batch_size=shard.shape[1], sampler=FixedBatches(shard), **fit_kw)
+    # `batch_size` keeps the reference's meaning under data parallelism: the GLOBAL points per iteration
+    solver.fit(niters=points.shape[0], batch_size=points.shape[1], sampler=FixedBatches(shard), **fit_kw)
     np.savez(os.path.join(out_dir, f'rank{rank}.npz'), losses=np.array([float(v) for v in solver.losses]),
              variables=_variables(solver), **{f'p{i}': p for i, p in enumerate(export_params(solver))})
     dist.destroy_process_group()
@@ -51,12 +52,14 @@ def _variables(solver):
 def _problem(path, pa, lib):
     """ -> (solver, batches [steps, N, d], fit kwargs, start parameters) """
     from helpers import make_solver
-    if path in ('fused', 'generic'):
+    if path in ('fused', 'generic', 'fused_uneven', 'generic_uneven'):
         g = Golden('cfg1')
         _, solver = make_solver('cfg1', pa, lib=lib, device='cpu')
-        if path == 'generic':
+        if path.startswith('generic'):
             solver.program = None
-        return solver, g.points[:3], dict(lr=g.lr), g.params
+        # `_uneven`: 99 points per iteration on two ranks -- shares of 50 and 49 points, weighted by the GLOBAL count
+        points = g.points[:3, :99] if path.endswith('_uneven') else g.points[:3]
+        return solver, np.ascontiguousarray(points), dict(lr=g.lr), g.params
     # tutorial cells 50-60: trainable variable in the equation + a constraint term; every rank evaluates the constraint,
     # the all-reduce sums the copies, hence its 1 / world scale
     from test_emu_engine import _variable_problem
@@ -86,7 +89,7 @@ def _run(path):
     single, points, fit_kw, start = _problem(path, pa, lib)
     load_params(single, start)
     single.fit(niters=points.shape[0], batch_size=points.shape[1], sampler=FixedBatches(points), **fit_kw)
-    assert single.last_fit_path == ('generic' if path in ('generic', 'constraint_generic') else 'fused')
+    assert single.last_fit_path == ('generic' if 'generic' in path else 'fused')
     want_losses = np.array([float(v) for v in single.losses])
     want, want_vars = export_params(single), _variables(single)
     with tempfile.TemporaryDirectory() as tmp:
@@ -105,6 +108,11 @@ def test_two_ranks_fused_path_equals_single_process():
 
 def test_two_ranks_generic_path_equals_single_process():
     _run('generic')
+
+
+def test_two_ranks_uneven_shares_of_the_global_batch():
+    _run('fused_uneven')
+    _run('generic_uneven')
 
 
 def test_two_ranks_constraint_term_and_variable_fused():

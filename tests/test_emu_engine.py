@@ -512,27 +512,6 @@ def test_layout_errors_are_loud(pa, emu_lib):
             pa.Solver(lambda f, x: pa.D(f, x), ndims=1, layout=layout, features=features, **emu_kwargs(emu_lib))
 
 
-@pytest.mark.parametrize('name', ['cfg4'])          # (Laplacian-type residuals take the combined-stream solo kernel)
-def test_two_team_kernel_agrees_with_solo_kernel(pa, emu_lib, name):
-    """ the experimental two-team form of the tile kernel (pinn_duo_kernel.h, off by default) must produce the same
-    gradients as the default kernel on the same points """
-    g = Golden(name)
-    grads = {}
-    try:
-        for disable in (1, 0):
-            emu_lib.pinn_debug_disable_duo(disable)
-            _, solver = make_solver(name, pa, **emu_kwargs(emu_lib))
-            load_params(solver, g.params)
-            solver._fused_step(torch.from_numpy(g.points[0].copy()), 1)
-            assert emu_lib.pinn_debug_last_kernel() == (2 if disable else 1)     # 2: the shape-specialised default kernel
-            grads[disable] = solver.grads.clone().numpy()
-    finally:
-        emu_lib.pinn_debug_disable_duo(1)
-    assert rel_l2(grads[0], grads[1]) < 1e-6
-    lay = solver.model.net.layout
-    assert abs(grads[0][lay.off_loss] - g.loss0) <= 1e-5 * g.loss0
-
-
 def test_deep_network_any_number_of_hidden_layers(pa, emu_lib):
     """ more hidden->hidden layers than the register-resident weight-gradient accumulators hold: generic kernel with
     read-modify-write accumulation in the workgroup's partial buffer """
