@@ -39,7 +39,7 @@ extern "C" {
 
 #define PINN_MAX_LAYERS   16   /* linear layers */
 #define PINN_MAX_INPUTS   8    /* ndims + nparams */
-#define PINN_MAX_DIRS     3    /* differentiated input columns */
+#define PINN_MAX_DIRS     4    /* differentiation directions of one call (3-D space + time) */
 #define PINN_EXTRA_SLOTS  16
 #define PINN_MAX_OPS      64   /* residual program length */
 #define PINN_MAX_CONSTS   32
@@ -123,6 +123,14 @@ typedef struct pinn_residual {
      * examples notebook cells 80-88), 0 = none: the ansatz then adds params[off_extra + slot] instead of the `ic_const`
      * argument and d(loss)/d(slot) = sum over points of d(loss)/du is added to grads[off_extra + slot]. */
     int ic_var1;
+    /* ic_rows != 0: the callable initial condition and its derivative streams come from the pre-pass (`pre`), which the
+     * host tracer extended by IC(x), dIC/dx_k, ... differentiated symbolically: stream s of the ansatz adds aux row
+     * ic_row[s] (if >= 0) or the constant ic_cst[s] -- in the stream layout of the call (combined second-order stream
+     * included). Needs has_ic and ic_streams == NULL. Replaces the per-iteration torch autograd over the IC callable
+     * (model_torch.py:124-127 under the nested D(...) of :174-178). */
+    int ic_rows;
+    int ic_row[PINN_MAX_STREAMS];
+    float ic_cst[PINN_MAX_STREAMS];
 } pinn_residual_t;
 
 /* Descriptor of network + ansatz.  Replaces ConvBlockModel.__init__/TorchModel.__init__ bookkeeping

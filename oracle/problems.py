@@ -41,6 +41,12 @@ def stream_form(name):
             d = np.zeros_like(u); d[4] = 0.5; d[5] = 1.5; d[6] = 0.5
             return r, d
         return dict(dir_cols=[0, 1, (0, 1)], n2=3, residual=residual)
+    if name == 'heat3d':                             # u_xx + u_yy + u_zz - u_t; dirs x,y,z (2nd) then t (1st):
+        def residual(u, xs):                         # streams u,ux,uy,uz,ut,uxx,uyy,uzz
+            r = u[5] + u[6] + u[7] - u[4]
+            d = np.zeros_like(u); d[5] = 1.0; d[6] = 1.0; d[7] = 1.0; d[4] = -1.0
+            return r, d
+        return dict(dir_cols=[0, 1, 2, 3], n2=3, residual=residual)
     raise KeyError(name)
 
 
@@ -56,6 +62,13 @@ def ic_streams_f64(name, xs, dir_cols, n2):
         out[0] = 10 * fx * fy
         out[1] = 10 * (1 - 2 * x) * fy; out[2] = 10 * fx * (1 - 2 * y)
         out[4] = -20 * fy; out[5] = -20 * fx
+        return out
+    if name == 'heat3d':                             # 8 x y z (1-x)(1-y)(1-z)
+        x, y, z = xs[:, 0], xs[:, 1], xs[:, 2]
+        fx, fy, fz = x * (1 - x), y * (1 - y), z * (1 - z)
+        out[0] = 8 * fx * fy * fz
+        out[1] = 8 * (1 - 2 * x) * fy * fz; out[2] = 8 * fx * (1 - 2 * y) * fz; out[3] = 8 * fx * fy * (1 - 2 * z)
+        out[5] = -16 * fy * fz; out[6] = -16 * fx * fz; out[7] = -16 * fx * fy
         return out
     if name == 'cfg4':
         out[0] = 1.0

@@ -1,4 +1,4 @@
-""" The five BASELINE.json workloads (+ two parity-only extras) in pydens form (equation callable + Solver kwargs + point sampler).
+""" The five BASELINE.json workloads (+ three parity-only extras) in pydens form (equation callable + Solver kwargs + point sampler).
 
 Neutral module: depends on neither the product package nor the oracle. `D` and `torch` are passed in so the
 same definitions drive the reference, the oracle and the HIP engine. Column order is pydens' (spatial..., t,
@@ -54,6 +54,14 @@ def make_config(name, D, torch):
                     solver_kwargs=dict(ndims=2, boundary_condition=0.5, layout='fa fa f', features=[24, 24, 1],
                                        activation='Tanh'),
                     n_points=4096, low=[0, 0], high=[1, 1])
+    if name == 'heat3d':                                         # heat equation in (x, y, z, t): four differentiation directions
+        def equation(f, x, y, z, t):
+            return D(D(f, x), x) + D(D(f, y), y) + D(D(f, z), z) - D(f, t)
+        return dict(equation=equation,
+                    solver_kwargs=dict(ndims=4, boundary_condition=0,
+                                       initial_condition=lambda x, y, z: 8 * x * y * z * (1 - x) * (1 - y) * (1 - z),
+                                       layout='fa fa fa f', features=[40, 40, 40, 1], activation='Tanh'),
+                    n_points=4096, low=[0, 0, 0, 0], high=[1, 1, 1, 1])
     raise KeyError(name)
 
 

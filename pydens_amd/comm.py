@@ -23,7 +23,7 @@ NCCL_FLOAT32, NCCL_SUM = 7, 0
 
 
 class _UniqueId(ctypes.Structure):
-    _fields_ = [('internal', ctypes.c_char * NCCL_UNIQUE_ID_BYTES)]
+    _fields_ = [('internal', ctypes.c_ubyte * NCCL_UNIQUE_ID_BYTES)]     # (c_char arrays read back NUL-terminated)
 
 
 _RCCL = None
@@ -66,15 +66,30 @@ class Communicator:
             uid = _UniqueId()
             if self.rank == 0:
                 _check(lib, lib.ncclGetUniqueId(ctypes.byref(uid)), 'ncclGetUniqueId')
-            box = torch.tensor(list(bytes(uid.internal)) if self.rank == 0 else [0] * NCCL_UNIQUE_ID_BYTES,
-                               dtype=torch.uint8, device=self.device)
+            box = torch.tensor(list(uid.internal), dtype=torch.uint8, device=self.device)      # all 128 bytes, zeros included
             dist.broadcast(box, src=0)
             raw = bytes(box.cpu().tolist())
+            assert len(raw) == NCCL_UNIQUE_ID_BYTES
             ctypes.memmove(ctypes.byref(uid), raw, NCCL_UNIQUE_ID_BYTES)
             comm = ctypes.c_void_p()
-            with torch.cuda.device(self.device):
-                _check(lib, lib.ncclCommInitRank(ctypes.byref(comm), self.world, uid, self.rank), 'ncclCommInitRank')
-            self.comm = comm
+            err = None
+            try:
+                with torch.cuda.device(self.device):
+                    _check(lib, lib.ncclCommInitRank(ctypes.byref(comm), self.world, uid, self.rank), 'ncclCommInitRank')
+            except RuntimeError as exc:
+                err = exc
+            # every rank must take the same path: agree on the outcome over the torch group
+            ok = torch.tensor([0 if err is not None else 1], dtype=torch.int32, device=self.device)
+            dist.all_reduce(ok, op=dist.ReduceOp.MIN)
+            if int(ok.item()) == 1:
+                self.comm = comm
+            else:
+                import warnings
+                warnings.warn(f'pydens_amd.comm: direct RCCL communicator unavailable ({err}); gradient all-reduce goes '
+                              'through torch.distributed (ProcessGroupNCCL, side stream)')
+                if err is None:
+                    lib.ncclCommDestroy(comm)
+                self.direct = False
 
     def all_reduce_(self, tensor, stream=None):
         if not self.direct:

@@ -93,8 +93,9 @@ launch_fn launcher_for(int hp) {
 
 // smallest compiled (nd, n2k) with n2k >= n2 (extra second-derivative streams get zero upstream gradient)
 int pick_n2(int nd, int n2) {
-    static const int avail[4][4] = {{1, 0, 0, 0}, {1, 1, 0, 0}, {1, 0, 1, 0}, {0, 0, 1, 1}};
-    if (nd < 0 || nd > 3 || n2 < 0 || n2 > nd) return -1;
+    // (nd = 4: first derivatives only; its second-order form exists as ONE combined stream, `comb`)
+    static const int avail[5][5] = {{1, 0, 0, 0, 0}, {1, 1, 0, 0, 0}, {1, 0, 1, 0, 0}, {0, 0, 1, 1, 0}, {1, 0, 0, 0, 0}};
+    if (nd < 0 || nd > 4 || n2 < 0 || n2 > nd) return -1;
     for (int k = n2; k <= nd; ++k)
         if (avail[nd][k]) return k;
     return -1;
@@ -126,6 +127,7 @@ struct Plan {
     int mt, comb;
     // WGX (widths >= 128): hidden->hidden weight gradients by pinn_wgrad_kernel from per-tile slabs in HBM
     int wgx, grid2;                 // grid2: workgroups of the weight-gradient kernel
+    int wt_global;                  // the kernel reads the transposed global copy of the hidden weights (pinn_transpose_kernel)
     wgrad_fn wfn;
     size_t gz_vec4_per_tile;
     int64_t chunk_tiles;            // tiles per pass through the two kernels
@@ -134,23 +136,32 @@ struct Plan {
     size_t gz_bytes() const { return wgx ? (size_t)chunk_tiles * gz_vec4_per_tile * 16 : 0; }
 };
 
+// `hint`: the arguments of the call being planned. The launcher picks shape-specialised instantiations from them
+// (pinn_spec_of), and those may differ from the general kernel in everything a plan holds -- workgroups per CU, tile
+// height, slab size, whether the transposed weight copy is needed -- so a call is planned with its own arguments;
+// sizing queries (no call yet) plan with the general probe AND with the arguments a typical training step of this net
+// would carry (typical_step_args) and take the larger answer.
 int make_plan(const pinn_net* net, int64_t n_points, int nd, int n2, Plan* plan, int mode = PINN_MODE_FORWARD,
-              int res_kind = PINN_RES_PROGRAM, int comb = 0) {
+              int res_kind = PINN_RES_PROGRAM, int comb = 0, const PinnKArgs* hint = nullptr) {
     plan->fn = launcher_for(net->lay.hp);
     if (!plan->fn) return fail("no kernel for padded hidden width %d (supported: 16, 32, 64, 128, 256)", net->lay.hp);
     plan->n2k = comb ? 1 : pick_n2(nd, n2);
-    if (comb && (n2 != 1 || nd < 2 || nd > 3)) return fail("combined second-order stream needs n2 == 1 and nd in {2, 3}");
-    if (plan->n2k < 0) return fail("unsupported derivative spec nd=%d n2=%d (nd <= 3, n2 <= nd)", nd, n2);
+    if (comb && (n2 != 1 || nd < 2 || nd > 4)) return fail("combined second-order stream needs n2 == 1 and nd in {2, 3, 4}");
+    if (plan->n2k < 0) return fail("unsupported derivative spec nd=%d n2=%d (nd <= 3 with n2 <= nd, or nd = 4 with n2 = 0 / one combined second-order stream)", nd, n2);
     PinnKArgs probe;
-    memset(&probe, 0, sizeof(probe));
-    probe.lh = net->lay.lh;
-    probe.act = net->act;
-    probe.act_codes = net->act_codes;
-    probe.n_skips = net->n_skips;
+    if (hint) {
+        probe = *hint;
+    } else {
+        memset(&probe, 0, sizeof(probe));
+        probe.lh = net->lay.lh;
+        probe.act = net->act;
+        probe.act_codes = net->act_codes;
+        probe.n_skips = net->n_skips;
+    }
     probe.mode = mode;
     probe.res_kind = res_kind;
     probe.comb = comb;
-    long long info[9] = {0, 0, 0, 1, 1, 0, 0, 0, 0};
+    long long info[10] = {0, 0, 0, 1, 1, 0, 0, 0, 0, 0};
     if (plan->fn(nd, plan->n2k, &probe, 0, nullptr, 1, info))
         return fail("no kernel instantiation for width %d with nd=%d n2=%d%s", net->lay.hp, nd, plan->n2k, comb ? " (combined)" : "");
     plan->smem = (size_t)info[0];
@@ -167,10 +178,11 @@ int make_plan(const pinn_net* net, int64_t n_points, int nd, int n2, Plan* plan,
     plan->mt = (int)info[4];
     plan->comb = comb;
     plan->wgx = (mode != PINN_MODE_FORWARD && info[6]) ? 1 : 0;
+    plan->wt_global = (int)info[9];
     plan->grid2 = 0; plan->wfn = nullptr; plan->gz_vec4_per_tile = 0; plan->chunk_tiles = wg_tiles;
     if (plan->wgx) {
         plan->wfn = wgrad_launcher_for(net->lay.hp);
-        long long winfo[9] = {0, 0, 0, 1, 1, 0, 0, 0, 0};
+        long long winfo[10] = {0, 0, 0, 1, 1, 0, 0, 0, 0, 0};
         if (!plan->wfn || plan->wfn(nd, plan->n2k, comb, plan->mt, &probe, 0, nullptr, 1, winfo))
             return fail("no weight-gradient kernel for width %d with nd=%d n2=%d%s", net->lay.hp, nd, plan->n2k, comb ? " (combined)" : "");
         int64_t grid2 = (int64_t)device_cus(net) * winfo[3];
@@ -214,6 +226,15 @@ void fill_args(const pinn_net* net, PinnKArgs* a, const float* params, const flo
 void set_tile_range(PinnKArgs* a, const Plan& plan, int64_t begin, int64_t end) {
     a->tile_begin = begin;
     a->tile_end = end < plan.ntiles ? end : plan.ntiles;
+}
+
+// what a fused training step of this net most likely passes: direction k = column k, constant affine coefficients
+void typical_step_args(const pinn_net* net, PinnKArgs* a, int64_t n, int nd, int n2) {
+    int dirs[PINN_MAX_DIRS];
+    for (int k = 0; k < PINN_MAX_DIRS; ++k) dirs[k] = k;
+    fill_args(net, a, nullptr, nullptr, n, dirs, nd, n2, nullptr, 0.0f);
+    for (int s = 0; s < PINN_MAX_STREAMS; ++s) a->coef_row[s] = -1;
+    a->src_row = -1;
 }
 
 int check_dirs(const pinn_net* net, const int* dir_cols, int nd, int n2) {
@@ -260,7 +281,7 @@ size_t align256(size_t v) { return (v + 255) / 256 * 256; }
 
 // widths >= 128 (PinnCfg::WTG): room for the transposed copy of the lh hidden->hidden matrices
 size_t wt_workspace_bytes(const pinn_net* net) {
-    return (net->lay.hp >= PINN_WTG_MIN_HP && net->lay.lh > 0) ? align256((size_t)net->lay.lh * net->lay.hp * net->lay.hp * sizeof(float)) : 0;
+    return net->lay.lh > 0 ? align256((size_t)net->lay.lh * net->lay.hp * net->lay.hp * sizeof(float)) : 0;
 }
 }  // namespace
 
@@ -446,22 +467,30 @@ int pinn_layout(const pinn_t* net, pinn_layout_t* out) {
 size_t pinn_workspace_bytes(const pinn_t* net, int64_t n_points, int nd, int n2) {
     if (!net) return 0;
     size_t need = 0;
+    bool any = false;
     const int modes[3][2] = {{PINN_MODE_STEP, PINN_RES_AFFINE}, {PINN_MODE_STEP, PINN_RES_PROGRAM}, {PINN_MODE_BACKWARD, 0}};
-    for (int i = 0; i < 4; ++i) {
+    for (int i = 0; i < 8; ++i) {
         Plan plan;
-        // i == 3: the combined-second-order form of an affine step (n2 folded to 1), only where it exists
-        const bool comb = (i == 3);
-        if (comb && (n2 < 2 || nd < 2 || nd > 3)) continue;
-        if (make_plan(net, n_points, nd, comb ? 1 : n2, &plan, comb ? PINN_MODE_STEP : modes[i][0],
-                      comb ? PINN_RES_AFFINE : modes[i][1], comb ? 1 : 0)) {
-            if (comb) continue;
-            return 0;
-        }
+        // i & 3 == 3: the combined-second-order form of an affine step (n2 folded to 1), only where it exists;
+        // i >= 4: the same modes planned with the arguments of a typical training step (shape-specialised kernels)
+        const int m = i & 3;
+        const bool comb = (m == 3);
+        if (comb && (n2 < 2 || nd < 2 || nd > 4)) continue;
+        const int n2q = comb ? 1 : n2;
+        PinnKArgs typical;
+        const bool with_hint = i >= 4 && nd <= net->lay.d;
+        if (i >= 4 && !with_hint) continue;
+        if (with_hint) typical_step_args(net, &typical, n_points, nd, n2q);
+        // (a shape may exist in one form only: nd = 4 with second derivatives runs as the combined stream alone)
+        if (make_plan(net, n_points, nd, n2q, &plan, comb ? PINN_MODE_STEP : modes[m][0],
+                      comb ? PINN_RES_AFFINE : modes[m][1], comb ? 1 : 0, with_hint ? &typical : nullptr)) continue;
+        any = true;
         const size_t v = align256((size_t)plan.rows() * net->lay.p_total * sizeof(float)) +
                          align256(plan.slab_bytes()) + align256(plan.gz_bytes()) +
                          align256((size_t)plan.grid * plan.wt_floats_per_wg * sizeof(float));
         if (v > need) need = v;
     }
+    if (!any) return 0;
     return need + align256((size_t)PINN_MAX_AUX * (size_t)n_points * sizeof(float)) + wt_workspace_bytes(net) + 256;
 }
 
@@ -490,7 +519,7 @@ static int run_train(pinn_t* net, PinnKArgs* a, const Plan& plan, int nd, float*
     // transposed hidden weights: one copy written by pinn_transpose_kernel (widths >= 128) or one scratch per workgroup
     // filled by the tile kernel itself (slab-in-LDS kernels)
     const size_t wt_bytes = plan.wt_floats_per_wg ? align256((size_t)plan.grid * plan.wt_floats_per_wg * sizeof(float))
-                                                  : wt_workspace_bytes(net);
+                                                  : (plan.wt_global ? wt_workspace_bytes(net) : 0);
     const size_t gz_bytes = align256(plan.gz_bytes());
     const size_t need = part_bytes + slab_bytes + aux_bytes + wt_bytes + gz_bytes;
     if (!workspace || workspace_bytes < need)
@@ -643,6 +672,15 @@ static int residual_step_impl(pinn_t* net, const pinn_residual_t* residual, cons
     if (a.ic_var1 > 0 && (!net->has_ic || ic_streams)) return fail("ic_var1 needs a problem with an initial condition and no ic_streams");
     a.comb = comb;
     for (int k = 0; k < PINN_MAX_DIRS; ++k) a.comb_w[k] = (comb && k < nd) ? residual->comb_w[k] : 0.0f;
+    a.ic_rows = residual->ic_rows ? 1 : 0;
+    if (a.ic_rows) {
+        if (!net->has_ic || ic_streams || residual->ic_var1 > 0) return fail("ic_rows needs a problem with an initial condition, no ic_streams and no ic_var1");
+        for (int s = 0; s < PINN_MAX_STREAMS; ++s) {
+            a.ic_row[s] = (s < s_user) ? residual->ic_row[s] : -1;
+            a.ic_cst[s] = (s < s_user) ? residual->ic_cst[s] : 0.0f;
+            if (a.ic_row[s] >= residual->n_aux) return fail("ic_row[%d] refers to a missing pre-pass row", s);
+        }
+    }
     if (residual->n_aux > 0 && check_program(residual->pre, d, PINN_MAX_CONSTS, true, residual->n_aux, "pre-pass")) return 1;
     if (residual->kind == PINN_RES_AFFINE) {
         for (int s = 0; s < PINN_MAX_STREAMS; ++s) {
@@ -675,6 +713,7 @@ static int residual_step_impl(pinn_t* net, const pinn_residual_t* residual, cons
     }
     a.mode = PINN_MODE_STEP;
     a.inv_n = inv_n_global;
+    if (make_plan(net, n_points, nd, n2, &plan, PINN_MODE_STEP, residual->kind, comb, &a)) return 1;      // with the call's own arguments
     return run_train(net, &a, plan, nd, grads, accumulate, workspace, workspace_bytes, stream, &residual->pre, adam);
 }
 

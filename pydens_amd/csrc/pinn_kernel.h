@@ -65,6 +65,9 @@ struct PinnKArgs {
     int p_core;                  // row stride of `partials` = length of the gradient buffer (user slots included)
     int off_extra, n_vars;       // first user slot; V(...) scalars a residual program reads (registers S+d+n_aux+k)
     int ic_var1;                 // 1 + user slot holding a trainable constant initial value (0: the ic_const argument)
+    int ic_rows;                 // 1: IC streams = pre-pass rows ic_row[s] (>= 0) or constants ic_cst[s]
+    int ic_row[PINN_MAX_STREAMS];
+    float ic_cst[PINN_MAX_STREAMS];
     int ndims, nsp, has_bc, has_ic;
     float bc_value, t0, ic_const, inv_n;
     float lo[PINN_MAX_INPUTS], hi[PINN_MAX_INPUTS];
@@ -103,7 +106,10 @@ struct PinnCfg {
     static constexpr int NTHREADS = NW * 64;
     // widths above 128: ONE activation buffer (two would not fit the 160 KB of LDS): the forward pass works in place and
     // the reverse pass keeps the weight-gradient B fragments of h_{a-1} in registers while gz_a replaces it in LDS
-    static constexpr bool ONEBUF = HP > 128;
+#ifndef PINN_ONEBUF_MIN_HP
+#define PINN_ONEBUF_MIN_HP 256
+#endif
+    static constexpr bool ONEBUF = HP >= PINN_ONEBUF_MIN_HP;
 #ifndef PINN_WTG_MIN_HP
 #define PINN_WTG_MIN_HP 128                                  // (experiment builds lower it: W^T from global memory instead of LDS)
 #endif
@@ -489,6 +495,11 @@ PINN_DEVICE void pinn_point_prefetch(const PinnKArgs& A, long long gidx, bool va
 #pragma unroll
             for (int s = 0; s < S; ++s)
                 if (s < SH::s_user(A) && valid) pre.ic[s] = A.ic_streams[(long long)s * A.n_points + gidx];
+        } else if (A.ic_rows) {
+            // callable IC lowered into the x-only pre-pass (value + derivative streams as aux rows / constants)
+#pragma unroll
+            for (int s = 0; s < S; ++s)
+                if (s < SH::s_user(A)) pre.ic[s] = (A.ic_row[s] >= 0) ? A.aux[(long long)A.ic_row[s] * A.n_points + gi] : A.ic_cst[s];
         } else {
             pre.ic[0] = (SPEC == 0 && A.ic_var1 > 0) ? A.params[A.off_extra + A.ic_var1 - 1] : A.ic_const;
         }
@@ -769,10 +780,11 @@ pinn_tile_kernel(const PinnKArgs A) {
     static_assert(!WGX || (DWG && !SKIPS && !SLABL), "WGX kernels: generic depth, no skips, global slab");
     static_assert(!SLABL || (((VAR >> 4) & 3) != 0 && LHC >= 1 && !(VAR & 8) && !(VAR & 1) && C::slabl_fits(LHC)),
                   "slab-in-LDS kernels: shape-specialised, static depth, no skips, and the jets must fit");
-    constexpr bool WTL = C::wt_fits(LHC) && !SLABL;        // transposed hidden weights staged in LDS
+    constexpr bool WTL = C::wt_fits(LHC) && !SLABL && !(VAR & 2);        // transposed hidden weights staged in LDS
     // widths >= 128: the data-gradient A operand comes from a transposed copy of the weights in global memory (one b128 per
     // K quad like the forward GEMM) instead of four strided global_load_dword per quad
-    constexpr bool WTG = C::WTG || SLABL;
+    // (VAR 2, two workgroups per CU: W^T of both does not fit the LDS beside the activation buffers)
+    constexpr bool WTG = C::WTG || SLABL || (VAR & 2) != 0;
     constexpr int SPEC = (VAR >> 4) & 3;                   // VAR 16/32/48: training shape 1/2/3 fixed at compile time
     using SH = PinnShape<SPEC, ND>;
     const int tid = PINN_TID, lane = tid & 63, wave = tid >> 6;
@@ -898,7 +910,7 @@ pinn_tile_kernel(const PinnKArgs A) {
 #ifndef PINN_REGB_MAX_SPEC
 #define PINN_REGB_MAX_SPEC 8
 #endif
-    constexpr bool REGB = !DWG && (S * MT * NTW <= (SPEC != 0 ? PINN_REGB_MAX_SPEC : PINN_REGB_MAX));
+    constexpr bool REGB = !DWG && !(VAR & 2) && (S * MT * NTW <= (SPEC != 0 ? PINN_REGB_MAX_SPEC : PINN_REGB_MAX));
     constexpr int W1R = 4;
     f32x4 accBr[REGB ? PINN_LHMAX + 1 : 1][NTW], accW1r[REGB ? W1R : 1][NTW];
 #pragma unroll
@@ -975,7 +987,8 @@ pinn_tile_kernel(const PinnKArgs A) {
     for (long long tile = A.tile_begin + PINN_BID; tile < ntiles; tile += PINN_NBLK, tile_parity ^= 1) {
         const long long base = tile * T;
         if (WGX && train) {
-            const size_t tl = (size_t)(tile - A.tile_begin);
+            // (debug flag 4, timing experiments only: every tile writes the first tile's slab -- stores stay in L2)
+            const size_t tl = (A.debug_flags & 4) ? 0 : (size_t)(tile - A.tile_begin);
             slab = A.slab + tl * C::slab_vec4_per_wg(lh);
             gzs = A.gzslab + tl * C::gz_vec4_per_tile(lh);
         }

@@ -81,14 +81,17 @@ pinn_wgrad_kernel(const PinnKArgs A) {
         // raw operands of a stage, straight from HBM (the tile kernel's lane-private layout: this thread reads what the
         // thread with the same id stored)
         auto load_raw = [&](long long tile, int mt, int s, f32x4 (&gzr)[NTW], f32x4 (&svr)[NTW]) {
-            const size_t tl = (size_t)(tile - A.tile_begin);
-            const f32x4* gzp = A.gzslab + tl * gz_tile + (((size_t)(li * S + s) * NTW) * MT + mt) * NTHREADS + tid;
-            const f32x4* svp = A.slab + tl * sv_tile + (((size_t)(li * S + s) * NTW) * MT + mt) * NTHREADS + tid;
+            // (uniform 64-bit base per slot + this thread's 32-bit index: scalar address arithmetic, one VGPR of offset)
+            // (debug flag 2, timing experiments only: every stage re-reads the first tile -- operands from L2 instead of HBM)
+            const size_t tl = (A.debug_flags & 2) ? 0 : (size_t)(tile - A.tile_begin);
+            const f32x4* gzp = A.gzslab + tl * gz_tile + (((size_t)(li * S + s) * NTW) * MT + mt) * NTHREADS;
+            const f32x4* svp = A.slab + tl * sv_tile + (((size_t)(li * S + s) * NTW) * MT + mt) * NTHREADS;
+            const unsigned t = (unsigned)tid;
 #pragma unroll
             for (int j = 0; j < NTW; ++j) {
-                gzr[j] = gzp[(size_t)j * MT * NTHREADS];
+                gzr[j] = (gzp + (size_t)j * MT * NTHREADS)[t];
                 if (li > 0 || s == 0) {
-                    svr[j] = svp[(size_t)j * MT * NTHREADS];
+                    svr[j] = (svp + (size_t)j * MT * NTHREADS)[t];
                 } else {
                     // first layer: only tanh(z) was saved; z_k = W1[:, col_k] (+ the diagonal partner), z_kk = 0
 #pragma unroll
@@ -97,8 +100,9 @@ pinn_wgrad_kernel(const PinnKArgs A) {
                 }
             }
         };
-        // h_s of the saved jets, stream by stream in ascending s (d1, d2 and the z_k^2 terms ride along in registers)
-        f32x4 d1v[NTW], d2v[NTW], zz[ND > 0 ? ND : 1][NTW];
+        // h_s of the saved jets, stream by stream in ascending s (d1, d2 and the z_k^2 terms ride along in registers: one
+        // running sum_k c_k z_k^2 for the combined second-order stream, else z_k^2 of the N2 directions that have one)
+        f32x4 d1v[NTW], d2v[NTW], zz[(COMB || N2 == 0) ? 1 : N2][NTW];
         auto transform = [&](int s, const f32x4 (&svr)[NTW], f32x4 (&hv)[NTW]) {
 #pragma unroll
             for (int j = 0; j < NTW; ++j) {
@@ -109,17 +113,13 @@ pinn_wgrad_kernel(const PinnKArgs A) {
                         pinn_act_d12(svr[j][r], act, d1, d2);
                         d1v[j][r] = d1; d2v[j][r] = d2;
                         hv[j][r] = pinn_act_value(svr[j][r], act);
+                        if (COMB) zz[0][j][r] = 0.0f;
                     } else if (s <= ND) {
                         hv[j][r] = d1v[j][r] * svr[j][r];
-                        zz[ND > 0 ? s - 1 : 0][j][r] = svr[j][r] * svr[j][r];
+                        if (COMB) zz[0][j][r] = fmaf(cw[s - 1], svr[j][r] * svr[j][r], zz[0][j][r]);
+                        else if (s - 1 < N2) zz[(COMB || N2 == 0) ? 0 : s - 1][j][r] = svr[j][r] * svr[j][r];
                     } else {
-                        float q = 0.0f;
-                        if (COMB) {
-#pragma unroll
-                            for (int k = 0; k < ND; ++k) q = fmaf(cw[k], zz[k][j][r], q);
-                        } else {
-                            q = zz[ND > 0 ? s - 1 - ND : 0][j][r];
-                        }
+                        const float q = zz[(COMB || N2 == 0) ? 0 : s - 1 - ND][j][r];
                         hv[j][r] = fmaf(d2v[j][r], q, d1v[j][r] * svr[j][r]);
                     }
                 }
@@ -139,19 +139,31 @@ pinn_wgrad_kernel(const PinnKArgs A) {
         // computes from LDS buffer p while the raw operands of stage i + 1 are in flight from HBM; they are turned into
         // buffer p ^ 1 right behind the MFMAs, one barrier per stage.
         auto mfma_stage = [&](const float* bg) {
+            // B fragments of the whole stage up front; A fragment of output tile row i + 1 in flight while the 4 * BN MFMAs
+            // of row i issue (pinned with sched barriers: left alone the scheduler hoists every fragment load to the top
+            // and the 128 accumulators no longer fit beside them)
             const float* bh = bg + OPER;
             f32x4 bf[BN];
 #pragma unroll
             for (int jn = 0; jn < BN; ++jn) bf[jn] = pinn_ld4(bh + (n0 + 16 * jn + lr) * LDK + 4 * lq);
+            f32x4 af = pinn_ld4(bg + (m0 + lr) * LDK + 4 * lq);
 #pragma unroll
             for (int i = 0; i < AM; ++i) {
-                const f32x4 af = pinn_ld4(bg + (m0 + 16 * i + lr) * LDK + 4 * lq);
+                PINN_SCHED_BARRIER();
+                f32x4 afn = af;
+                if (i + 1 < AM) afn = pinn_ld4(bg + (m0 + 16 * (i + 1) + lr) * LDK + 4 * lq);
 #pragma unroll
                 for (int kk = 0; kk < 4; ++kk)
 #pragma unroll
                     for (int jn = 0; jn < BN; ++jn) acc[i][jn] = pinn_mfma16(af[kk], bf[jn][kk], acc[i][jn]);
+                PINN_SCHED_BARRIER();
+                af = afn;
             }
         };
+#ifndef PINN_WG_PF
+#define PINN_WG_PF 2          // stages the HBM loads run ahead of the MFMAs (1: one register set, 2: two)
+#endif
+#if PINN_WG_PF == 1
         f32x4 gzr[NTW], svr[NTW], hv[NTW];
         int p = 0;
         if (t_first < A.tile_end) {
@@ -180,6 +192,55 @@ pinn_wgrad_kernel(const PinnKArgs A) {
                 }
             }
         }
+#else
+        // Two register sets: while stage i computes from LDS buffer i & 1, the operands of stage i + 1 (loaded during
+        // stage i - 1) are turned into buffer (i + 1) & 1 and those of stage i + 2 are requested from HBM -- a load has
+        // two stage times (about 16 K cycles at width 256) to arrive; with one set it had one, and under the load of 256
+        // workgroups streaming at once that was not always enough (the waves sat in s_waitcnt vmcnt for a quarter of
+        // the kernel). Stage parity must be a compile-time fact (it selects registers): U groups of S stages are
+        // unrolled so that U * S is even.
+        constexpr int U = (S % 2 == 0) ? 1 : 2;
+        long long n_tiles_wg = 0;
+        if (t_first < A.tile_end) n_tiles_wg = (A.tile_end - t_first + t_step - 1) / t_step;
+        const long long n_stages = n_tiles_wg * MT * S;
+        auto stage_pos = [&](long long j, long long& tile, int& mt) {
+            const long long g = j / S;
+            tile = t_first + (g / MT) * t_step;
+            mt = (int)(g % MT);
+        };
+        f32x4 gz0[NTW], sv0[NTW], gz1[NTW], sv1[NTW], hv[NTW];
+        if (n_stages > 0) {
+            load_raw(t_first, 0, 0, gz0, sv0);
+            if (n_stages > 1) {
+                long long t1; int m1;
+                stage_pos(1, t1, m1);
+                load_raw(t1, m1, 1 % S, gz1, sv1);
+            }
+            transform(0, sv0, hv);
+            write_stage(smem, gz0, hv);
+        }
+        PINN_SYNC();
+        for (long long i0 = 0; i0 < n_stages; i0 += U * S) {
+#pragma unroll
+            for (int u = 0; u < U * S; ++u) {
+                const long long i = i0 + u;
+                if (i < n_stages) {
+                    const int s1 = (u + 1) % S, s2 = (u + 2) % S;       // streams of stages i + 1, i + 2 (compile time)
+                    if (i + 2 < n_stages) {
+                        long long t2; int m2;
+                        stage_pos(i + 2, t2, m2);
+                        if (u % 2 == 0) load_raw(t2, m2, s2, gz0, sv0); else load_raw(t2, m2, s2, gz1, sv1);
+                    }
+                    mfma_stage(smem + (u % 2) * 2 * OPER);
+                    if (i + 1 < n_stages) {
+                        if (u % 2 == 0) { transform(s1, sv1, hv); write_stage(smem + 2 * OPER, gz1, hv); }
+                        else { transform(s1, sv0, hv); write_stage(smem, gz0, hv); }
+                    }
+                    PINN_SYNC();
+                }
+            }
+        }
+#endif
         // this workgroup's dW_li: D[(l >> 4) * 4 + r][l & 15] of tile (i, jn) -> row (out) m0 + 16 i + 4 lq + r, column (in) n0 + 16 jn + lr
         float* dst = part + A.off_wh + (size_t)li * A.hidden_stride;
 #pragma unroll

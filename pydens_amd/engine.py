@@ -13,7 +13,7 @@ import torch
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_NAME = 'libpinn_hip.so'
 
-MAX_LAYERS, MAX_INPUTS, MAX_DIRS, EXTRA_SLOTS = 16, 8, 3, 16
+MAX_LAYERS, MAX_INPUTS, MAX_DIRS, EXTRA_SLOTS = 16, 8, 4, 16
 MAX_OPS, MAX_CONSTS, MAX_REGS = 64, 32, 40
 MAX_STREAMS, MAX_AUX, MAX_VARS = 7, 8, 8
 SAMPLE_UNIFORM, SAMPLE_NORMAL, SAMPLE_CONST = 0, 1, 2
@@ -53,10 +53,12 @@ class Residual(ctypes.Structure):
                 ('coef', ctypes.c_float * MAX_STREAMS), ('coef_row', ctypes.c_int * MAX_STREAMS),
                 ('src_const', ctypes.c_float), ('src_row', ctypes.c_int),
                 ('combined', ctypes.c_int), ('comb_w', ctypes.c_float * MAX_DIRS), ('n_vars', ctypes.c_int),
-                ('ic_var1', ctypes.c_int)]
+                ('ic_var1', ctypes.c_int), ('ic_rows', ctypes.c_int), ('ic_row', ctypes.c_int * MAX_STREAMS),
+                ('ic_cst', ctypes.c_float * MAX_STREAMS)]
 
     @classmethod
-    def build(cls, kind, n_aux, pre, program=None, coef=(), coef_row=(), src_const=0.0, src_row=-1, comb_w=None, n_vars=0):
+    def build(cls, kind, n_aux, pre, program=None, coef=(), coef_row=(), src_const=0.0, src_row=-1, comb_w=None, n_vars=0,
+              ic_row=None, ic_const=None):
         res = cls()
         res.kind, res.n_aux, res.n_vars = kind, n_aux, n_vars
         res.pre = Program.from_lists(*pre) if pre is not None else Program()
@@ -68,6 +70,10 @@ class Residual(ctypes.Structure):
         res.combined = 1 if comb_w is not None else 0
         for i in range(MAX_DIRS):
             res.comb_w[i] = comb_w[i] if comb_w is not None and i < len(comb_w) else 0.0
+        res.ic_rows = 0 if ic_row is None else 1
+        for i in range(MAX_STREAMS):
+            res.ic_row[i] = ic_row[i] if ic_row is not None and i < len(ic_row) else -1
+            res.ic_cst[i] = ic_const[i] if ic_const is not None and i < len(ic_const) else 0.0
         return res
 
 

@@ -124,7 +124,8 @@ class Solver:
     def _trace_equation(self):
         """ which streams does the equation need, and can it be lowered to a residual program? (construction, and again at
         the start of a fit call whenever the cached lowering no longer reproduces the live callable) """
-        self.spec, self.needs_x_grad = trace.discover(self.equation, self.ctx.run, self.model.total, self.device)
+        self.spec, self.needs_x_grad = trace.discover(self.equation, self.ctx.run, self.model.total, self.device,
+                                                      hp=self.model.net.layout.hp)
         # a callable initial condition that IS one scalar trainable variable (`lambda *a: V('init', ...)`, reference
         # examples notebook cells 80-88) stays on the fused path: the kernels read it from its user slot and return its
         # gradient there (pinn_residual_t::ic_var1); any other dependence on variables needs torch autograd (generic path)
@@ -197,14 +198,51 @@ class Solver:
         total = self.model.total
         try:
             root = trace.symbolic(self.equation, self.ctx.run, total, variable_slot=self._variable_slot)
-            plan = trace.lower_residual(root, self.spec, total)
+            ic_root = self._symbolic_initial_condition()
+            plan = trace.lower_residual(root, self.spec, total, ic_root=ic_root)
             trace.combine_second_order(plan, self.spec)
             if not self._plan_matches(plan):
                 raise trace.TraceUnsupported('traced program disagrees with the callable (data-dependent control flow?)')
+            if plan.comb_w is None and not self.spec.single_call:
+                raise trace.TraceUnsupported(f'{self.spec} needs several kernel calls (generic path)')
+            self._attach_initial_condition(plan, ic_root)
             self.residual_plan = plan
             return self._with_ic_variable(plan.to_struct()), None
         except trace.TraceUnsupported as err:
             return None, str(err)
+
+    def _symbolic_initial_condition(self):
+        """ Sym DAG of a callable IC without trainable variables, or None (constant / trainable / untraceable IC) """
+        m = self.model
+        self.ic_lowering_error = None
+        if m.initial_condition is None or m.ic_constant is not None or self.ic_var_slot is not None or self.ic_trainable:
+            return None
+        try:
+            return trace.symbolic_initial_condition(m.initial_condition, self.ctx.run, m.ndims_spatial)
+        except trace.TraceUnsupported as err:
+            self.ic_lowering_error = str(err)
+            return None
+
+    def _attach_initial_condition(self, plan, ic_root):
+        """ callable IC without trainable variables: IC(x) and its derivative streams join the x-only pre-pass (symbolic
+        differentiation, trace.attach_initial_condition / lower_residual), so that a fused step holds no torch arithmetic
+        at all; anything the tracer cannot lower keeps `_ic_streams` (torch autograd over the callable, per iteration). """
+        if ic_root is None:
+            return
+        try:
+            if plan.kind == trace.RES_AFFINE:
+                trace.attach_initial_condition(plan, self.spec, ic_root)
+            if plan.ic_row is None:
+                raise trace.TraceUnsupported('initial condition does not fit the pre-pass')
+            # validation against torch autograd over the callable on random points
+            pts = torch.rand((17, self.model.total), device=self.device) + 0.25
+            want = self._ic_stream_tensor(pts, plan.comb_w)
+            got = trace.run_ic_numpy(plan, pts.cpu().numpy().astype(np.float64))
+            if got.shape != tuple(want.shape) or not np.allclose(got, want.double().cpu().numpy(), rtol=1e-4, atol=1e-5):
+                raise trace.TraceUnsupported('lowered initial condition disagrees with the callable')
+        except (trace.TraceUnsupported, NotImplementedError) as err:
+            plan.ic_row, plan.ic_const = None, None          # (unused rows stay in the pre-pass: harmless)
+            self.ic_lowering_error = str(err)
 
     def _try_compile_constraint(self, constraint):
         """ -> ({'program', 'plan', 'points', 'ic'}, None) or (None, reason). """
@@ -317,6 +355,21 @@ class Solver:
         if not create_graph:
             out = [None if t is None else t.detach() for t in out]
         return out
+
+    def _ic_stream_tensor(self, xs, comb_w):
+        """ [S_kernel, N] IC streams by torch autograd over the callable (ICs the tracer could not lower) """
+        spec = self.spec
+        n2 = spec.n2 if comb_w is None else 1
+        parts = self._ic_streams(xs, create_graph=False)
+        ic_streams = torch.zeros((1 + spec.nd + n2, xs.shape[0]), dtype=torch.float32, device=self.device)
+        for i, t in enumerate(parts):
+            if t is None:
+                continue
+            if comb_w is not None and i > spec.nd:
+                ic_streams[1 + spec.nd] += comb_w[i - 1 - spec.nd] * t.reshape(-1)
+            else:
+                ic_streams[i] = t.reshape(-1)
+        return ic_streams
 
     # ---- reference API -----------------------------------------------------------------------------------------------
     @property
@@ -530,16 +583,9 @@ class Solver:
         comb_w = self.residual_plan.comb_w if self.residual_plan is not None else None
         n2 = spec.n2 if comb_w is None else 1               # combined second-order stream: [u, firsts, sum_k c_k u_kk]
         ic_streams = None
-        if model.initial_condition is not None and model.ic_constant is None and self.ic_var_slot is None:
-            parts = self._ic_streams(xs, create_graph=False)
-            ic_streams = torch.zeros((1 + spec.nd + n2, xs.shape[0]), dtype=torch.float32, device=self.device)
-            for i, t in enumerate(parts):
-                if t is None:
-                    continue
-                if comb_w is not None and i > spec.nd:
-                    ic_streams[1 + spec.nd] += comb_w[i - 1 - spec.nd] * t.reshape(-1)
-                else:
-                    ic_streams[i] = t.reshape(-1)
+        lowered_ic = self.residual_plan is not None and self.residual_plan.ic_row is not None
+        if model.initial_condition is not None and model.ic_constant is None and self.ic_var_slot is None and not lowered_ic:
+            ic_streams = self._ic_stream_tensor(xs, comb_w)
         ws = model.workspace(xs.shape[0], spec.nd, spec.n2)
         if adam is not None:
             adam.t += 1
@@ -569,8 +615,16 @@ class Solver:
             n_global = self._global_batch if (world > 1 and getattr(self, '_global_batch', None)) else xs.shape[0] * world
             w_eq, w_con = xs.shape[0] / n_global, 1.0 / world
             if 'equation' in loss_terms:
-                leaf = model.net.jet_forward(model.flat, xs, spec.dir_cols, spec.n2,
-                                             ic_const=model.kernel_ic_const()).requires_grad_()
+                if len(spec.groups) == 1:
+                    leaf = model.net.jet_forward(model.flat, xs, spec.dir_cols, spec.n2,
+                                                 ic_const=model.kernel_ic_const()).requires_grad_()
+                else:
+                    # more directions than one kernel call carries: one forward per group of directions (u comes with each)
+                    leaf = torch.empty((spec.n_streams, xs.shape[0]), dtype=torch.float32, device=self.device)
+                    for dirs_g, n2g, idx in spec.groups:
+                        part = model.net.jet_forward(model.flat, xs, dirs_g, n2g, ic_const=model.kernel_ic_const())
+                        leaf[idx] = part
+                    leaf.requires_grad_()
                 ic_streams = None
                 if model.initial_condition is not None and model.ic_constant is None:
                     ic_streams = self._ic_streams(xs, create_graph=True)
@@ -587,9 +641,20 @@ class Solver:
                 loss = loss + (term if world == 1 else term * w_con)
             loss.backward()
             if leaf is not None and leaf.grad is not None:
-                ws = model.workspace(xs.shape[0], spec.nd, spec.n2)
-                model.net.jet_backward(model.flat, xs, leaf.grad.contiguous(), self.grads, ws, spec.dir_cols, spec.n2,
-                                       ic_const=model.kernel_ic_const(), accumulate=True)
+                if len(spec.groups) == 1:
+                    ws = model.workspace(xs.shape[0], spec.nd, spec.n2)
+                    model.net.jet_backward(model.flat, xs, leaf.grad.contiguous(), self.grads, ws, spec.dir_cols, spec.n2,
+                                           ic_const=model.kernel_ic_const(), accumulate=True)
+                else:
+                    # the parameter gradient is linear in the upstream stream gradients: one backward per group, the
+                    # gradient of u itself rides with the first group only
+                    for num, (dirs_g, n2g, idx) in enumerate(spec.groups):
+                        gin = leaf.grad[idx].contiguous()
+                        if num > 0:
+                            gin[0].zero_()
+                        ws = model.workspace(xs.shape[0], len(dirs_g), n2g)
+                        model.net.jet_backward(model.flat, xs, gin, self.grads, ws, dirs_g, n2g,
+                                               ic_const=model.kernel_ic_const(), accumulate=True)
             for name, (off, n) in model.variables.items():
                 p = getattr(model, name)
                 if p.grad is not None:

@@ -45,8 +45,14 @@ class StreamSpec:
     () = u, (c,) = du/dx_c, (c, c) = d2u/dx_c2, (a, b) = mixed partial. The kernels differentiate along
     *directions*: an input column, or -- for a mixed partial -- the diagonal e_a + e_b, whose second derivative
     u_vv = u_aa + 2 u_ab + u_bb yields u_ab = (u_vv - u_aa - u_bb) / 2 (stream index keyed ('d', a, b)).
-    Directions needing a second derivative come first. """
-    def __init__(self, requested):
+    Directions needing a second derivative come first.
+
+    One kernel call carries (nd, n2) with nd <= 3 (n2 <= nd; (3, 3) not at width 256), nd = 4 first derivatives, or -- for
+    nd <= 4 -- ONE combined second-order stream (affine residuals, `combine_second_order`). Anything beyond that
+    (five directions, four separate second derivatives, ...) is served by several calls over `groups` of at most two
+    directions each on the generic path: the streams of different directions are independent given the network, and the
+    parameter gradient is linear in the upstream stream gradients, so forward and backward split by direction. """
+    def __init__(self, requested, hp=None):
         firsts, seconds, mixed = set(), set(), set()
         for alpha in requested:
             if len(alpha) == 1:
@@ -63,9 +69,6 @@ class StreamSpec:
         self.dirs = ([(c,) for c in sorted(seconds)] + sorted(mixed) + [(c,) for c in sorted(firsts - seconds)])
         self.n2 = len(seconds) + len(mixed)
         self.nd = len(self.dirs)
-        if self.nd > MAX_DIRS:
-            raise NotImplementedError(f'{self.nd} differentiation directions ({self.dirs}) > {MAX_DIRS} supported by the '
-                                      'kernels (each mixed partial costs one extra direction)')
         self.dir_cols = [dir_code(d) for d in self.dirs]
         self.n_streams = 1 + self.nd + self.n2
         self.index = {(): 0}
@@ -78,6 +81,19 @@ class StreamSpec:
                 self.index[('d',) + d] = 1 + self.nd + k
         self.mixed = {ab: (self.index[('d',) + ab], self.index[(ab[0], ab[0])], self.index[(ab[1], ab[1])])
                       for ab in sorted(mixed)}
+        # can ONE kernel call produce all of it as separate streams?
+        self.single_call = (self.nd <= 3 and not (self.nd == 3 and self.n2 == 3 and hp == 256)) or \
+                           (self.nd == 4 and self.n2 == 0)
+        # ... or as [u, firsts, one combined second-order stream] (affine residuals only)
+        self.combinable = self.nd <= MAX_DIRS and self.n2 >= 2
+        # groups for the generic path: (direction codes, n2 of the group, stream index of each of the group's streams)
+        self.groups = []
+        step = self.nd if self.single_call else 2
+        for g0 in range(0, max(self.nd, 1), max(step, 1)):
+            ks = list(range(g0, min(g0 + step, self.nd)))
+            n2g = sum(1 for k in ks if k < self.n2)
+            idx = [0] + [1 + k for k in ks] + [1 + self.nd + k for k in ks if k < self.n2]
+            self.groups.append(([self.dir_cols[k] for k in ks], n2g, idx))
 
     def __repr__(self):
         return f'StreamSpec(dirs={self.dirs}, n2={self.n2})'
@@ -123,7 +139,7 @@ def call_with_streams(sc, equation, *args):
         active_streams.reset(token)
 
 
-def discover(equation, ctx_run, n_inputs, device='cpu'):
+def discover(equation, ctx_run, n_inputs, device='cpu', hp=None):
     """ fake run (reference model_torch.py:319-325): which streams does the equation request?
     Returns (StreamSpec, needs_x_grad). """
     sc = StreamContext(n_inputs)
@@ -135,7 +151,7 @@ def discover(equation, ctx_run, n_inputs, device='cpu'):
         xs.append(x)
     u = sc.tag(torch.rand((3, 1), device=device).requires_grad_(), ())
     ctx_run(call_with_streams, sc, equation, u, *xs)
-    return StreamSpec(sc.requested), sc.used_autograd_fallback
+    return StreamSpec(sc.requested, hp=hp), sc.used_autograd_fallback
 
 
 # ---------------------------------------------------------------------------------------------------------------
@@ -408,9 +424,13 @@ def symbolic_constraint(constraint, ctx_run, n_inputs, to_points, variable_slot=
 
 
 class _Emitter:
-    """ register-code emitter shared by the pre-pass and the main program. """
-    def __init__(self, first_temp):
+    """ register-code emitter shared by the pre-pass and the main program. Main programs are single-assignment (the
+    reverse sweep of the interpreter relies on it); the pre-pass has no reverse sweep, so with `reuse=True` its code is
+    emitted over virtual registers and `finish()` maps them onto the MAX_REGS physical ones, recycling a register after
+    its last use (an initial condition with its derivatives easily takes more ops than there are registers). """
+    def __init__(self, first_temp, reuse=False):
         self.first_temp, self.code, self.consts, self.memo, self._cidx = first_temp, [], [], {}, {}
+        self.reuse = reuse
 
     def const_slot(self, v):
         key = float(np.float32(v))
@@ -423,7 +443,7 @@ class _Emitter:
 
     def emit(self, op, a=0, b=0):
         dst = self.first_temp + sum(1 for c in self.code if c[0] != OPS['STORE'])
-        if dst >= MAX_REGS or len(self.code) >= MAX_OPS:
+        if (dst >= MAX_REGS and not self.reuse) or len(self.code) >= MAX_OPS:
             raise TraceUnsupported('residual program too long')
         self.code.append((OPS[op], dst, a, b))
         return dst
@@ -446,6 +466,52 @@ class _Emitter:
                 reg = self.emit(node.op, ra, rb)
         self.memo[key] = reg
         return reg
+
+    def finish(self):
+        """ -> (code, consts) over physical registers """
+        if not self.reuse:
+            return self.code, self.consts
+        two_reg = {OPS[k] for k in ('ADD', 'SUB', 'MUL', 'DIV')}
+        last_use = {}
+        for i, (op, dst, a, b) in enumerate(self.code):
+            if op == OPS['STORE']:
+                last_use[a] = i
+                continue
+            if op != OPS['CONST']:
+                last_use[a] = i
+            if op in two_reg:
+                last_use[b] = i
+        phys, free, out = {}, [], []
+        nxt = self.first_temp
+
+        def reg(v):
+            return v if v < self.first_temp else phys[v]
+        for i, (op, dst, a, b) in enumerate(self.code):
+            if op == OPS['STORE']:
+                out.append((op, 0, reg(a), b))
+                srcs = [a]
+            else:
+                ra = a if op == OPS['CONST'] else reg(a)
+                rb = reg(b) if op in two_reg else b
+                srcs = ([] if op == OPS['CONST'] else [a]) + ([b] if op in two_reg else [])
+                # sources that die here may lend their register to the result
+                for v in srcs:
+                    if v >= self.first_temp and last_use.get(v) == i and phys[v] not in free:
+                        free.append(phys[v])
+                if free:
+                    p = free.pop()
+                else:
+                    p = nxt
+                    nxt += 1
+                    if p >= MAX_REGS:
+                        raise TraceUnsupported('pre-pass needs more than %d live registers' % MAX_REGS)
+                phys[dst] = p
+                out.append((op, p, ra, rb))
+                continue
+            for v in srcs:
+                if v >= self.first_temp and last_use.get(v) == i and phys[v] not in free:
+                    free.append(phys[v])
+        return out, self.consts
 
 
 def _uses_streams(node, memo):
@@ -504,6 +570,9 @@ class ResidualPlan:
         self.coef_row = coef_row or [-1] * n_streams
         self.src_const, self.src_row = src_const, src_row
         self.comb_w = None          # set by `combine_second_order`: weights of the single combined second-order stream
+        # set by `attach_initial_condition`: the callable IC and its derivative streams as pre-pass rows / constants
+        self.ic_row, self.ic_const = None, None
+        self._pre_emitter, self._rows = None, None
 
     @property
     def kernel_n2(self):
@@ -513,7 +582,8 @@ class ResidualPlan:
     def to_struct(self):
         from .engine import Residual
         return Residual.build(self.kind, self.n_aux, self.pre if self.n_aux else None, self.program, self.coef,
-                              self.coef_row, self.src_const, self.src_row, self.comb_w, n_vars=self.n_vars)
+                              self.coef_row, self.src_const, self.src_row, self.comb_w, n_vars=self.n_vars,
+                              ic_row=self.ic_row, ic_const=self.ic_const)
 
 
 def combine_second_order(plan, spec):
@@ -536,11 +606,101 @@ def combine_second_order(plan, spec):
 
 
 
-def lower_residual(root, spec, n_inputs):
+def symbolic_initial_condition(initial_condition, ctx_run, n_spatial):
+    """ the callable IC (reference model_torch.py:124-127: called with the 1-D spatial columns) as a Sym DAG over input
+    columns 0 .. n_spatial-1. Raises TraceUnsupported (trainable variables, tensor constants, ops outside the program ISA). """
+    xs = [Sym('input', col=c) for c in range(n_spatial)]
+    try:
+        root = ctx_run(_call_with_variables, None, initial_condition, *xs)
+    except TraceUnsupported:
+        raise
+    except (TypeError, ValueError, AttributeError, RuntimeError, LookupError) as err:
+        raise TraceUnsupported(f'{type(err).__name__}: {err}') from err
+
+    def has_var(node, seen):
+        if id(node) in seen:
+            return False
+        seen.add(id(node))
+        return node.kind in ('var', 'stream') or any(has_var(a, seen) for a in node.args)
+    if has_var(root, set()):
+        raise TraceUnsupported('initial condition depends on trainable variables')
+    return root
+
+
+def _emit_ic_rows(pre, pre_leaf, rows, spec, ic_root, comb_w):
+    """ IC(x) and its derivative streams as further pre-pass rows -> (ic_row, ic_const) in the kernel's stream layout """
+    def along(node, direction):
+        total = Sym('const', value=0.0)
+        for c in direction:
+            total = _s_add(total, _differentiate(node, c, {}))
+        return total
+    firsts = [along(ic_root, d) for d in spec.dirs]
+    seconds = [along(firsts[k], spec.dirs[k]) for k in range(spec.n2)]
+    if comb_w is not None:
+        comb = Sym('const', value=0.0)
+        for k, w in enumerate(comb_w):
+            if w != 0.0 and k < len(seconds):
+                comb = _s_add(comb, _s_mul(Sym('const', value=float(w)), seconds[k]))
+        exprs = [ic_root] + firsts + [comb]
+    else:
+        exprs = [ic_root] + firsts + seconds
+    ic_row, ic_const = [-1] * len(exprs), [0.0] * len(exprs)
+    for s_idx, expr in enumerate(exprs):
+        if expr.kind == 'const':
+            ic_const[s_idx] = expr.value
+            continue
+        reg = pre.visit(expr, pre_leaf)
+        if reg not in rows:
+            if len(rows) >= MAX_AUX:
+                raise TraceUnsupported(f'more than {MAX_AUX} pre-pass rows with the initial condition')
+            rows.append(reg)
+            pre.code.append((OPS['STORE'], 0, reg, len(rows) - 1))
+            if len(pre.code) > MAX_OPS:
+                raise TraceUnsupported('pre-pass program too long with the initial condition')
+        ic_row[s_idx] = rows.index(reg)
+    return ic_row, ic_const
+
+
+def attach_initial_condition(plan, spec, ic_root):
+    """ IC(x) and the derivative streams the ansatz adds to u (model_torch.py:124-127 under nested D(...)): value, first /
+    second directional derivatives along the spec's directions (the combined second-order stream when the plan has one),
+    differentiated symbolically and appended to the plan's x-only pre-pass as further rows -- the step then contains no
+    torch autograd over the IC callable. Streams that are constant (zero: directions the IC does not depend on) become
+    plain numbers. AFFINE plans only (call it after `combine_second_order`); a residual PROGRAM numbers its registers
+    behind the pre-pass rows, so there the rows are emitted by `lower_residual(..., ic_root=...)` itself.
+    Raises TraceUnsupported when rows / registers / ops run out (the caller keeps torch autograd). """
+    if plan._pre_emitter is None or plan.kind != RES_AFFINE:
+        raise TraceUnsupported('plan without an open pre-pass emitter')
+    (pre, pre_leaf), rows = plan._pre_emitter, plan._rows
+    saved = (list(pre.code), list(pre.consts), dict(pre.memo), dict(pre._cidx), list(rows))
+    try:
+        ic_row, ic_const = _emit_ic_rows(pre, pre_leaf, rows, spec, ic_root, plan.comb_w)
+        plan.pre = pre.finish()
+    except TraceUnsupported:
+        pre.code[:], pre.consts[:] = saved[0], saved[1]
+        pre.memo.clear(); pre.memo.update(saved[2])
+        pre._cidx.clear(); pre._cidx.update(saved[3])
+        rows[:] = saved[4]
+        raise
+    plan.n_aux = len(rows)
+    plan.ic_row, plan.ic_const = ic_row, ic_const
+    return plan
+
+
+def run_ic_numpy(plan, xs):
+    """ fp64 host evaluation of the IC rows of a plan: [S_kernel, N] (validation of `attach_initial_condition`) """
+    n, d = xs.shape
+    aux = {}
+    regs = {c: xs[:, c].astype(np.float64) for c in range(d)}
+    _run_code_numpy(plan.pre[0], plan.pre[1], regs, n, aux)
+    return np.stack([aux[r] if r >= 0 else np.full(n, c, dtype=np.float64) for r, c in zip(plan.ic_row, plan.ic_const)])
+
+
+def lower_residual(root, spec, n_inputs, ic_root=None):
     """ DAG -> ResidualPlan. x-only sub-expressions go to the pre-pass; if the rest is affine in the streams the
     step needs no interpreter at all (every linear PDE), otherwise a register program is emitted. """
     S = spec.n_streams
-    pre = _Emitter(first_temp=n_inputs)
+    pre = _Emitter(first_temp=n_inputs, reuse=True)
     rows = []
 
     def pre_leaf(node):
@@ -569,8 +729,10 @@ def lower_residual(root, spec, n_inputs):
             else:
                 coef_row[idx] = aux_row(expr)
         src_const, src_row = (src.value, -1) if src.kind == 'const' else (0.0, aux_row(src))
-        return ResidualPlan(RES_AFFINE, n_inputs, S, (pre.code, pre.consts), len(rows), coef=coef, coef_row=coef_row,
+        plan = ResidualPlan(RES_AFFINE, n_inputs, S, pre.finish(), len(rows), coef=coef, coef_row=coef_row,
                             src_const=src_const, src_row=src_row)
+        plan._pre_emitter, plan._rows = (pre, pre_leaf), rows
+        return plan
 
     # general program: maximal x-only sub-expressions (with at least one op) become pre-pass rows
     uses = {}
@@ -584,6 +746,18 @@ def lower_residual(root, spec, n_inputs):
         for a in node.args:
             collect(a)
     collect(root)
+    ic_row = ic_const = None
+    if ic_root is not None:
+        # the callable IC joins the pre-pass BEFORE the program numbers its registers (they start behind the rows)
+        saved = (list(pre.code), list(pre.consts), dict(pre.memo), dict(pre._cidx), list(rows))
+        try:
+            ic_row, ic_const = _emit_ic_rows(pre, pre_leaf, rows, spec, ic_root, None)
+        except TraceUnsupported:
+            pre.code[:], pre.consts[:] = saved[0], saved[1]
+            pre.memo.clear(); pre.memo.update(saved[2])
+            pre._cidx.clear(); pre._cidx.update(saved[3])
+            rows[:] = saved[4]
+            ic_row = ic_const = None
     n_aux = len(rows)
     slots = set()
 
@@ -613,8 +787,10 @@ def lower_residual(root, spec, n_inputs):
     res = main.visit(root, main_leaf)
     if not main.code or main.code[-1][1] != res:
         main.emit('COPY', res)                      # the residual must be the value of the last instruction
-    return ResidualPlan(RES_PROGRAM, n_inputs, S, (pre.code, pre.consts), n_aux, program=(main.code, main.consts),
-                        n_vars=n_vars)
+    plan = ResidualPlan(RES_PROGRAM, n_inputs, S, pre.finish(), n_aux, program=(main.code, main.consts), n_vars=n_vars)
+    plan._pre_emitter, plan._rows = (pre, pre_leaf), rows
+    plan.ic_row, plan.ic_const = ic_row, ic_const
+    return plan
 
 
 def compile_program(root, spec, n_inputs):

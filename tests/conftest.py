@@ -9,7 +9,7 @@ if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
 GOLDEN_DIR = os.path.join(ROOT, 'tests', 'golden')
-GOLDEN_NAMES = ('cfg1', 'cfg2', 'cfg3', 'cfg4', 'cfg5', 'ode_sigmoid', 'mixed')
+GOLDEN_NAMES = ('cfg1', 'cfg2', 'cfg3', 'cfg4', 'cfg5', 'ode_sigmoid', 'mixed', 'heat3d')
 
 
 def pytest_configure(config):
@@ -33,6 +33,22 @@ class Golden:
 @pytest.fixture(params=GOLDEN_NAMES)
 def golden(request):
     return Golden(request.param)
+
+
+@pytest.fixture(autouse=True)
+def _deterministic_torch_rng():
+    """ every test starts from the same torch RNG state: nets are initialised from it and `Solver.fit` draws its sampler
+    key from it, so without this a test's random initial weights would depend on which tests ran before it """
+    import torch
+    torch.manual_seed(20240926)
+    yield
+
+
+def params_close(got, want, rtol, atol=3e-7):
+    """ trained parameters: relative L2 tolerance plus an absolute floor per element -- a bias that Adam has walked to
+    1e-4 carries the fp32 noise of steps of size lr, which no relative tolerance on the bias itself can absorb """
+    a, b = np.asarray(got, dtype=np.float64).ravel(), np.asarray(want, dtype=np.float64).ravel()
+    return float(np.linalg.norm(a - b)) <= rtol * float(np.linalg.norm(b)) + atol * np.sqrt(a.size)
 
 
 def rel_l2(a, b):

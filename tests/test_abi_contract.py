@@ -57,7 +57,7 @@ def test_layout_is_consistent(lib):
     assert lay.off_bl == lay.off_wl + lay.hp and lay.off_log_scale == lay.off_bl + 1 and lay.off_loss == lay.off_bl + 2
     assert lay.p_core % 4 == 0 and lay.off_extra == lay.p_core and lay.p_total == lay.p_core + 16
     a, b = net.workspace_bytes(1000, 2, 2), net.workspace_bytes(100000, 2, 2)
-    assert 0 < a <= b and net.workspace_bytes(1000, 4, 0) == 0                # nd > PINN_MAX_DIRS: no plan
+    assert 0 < a <= b and net.workspace_bytes(1000, 5, 0) == 0                # nd > PINN_MAX_DIRS: no plan
 
 
 def test_forward_and_backward_argument_checks(lib):

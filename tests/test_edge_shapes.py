@@ -6,7 +6,7 @@ import numpy as np
 import pytest
 import torch
 
-from conftest import rel_l2
+from conftest import params_close, rel_l2
 from helpers import FixedBatches, export_params, load_params
 
 CASES = {
@@ -50,7 +50,7 @@ def _run(pa, name, extra, batch):
     assert solver.last_fit_path == 'fused', solver.program_error
     np.testing.assert_allclose([float(v) for v in solver.losses], [float(v) for v in oracle.losses], rtol=2e-5)
     for got, want in zip(export_params(solver), oracle.export_params()):
-        assert rel_l2(got, want) < 5e-5
+        assert params_close(got, want, 5e-5)
     grid = [np.linspace(0.1, 0.9, 5).astype(np.float32)] * d
     assert np.abs(solver.predict(*grid) - oracle.predict(*grid)).max() < 2e-5
 

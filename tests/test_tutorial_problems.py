@@ -7,7 +7,7 @@ import numpy as np
 import pytest
 import torch
 
-from conftest import rel_l2
+from conftest import params_close, rel_l2
 from helpers import FixedBatches, export_params, load_params
 
 
@@ -95,7 +95,7 @@ def _run(pa, name, solver_extra, niters=4):
     assert solver.last_fit_path == path, (solver.last_fit_path, solver.program_error)
     np.testing.assert_allclose([float(v) for v in solver.losses], [float(v) for v in oracle.losses], rtol=5e-5)
     for got, want in zip(export_params(solver), oracle.export_params()):
-        assert rel_l2(got, want) < 1e-4
+        assert params_close(got, want, 1e-4)
     got_vars, want_vars = _variables(solver.model), _variables(oracle.model)
     assert got_vars.keys() == want_vars.keys()
     for key in got_vars:

@@ -13,33 +13,46 @@ import pydens_amd as pa     # noqa: E402
 from pydens_amd import engine   # noqa: E402
 
 
-def bench(cfg_name, lib_path, n=None, reps=30, rounds=3):
+def bench(cfg_name, lib_path, n=None, reps=None, rounds=3):
+    reps = reps or (8 if cfg_name in ('cfg3', 'cfg5') else 30)
     lib = engine.bind(ctypes.CDLL(lib_path))
     torch.manual_seed(0)
     cfg = pc.make_config(cfg_name, pa.D, torch)
     solver = pa.Solver(cfg['equation'], **cfg['solver_kwargs'], lib=lib)
-    n = n or min(cfg['n_points'], 131072)
+    n = n or (cfg['n_points'] if cfg_name == 'cfg3' else min(cfg['n_points'], 131072))
     xs = torch.from_numpy(pc.sample_points(cfg, n, seed=1)).cuda()
     for _ in range(5):
         solver._fused_step(xs, 1)
     torch.cuda.synchronize()
     lay = solver.model.net.layout
     out = []
+    lib.pinn_debug_set_flags(FLAGS)
     lib.pinn_profile_tile(1)
+    wg = []
     for _ in range(rounds):
-        ts = []
+        ts, tw = [], []
         for _ in range(reps):
             solver._fused_step(xs, 1)
             ts.append(float(lib.pinn_last_tile_ms()))
-        out.append(float(np.median(ts)))
+            tw.append(float(lib.pinn_last_wgrad_ms()))
+        out.append(round(float(np.median(ts)), 4))
+        wg.append(round(max(float(np.median(tw)), 0.0), 4))
+    if max(wg) > 0:
+        out = [f'{a:.4f}+{b:.4f}={a + b:.4f}' for a, b in zip(out, wg)]
     lib.pinn_profile_tile(0)
+    lib.pinn_debug_set_flags(0)
     loss = float(solver.grads[lay.off_loss])
     gsum = float(solver.grads[:lay.p_core].double().abs().sum())
     return out, loss, gsum, n
 
 
+FLAGS = 0
+
+
 if __name__ == '__main__':
     args = sys.argv[1:]
+    if args and args[0].startswith('--flags='):
+        FLAGS = int(args.pop(0).split('=')[1])
     cfg_name = 'cfg2'
     if args and not args[0].endswith('.so'):
         cfg_name = args.pop(0)
