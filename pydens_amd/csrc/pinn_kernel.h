@@ -751,6 +751,24 @@ PINN_DEVICE void pinn_atomic_add_wg(float* p, float v) { *p += v; }
 #endif
 
 PINN_DEVICE f32x4 pinn_ld4(const float* p) { return *reinterpret_cast<const f32x4*>(p); }
+// the per-tile slabs of the WGX kernels are written once and read once, by another launch: streaming (non-temporal) accesses
+// (same-box A/B, MI355X: at width 256 -- 5.9 GB of slab per 131 072 points -- non-temporal stores and loads take 4.8 % off
+//  the two kernels, 9.07 -> 8.64 ms; at width 128 they change nothing, so PINN_SLAB_NT_MIN_HP picks the widths)
+#ifndef PINN_SLAB_NT_MIN_HP
+#define PINN_SLAB_NT_MIN_HP 256
+#endif
+template <bool NT> PINN_DEVICE void pinn_st4_stream(f32x4* p, f32x4 v) {
+#ifndef PINN_EMU
+    if (NT) { __builtin_nontemporal_store(v, p); return; }
+#endif
+    *p = v;
+}
+template <bool NT> PINN_DEVICE f32x4 pinn_ld4_stream(const f32x4* p) {
+#ifndef PINN_EMU
+    if (NT) return __builtin_nontemporal_load(p);
+#endif
+    return *p;
+}
 PINN_DEVICE void pinn_st4(float* p, f32x4 v) { *reinterpret_cast<f32x4*>(p) = v; }
 
 // VAR (experiment bits): 1 = accumulate dW in the partial buffer although the layer count is static, 2 = two waves per
@@ -777,6 +795,7 @@ pinn_tile_kernel(const PinnKArgs A) {
     // global scratch, written in the prologue (the LDS it used to occupy is what the jets need)
     constexpr bool SLABL = (VAR & 64) != 0;
     constexpr bool WGX = (VAR & 128) != 0;
+    constexpr bool SNT = HP >= PINN_SLAB_NT_MIN_HP;        // streaming (non-temporal) slab stores
     static_assert(!WGX || (DWG && !SKIPS && !SLABL), "WGX kernels: generic depth, no skips, global slab");
     static_assert(!SLABL || (((VAR >> 4) & 3) != 0 && LHC >= 1 && !(VAR & 8) && !(VAR & 1) && C::slabl_fits(LHC)),
                   "slab-in-LDS kernels: shape-specialised, static depth, no skips, and the jets must fit");
@@ -1074,7 +1093,8 @@ pinn_tile_kernel(const PinnKArgs A) {
 #pragma unroll
                         for (int s = 0; s < S; ++s) svtop[j][mt][s] = sv[s];
                     } else {
-                        *slab_at(0, 0, j, mt) = sv[0];     // z_k = W1[:, col_k] and z_kk = 0 are rebuilt in the reverse half
+                        if (WGX) pinn_st4_stream<SNT>(slab_at(0, 0, j, mt), sv[0]);
+                        else *slab_at(0, 0, j, mt) = sv[0];     // z_k = W1[:, col_k] and z_kk = 0 are rebuilt in the reverse half
                     }
                 }
             }
@@ -1182,7 +1202,10 @@ pinn_tile_kernel(const PinnKArgs A) {
                             for (int s = 0; s < S; ++s) svtop[j][mt][s] = sv[s];
                         } else {
 #pragma unroll
-                            for (int s = 0; s < S; ++s) *slab_at(li + 1, s, j, mt) = sv[s];
+                            for (int s = 0; s < S; ++s) {
+                                if (WGX) pinn_st4_stream<SNT>(slab_at(li + 1, s, j, mt), sv[s]);
+                                else *slab_at(li + 1, s, j, mt) = sv[s];
+                            }
                         }
                     }
                 }
@@ -1397,14 +1420,23 @@ pinn_tile_kernel(const PinnKArgs A) {
             };
             // B fragments of the weight-gradient GEMM (h_{a-1}): lane (lr, lq) needs h[pt = wg_pt(m)][its unit column]
             float hfrag[(ONEBUF && !WGX) ? MT * S : 1][NTW][4];
-            if constexpr (WGX) {
-                stage(nxt, gz);
+            // gz_a goes to HBM behind the data-gradient GEMM instead of in front of it where the registers allow (width 128:
+            // -1.5 % in a same-box A/B; the GEMM's first weight loads no longer queue behind 20 stores per lane)
+#ifndef PINN_GZ_LATE_MAX_HP
+#define PINN_GZ_LATE_MAX_HP 128
+#endif
+            constexpr bool GZ_LATE = HP <= PINN_GZ_LATE_MAX_HP;
+            auto store_gz = [&]() {
 #pragma unroll
                 for (int j = 0; j < NTW; ++j)
 #pragma unroll
                     for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
-                        for (int s = 0; s < S; ++s) *gz_at(a, s, j, mt) = gz[j][mt][s];
+                        for (int s = 0; s < S; ++s) pinn_st4_stream<SNT>(gz_at(a, s, j, mt), gz[j][mt][s]);
+            };
+            if constexpr (WGX) {
+                stage(nxt, gz);
+                if (!GZ_LATE) store_gz();
             } else if constexpr (ONEBUF) {
                 // one LDS buffer: h_{a-1} -> LDS -> fragments in registers, then gz_a takes its place
                 if (!top) { stage(cur, hv); PINN_SYNC(); }
@@ -1624,6 +1656,7 @@ pinn_tile_kernel(const PinnKArgs A) {
                     PINN_SCHED_BARRIER();
                 }
             }
+            if (WGX && GZ_LATE) store_gz();
             PH(13)
             PINN_SYNC();
             PH(14)

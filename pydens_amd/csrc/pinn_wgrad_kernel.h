@@ -89,9 +89,9 @@ pinn_wgrad_kernel(const PinnKArgs A) {
             const unsigned t = (unsigned)tid;
 #pragma unroll
             for (int j = 0; j < NTW; ++j) {
-                gzr[j] = (gzp + (size_t)j * MT * NTHREADS)[t];
+                gzr[j] = pinn_ld4_stream<(HP >= PINN_SLAB_NT_MIN_HP)>(gzp + (size_t)j * MT * NTHREADS + t);
                 if (li > 0 || s == 0) {
-                    svr[j] = (svp + (size_t)j * MT * NTHREADS)[t];
+                    svr[j] = pinn_ld4_stream<(HP >= PINN_SLAB_NT_MIN_HP)>(svp + (size_t)j * MT * NTHREADS + t);
                 } else {
                     // first layer: only tanh(z) was saved; z_k = W1[:, col_k] (+ the diagonal partner), z_kk = 0
 #pragma unroll
@@ -161,7 +161,8 @@ pinn_wgrad_kernel(const PinnKArgs A) {
             }
         };
 #ifndef PINN_WG_PF
-#define PINN_WG_PF 2          // stages the HBM loads run ahead of the MFMAs (1: one register set, 2: two)
+#define PINN_WG_PF 1          // stages the HBM loads run ahead of the MFMAs (1: one register set, 2: two -- measured 1-5 %
+                              // SLOWER on MI355X: the loads are not what the waves wait for)
 #endif
 #if PINN_WG_PF == 1
         f32x4 gzr[NTW], svr[NTW], hv[NTW];
@@ -197,7 +198,7 @@ pinn_wgrad_kernel(const PinnKArgs A) {
         // stage i - 1) are turned into buffer (i + 1) & 1 and those of stage i + 2 are requested from HBM -- a load has
         // two stage times (about 16 K cycles at width 256) to arrive; with one set it had one, and under the load of 256
         // workgroups streaming at once that was not always enough (the waves sat in s_waitcnt vmcnt for a quarter of
-        // the kernel). Stage parity must be a compile-time fact (it selects registers): U groups of S stages are
+        // the kernel) -- that was the hypothesis; measured, the second set costs more than it hides. Stage parity must be a compile-time fact (it selects registers): U groups of S stages are
         // unrolled so that U * S is even.
         constexpr int U = (S % 2 == 0) ? 1 : 2;
         long long n_tiles_wg = 0;

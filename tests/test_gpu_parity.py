@@ -322,7 +322,11 @@ def test_layout_breadth_matches_the_oracle(pa, net, which):
         assert solver.last_fit_path == path
         np.testing.assert_allclose([float(v) for v in solver.losses], [float(v) for v in oracle.losses], rtol=3e-5)
         for got, want in zip(export_params(solver), oracle.export_params()):
-            assert params_close(got, want, 3e-5)
+            # (three Adam steps of size lr = 0.01: from the second step on an entry moves by lr * f(g2 / g1), so the
+            #  1e-4-level relative noise two fp32 implementations have on SMALL gradient entries of a second-order residual
+            #  shows up as ~3e-6 absolute per entry, whatever the entry's own size -- hence the absolute term; a wrong
+            #  update rule is off by lr * O(0.1 .. 1) = 1e-3 .. 1e-2. The losses above are the sharp check.)
+            assert params_close(got, want, 3e-5, atol=2e-5)
     xs = [pts[0][:, i] for i in range(2)]
     assert np.abs(solver.predict(*xs) - oracle.predict(*xs)).max() < 2e-5
 
@@ -652,3 +656,65 @@ def test_convblockmodel_subclass_as_model_plugin(pa):
     assert solver.last_fit_path == 'fused' and float(solver.losses[-1]) < float(solver.losses[0])
     with pytest.raises(NotImplementedError):
         pa.Solver(pde, ndims=1, initial_condition=0.5, model=Custom)
+
+
+def test_full_size_cfg4_against_the_chunked_oracle(pa):
+    """ BASELINE config 4 at the per-GPU batch of its 8-GPU step (131 072 points): loss and every gradient tensor against the
+    oracle evaluated in chunks (S = 2 streams: cheap enough for a test run) -- beside the prefix + shard-sum properties the
+    1 048 576-point case is tied to the oracle with. """
+    from oracle import pinn_oracle as po
+    torch.manual_seed(5)
+    cfg, solver = make_solver('cfg4', pa)
+    ocfg = pc.make_config('cfg4', po.D, torch)
+    oracle = po.OracleSolver(ocfg['equation'], **ocfg['solver_kwargs'])
+    oracle.import_params(export_params(solver))
+    pts = pc.sample_points(cfg, 131072, seed=2)
+    ev = oracle.evaluate(pts, chunk=32768)
+    solver._fused_step(torch.from_numpy(pts).cuda(), 1)
+    lay = solver.model.net.layout
+    assert abs(float(solver.grads[lay.off_loss]) - ev['loss']) <= 1e-5 * ev['loss']
+    for got, want in zip(export_grads(solver), oracle.export_grads()):
+        if want is not None:
+            assert rel_l2(got, want) < 1e-4
+
+
+def test_known_answers_of_the_tutorial(pa):
+    """ the analytic solutions the reference's tutorial plots its approximations against
+    (tutorials/1. Solving PDEs.ipynb cells 12-16, 28-34, 50-63), trained with the tutorial's own settings on the device:
+    ODE f' = 2 pi cos(2 pi x), f(0) = 1/2 -> sin(2 pi x) + 1/2; the parametric family f' = e pi cos(e pi x), f(0) = 2 ->
+    sin(e pi x) + 2; the inverse problem f' = 2 pi cos(2 pi x) - V, f(0) = 1, constraint f(1/2) = 0 -> V = 2 and
+    f = sin(2 pi x) + 1 - 2 x. """
+    xs = np.linspace(0, 1, 100).astype(np.float32)
+    torch.manual_seed(3)
+    solver = pa.Solver(lambda f, x: pa.D(f, x) - 2 * np.pi * torch.cos(2 * np.pi * x), ndims=1, initial_condition=.5,
+                       activation='Tanh', layout='fafaf', features=[12, 10, 1])
+    solver.fit(niters=500, batch_size=400, lr=0.02)
+    err = np.abs(solver.predict(xs)[:, 0] - (np.sin(2 * np.pi * xs) + .5)).max()
+    assert solver.last_fit_path == 'fused' and err < 0.02, err          # (the reference's own step reaches 0.002)
+
+    torch.manual_seed(3)
+    solver = pa.Solver(lambda f, x, e: pa.D(f, x) - e * np.pi * torch.cos(e * np.pi * x), ndims=1, initial_condition=2.0,
+                       nparams=1)                                   # default net: 'fafaf' [20, 30, 1] Sigmoid
+    sampler = pa.NS('u') & pa.NS('u', low=.5, high=5.5)
+    solver.fit(niters=7000, batch_size=700, sampler=sampler, lr=0.01)
+    for eps in (1.0, 2.5, 4.0):
+        err = np.abs(solver.predict(xs, eps)[:, 0] - (np.sin(eps * np.pi * xs) + 2)).max()
+        assert err < 0.08, (eps, err)                                # (reference: 0.013 .. 0.018)
+
+    torch.manual_seed(3)
+
+    def odevar(f, x):
+        return pa.D(f, x) - 2 * np.pi * torch.cos(2 * np.pi * x) + pa.V('new_var', data=torch.Tensor([1.0]))
+    solver = pa.Solver(odevar, ndims=1, initial_condition=1, constraints=lambda f, x: f(torch.tensor([0.5])))
+    solver.model.freeze_trainable(variables=('new_var',))
+    solver.fit(niters=200, batch_size=500, lr=0.1)
+    assert float(solver.model.new_var) == 1.0
+    err = np.abs(solver.predict(xs)[:, 0] - (np.sin(2 * np.pi * xs) + 1 - xs)).max()      # V frozen at 1
+    assert err < 0.15, err                                          # (reference: 0.02 .. 0.05)
+    solver.model.unfreeze_trainable(variables=['new_var'])
+    for _ in range(4):                                              # the tutorial's cell 60, repeated until V settles
+        solver.fit(niters=100, batch_size=100, lr=0.1, loss_terms=['equation', 'constraint_0'])
+    assert solver.last_fit_path == 'fused'
+    v = float(solver.model.new_var)
+    err = np.abs(solver.predict(xs)[:, 0] - (np.sin(2 * np.pi * xs) + 1 - 2 * xs)).max()
+    assert abs(v - 2.0) < 0.05 and err < 0.1, (v, err)              # (reference: V = 1.997 .. 2.004, error 0.006 .. 0.02)
