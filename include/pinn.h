@@ -26,6 +26,9 @@
  * direction k; 1+nd..nd+n2 = second derivative along the first n2 directions. A direction dir_cols[k] is an input
  * column c (value c) or the diagonal e_a + e_b of two columns (value a | (b + 1) << 4): the host obtains mixed partials
  * by polarisation, u_ab = (u_vv - u_aa - u_bb) / 2.  Stream arrays are stream-major: [S][N], S = 1 + nd + n2.
+ * Third order: wherever an entry point takes `n2`, the value may be PACKED as n2 | n3 << 3 -- n3 of the n2 second-order
+ * directions (the first ones, single columns) also carry a third derivative, streams 1+nd+n2 .. nd+n2+n3, S = 1 + nd + n2 + n3
+ * (built: one third-order direction with nd <= 2, i.e. u_xxx-type equations such as KdV; plain n2 < 8 means n3 = 0).
  */
 #ifndef PINN_H
 #define PINN_H

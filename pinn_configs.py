@@ -62,6 +62,13 @@ def make_config(name, D, torch):
                                        initial_condition=lambda x, y, z: 8 * x * y * z * (1 - x) * (1 - y) * (1 - z),
                                        layout='fa fa fa f', features=[40, 40, 40, 1], activation='Tanh'),
                     n_points=4096, low=[0, 0, 0, 0], high=[1, 1, 1, 1])
+    if name == 'kdv':                                            # Korteweg-de Vries: third derivative in x, first in t
+        def equation(f, x, t):
+            return D(f, t) + 6 * f * D(f, x) + D(D(D(f, x), x), x)
+        return dict(equation=equation,
+                    solver_kwargs=dict(ndims=2, boundary_condition=0.2, initial_condition=lambda x: torch.sin(PI * x) * x,
+                                       layout='fa fa fa f', features=[24, 24, 24, 1], activation='Tanh'),
+                    n_points=4096, low=[0, 0], high=[1, 1])
     raise KeyError(name)
 
 

@@ -95,6 +95,8 @@ launch_fn launcher_for(int hp) {
 int pick_n2(int nd, int n2) {
     // (nd = 4: first derivatives only; its second-order form exists as ONE combined stream, `comb`)
     static const int avail[5][5] = {{1, 0, 0, 0, 0}, {1, 1, 0, 0, 0}, {1, 0, 1, 0, 0}, {0, 0, 1, 1, 0}, {1, 0, 0, 0, 0}};
+    if (pinn_n3(n2) > 0)            // packed count with third-order streams: exact instantiations only
+        return ((nd == 1 || nd == 2) && n2 == 9) ? n2 : -1;
     if (nd < 0 || nd > 4 || n2 < 0 || n2 > nd) return -1;
     for (int k = n2; k <= nd; ++k)
         if (avail[nd][k]) return k;
@@ -147,7 +149,7 @@ int make_plan(const pinn_net* net, int64_t n_points, int nd, int n2, Plan* plan,
     if (!plan->fn) return fail("no kernel for padded hidden width %d (supported: 16, 32, 64, 128, 256)", net->lay.hp);
     plan->n2k = comb ? 1 : pick_n2(nd, n2);
     if (comb && (n2 != 1 || nd < 2 || nd > 4)) return fail("combined second-order stream needs n2 == 1 and nd in {2, 3, 4}");
-    if (plan->n2k < 0) return fail("unsupported derivative spec nd=%d n2=%d (nd <= 3 with n2 <= nd, or nd = 4 with n2 = 0 / one combined second-order stream)", nd, n2);
+    if (plan->n2k < 0) return fail("unsupported derivative spec nd=%d n2=%d n3=%d (nd <= 3 with n2 <= nd, nd = 4 with n2 = 0 / one combined second-order stream, or one third-order direction with nd <= 2)", nd, pinn_n2(n2), pinn_n3(n2));
     PinnKArgs probe;
     if (hint) {
         probe = *hint;
@@ -218,7 +220,7 @@ void fill_args(const pinn_net* net, PinnKArgs* a, const float* params, const flo
         a->inv_w[i] = 1.0f / (net->hi[i] - net->lo[i]);
     }
     for (int k = 0; k < PINN_MAX_DIRS; ++k) a->dir_cols[k] = (k < nd) ? dir_cols[k] : 0;
-    a->s_user = 1 + nd + n2;
+    a->s_user = pinn_ns(nd, n2);
     a->tile_begin = 0;
     a->tile_end = 0;                // set from the plan (set_tile_range) before every launch
 }
@@ -237,13 +239,15 @@ void typical_step_args(const pinn_net* net, PinnKArgs* a, int64_t n, int nd, int
     a->src_row = -1;
 }
 
-int check_dirs(const pinn_net* net, const int* dir_cols, int nd, int n2) {
-    if (nd < 0 || nd > PINN_MAX_DIRS || n2 < 0 || n2 > nd) return fail("bad derivative spec nd=%d n2=%d", nd, n2);
+int check_dirs(const pinn_net* net, const int* dir_cols, int nd, int n2p) {
+    const int n2 = pinn_n2(n2p), n3 = pinn_n3(n2p);       // packed count: seconds | thirds << 3 (include/pinn.h)
+    if (nd < 0 || nd > PINN_MAX_DIRS || n2 > nd || n3 > n2 || n2p < 0) return fail("bad derivative spec nd=%d n2=%d n3=%d", nd, n2, n3);
     for (int k = 0; k < nd; ++k) {
         // direction code: column a, or the diagonal e_a + e_b as a | (b + 1) << 4 (include/pinn.h)
         if (!dir_cols || dir_cols[k] < 0 || dir_cols[k] > 255) return fail("dir_cols[%d] out of range", k);
         const int a = dir_cols[k] & 15, b = ((dir_cols[k] >> 4) & 15) - 1;
         if (a >= net->lay.d || b >= net->lay.d || a == b) return fail("dir_cols[%d] names a column outside the %d inputs", k, net->lay.d);
+        if (k < n3 && b >= 0) return fail("dir_cols[%d]: third derivatives are taken along single columns, not diagonals", k);
     }
     return 0;
 }
@@ -475,7 +479,7 @@ size_t pinn_workspace_bytes(const pinn_t* net, int64_t n_points, int nd, int n2)
         // i >= 4: the same modes planned with the arguments of a typical training step (shape-specialised kernels)
         const int m = i & 3;
         const bool comb = (m == 3);
-        if (comb && (n2 < 2 || nd < 2 || nd > 4)) continue;
+        if (comb && (n2 < 2 || nd < 2 || nd > 4 || pinn_n3(n2) > 0)) continue;
         const int n2q = comb ? 1 : n2;
         PinnKArgs typical;
         const bool with_hint = i >= 4 && nd <= net->lay.d;
@@ -658,7 +662,7 @@ static int residual_step_impl(pinn_t* net, const pinn_residual_t* residual, cons
     const int comb = residual->combined ? 1 : 0;
     if (make_plan(net, n_points, nd, n2, &plan, PINN_MODE_STEP, residual->kind, comb)) return 1;
     const int d = net->lay.d;
-    const int s_user = 1 + nd + n2, s_kernel = 1 + nd + plan.n2k, shift = s_kernel - s_user;
+    const int s_user = pinn_ns(nd, n2), s_kernel = pinn_ns(nd, plan.n2k), shift = s_kernel - s_user;
     PinnKArgs a;
     fill_args(net, &a, params, xs, n_points, dir_cols, nd, n2, ic_streams, ic_const);
     a.res_kind = residual->kind;

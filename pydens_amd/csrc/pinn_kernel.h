@@ -39,6 +39,13 @@
 
 enum { PINN_MODE_FORWARD = 0, PINN_MODE_STEP = 1, PINN_MODE_BACKWARD = 2 };
 
+// Higher-order stream counts travel PACKED in one integer wherever the interface says "n2" (template parameter N2P, the
+// n2 argument of the C-ABI): low three bits = directions with a second derivative, bits 3.. = how many of THOSE (the
+// first ones) also carry a third derivative. Stream layout: [u | firsts (nd) | seconds (n2) | thirds (n3)].
+PINN_HOST_DEVICE constexpr int pinn_n2(int n2p) { return n2p & 7; }
+PINN_HOST_DEVICE constexpr int pinn_n3(int n2p) { return n2p >> 3; }
+PINN_HOST_DEVICE constexpr int pinn_ns(int nd, int n2p) { return 1 + nd + (n2p & 7) + (n2p >> 3); }
+
 constexpr int PINN_LHMAX = 4;      // hidden->hidden layers whose dW accumulators live in registers
 constexpr int PINN_XS_LD = PINN_MAX_INPUTS;
 
@@ -90,8 +97,8 @@ struct PinnKArgs {
 
 template <int HP_, int ND_, int N2_, int MT_ = 1>
 struct PinnCfg {
-    static constexpr int HP = HP_, ND = ND_, N2 = N2_, MT = MT_;
-    static constexpr int S = 1 + ND + N2;
+    static constexpr int HP = HP_, ND = ND_, N2 = pinn_n2(N2_), N3 = pinn_n3(N2_), MT = MT_;
+    static constexpr int S = pinn_ns(ND_, N2_);
     static constexpr int NT = HP / 16;                       // 16-wide unit tiles
 #ifndef PINN_NW_MAX
 #define PINN_NW_MAX 8
@@ -230,6 +237,17 @@ PINN_DEVICE float pinn_act_d3(float sv, float d1, float d2, int act) {
     return 0.0f;
 }
 
+// fourth derivative from the activation value (reverse sweep of third-order streams)
+PINN_DEVICE float pinn_act_d4(float sv, float d1, float d2, int act) {
+    if (act == PINN_ACT_TANH) return d1 * sv * (16.0f - 24.0f * sv * sv);
+    if (act == PINN_ACT_SIGMOID) {
+        const float q = 1.0f - 2.0f * sv;                        // with a = s(1 - s): s2 = a q, s3 = a (q^2 - 2 a), s4 = a q (q^2 - 8 a)
+        return d1 * q * (q * q - 8.0f * d1);
+    }
+    if (act == PINN_ACT_SIN) return sinf(sv);
+    return 0.0f;
+}
+
 // A differentiation direction is an input column c or the diagonal e_a + e_b of two columns (mixed partials by
 // polarisation: u_ab = (u_vv - u_aa - u_bb) / 2 with v = e_a + e_b). Code: a | (b + 1) << 4, b + 1 == 0 for a single column.
 PINN_DEVICE int pinn_dir_a(int code) { return code & 15; }
@@ -245,18 +263,23 @@ PINN_DEVICE float pinn_dir_weight(const float* w1row, int code) {
 // sum_k c_k d2/dx_k2 over all ND directions with run-time weights c_k (a Laplacian / wave / heat operator needs only
 // that combination, which saves N2-1 streams through every GEMM). Both are instances of "second stream j collects
 // direction k with weight w": the helpers below give the stream index and weight of direction k.
-template <int ND, int N2, bool COMB>
+template <int ND, int N2P, bool COMB>
 struct PinnJet {
-    static constexpr int S = 1 + ND + N2;
+    static constexpr int N2 = pinn_n2(N2P), N3 = pinn_n3(N2P);
+    static constexpr int S = pinn_ns(ND, N2P);
+    static_assert(!COMB || N3 == 0, "third-order streams do not combine");
+    static_assert(N3 <= N2 && N2 <= ND, "third-order directions are the first of the second-order ones");
+    static PINN_DEVICE int idx3(int k) { return 1 + ND + N2 + k; }         // third derivative along direction k < N3
     static PINN_DEVICE bool has2(int k) { return COMB ? true : k < N2; }
     static PINN_DEVICE int idx2(int k) { return COMB ? 1 + ND : 1 + ND + k; }
     static PINN_DEVICE float w(int k, const float* cw) { return COMB ? cw[k] : 1.0f; }
 };
 
 // forward jet of one (point, unit): z[S] pre-activations -> h[S] activations
-template <int ND, int N2, bool COMB = false>
-PINN_DEVICE void pinn_jet_fwd(const float (&z)[1 + ND + N2], int act, float (&h)[1 + ND + N2], const float* cw = nullptr) {
-    using J = PinnJet<ND, N2, COMB>;
+template <int ND, int N2P, bool COMB = false>
+PINN_DEVICE void pinn_jet_fwd(const float (&z)[pinn_ns(ND, N2P)], int act, float (&h)[pinn_ns(ND, N2P)], const float* cw = nullptr) {
+    using J = PinnJet<ND, N2P, COMB>;
+    constexpr int N2 = J::N2, N3 = J::N3;
     const float v = pinn_act(z[0], act);
     float d1, d2;
     pinn_act_d12(pinn_act_saved(v, z[0], act), act, d1, d2);
@@ -268,13 +291,23 @@ PINN_DEVICE void pinn_jet_fwd(const float (&z)[1 + ND + N2], int act, float (&h)
 #pragma unroll
     for (int k = 0; k < ND; ++k)
         if (J::has2(k)) h[J::idx2(k)] += d2 * J::w(k, cw) * z[1 + k] * z[1 + k];
+    if (N3 > 0) {
+        // third order along direction k < N3: h''' = s' z''' + 3 s'' z' z'' + s''' z'^3
+        const float d3 = pinn_act_d3(pinn_act_saved(v, z[0], act), d1, d2, act);
+#pragma unroll
+        for (int k = 0; k < N3; ++k) {
+            const float z1 = z[1 + k], z2 = z[1 + ND + k];
+            h[J::idx3(k)] = d1 * z[J::idx3(k)] + 3.0f * d2 * z1 * z2 + d3 * z1 * z1 * z1;
+        }
+    }
 }
 
 // activations h[S] recomputed from the saved form (v, z_k, z_kk)
-template <int ND, int N2, bool COMB = false>
-PINN_DEVICE void pinn_jet_recompute(const float (&sv)[1 + ND + N2], int act, float (&h)[1 + ND + N2],
+template <int ND, int N2P, bool COMB = false>
+PINN_DEVICE void pinn_jet_recompute(const float (&sv)[pinn_ns(ND, N2P)], int act, float (&h)[pinn_ns(ND, N2P)],
                                     const float* cw = nullptr) {
-    using J = PinnJet<ND, N2, COMB>;
+    using J = PinnJet<ND, N2P, COMB>;
+    constexpr int N2 = J::N2, N3 = J::N3;
     float d1, d2;
     pinn_act_d12(sv[0], act, d1, d2);
     h[0] = pinn_act_value(sv[0], act);
@@ -285,13 +318,22 @@ PINN_DEVICE void pinn_jet_recompute(const float (&sv)[1 + ND + N2], int act, flo
 #pragma unroll
     for (int k = 0; k < ND; ++k)
         if (J::has2(k)) h[J::idx2(k)] += d2 * J::w(k, cw) * sv[1 + k] * sv[1 + k];
+    if (N3 > 0) {
+        const float d3 = pinn_act_d3(sv[0], d1, d2, act);
+#pragma unroll
+        for (int k = 0; k < N3; ++k) {
+            const float z1 = sv[1 + k], z2 = sv[1 + ND + k];
+            h[J::idx3(k)] = d1 * sv[J::idx3(k)] + 3.0f * d2 * z1 * z2 + d3 * z1 * z1 * z1;
+        }
+    }
 }
 
 // reverse jet: gh[S] = dL/dh streams -> gz[S] = dL/dz streams
-template <int ND, int N2, bool COMB = false>
-PINN_DEVICE void pinn_jet_bwd(const float (&gh)[1 + ND + N2], const float (&sv)[1 + ND + N2], int act,
-                              float (&gz)[1 + ND + N2], const float* cw = nullptr) {
-    using J = PinnJet<ND, N2, COMB>;
+template <int ND, int N2P, bool COMB = false>
+PINN_DEVICE void pinn_jet_bwd(const float (&gh)[pinn_ns(ND, N2P)], const float (&sv)[pinn_ns(ND, N2P)], int act,
+                              float (&gz)[pinn_ns(ND, N2P)], const float* cw = nullptr) {
+    using J = PinnJet<ND, N2P, COMB>;
+    constexpr int N2 = J::N2, N3 = J::N3;
     const float v = sv[0];
     float d1, d2;
     pinn_act_d12(v, act, d1, d2);
@@ -313,6 +355,18 @@ PINN_DEVICE void pinn_jet_bwd(const float (&gh)[1 + ND + N2], const float (&sv)[
             acc += d3 * zk * zk * ghkk;
         }
         gz[1 + k] = gzk;
+    }
+    if (N3 > 0) {
+        // adjoint of h''' = s' z''' + 3 s'' z' z'' + s''' z'^3 (the activation's derivatives depend on z0 as well)
+        const float d4 = pinn_act_d4(v, d1, d2, act);
+#pragma unroll
+        for (int k = 0; k < N3; ++k) {
+            const float z1 = sv[1 + k], z2 = sv[1 + ND + k], z3 = sv[J::idx3(k)], g3 = gh[J::idx3(k)];
+            gz[J::idx3(k)] = d1 * g3;
+            gz[1 + ND + k] += 3.0f * d2 * z1 * g3;
+            gz[1 + k] += (3.0f * d3 * z1 * z1 + 3.0f * d2 * z2) * g3;
+            acc += (d4 * z1 * z1 * z1 + 3.0f * d3 * z1 * z2 + d2 * z3) * g3;
+        }
     }
     gz[0] = acc;
 }
@@ -428,9 +482,9 @@ PINN_DEVICE void pinn_prog_backward(const pinn_program_t& pg, const float* regs,
 // point stage: ansatz forward, residual / upstream gradient, ansatz reverse.  One thread per point of the tile.
 // Formulas: oracle/jet_f64.py (ansatz_forward / ansatz_backward), i.e. model_torch.py:107-128 + product rule.
 // ------------------------------------------------------------------------------------------------------------
-template <int ND, int N2>
+template <int ND, int N2P>
 struct PinnPointOut {
-    float gnet[1 + ND + N2];
+    float gnet[pinn_ns(ND, N2P)];
     float loss, g_ls;
     float g_ic;        // d(loss)/du of the point = its share of d(loss)/d(constant initial value)
 };
@@ -463,17 +517,17 @@ struct PinnShape {
     static PINN_DEVICE int coef_row(const PinnKArgs& A, int s) { return FIXED ? -1 : A.coef_row[s]; }
 };
 
-template <int ND, int N2>
+template <int ND, int N2P>
 struct PinnPointPre {
     float src;                       // affine source term F
-    float cs[1 + ND + N2];           // affine coefficients C_s
-    float ic[1 + ND + N2];           // IC streams
+    float cs[pinn_ns(ND, N2P)];      // affine coefficients C_s
+    float ic[pinn_ns(ND, N2P)];      // IC streams
 };
 
-template <int ND, int N2, int SPEC = 0>
+template <int ND, int N2P, int SPEC = 0>
 PINN_DEVICE void pinn_point_prefetch(const PinnKArgs& A, long long gidx, bool valid, float* pregs, int T,
-                                     PinnPointPre<ND, N2>& pre) {
-    constexpr int S = 1 + ND + N2;
+                                     PinnPointPre<ND, N2P>& pre) {
+    constexpr int S = pinn_ns(ND, N2P);
     using SH = PinnShape<SPEC, ND>;
     const long long gi = valid ? gidx : 0;
     pre.src = A.src_const;
@@ -506,12 +560,12 @@ PINN_DEVICE void pinn_point_prefetch(const PinnKArgs& A, long long gidx, bool va
     }
 }
 
-template <int ND, int N2, bool WITH_PROGRAMS = true, bool COMB = false, int SPEC = 0>
-PINN_DEVICE void pinn_point_stage(const PinnKArgs& A, const float (&net)[1 + ND + N2], const float* x /*[d]*/,
+template <int ND, int N2P, bool WITH_PROGRAMS = true, bool COMB = false, int SPEC = 0>
+PINN_DEVICE void pinn_point_stage(const PinnKArgs& A, const float (&net)[pinn_ns(ND, N2P)], const float* x /*[d]*/,
                                   long long gidx, bool valid, float* pregs, float* padj, int T,
-                                  const PinnPointPre<ND, N2>& pre, PinnPointOut<ND, N2>& out) {
-    constexpr int S = 1 + ND + N2;
-    using J = PinnJet<ND, N2, COMB>;
+                                  const PinnPointPre<ND, N2P>& pre, PinnPointOut<ND, N2P>& out) {
+    constexpr int S = pinn_ns(ND, N2P), N2 = pinn_n2(N2P), N3 = pinn_n3(N2P);
+    using J = PinnJet<ND, N2P, COMB>;
     using SH = PinnShape<SPEC, ND>;
     constexpr int NIN = SH::FIXED ? (ND > 0 ? ND : 1) : PINN_MAX_INPUTS;   // input columns the box factors may range over
     const float* cw = A.comb_w;
@@ -577,14 +631,22 @@ PINN_DEVICE void pinn_point_stage(const PinnKArgs& A, const float (&net)[1 + ND 
 #pragma unroll
         for (int k = 0; k < ND; ++k)
             if (J::has2(k)) Q[J::idx2(k)] += J::w(k, cw) * (2.0f * net[1 + k] * Pk[k] + net[0] * Pkk[k]);
+        // third order (single-column directions: every factor of P is quadratic in its column, so P''' = 0):
+        // Q''' = net''' P + 3 net'' P' + 3 net' P''
+#pragma unroll
+        for (int k = 0; k < N3; ++k)
+            Q[J::idx3(k)] = net[J::idx3(k)] * P + 3.0f * (net[1 + ND + k] * Pk[k] + net[1 + k] * Pkk[k]);
     }
     // ---- IC gate G = sigmoid(tau) - 1/2, tau = (t - t0) exp(-log_scale) -----------------------------------------
     float u[S];
 #pragma unroll
     for (int s = 0; s < S; ++s) u[s] = Q[s];
     float G = 1.0f, Gk[ND > 0 ? ND : 1], Gkk[ND > 0 ? ND : 1], dG = 0.0f, dGk[ND > 0 ? ND : 1], dGkk[ND > 0 ? ND : 1];
+    float Gkkk[N3 > 0 ? N3 : 1], dGkkk[N3 > 0 ? N3 : 1];
 #pragma unroll
     for (int k = 0; k < ND; ++k) { Gk[k] = 0.0f; Gkk[k] = 0.0f; dGk[k] = 0.0f; dGkk[k] = 0.0f; }
+#pragma unroll
+    for (int k = 0; k < (N3 > 0 ? N3 : 1); ++k) { Gkkk[k] = 0.0f; dGkkk[k] = 0.0f; }
     if (SH::has_ic(A)) {
         const int tcol = SH::ndims(A) - 1;
         const float es = expf(-A.params[A.off_ls]);
@@ -601,6 +663,12 @@ PINN_DEVICE void pinn_point_stage(const PinnKArgs& A, const float (&net)[1 + ND 
                 Gk[k] = d1 * es; Gkk[k] = d2 * es * es;
                 dGk[k] = es * (-tau * d2 - d1);
                 dGkk[k] = es * es * (-tau * d3 - 2.0f * d2);
+                if (k < N3) {
+                    // G''' = s'''(tau) es^3 and its derivative with respect to log_scale (d tau / ds = -tau, d es / ds = -es)
+                    const float d4 = pinn_act_d4(sg, d1, d2, PINN_ACT_SIGMOID);
+                    Gkkk[k] = d3 * es * es * es;
+                    dGkkk[k] = es * es * es * (-tau * d4 - 3.0f * d3);
+                }
             }
         }
         u[0] = G * Q[0];
@@ -611,6 +679,10 @@ PINN_DEVICE void pinn_point_stage(const PinnKArgs& A, const float (&net)[1 + ND 
 #pragma unroll
         for (int k = 0; k < ND; ++k)
             if (J::has2(k)) u[J::idx2(k)] += J::w(k, cw) * (Gkk[k] * Q[0] + 2.0f * Gk[k] * Q[1 + k]);
+        // u''' = G Q''' + 3 G' Q'' + 3 G'' Q' + G''' Q
+#pragma unroll
+        for (int k = 0; k < N3; ++k)
+            u[J::idx3(k)] = G * Q[J::idx3(k)] + 3.0f * (Gk[k] * Q[1 + ND + k] + Gkk[k] * Q[1 + k]) + Gkkk[k] * Q[0];
 #pragma unroll
         for (int s = 0; s < S; ++s) u[s] += pre.ic[s];
     }
@@ -691,6 +763,16 @@ PINN_DEVICE void pinn_point_stage(const PinnKArgs& A, const float (&net)[1 + ND 
             }
             g_ls += gGk * dGk[k];
         }
+#pragma unroll
+        for (int k = 0; k < N3; ++k) {
+            const float g3 = gu[J::idx3(k)];
+            gQ[J::idx3(k)] = g3 * G;
+            gQ[1 + ND + k] += 3.0f * g3 * Gk[k];
+            gQ[1 + k] += 3.0f * g3 * Gkk[k];
+            gQ[0] += g3 * Gkkk[k];
+            gG += g3 * Q[J::idx3(k)];
+            g_ls += g3 * (3.0f * (Q[1 + ND + k] * dGk[k] + Q[1 + k] * dGkk[k]) + Q[0] * dGkkk[k]);
+        }
         g_ls += gG * dG;
     }
     // ---- reverse: Q -> net (BC factor) -----------------------------------------------------------------------
@@ -710,6 +792,13 @@ PINN_DEVICE void pinn_point_stage(const PinnKArgs& A, const float (&net)[1 + ND 
                 g1 += 2.0f * gkk * Pk[k];
             }
             out.gnet[1 + k] = g1;
+        }
+#pragma unroll
+        for (int k = 0; k < N3; ++k) {
+            const float g3 = gQ[J::idx3(k)];
+            out.gnet[J::idx3(k)] = g3 * P;
+            out.gnet[1 + ND + k] += 3.0f * g3 * Pk[k];
+            out.gnet[1 + k] += 3.0f * g3 * Pkk[k];
         }
         out.gnet[0] = g0;
     }
@@ -1073,7 +1162,7 @@ pinn_tile_kernel(const PinnKArgs A) {
 #pragma unroll
                     for (int k = 0; k < ND; ++k) z[1 + k] = pinn_dir_weight(W1s + n * PINN_XS_LD, SH::dir(A, k));
 #pragma unroll
-                    for (int k = 0; k < N2; ++k) z[1 + ND + k] = 0.0f;
+                    for (int s = 1 + ND; s < S; ++s) z[s] = 0.0f;              // z_kk = z_kkk = 0 in the first layer
                     pinn_jet_fwd<ND, N2, COMB>(z, act0, h, cw);
 #pragma unroll
                     for (int s = 0; s < S; ++s) { hv[s][r] = h[s]; sv[s][r] = (s == 0) ? pinn_act_saved(h[0], z[0], act0) : z[s]; }
@@ -1297,7 +1386,7 @@ pinn_tile_kernel(const PinnKArgs A) {
                             for (int k = 0; k < ND; ++k)
                                 dst[j][mt][1 + k][r] = pinn_dir_weight(W1s + (unit0(j) + r) * PINN_XS_LD, SH::dir(A, k));
 #pragma unroll
-                            for (int k = 0; k < N2; ++k) dst[j][mt][1 + ND + k][r] = 0.0f;
+                            for (int s = 1 + ND; s < S; ++s) dst[j][mt][s][r] = 0.0f;
                         }
                     } else {
 #pragma unroll

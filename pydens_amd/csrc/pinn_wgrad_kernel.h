@@ -41,7 +41,7 @@ PINN_GLOBAL void PINN_LAUNCH_BOUNDS2((PinnWgCfg<HP, ND, N2, MT>::NTHREADS), (2 *
 pinn_wgrad_kernel(const PinnKArgs A) {
     using W = PinnWgCfg<HP, ND, N2, MT>;
     using C = typename W::C;
-    using J = PinnJet<ND, N2, COMB>;
+    constexpr int N2n = pinn_n2(N2), N3n = pinn_n3(N2);           // (N2 is the packed count, pinn_kernel.h)
     constexpr int S = W::S, NTW = W::NTW, NTHREADS = W::NTHREADS, LDK = W::LDK, AM = W::AM, BN = W::BN, OPER = W::OPER;
     const int tid = PINN_TID, lane = tid & 63, wave = tid >> 6;
     const int lr = lane & 15, lq = lane >> 4;
@@ -102,7 +102,8 @@ pinn_wgrad_kernel(const PinnKArgs A) {
         };
         // h_s of the saved jets, stream by stream in ascending s (d1, d2 and the z_k^2 terms ride along in registers: one
         // running sum_k c_k z_k^2 for the combined second-order stream, else z_k^2 of the N2 directions that have one)
-        f32x4 d1v[NTW], d2v[NTW], zz[(COMB || N2 == 0) ? 1 : N2][NTW];
+        f32x4 d1v[NTW], d2v[NTW], zz[(COMB || N2n == 0) ? 1 : N2n][NTW];
+        f32x4 z1v[N3n > 0 ? N3n : 1][NTW], z2v[N3n > 0 ? N3n : 1][NTW];      // first / second streams of the third-order directions
         auto transform = [&](int s, const f32x4 (&svr)[NTW], f32x4 (&hv)[NTW]) {
 #pragma unroll
             for (int j = 0; j < NTW; ++j) {
@@ -117,10 +118,19 @@ pinn_wgrad_kernel(const PinnKArgs A) {
                     } else if (s <= ND) {
                         hv[j][r] = d1v[j][r] * svr[j][r];
                         if (COMB) zz[0][j][r] = fmaf(cw[s - 1], svr[j][r] * svr[j][r], zz[0][j][r]);
-                        else if (s - 1 < N2) zz[(COMB || N2 == 0) ? 0 : s - 1][j][r] = svr[j][r] * svr[j][r];
-                    } else {
-                        const float q = zz[(COMB || N2 == 0) ? 0 : s - 1 - ND][j][r];
+                        else if (s - 1 < N2n) zz[(COMB || N2n == 0) ? 0 : s - 1][j][r] = svr[j][r] * svr[j][r];
+                        if (s - 1 < N3n) z1v[N3n > 0 ? s - 1 : 0][j][r] = svr[j][r];
+                    } else if (s <= ND + N2n) {
+                        const float q = zz[(COMB || N2n == 0) ? 0 : s - 1 - ND][j][r];
                         hv[j][r] = fmaf(d2v[j][r], q, d1v[j][r] * svr[j][r]);
+                        if (s - 1 - ND < N3n) z2v[N3n > 0 ? s - 1 - ND : 0][j][r] = svr[j][r];
+                    } else {
+                        // third order: h3 = a1 z3 + 3 a2 z1 z2 + a3 z1^3 with the activation's derivatives a1, a2, a3; a3 from
+                        // a1 (tanh: a1 (4 - 6 a1), sigmoid: a1 (1 - 6 a1) -- the only activations that reach this kernel)
+                        const int k = N3n > 0 ? s - 1 - ND - N2n : 0;
+                        const float d1 = d1v[j][r], d2 = d2v[j][r], z1 = z1v[k][j][r], z2 = z2v[k][j][r];
+                        const float d3 = (act == PINN_ACT_TANH) ? d1 * (4.0f - 6.0f * d1) : d1 * (1.0f - 6.0f * d1);
+                        hv[j][r] = d1 * svr[j][r] + 3.0f * d2 * z1 * z2 + d3 * z1 * z1 * z1;
                     }
                 }
             }

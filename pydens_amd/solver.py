@@ -352,6 +352,10 @@ class Solver:
                     g2 = along(g1, direction)
                     if g2 is not None:
                         out[1 + spec.nd + k] = g2.view(-1, 1)
+                        if k < spec.n3:
+                            g3 = along(g2, direction)
+                            if g3 is not None:
+                                out[1 + spec.nd + spec.n2 + k] = g3.view(-1, 1)
         if not create_graph:
             out = [None if t is None else t.detach() for t in out]
         return out
@@ -361,7 +365,8 @@ class Solver:
         spec = self.spec
         n2 = spec.n2 if comb_w is None else 1
         parts = self._ic_streams(xs, create_graph=False)
-        ic_streams = torch.zeros((1 + spec.nd + n2, xs.shape[0]), dtype=torch.float32, device=self.device)
+        ic_streams = torch.zeros((1 + spec.nd + n2 + (spec.n3 if comb_w is None else 0), xs.shape[0]), dtype=torch.float32,
+                                 device=self.device)
         for i, t in enumerate(parts):
             if t is None:
                 continue
@@ -581,12 +586,12 @@ class Solver:
     def _fused_step(self, xs, world, adam=None, loss_out=None, stream=None):
         model, spec = self.model, self.spec
         comb_w = self.residual_plan.comb_w if self.residual_plan is not None else None
-        n2 = spec.n2 if comb_w is None else 1               # combined second-order stream: [u, firsts, sum_k c_k u_kk]
+        n2 = spec.n2p if comb_w is None else 1              # combined second-order stream: [u, firsts, sum_k c_k u_kk]
         ic_streams = None
         lowered_ic = self.residual_plan is not None and self.residual_plan.ic_row is not None
         if model.initial_condition is not None and model.ic_constant is None and self.ic_var_slot is None and not lowered_ic:
             ic_streams = self._ic_stream_tensor(xs, comb_w)
-        ws = model.workspace(xs.shape[0], spec.nd, spec.n2)
+        ws = model.workspace(xs.shape[0], spec.nd, spec.n2p)
         if adam is not None:
             adam.t += 1
             model.net.residual_adam_step(self.program, model.flat, xs, self.grads, ws, adam.exp_avg, adam.exp_avg_sq,
@@ -616,7 +621,7 @@ class Solver:
             w_eq, w_con = xs.shape[0] / n_global, 1.0 / world
             if 'equation' in loss_terms:
                 if len(spec.groups) == 1:
-                    leaf = model.net.jet_forward(model.flat, xs, spec.dir_cols, spec.n2,
+                    leaf = model.net.jet_forward(model.flat, xs, spec.dir_cols, spec.n2p,
                                                  ic_const=model.kernel_ic_const()).requires_grad_()
                 else:
                     # more directions than one kernel call carries: one forward per group of directions (u comes with each)
@@ -642,8 +647,8 @@ class Solver:
             loss.backward()
             if leaf is not None and leaf.grad is not None:
                 if len(spec.groups) == 1:
-                    ws = model.workspace(xs.shape[0], spec.nd, spec.n2)
-                    model.net.jet_backward(model.flat, xs, leaf.grad.contiguous(), self.grads, ws, spec.dir_cols, spec.n2,
+                    ws = model.workspace(xs.shape[0], spec.nd, spec.n2p)
+                    model.net.jet_backward(model.flat, xs, leaf.grad.contiguous(), self.grads, ws, spec.dir_cols, spec.n2p,
                                            ic_const=model.kernel_ic_const(), accumulate=True)
                 else:
                     # the parameter gradient is linear in the upstream stream gradients: one backward per group, the

@@ -53,7 +53,7 @@ class StreamSpec:
     directions each on the generic path: the streams of different directions are independent given the network, and the
     parameter gradient is linear in the upstream stream gradients, so forward and backward split by direction. """
     def __init__(self, requested, hp=None):
-        firsts, seconds, mixed = set(), set(), set()
+        firsts, seconds, mixed, thirds = set(), set(), set(), set()
         for alpha in requested:
             if len(alpha) == 1:
                 firsts.add(alpha[0])
@@ -61,39 +61,58 @@ class StreamSpec:
                 seconds.add(alpha[0])
             elif len(alpha) == 2:
                 mixed.add(tuple(alpha)); seconds.update(alpha)
+            elif len(alpha) == 3 and alpha[0] == alpha[1] == alpha[2]:
+                thirds.add(alpha[0]); seconds.add(alpha[0])
             elif len(alpha) > 2:
                 raise NotImplementedError(
-                    f'derivative multi-index {alpha}: the HIP kernels provide first and second derivatives '
-                    '(third order is listed under "next" in DESIGN.md)')
+                    f'derivative multi-index {alpha}: the HIP kernels provide first and second derivatives incl. mixed '
+                    'partials, and third derivatives along single columns (u_xxx); mixed third-order partials and orders '
+                    'above three are not built')
         firsts |= seconds
-        self.dirs = ([(c,) for c in sorted(seconds)] + sorted(mixed) + [(c,) for c in sorted(firsts - seconds)])
+        # directions: third-order columns first, then the other second-order ones, the diagonals, the first-order rest
+        self.dirs = ([(c,) for c in sorted(thirds)] + [(c,) for c in sorted(seconds - thirds)] + sorted(mixed)
+                     + [(c,) for c in sorted(firsts - seconds)])
+        self.n3 = len(thirds)
         self.n2 = len(seconds) + len(mixed)
         self.nd = len(self.dirs)
+        self.n2p = self.n2 | (self.n3 << 3)          # packed count of the C-ABI (include/pinn.h)
         self.dir_cols = [dir_code(d) for d in self.dirs]
-        self.n_streams = 1 + self.nd + self.n2
+        self.n_streams = 1 + self.nd + self.n2 + self.n3
         self.index = {(): 0}
         for k, d in enumerate(self.dirs):
             if len(d) == 1:
                 self.index[(d[0],)] = 1 + k
                 if k < self.n2:
                     self.index[(d[0], d[0])] = 1 + self.nd + k
+                if k < self.n3:
+                    self.index[(d[0], d[0], d[0])] = 1 + self.nd + self.n2 + k
             else:
                 self.index[('d',) + d] = 1 + self.nd + k
         self.mixed = {ab: (self.index[('d',) + ab], self.index[(ab[0], ab[0])], self.index[(ab[1], ab[1])])
                       for ab in sorted(mixed)}
         # can ONE kernel call produce all of it as separate streams?
-        self.single_call = (self.nd <= 3 and not (self.nd == 3 and self.n2 == 3 and hp == 256)) or \
-                           (self.nd == 4 and self.n2 == 0)
+        if self.n3 > 0:
+            # third order: one such direction, at most two directions in all, nothing else of second order (u_xxx-type
+            # equations: KdV in (x, t), third-order ODEs); anything else with a third derivative is not built
+            if not (self.n3 == 1 and self.n2 == 1 and self.nd <= 2):
+                raise NotImplementedError(f'{self.dirs} with third derivatives: the kernels are built for one third-order '
+                                          'column plus at most one first-order column (u_xxx-type equations)')
+            self.single_call = True
+        else:
+            self.single_call = (self.nd <= 3 and not (self.nd == 3 and self.n2 == 3 and hp == 256)) or \
+                               (self.nd == 4 and self.n2 == 0)
         # ... or as [u, firsts, one combined second-order stream] (affine residuals only)
-        self.combinable = self.nd <= MAX_DIRS and self.n2 >= 2
-        # groups for the generic path: (direction codes, n2 of the group, stream index of each of the group's streams)
+        self.combinable = self.nd <= MAX_DIRS and self.n2 >= 2 and self.n3 == 0
+        # groups for the generic path: (direction codes, packed n2 of the group, stream index of each of the group's streams)
         self.groups = []
         step = self.nd if self.single_call else 2
         for g0 in range(0, max(self.nd, 1), max(step, 1)):
             ks = list(range(g0, min(g0 + step, self.nd)))
             n2g = sum(1 for k in ks if k < self.n2)
-            idx = [0] + [1 + k for k in ks] + [1 + self.nd + k for k in ks if k < self.n2]
-            self.groups.append(([self.dir_cols[k] for k in ks], n2g, idx))
+            n3g = sum(1 for k in ks if k < self.n3)
+            idx = ([0] + [1 + k for k in ks] + [1 + self.nd + k for k in ks if k < self.n2]
+                   + [1 + self.nd + self.n2 + k for k in ks if k < self.n3])
+            self.groups.append(([self.dir_cols[k] for k in ks], n2g | (n3g << 3), idx))
 
     def __repr__(self):
         return f'StreamSpec(dirs={self.dirs}, n2={self.n2})'
@@ -300,8 +319,9 @@ def _differentiate(node, col, memo):
     elif node.kind == 'input':
         out = one if node.col == col else zero
     elif node.kind == 'stream':
-        if not all(isinstance(c, int) for c in node.alpha) or len(node.alpha) >= 2:
-            raise TraceUnsupported('derivative of a second-order stream (third order)')
+        if not all(isinstance(c, int) for c in node.alpha) or len(node.alpha) >= 3 or \
+                (len(node.alpha) == 2 and not (node.alpha[0] == node.alpha[1] == col)):
+            raise TraceUnsupported('derivative of a second-order stream beyond u_ccc (mixed third order / fourth order)')
         alpha = tuple(sorted(node.alpha + (col,)))
         if len(alpha) == 2 and alpha[0] != alpha[1]:
             # mixed partial by polarisation over the diagonal direction e_a + e_b
@@ -590,7 +610,7 @@ def combine_second_order(plan, spec):
     """ Affine residual whose second derivatives enter only as  sum_k c_k u_kk  with CONSTANT c_k (Laplacian, wave,
     heat operators): propagate that one combination instead of n2 separate streams. Rewrites the plan in place to the
     stream layout [u, firsts (nd), combined] and returns True; otherwise leaves it alone. """
-    if plan.kind != RES_AFFINE or spec.n2 < 2 or spec.nd > MAX_DIRS or plan.comb_w is not None:
+    if plan.kind != RES_AFFINE or spec.n2 < 2 or spec.n3 > 0 or spec.nd > MAX_DIRS or plan.comb_w is not None:
         return False
     first2 = 1 + spec.nd
     if any(plan.coef_row[first2 + k] >= 0 for k in range(spec.n2)):
@@ -636,6 +656,7 @@ def _emit_ic_rows(pre, pre_leaf, rows, spec, ic_root, comb_w):
         return total
     firsts = [along(ic_root, d) for d in spec.dirs]
     seconds = [along(firsts[k], spec.dirs[k]) for k in range(spec.n2)]
+    thirds = [along(seconds[k], spec.dirs[k]) for k in range(spec.n3)]
     if comb_w is not None:
         comb = Sym('const', value=0.0)
         for k, w in enumerate(comb_w):
@@ -643,7 +664,7 @@ def _emit_ic_rows(pre, pre_leaf, rows, spec, ic_root, comb_w):
                 comb = _s_add(comb, _s_mul(Sym('const', value=float(w)), seconds[k]))
         exprs = [ic_root] + firsts + [comb]
     else:
-        exprs = [ic_root] + firsts + seconds
+        exprs = [ic_root] + firsts + seconds + thirds
     ic_row, ic_const = [-1] * len(exprs), [0.0] * len(exprs)
     for s_idx, expr in enumerate(exprs):
         if expr.kind == 'const':

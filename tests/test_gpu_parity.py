@@ -12,7 +12,7 @@ from helpers import FixedBatches, export_grads, export_params, fit_rtol, load_pa
 
 pytestmark = pytest.mark.gpu
 
-SUPPORTED = ('cfg1', 'cfg2', 'cfg3', 'cfg4', 'cfg5', 'ode_sigmoid', 'mixed', 'heat3d')
+SUPPORTED = ('cfg1', 'cfg2', 'cfg3', 'cfg4', 'cfg5', 'ode_sigmoid', 'mixed', 'heat3d', 'kdv')
 
 
 @pytest.fixture(scope='module')
@@ -718,3 +718,45 @@ def test_known_answers_of_the_tutorial(pa):
     v = float(solver.model.new_var)
     err = np.abs(solver.predict(xs)[:, 0] - (np.sin(2 * np.pi * xs) + 1 - 2 * xs)).max()
     assert abs(v - 2.0) < 0.05 and err < 0.1, (v, err)              # (reference: V = 1.997 .. 2.004, error 0.006 .. 0.02)
+
+
+@pytest.mark.parametrize('which', ['ode_space', 'ode_time', 'wide_wgx'])
+def test_third_order_streams_on_the_gpu(pa, which):
+    """ u_xxx-type equations: third-order jets, ansatz product rules and reverse sweep on the device (fused and generic
+    paths, widths 32 and 128 -- the latter through the streamed weight-gradient kernel), arbitrated by the fp64 oracle: three
+    nested fp32 autograd sweeps of the reference's own arithmetic are off by up to 1.5e-4 here """
+    from oracle import pinn_oracle as po
+    import test_emu_engine as te
+    eq_o, kw = te._third_order_problems(po.D, torch, which)
+    oracle32 = po.OracleSolver(eq_o, **kw)
+    oracle = po.OracleSolver(eq_o, dtype=torch.float64, **kw)
+    start = oracle32.export_params()
+    oracle.import_params(start)
+    d, n = kw['ndims'], 700
+    pts = np.random.RandomState(7).rand(3, n, d).astype(np.float32)
+    if which == 'ode_time':
+        pts = 0.5 + 1.5 * pts
+    ev32, g32 = oracle32.evaluate(pts[0]), oracle32.export_grads()
+    ev, g_want = oracle.evaluate(pts[0]), oracle.export_grads()
+    oracle.fit(niters=3, batch_size=n, points=pts, lr=0.01)
+    for path in ('fused', 'generic'):
+        eq_p, kw = te._third_order_problems(pa.D, torch, which)
+        solver = pa.Solver(eq_p, **kw)
+        assert solver.spec.n3 == 1 and solver.program is not None, solver.program_error
+        load_params(solver, start)
+        if path == 'generic':
+            solver.program = None
+        else:
+            solver._fused_step(torch.from_numpy(pts[0].copy()).cuda(), 1)
+            lay = solver.model.net.layout
+            loss = float(solver.grads[lay.off_loss])
+            assert abs(loss - ev['loss']) <= max(2 * abs(ev32['loss'] - ev['loss']), 1e-5 * ev['loss'])
+            for got, want, w32 in zip(export_grads(solver), g_want, g32):
+                if want is not None:
+                    err = np.linalg.norm(np.asarray(got, dtype=np.float64) - want)
+                    assert err <= max(2 * np.linalg.norm(np.asarray(w32, dtype=np.float64) - want), 1e-4 * np.linalg.norm(want))
+        solver.fit(niters=3, batch_size=n, sampler=FixedBatches(pts), lr=0.01)
+        assert solver.last_fit_path == path
+        np.testing.assert_allclose([float(v) for v in solver.losses], [float(v) for v in oracle.losses], rtol=1e-4)
+        for got, want in zip(export_params(solver), oracle.export_params()):
+            assert params_close(got, want, 1e-4, atol=2e-5)

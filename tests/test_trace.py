@@ -36,8 +36,12 @@ def test_mixed_partials_take_a_diagonal_direction():
     plan = trace.lower_residual(trace.symbolic(eq, run, 2), spec, 2)
     assert trace.combine_second_order(plan, spec)
     np.testing.assert_allclose(plan.comb_w, [0.5, 1.5, 0.5])               # u_xy = (u_vv - u_xx - u_yy) / 2
-    with pytest.raises(NotImplementedError, match='third order'):
-        trace.discover(lambda f, x: D(D(D(f, x), x), x), run, 1)
+    # third order along ONE column is a stream of its own (packed count n2 | n3 << 3 = 9); mixed third-order partials are not built
+    spec3, _ = trace.discover(lambda f, x, t: D(f, t) + D(D(D(f, x), x), x), run, 2)
+    assert (spec3.dirs, spec3.n2, spec3.n3, spec3.n2p, spec3.n_streams) == ([(0,), (1,)], 1, 1, 9, 5)
+    assert spec3.index[(0, 0, 0)] == 4 and spec3.single_call
+    with pytest.raises(NotImplementedError, match='third'):
+        trace.discover(lambda f, x, y: D(D(D(f, x), x), y), run, 2)
     # 3 columns + 2 diagonals = 5 directions, each with a second derivative: more than one kernel call carries -> served
     # by several calls over groups of two directions (generic path), never refused
     spec, _ = trace.discover(lambda f, x, y, z: D(D(f, x), y) + D(D(f, y), z), run, 3)
@@ -210,8 +214,12 @@ def test_D_of_composite_expressions_is_differentiated_symbolically():
     streams, pts = rng.randn(spec.n_streams, 9), rng.rand(9, 2)
     got, want = [trace.run_residual_numpy(p, streams, pts) for p in plans]
     np.testing.assert_allclose(got, want, rtol=1e-12)
+    # D through a second-order stream along its own column is the third-order stream now; a MIXED third order is refused
+    root = trace.symbolic(lambda f, x: D(x * D(D(f, x), x), x), run, 1)
+    spec3, _ = trace.discover(lambda f, x: D(x * D(D(f, x), x), x), run, 1)
+    assert spec3.n3 == 1 and trace.lower_residual(root, spec3, 1).kind == trace.RES_AFFINE
     with pytest.raises(trace.TraceUnsupported, match='third order'):
-        trace.symbolic(lambda f, x: D(x * D(D(f, x), x), x), run, 1)
+        trace.symbolic(lambda f, x, y: D(x * D(D(f, x), x), y), run, 2)
 
 
 def test_random_expression_trees_survive_the_lowering():
