@@ -660,9 +660,12 @@ static int residual_step_impl(pinn_t* net, const pinn_residual_t* residual, cons
     if (residual->kind != PINN_RES_AFFINE && residual->kind != PINN_RES_PROGRAM) return fail("unknown residual kind %d", residual->kind);
     Plan plan;
     const int comb = residual->combined ? 1 : 0;
-    if (make_plan(net, n_points, nd, n2, &plan, PINN_MODE_STEP, residual->kind, comb)) return 1;
+    // (the plan itself is made below, with the call's own arguments; here only the stream count of the instantiation)
+    const int n2k = comb ? 1 : pick_n2(nd, n2);
+    if (comb && (n2 != 1 || nd < 2 || nd > 4)) return fail("combined second-order stream needs n2 == 1 and nd in {2, 3, 4}");
+    if (n2k < 0) return fail("unsupported derivative spec nd=%d n2=%d n3=%d", nd, pinn_n2(n2), pinn_n3(n2));
     const int d = net->lay.d;
-    const int s_user = pinn_ns(nd, n2), s_kernel = pinn_ns(nd, plan.n2k), shift = s_kernel - s_user;
+    const int s_user = pinn_ns(nd, n2), s_kernel = pinn_ns(nd, n2k), shift = s_kernel - s_user;
     PinnKArgs a;
     fill_args(net, &a, params, xs, n_points, dir_cols, nd, n2, ic_streams, ic_const);
     a.res_kind = residual->kind;

@@ -1018,13 +1018,18 @@ pinn_tile_kernel(const PinnKArgs A) {
 #ifndef PINN_REGB_MAX_SPEC
 #define PINN_REGB_MAX_SPEC 8
 #endif
-    constexpr bool REGB = !DWG && !(VAR & 2) && (S * MT * NTW <= (SPEC != 0 ? PINN_REGB_MAX_SPEC : PINN_REGB_MAX));
-    constexpr int W1R = 4;
-    f32x4 accBr[REGB ? PINN_LHMAX + 1 : 1][NTW], accW1r[REGB ? W1R : 1][NTW];
+#ifndef PINN_REGB_V2
+#define PINN_REGB_V2 0      // register accumulators for the bias / first-layer gradients in the two-workgroups-per-CU kernels too
+#endif
+    constexpr bool REGB = !DWG && (PINN_REGB_V2 || !(VAR & 2)) && (S * MT * NTW <= (SPEC != 0 ? PINN_REGB_MAX_SPEC : PINN_REGB_MAX));
+    // (two workgroups per CU live on 256 registers: accumulators for the layers that exist and two input columns only)
+    constexpr int W1R = (VAR & 2) ? 2 : 4;
+    constexpr int NBR = (VAR & 2) && LHC >= 0 ? LHC + 1 : PINN_LHMAX + 1;
+    f32x4 accBr[REGB ? NBR : 1][NTW], accW1r[REGB ? W1R : 1][NTW];
 #pragma unroll
     for (int j = 0; j < NTW; ++j) {
 #pragma unroll
-        for (int a = 0; a < (REGB ? PINN_LHMAX + 1 : 1); ++a) accBr[a][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+        for (int a = 0; a < (REGB ? NBR : 1); ++a) accBr[a][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
         for (int c = 0; c < (REGB ? W1R : 1); ++c) accW1r[c][j] = f32x4{0.f, 0.f, 0.f, 0.f};
     }
@@ -1755,7 +1760,7 @@ pinn_tile_kernel(const PinnKArgs A) {
         } else {
 #pragma unroll
             for (int a = PINN_LHMAX; a >= 1; --a) {
-                if (a <= lh) hidden_reverse(a, dW[a - 1], accBr[REGB ? a : 0]);
+                if (a <= lh) hidden_reverse(a, dW[a - 1], accBr[REGB && a < NBR ? a : 0]);
             }
         }
         {
@@ -1809,7 +1814,7 @@ pinn_tile_kernel(const PinnKArgs A) {
                 if (a <= lh) {
 #pragma unroll
                     for (int r = 0; r < 4; ++r) {
-                        const float t = pinn_row_sum16(accBr[REGB ? a : 0][j][r]);
+                        const float t = pinn_row_sum16(accBr[REGB && a < NBR ? a : 0][j][r]);
                         if (lr == 0) accB[a * HP + unit0(j) + r] += t;
                     }
                 }

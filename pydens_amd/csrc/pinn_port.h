@@ -78,6 +78,14 @@ PINN_DEVICE void pinn_sched_interleave() {
     if (N_MFMA - USED > 0) __builtin_amdgcn_sched_group_barrier(0x008, N_MFMA - USED > 0 ? N_MFMA - USED : 1, 0);
 #endif
 }
+// issue order inside one scheduling region: the next N_DS LDS reads FIRST, then N_MFMA matrix instructions (a fragment
+// prefetch must start its round trip before the MFMAs it hides behind; left alone the scheduler sinks it to the end of the
+// region, right in front of its first use)
+template <int N_DS, int N_MFMA>
+PINN_DEVICE void pinn_sched_reads_first() {
+    __builtin_amdgcn_sched_group_barrier(0x100, N_DS, 0);        // DS read
+    __builtin_amdgcn_sched_group_barrier(0x008, N_MFMA, 0);      // MFMA
+}
 #define PINN_INLINE_LAMBDA __attribute__((always_inline))
 #define PINN_SETPRIO(n) __builtin_amdgcn_s_setprio(n)
 #endif

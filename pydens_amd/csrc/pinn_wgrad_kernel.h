@@ -166,6 +166,7 @@ pinn_wgrad_kernel(const PinnKArgs A) {
                 for (int kk = 0; kk < 4; ++kk)
 #pragma unroll
                     for (int jn = 0; jn < BN; ++jn) acc[i][jn] = pinn_mfma16(af[kk], bf[jn][kk], acc[i][jn]);
+                if (i + 1 < AM) pinn_sched_reads_first<1, 4 * BN>();
                 PINN_SCHED_BARRIER();
                 af = afn;
             }
@@ -192,13 +193,14 @@ pinn_wgrad_kernel(const PinnKArgs A) {
                     const bool has_next = !(last_group && k + 1 == S);
                     const int nmt = (k + 1 == S) ? (mt + 1) % MT : mt;
                     const long long ntile = (k + 1 == S && mt + 1 == MT) ? tile + t_step : tile;
-                    if (has_next) load_raw(ntile, nmt, ns, gzr, svr);
+                    // (debug flags 8 / 16 / 32, timing experiments only: no barrier / no LDS staging / no HBM loads)
+                    if (has_next && !(A.debug_flags & 32)) load_raw(ntile, nmt, ns, gzr, svr);
                     mfma_stage(smem + p * 2 * OPER);
-                    if (has_next) {
+                    if (has_next && !(A.debug_flags & 16)) {
                         transform(ns, svr, hv);
                         write_stage(smem + (p ^ 1) * 2 * OPER, gzr, hv);
                     }
-                    PINN_SYNC();
+                    if (!(A.debug_flags & 8)) PINN_SYNC();
                     p ^= 1;
                 }
             }

@@ -49,5 +49,6 @@ static inline float pinn_rcp(float x) { return 1.0f / x; }
 #define PINN_SCHED_BARRIER()
 #define PINN_SCHED_IL 0
 template <int N_MFMA, int N_MEM> static inline void pinn_sched_interleave() {}
+template <int N_DS, int N_MFMA> static inline void pinn_sched_reads_first() {}
 #define PINN_INLINE_LAMBDA
 #define PINN_SETPRIO(n)
