@@ -163,7 +163,7 @@ int make_plan(const pinn_net* net, int64_t n_points, int nd, int n2, Plan* plan,
     probe.mode = mode;
     probe.res_kind = res_kind;
     probe.comb = comb;
-    long long info[10] = {0, 0, 0, 1, 1, 0, 0, 0, 0, 0};
+    long long info[11] = {0, 0, 0, 1, 1, 0, 0, 0, 0, 0, 1};
     if (plan->fn(nd, plan->n2k, &probe, 0, nullptr, 1, info))
         return fail("no kernel instantiation for width %d with nd=%d n2=%d%s", net->lay.hp, nd, plan->n2k, comb ? " (combined)" : "");
     plan->smem = (size_t)info[0];
@@ -173,7 +173,8 @@ int make_plan(const pinn_net* net, int64_t n_points, int nd, int n2, Plan* plan,
     const int64_t ntiles = (n_points + 15) / 16;
     const int64_t wg_tiles = (ntiles + info[4] - 1) / info[4];       // a two-team workgroup streams two tiles at a time
     int64_t grid = (int64_t)device_cus(net) * info[3];
-    if (grid > wg_tiles) grid = wg_tiles;
+    const int64_t teams = info[10] > 0 ? info[10] : 1;              // a two-team workgroup streams two tiles at a time
+    if (grid > (wg_tiles + teams - 1) / teams) grid = (wg_tiles + teams - 1) / teams;
     if (grid < 1) grid = 1;
     plan->grid = (int)grid;
     plan->ntiles = wg_tiles;
@@ -184,7 +185,7 @@ int make_plan(const pinn_net* net, int64_t n_points, int nd, int n2, Plan* plan,
     plan->grid2 = 0; plan->wfn = nullptr; plan->gz_vec4_per_tile = 0; plan->chunk_tiles = wg_tiles;
     if (plan->wgx) {
         plan->wfn = wgrad_launcher_for(net->lay.hp);
-        long long winfo[10] = {0, 0, 0, 1, 1, 0, 0, 0, 0, 0};
+        long long winfo[11] = {0, 0, 0, 1, 1, 0, 0, 0, 0, 0, 1};
         if (!plan->wfn || plan->wfn(nd, plan->n2k, comb, plan->mt, &probe, 0, nullptr, 1, winfo))
             return fail("no weight-gradient kernel for width %d with nd=%d n2=%d%s", net->lay.hp, nd, plan->n2k, comb ? " (combined)" : "");
         int64_t grid2 = (int64_t)device_cus(net) * winfo[3];

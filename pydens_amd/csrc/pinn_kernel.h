@@ -145,6 +145,11 @@ struct PinnCfg {
     PINN_HOST_DEVICE static constexpr int smem_floats(int lh_static) {
         return SMEM_FLOATS + (wt_fits(lh_static) ? lh_static * HP * WT_LD : 0);
     }
+    // two-team kernels (VAR 256): each team owns a block [0, O_PREG) of this carve (shape-specialised: no program registers),
+    // W^T of the static-depth net sits once behind both blocks
+    static constexpr int TEAM_FLOATS = O_PREG;
+    PINN_HOST_DEVICE static constexpr int smem_floats_teams(int lh) { return 2 * TEAM_FLOATS + (lh > 0 ? lh : 0) * HP * WT_LD; }
+    PINN_HOST_DEVICE static constexpr bool wt_fits_teams(int lh) { return lh > 0 && HP <= 64 && smem_floats_teams(lh) * 4 <= 160 * 1024; }
     // "slab in LDS" kernels (shape-specialised, affine residual: no program registers): the saved jets take the LDS
     // from O_PREG on -- one value per layer-0 unit, S jets per further activation below the top one (which stays in
     // registers) -- instead of a global slab, and W^T moves from LDS to a per-workgroup global scratch (A.wt)
@@ -864,6 +869,10 @@ PINN_DEVICE void pinn_st4(float* p, f32x4 v) { *reinterpret_cast<f32x4*>(p) = v;
 // SIMD (two workgroups per CU), 4 = no whole-layer weight prefetch; 8 = layout breadth: Sin / identity activations and
 // skip connections ('R ... +' layouts; the skipped activations ride in registers through the forward half and in extra
 // slab slots through the reverse half); 16, 32, 48 = shape facts of a common training step (PinnShape 1, 2, 3) fixed at compile time;
+// 256 = two TEAMS: one 8-wave workgroup runs two independent tile streams (team = waves 0-3 / 4-7, each with its own LDS
+// activation buffers, accumulators and slab) that share the read-only staging of W^T in LDS and end in ONE partial row --
+// the second wave per SIMD of the two-workgroups-per-CU form (VAR 2) without its prices: no transposed global weight copy
+// (a launch per step), no second partial row per CU in the reduction. Shape-specialised, static-depth kernels only.
 // 128 = WGX: the weight gradients of the hidden->hidden layers are NOT accumulated here -- the kernel streams gz_a and the
 // saved jets of every tile to HBM (lane-private, coalesced) and pinn_wgrad_kernel (pinn_wgrad_kernel.h) turns them into dW
 // with the whole HP x HP accumulator in registers (widths >= 128, where a workgroup's dW does not fit on chip).
@@ -873,8 +882,8 @@ template <int HP, int ND, int N2, int MT, int LHC, int ACTC, bool COMB = false, 
 #ifndef PINN_WAVES_PER_SIMD
 #define PINN_WAVES_PER_SIMD 1
 #endif
-PINN_GLOBAL void PINN_LAUNCH_BOUNDS2((PinnCfg<HP, ND, N2, MT>::NTHREADS),
-                                    (PinnCfg<HP, ND, N2, MT>::NW < 4 || (VAR & 2) ? 2 : PINN_WAVES_PER_SIMD))
+PINN_GLOBAL void PINN_LAUNCH_BOUNDS2((PinnCfg<HP, ND, N2, MT>::NTHREADS * ((VAR & 256) ? 2 : 1)),
+                                    (PinnCfg<HP, ND, N2, MT>::NW < 4 || (VAR & (2 | 256)) ? 2 : PINN_WAVES_PER_SIMD))
 pinn_tile_kernel(const PinnKArgs A) {
     using C = PinnCfg<HP, ND, N2, MT>;
     constexpr int S = C::S, NT = C::NT, NTW = C::NTW, NW = C::NW, T = C::T, LDA = C::LDA, NTHREADS = C::NTHREADS;
@@ -884,18 +893,26 @@ pinn_tile_kernel(const PinnKArgs A) {
     // global scratch, written in the prologue (the LDS it used to occupy is what the jets need)
     constexpr bool SLABL = (VAR & 64) != 0;
     constexpr bool WGX = (VAR & 128) != 0;
+    constexpr bool TEAMS2 = (VAR & 256) != 0;
+    constexpr int TEAMS = TEAMS2 ? 2 : 1;
+    static_assert(!TEAMS2 || (((VAR >> 4) & 3) != 0 && LHC >= 1 && !(VAR & (1 | 2 | 8 | 64 | 128)) && NW == 4 && C::wt_fits_teams(LHC)),
+                  "two-team kernels: shape-specialised, static depth, 4 waves per team, W^T of all layers in LDS");
     constexpr bool SNT = HP >= PINN_SLAB_NT_MIN_HP;        // streaming (non-temporal) slab stores
     static_assert(!WGX || (DWG && !SKIPS && !SLABL), "WGX kernels: generic depth, no skips, global slab");
     static_assert(!SLABL || (((VAR >> 4) & 3) != 0 && LHC >= 1 && !(VAR & 8) && !(VAR & 1) && C::slabl_fits(LHC)),
                   "slab-in-LDS kernels: shape-specialised, static depth, no skips, and the jets must fit");
-    constexpr bool WTL = C::wt_fits(LHC) && !SLABL && !(VAR & 2);        // transposed hidden weights staged in LDS
+    constexpr bool WTL = (C::wt_fits(LHC) && !SLABL && !(VAR & 2)) || TEAMS2;        // transposed hidden weights staged in LDS
     // widths >= 128: the data-gradient A operand comes from a transposed copy of the weights in global memory (one b128 per
     // K quad like the forward GEMM) instead of four strided global_load_dword per quad
     // (VAR 2, two workgroups per CU: W^T of both does not fit the LDS beside the activation buffers)
     constexpr bool WTG = C::WTG || SLABL || (VAR & 2) != 0;
     constexpr int SPEC = (VAR >> 4) & 3;                   // VAR 16/32/48: training shape 1/2/3 fixed at compile time
     using SH = PinnShape<SPEC, ND>;
-    const int tid = PINN_TID, lane = tid & 63, wave = tid >> 6;
+    // two teams: everything below is written in TEAM-local terms (tid, wave, LDS block, virtual block index); the teams meet
+    // at the barriers only (same trip counts by construction) and in the shared W^T
+    const int gtid = PINN_TID, team = TEAMS2 ? gtid / NTHREADS : 0;
+    const int tid = TEAMS2 ? gtid % NTHREADS : gtid, lane = tid & 63, wave = tid >> 6;
+    const int vbid = PINN_BID * TEAMS + team, vnblk = PINN_NBLK * TEAMS;
     const int lr = lane & 15, lq = lane >> 4;
     const int lh = (LHC >= 0) ? LHC : A.lh;
     // activation of index a (0: first layer ... lh: last hidden layer)
@@ -919,7 +936,8 @@ pinn_tile_kernel(const PinnKArgs A) {
     const int d = SH::d(A);
     const bool train = SH::mode(A) != PINN_MODE_FORWARD;
 
-    PINN_SMEM(smem);
+    PINN_SMEM(smem_all);
+    float* smem = smem_all + team * C::TEAM_FLOATS;            // (one team: the whole block)
     float* xs_base = smem + C::O_XS;
     float* W1s = smem + C::O_W1;
     float* b1s = smem + C::O_B1;
@@ -942,7 +960,7 @@ pinn_tile_kernel(const PinnKArgs A) {
     }
     for (int i = tid; i < HP; i += NTHREADS) { b1s[i] = A.params[A.off_b1 + i]; WLs[i] = A.params[A.off_wl + i]; }
     for (int i = tid; i < PINN_MAX_LAYERS * HP; i += NTHREADS) accB[i] = 0.0f;
-    float* WTs = smem + C::O_WT;
+    float* WTs = TEAMS2 ? smem_all + 2 * C::TEAM_FLOATS : smem + C::O_WT;
     const float* wtg = A.wt + (SLABL ? (size_t)PINN_BID * (size_t)lh * HP * HP : (size_t)0);
     if (SLABL && train) {
         // wt[l][k][n] = W_l[n][k] in this workgroup's scratch: coalesced reads along k, strided fire-and-forget writes;
@@ -959,7 +977,8 @@ pinn_tile_kernel(const PinnKArgs A) {
         // launch's Adam on other XCDs, so every batch of loads pays a full L2-miss round trip -- one instead of six or more
         // (prologue phase counters: 9.4 K -> cycles of one round trip on cfg2)
         constexpr int WT_TOTAL = (LHC > 0 ? LHC : 0) * HP * HP;
-        constexpr int WT_PER = (WT_TOTAL + NTHREADS - 1) / NTHREADS;
+        constexpr int NTH_ALL = NTHREADS * TEAMS;               // both teams stage the shared copy together
+        constexpr int WT_PER = (WT_TOTAL + NTH_ALL - 1) / NTH_ALL;
 #ifndef PINN_WT_STAGE_BATCH
 #define PINN_WT_STAGE_BATCH 64
 #endif
@@ -968,19 +987,19 @@ pinn_tile_kernel(const PinnKArgs A) {
             float wreg[WT_B];
 #pragma unroll
             for (int e = 0; e < WT_B; ++e) {
-                const int i = tid + (e0 + e) * NTHREADS;
+                const int i = gtid + (e0 + e) * NTH_ALL;
                 const int l = i / (HP * HP), n = (i / HP) % HP, k = i % HP;
                 wreg[e] = (i < WT_TOTAL) ? A.params[A.off_wh + (size_t)l * A.hidden_stride + n * HP + k] : 0.0f;
             }
 #pragma unroll
             for (int e = 0; e < WT_B; ++e) {
-                const int i = tid + (e0 + e) * NTHREADS;
+                const int i = gtid + (e0 + e) * NTH_ALL;
                 const int l = i / (HP * HP), n = (i / HP) % HP, k = i % HP;
                 if (i < WT_TOTAL) WTs[(l * HP + k) * C::WT_LD + n] = wreg[e];
             }
         }
     }
-    if (!SLABL) for (int i = tid; i < PINN_MAX_REGS * T; i += NTHREADS) padj[i] = 0.0f;
+    if (!SLABL && !TEAMS2) for (int i = tid; i < PINN_MAX_REGS * T; i += NTHREADS) padj[i] = 0.0f;   // (team blocks end before the program registers)
     const float bL = A.params[A.off_bl];
 
     // persistent per-lane accumulators
@@ -1021,10 +1040,10 @@ pinn_tile_kernel(const PinnKArgs A) {
 #ifndef PINN_REGB_V2
 #define PINN_REGB_V2 0      // register accumulators for the bias / first-layer gradients in the two-workgroups-per-CU kernels too
 #endif
-    constexpr bool REGB = !DWG && (PINN_REGB_V2 || !(VAR & 2)) && (S * MT * NTW <= (SPEC != 0 ? PINN_REGB_MAX_SPEC : PINN_REGB_MAX));
+    constexpr bool REGB = !DWG && (PINN_REGB_V2 || !(VAR & (2 | 256))) && (S * MT * NTW <= (SPEC != 0 ? PINN_REGB_MAX_SPEC : PINN_REGB_MAX));
     // (two workgroups per CU live on 256 registers: accumulators for the layers that exist and two input columns only)
-    constexpr int W1R = (VAR & 2) ? 2 : 4;
-    constexpr int NBR = (VAR & 2) && LHC >= 0 ? LHC + 1 : PINN_LHMAX + 1;
+    constexpr int W1R = (VAR & (2 | 256)) ? 2 : 4;
+    constexpr int NBR = (VAR & (2 | 256)) && LHC >= 0 ? LHC + 1 : PINN_LHMAX + 1;
     f32x4 accBr[REGB ? NBR : 1][NTW], accW1r[REGB ? W1R : 1][NTW];
 #pragma unroll
     for (int j = 0; j < NTW; ++j) {
@@ -1036,7 +1055,7 @@ pinn_tile_kernel(const PinnKArgs A) {
     float sum_loss = 0.0f, sum_ls = 0.0f, sum_bl = 0.0f, sum_ic = 0.0f;
 
     f32x4* slab = SLABL ? reinterpret_cast<f32x4*>(smem + C::O_PREG)
-                        : (A.slab ? A.slab + (size_t)PINN_BID * C::slab_vec4_per_wg(lh, SKIPS ? A.n_skips : 0) : nullptr);
+                        : (A.slab ? A.slab + (size_t)vbid * C::slab_vec4_per_wg(lh, SKIPS ? A.n_skips : 0) : nullptr);
     f32x4* gzs = nullptr;            // WGX: this tile's block of A.gzslab (set per tile, like `slab`)
     auto gz_at = [&](int a, int s, int j, int mt) -> f32x4* {      // a = 1 .. lh
         return gzs + (((size_t)((a - 1) * S + s) * NTW + j) * MT + mt) * NTHREADS + tid;
@@ -1084,20 +1103,23 @@ pinn_tile_kernel(const PinnKArgs A) {
 #else
         float* pp_regs = (A.pre_nregs * NTHREADS <= C::O_NET - C::O_BUFA) ? smem + C::O_BUFA + tid : nullptr;
 #endif
-        for (long long tile = A.tile_begin + PINN_BID + (long long)(tid / T) * PINN_NBLK; tile < ntiles; tile += (long long)(NTHREADS / T) * PINN_NBLK) {
+        for (long long tile = A.tile_begin + vbid + (long long)(tid / T) * vnblk; tile < ntiles; tile += (long long)(NTHREADS / T) * vnblk) {
             const long long gi = tile * T + tid % T;
             if (gi < A.n_points) pinn_prepass_point(A.pre, A.xs + gi * d, d, A.aux, A.n_points, gi, pp_regs, NTHREADS);
         }
         PINN_FENCE_BLOCK();
     }
-    fetch_points(A.tile_begin + PINN_BID);
+    fetch_points(A.tile_begin + vbid);
     store_points(xs_base);
-    fetch_points(A.tile_begin + PINN_BID + PINN_NBLK);
+    fetch_points(A.tile_begin + vbid + vnblk);
     PINN_SYNC();
     PH_DECL
 
     int tile_parity = 0;
-    for (long long tile = A.tile_begin + PINN_BID; tile < ntiles; tile += PINN_NBLK, tile_parity ^= 1) {
+    // (two teams: both run as many rounds as team 0 has tiles -- a team without a tile in the last round works on an empty
+    //  one: zero points, every sample invalid, contributions zero -- so that the barriers match)
+    for (long long tile0 = A.tile_begin + (long long)PINN_BID * TEAMS; tile0 < ntiles; tile0 += vnblk, tile_parity ^= 1) {
+        const long long tile = tile0 + team;
         const long long base = tile * T;
         if (WGX && train) {
             // (debug flag 4, timing experiments only: every tile writes the first tile's slab -- stores stay in L2)
@@ -1349,7 +1371,7 @@ pinn_tile_kernel(const PinnKArgs A) {
 
         // ---- (4) ansatz + residual + their reverse, one thread per point; all threads: stage the NEXT tile's points ------
         store_points(xs_next);
-        fetch_points(tile + 2LL * PINN_NBLK);
+        fetch_points(tile + 2LL * vnblk);
         if (tid < T) {
             const int pt = tid;
             float net[S];
@@ -1832,56 +1854,64 @@ pinn_tile_kernel(const PinnKArgs A) {
         }
     }
     // ---- write this workgroup's partial gradient ---------------------------------------------------------------
-    PINN_SYNC();
-    float* part = A.partials + (size_t)PINN_BID * A.p_core;
-#pragma unroll
-    for (int l = 0; l < (DWG ? 0 : PINN_LHMAX); ++l) {
-        if (l < lh) {
-            float* dst = part + A.off_wh + (size_t)l * A.hidden_stride;
-#pragma unroll
-            for (int o = 0; o < NT; ++o)
-#pragma unroll
-                for (int j = 0; j < NTW; ++j)
-#pragma unroll
-                    for (int r = 0; r < 4; ++r)
-                        dst[(o * 16 + lq * 4 + r) * HP + (wave * NTW + j) * 16 + lr] = dW[l][o][j][r];
-        }
-    }
-    for (int i = tid; i < (lh + 1) * HP; i += NTHREADS) {
-        const int a = i / HP, n = i % HP;
-        const int dst = (a == 0) ? A.off_b1 + n : A.off_wh + (a - 1) * A.hidden_stride + HP * HP + n;
-        part[dst] = accB[i];
-    }
-    for (int i = tid; i < HP * d; i += NTHREADS) part[i] = accW1[(i / d) * PINN_XS_LD + (i % d)];
-#pragma unroll
-    for (int j = 0; j < NTW; ++j) {
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            const float v = pinn_row_sum16(accWL[j][r]);
-            if (lr == 0) part[A.off_wl + unit0(j) + r] = v;
-        }
-    }
+    // (two teams: ONE row per workgroup -- team 0 stores, team 1 adds on top behind a barrier)
     if (tid < T) { scal[tid * 4 + 0] = sum_loss; scal[tid * 4 + 1] = sum_ls; scal[tid * 4 + 2] = sum_bl; scal[tid * 4 + 3] = sum_ic; }
     PINN_SYNC();
-    if (tid == 0) {
-        float l0 = 0.0f, l1 = 0.0f, l2 = 0.0f;
-        for (int i = 0; i < T; ++i) { l0 += scal[i * 4]; l1 += scal[i * 4 + 1]; l2 += scal[i * 4 + 2]; }
-        part[A.off_loss] = l0;
-        part[A.off_ls] = l1;
-        part[A.off_bl] = l2;
-        for (int i = A.off_loss + 1; i < A.p_core; ++i) part[i] = 0.0f;
-        if (SPEC == 0 && SH::mode(A) == PINN_MODE_STEP && A.res_kind == PINN_RES_PROGRAM) {
-            const int vbase = S + d + A.n_aux;
-            for (int k = 0; k < A.n_vars; ++k) {
-                float g = 0.0f;
-                for (int i = 0; i < T; ++i) g += padj[(vbase + k) * T + i];
-                part[A.off_extra + k] = g;
+    float* part = A.partials + (size_t)PINN_BID * A.p_core;
+    for (int round = 0; round < TEAMS; ++round) {
+        if (team == round) {
+            const bool add = round > 0;
+            auto put = [&](float* p, float v) { *p = add ? *p + v : v; };
+#pragma unroll
+            for (int l = 0; l < (DWG ? 0 : PINN_LHMAX); ++l) {
+                if (l < lh) {
+                    float* dst = part + A.off_wh + (size_t)l * A.hidden_stride;
+#pragma unroll
+                    for (int o = 0; o < NT; ++o)
+#pragma unroll
+                        for (int j = 0; j < NTW; ++j)
+#pragma unroll
+                            for (int r = 0; r < 4; ++r)
+                                put(dst + (o * 16 + lq * 4 + r) * HP + (wave * NTW + j) * 16 + lr, dW[l][o][j][r]);
+                }
+            }
+            for (int i = tid; i < (lh + 1) * HP; i += NTHREADS) {
+                const int a_ = i / HP, n = i % HP;
+                const int dst = (a_ == 0) ? A.off_b1 + n : A.off_wh + (a_ - 1) * A.hidden_stride + HP * HP + n;
+                put(part + dst, accB[i]);
+            }
+            for (int i = tid; i < HP * d; i += NTHREADS) put(part + i, accW1[(i / d) * PINN_XS_LD + (i % d)]);
+#pragma unroll
+            for (int j = 0; j < NTW; ++j) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const float v = pinn_row_sum16(accWL[j][r]);
+                    if (lr == 0) put(part + A.off_wl + unit0(j) + r, v);
+                }
+            }
+            if (tid == 0) {
+                float l0 = 0.0f, l1 = 0.0f, l2 = 0.0f;
+                for (int i = 0; i < T; ++i) { l0 += scal[i * 4]; l1 += scal[i * 4 + 1]; l2 += scal[i * 4 + 2]; }
+                put(part + A.off_loss, l0);
+                put(part + A.off_ls, l1);
+                put(part + A.off_bl, l2);
+                if (!add)
+                    for (int i = A.off_loss + 1; i < A.p_core; ++i) part[i] = 0.0f;
+                if (SPEC == 0 && SH::mode(A) == PINN_MODE_STEP && A.res_kind == PINN_RES_PROGRAM) {
+                    const int vbase = S + d + A.n_aux;
+                    for (int k = 0; k < A.n_vars; ++k) {
+                        float g = 0.0f;
+                        for (int i = 0; i < T; ++i) g += padj[(vbase + k) * T + i];
+                        part[A.off_extra + k] = g;
+                    }
+                }
+                if (SPEC == 0 && A.ic_var1 > 0 && SH::mode(A) == PINN_MODE_STEP) {
+                    float l3 = 0.0f;
+                    for (int i = 0; i < T; ++i) l3 += scal[i * 4 + 3];
+                    part[A.off_extra + A.ic_var1 - 1] += l3;
+                }
             }
         }
-        if (SPEC == 0 && A.ic_var1 > 0 && SH::mode(A) == PINN_MODE_STEP) {
-            float l3 = 0.0f;
-            for (int i = 0; i < T; ++i) l3 += scal[i * 4 + 3];
-            part[A.off_extra + A.ic_var1 - 1] += l3;
-        }
+        if (TEAMS2) { PINN_FENCE_BLOCK(); PINN_SYNC(); }
     }
 }
