@@ -20,7 +20,13 @@ FLAGS = ['--offload-arch=gfx950', '-O3', '-std=c++17', '-fPIC', '-x', 'hip', '-W
 # section 6): the width-256 kernels (256 VGPRs, spilling) run 4.9 % faster under `iterative-maxocc` (4.1 % under
 # `iterative-ilp`, 10 % slower under `iterative-minreg` / `max-memory-clause`); the other widths are within 1 % of the
 # default either way and keep it
-WIDTH_FLAGS = {256: ['-mllvm', '-amdgpu-sched-strategy=iterative-maxocc']}
+# round 2 (two-team width-64 kernels, streamed weight gradients): width 64 gains 1.5 % on cfg4 under `iterative-ilp` (cfg2 +-0);
+# width 256 is within 0.3 % between the default and `iterative-maxocc` now (`iterative-ilp` costs its weight-gradient kernel 27 %);
+# width 128 is within 1 % everywhere
+WIDTH_FLAGS = {256: ['-mllvm', '-amdgpu-sched-strategy=iterative-maxocc'], 64: ['-mllvm', '-amdgpu-sched-strategy=iterative-ilp']}
+if os.environ.get('PINN_WIDTH_FLAGS'):          # experiment builds: JSON {width: [flags]} replaces the table above
+    import json
+    WIDTH_FLAGS = {int(k): v for k, v in json.loads(os.environ['PINN_WIDTH_FLAGS']).items()}
 
 
 def _sources():
