@@ -231,9 +231,12 @@ float pinn_last_wgrad_ms(void);
  * "pinn_tile_kernel<64,2,1,2,3,0,true,16>" (the symbol rocprofv3 shows): bench.py names the kernel it prices with it. */
 const char* pinn_last_kernel_name(void);
 
-/* Diagnostics (tests, tools/): never used on the training path, no effect on results.
+/* Diagnostics (tests, tools/): never used on the training path. All but pinn_debug_set_flags leave results untouched;
+ * the flag bits are TIMING experiments (kernels skip loads / stores / barriers: results of such a call are meaningless).
  *   pinn_debug_last_kernel        0 = general tile kernel, 2 = shape-specialised tile kernel took the last launch
- *   pinn_debug_set_flags          experiment bits handed to the kernels (PinnKArgs::debug_flags)
+ *   pinn_debug_set_flags          experiment bits handed to the kernels (PinnKArgs::debug_flags; 0 = off, the default):
+ *                                 2 / 4 slab reads / writes of the widths >= 128 pinned to one tile (L2-resident),
+ *                                 8 / 16 / 32 weight-gradient kernel without barrier / LDS staging / HBM loads
  *   pinn_debug_prepass_in_kernel  0: x-only pre-pass as its own launch (pinn_aux_kernel) instead of the tile kernel's prologue
  *   pinn_debug_phase_buffer       device buffer for per-phase cycle counters (-DPINN_PROFILE_PHASES builds, tools/phases.py)
  *   pinn_debug_wgx_chunk_bytes    slab budget per pass of the widths >= 128 (default 6.5 GB; <= 0 restores it): tests force

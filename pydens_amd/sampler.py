@@ -44,9 +44,12 @@ class Sampler:
         if not seeds or any(s is None for s in seeds):
             return None
         key = 0x9E3779B97F4A7C15
-        for s in seeds:                       # splitmix64-style fold
-            key = (key ^ (int(s) & (2 ** 64 - 1))) * 0xBF58476D1CE4E5B9 & (2 ** 64 - 1)
-            key ^= key >> 31
+        try:
+            for s in seeds:                       # splitmix64-style fold
+                key = (key ^ (int(s) & (2 ** 64 - 1))) * 0xBF58476D1CE4E5B9 & (2 ** 64 - 1)
+                key ^= key >> 31
+        except (TypeError, ValueError):           # array-like seeds (numpy accepts them): no single integer to key a stream with
+            return None
         return key
 
     def next_device_call(self):

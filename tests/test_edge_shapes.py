@@ -31,6 +31,14 @@ CASES = {
     'sgd_by_name': (lambda D: (lambda u, x: D(u, x) - u),
                     dict(ndims=1, initial_condition=1.0, layout='fafaf', features=[8, 8, 1], activation='Tanh'), 1,
                     dict(optimizer='SGD')),
+    # the two-team kernels of the BASELINE width-64 shapes (two tile streams in one workgroup): odd tile counts leave team 1
+    # an empty tile in the last round, a batch below one tile leaves it nothing at all
+    'poisson_4x64_two_teams': (lambda D: (lambda u, x, y: D(D(u, x), x) + D(D(u, y), y) - 5 * torch.sin(np.pi * (x + y))),
+                               dict(ndims=2, boundary_condition=1, layout='fa' * 4 + 'f', features=[64] * 4 + [1],
+                                    activation='Tanh'), 2, {}),
+    'ode_family_4x64_two_teams': (lambda D: (lambda u, x, e: D(u, x) - e * np.pi * torch.cos(e * np.pi * x)),
+                                  dict(ndims=1, nparams=1, initial_condition=1, layout='fa' * 4 + 'f',
+                                       features=[64] * 4 + [1], activation='Tanh'), 2, {}),
     'shifted_domain': (lambda D: (lambda u, x, y: D(D(u, x), x) + D(D(u, y), y) - torch.exp(x)),
                        dict(ndims=2, boundary_condition=1, domain=(-1, 2), layout='fafaf', features=[16, 16, 1],
                             activation='Tanh'), 2, {}),
@@ -47,12 +55,14 @@ def _run(pa, name, extra, batch):
     pts = np.random.RandomState(2).rand(3, batch, d).astype(np.float32)
     oracle.fit(niters=3, batch_size=batch, points=pts, lr=0.01, **fit_kw)
     solver.fit(niters=3, batch_size=batch, sampler=FixedBatches(pts), lr=0.01, **fit_kw)
+    kernel = solver.model.net.lib.pinn_last_kernel_name().decode()
     assert solver.last_fit_path == 'fused', solver.program_error
     np.testing.assert_allclose([float(v) for v in solver.losses], [float(v) for v in oracle.losses], rtol=2e-5)
     for got, want in zip(export_params(solver), oracle.export_params()):
         assert params_close(got, want, 5e-5)
     grid = [np.linspace(0.1, 0.9, 5).astype(np.float32)] * d
     assert np.abs(solver.predict(*grid) - oracle.predict(*grid)).max() < 2e-5
+    return kernel
 
 
 @pytest.fixture(scope='module')
@@ -69,7 +79,11 @@ def emu_lib():
 @pytest.mark.parametrize('name', sorted(CASES))
 def test_edge_shape_on_the_emulated_kernels(name, emu_lib):
     import pydens_amd as pa
-    _run(pa, name, dict(lib=emu_lib, device='cpu'), batch=37 if 'width_100' not in name else 19)
+    kernel = _run(pa, name, dict(lib=emu_lib, device='cpu'), batch=37 if 'width_100' not in name else 19)
+    if 'two_teams' in name:
+        assert kernel.rstrip('>').endswith(('272', '304')), kernel                               # VAR 16 | 256, 48 | 256
+        _run(pa, name, dict(lib=emu_lib, device='cpu'), batch=5)                                 # less than one tile
+        _run(pa, name, dict(lib=emu_lib, device='cpu'), batch=97)                                # 7 / 4 tiles on 2 x 2 teams
 
 
 @pytest.mark.gpu
