@@ -57,6 +57,9 @@ extern "C" {
 #define PINN_ACT_SIGMOID  1
 #define PINN_ACT_SIN      2
 #define PINN_ACT_IDENTITY 3    /* no 'a' between two 'f' of the layout */
+#define PINN_ACT_SOFTPLUS 4    /* torch.nn.Softplus (beta 1, threshold 20) */
+#define PINN_ACT_SILU     5    /* torch.nn.SiLU (swish) */
+#define PINN_ACT_GELU     6    /* torch.nn.GELU (erf form) */
 
 typedef struct pinn_net pinn_t;
 

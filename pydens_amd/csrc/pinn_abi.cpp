@@ -57,7 +57,7 @@ int g_pinn_debug_flags = 0;
 struct pinn_net {
     pinn_layout_t lay;
     int n_layers, act, ndims, nparams, has_bc, has_ic, nsp;      // act: uniform activation code or -1
-    unsigned act_codes;                                           // 2 bits per activation index
+    unsigned long long act_codes;                                 // 4 bits per activation index
     int n_skips, skip_src[PINN_MAX_SKIPS], skip_dst[PINN_MAX_SKIPS];
     int dims[PINN_MAX_LAYERS + 1];
     float lo[PINN_MAX_INPUTS], hi[PINN_MAX_INPUTS], bc_value;
@@ -389,7 +389,7 @@ int pinn_create_ex(const int* layer_dims, int n_layers, const int* acts, int n_s
     if (!layer_dims || !out || !acts) return fail("null argument");
     if (n_layers < 2 || n_layers > PINN_MAX_LAYERS) return fail("n_layers=%d outside [2, %d]", n_layers, PINN_MAX_LAYERS);
     for (int a = 0; a + 1 < n_layers; ++a)
-        if (acts[a] < PINN_ACT_TANH || acts[a] > PINN_ACT_IDENTITY) return fail("unknown activation code %d (activation %d)", acts[a], a);
+        if (acts[a] < PINN_ACT_TANH || acts[a] > PINN_ACT_GELU) return fail("unknown activation code %d (activation %d)", acts[a], a);
     if (n_skips < 0 || n_skips > PINN_MAX_SKIPS || (n_skips > 0 && (!skip_src || !skip_dst)))
         return fail("n_skips=%d outside [0, %d]", n_skips, PINN_MAX_SKIPS);
     for (int k = 0; k < n_skips; ++k) {
@@ -420,7 +420,7 @@ int pinn_create_ex(const int* layer_dims, int n_layers, const int* acts, int n_s
     memset(net, 0, sizeof(*net));
     net->n_layers = n_layers; net->act = act; net->ndims = ndims; net->nparams = nparams;
     for (int a = 0; a + 1 < n_layers; ++a) {
-        net->act_codes |= (unsigned)acts[a] << (2 * a);
+        net->act_codes |= (unsigned long long)acts[a] << (4 * a);
         if (acts[a] != act) net->act = -1;
     }
     net->n_skips = n_skips;

@@ -65,7 +65,7 @@ struct PinnKArgs {
     int debug_flags;             // bit 0: two-team kernel runs team 0 only (experiments)
     long long n_points;
     int lh, d, act, mode;        // act: the activation code shared by every layer, or -1 when they differ (act_codes)
-    unsigned act_codes;          // 2 bits per activation index a = 0..lh (a = 0: first layer)
+    unsigned long long act_codes;   // 4 bits per activation index a = 0..lh (a = 0: first layer)
     int n_skips;                 // skip connections 'R ... +': h_out[skip_dst] += h_out[skip_src] (activation indices)
     int skip_src[PINN_MAX_SKIPS], skip_dst[PINN_MAX_SKIPS];
     int off_b1, off_wh, hidden_stride, off_wl, off_bl, off_ls, off_loss;
@@ -220,16 +220,38 @@ PINN_DEVICE float pinn_act(float z, int act) {
     }
     if (act == PINN_ACT_SIGMOID) return pinn_rcp(1.0f + pinn_exp2(z * -1.4426950408889634f));
     if (act == PINN_ACT_SIN) return sinf(z);
+    if (act == PINN_ACT_SOFTPLUS) return z > 20.0f ? z : log1pf(expf(z));           // torch.nn.Softplus (beta 1, threshold 20)
+    if (act == PINN_ACT_SILU) return z / (1.0f + expf(-z));
+    if (act == PINN_ACT_GELU) return 0.5f * z * (1.0f + erff(z * 0.70710678118654752f));   // torch.nn.GELU (erf form)
     return z;                                                     // PINN_ACT_IDENTITY ('f f': no activation in between)
 }
-// what the reverse half keeps of an activation: its VALUE (tanh, sigmoid, identity: all derivatives follow from it) or,
-// for sin, the pre-activation (cos z is not a function of sin z)
-PINN_DEVICE float pinn_act_saved(float v, float z, int act) { return act == PINN_ACT_SIN ? z : v; }
-PINN_DEVICE float pinn_act_value(float saved, int act) { return act == PINN_ACT_SIN ? sinf(saved) : saved; }
+// what the reverse half keeps of an activation: its VALUE (tanh, sigmoid, identity: all derivatives follow from it) or the
+// pre-activation (sin, softplus, SiLU, GELU: their derivatives are functions of z)
+PINN_DEVICE bool pinn_act_keeps_z(int act) { return act == PINN_ACT_SIN || act >= PINN_ACT_SOFTPLUS; }
+PINN_DEVICE float pinn_act_saved(float v, float z, int act) { return pinn_act_keeps_z(act) ? z : v; }
+PINN_DEVICE float pinn_act_value(float saved, int act) { return pinn_act_keeps_z(act) ? pinn_act(saved, act) : saved; }
+// derivatives 1..4 of the z-keeping smooth activations, from z. With s = sigmoid(z), a = s (1 - s), q = 1 - 2 s (so that
+// s' = a, a' = a q, q' = -2 a) and phi = exp(-z^2 / 2) / sqrt(2 pi), Phi' = phi, phi' = -z phi:
+//   softplus: s | a | a q | a (q^2 - 2 a)
+//   SiLU z s:  s + z a | 2 a + z a q | 3 a q + z a (q^2 - 2 a) | 4 a (q^2 - 2 a) + z a q (q^2 - 8 a)
+//   GELU z Phi: Phi + z phi | phi (2 - z^2) | phi z (z^2 - 4) | phi (-z^4 + 7 z^2 - 4)
+PINN_DEVICE void pinn_act_zderivs(float z, int act, float& d1, float& d2, float& d3, float& d4) {
+    if (act == PINN_ACT_GELU) {
+        const float phi = 0.3989422804014327f * expf(-0.5f * z * z), Phi = 0.5f * (1.0f + erff(z * 0.70710678118654752f));
+        const float z2 = z * z;
+        d1 = Phi + z * phi; d2 = phi * (2.0f - z2); d3 = phi * z * (z2 - 4.0f); d4 = phi * ((7.0f - z2) * z2 - 4.0f);
+        return;
+    }
+    const float sg = 1.0f / (1.0f + expf(-z)), a = sg * (1.0f - sg), q = 1.0f - 2.0f * sg;
+    const float a3 = a * (q * q - 2.0f * a), a4 = a * q * (q * q - 8.0f * a);       // s''' and s''''
+    if (act == PINN_ACT_SOFTPLUS) { d1 = sg; d2 = a; d3 = a * q; d4 = a3; }
+    else { d1 = sg + z * a; d2 = 2.0f * a + z * a * q; d3 = 3.0f * a * q + z * a3; d4 = 4.0f * a3 + z * a4; }   // SiLU
+}
 PINN_DEVICE void pinn_act_d12(float sv, int act, float& d1, float& d2) {
     if (act == PINN_ACT_TANH) { d1 = 1.0f - sv * sv; d2 = -2.0f * sv * d1; }
     else if (act == PINN_ACT_SIGMOID) { d1 = sv * (1.0f - sv); d2 = d1 * (1.0f - 2.0f * sv); }
     else if (act == PINN_ACT_SIN) { d1 = cosf(sv); d2 = -sinf(sv); }
+    else if (act >= PINN_ACT_SOFTPLUS) { float d3, d4; pinn_act_zderivs(sv, act, d1, d2, d3, d4); }
     else { d1 = 1.0f; d2 = 0.0f; }
 }
 PINN_DEVICE float pinn_act_d3(float sv, float d1, float d2, int act) {
@@ -239,6 +261,7 @@ PINN_DEVICE float pinn_act_d3(float sv, float d1, float d2, int act) {
         return d1 * (q * q - 2.0f * d1);
     }
     if (act == PINN_ACT_SIN) return -d1;
+    if (act >= PINN_ACT_SOFTPLUS) { float e1, e2, d3, d4; pinn_act_zderivs(sv, act, e1, e2, d3, d4); return d3; }
     return 0.0f;
 }
 
@@ -250,6 +273,7 @@ PINN_DEVICE float pinn_act_d4(float sv, float d1, float d2, int act) {
         return d1 * q * (q * q - 8.0f * d1);
     }
     if (act == PINN_ACT_SIN) return sinf(sv);
+    if (act >= PINN_ACT_SOFTPLUS) { float e1, e2, e3, d4; pinn_act_zderivs(sv, act, e1, e2, e3, d4); return d4; }
     return 0.0f;
 }
 
@@ -919,7 +943,7 @@ pinn_tile_kernel(const PinnKArgs A) {
     // (plain instantiations only know tanh / sigmoid -- one bit, which lets the compiler drop the sin / identity paths;
     //  the full set runs on the VAR 8 instantiations, see the launcher)
     auto act_at = [&](int a) -> int {
-        return (ACTC >= 0) ? ACTC : (int)((A.act_codes >> (2 * a)) & (SKIPS ? 3u : 1u));
+        return (ACTC >= 0) ? ACTC : (int)((A.act_codes >> (4 * a)) & (SKIPS ? 15ull : 1ull));
     };
     // skip connection ending / starting at activation a (or -1); slab slot of skip k
     auto skip_into = [&](int a) -> int {
@@ -1116,6 +1140,10 @@ pinn_tile_kernel(const PinnKArgs A) {
     PH_DECL
 
     int tile_parity = 0;
+#ifndef PINN_TEAM_SKEW
+#define PINN_TEAM_SKEW 0       // two-team kernels: team 1 runs one barrier behind team 0 (its vector phases then meet team 0's GEMM phases)
+#endif
+    if (TEAMS2 && PINN_TEAM_SKEW && team == 1) PINN_SYNC();
     // (two teams: both run as many rounds as team 0 has tiles -- a team without a tile in the last round works on an empty
     //  one: zero points, every sample invalid, contributions zero -- so that the barriers match)
     for (long long tile0 = A.tile_begin + (long long)PINN_BID * TEAMS; tile0 < ntiles; tile0 += vnblk, tile_parity ^= 1) {
@@ -1825,6 +1853,7 @@ pinn_tile_kernel(const PinnKArgs A) {
         PH(15)
     }
     PH_FLUSH
+    if (TEAMS2 && PINN_TEAM_SKEW && team == 0) PINN_SYNC();
 
     if (!train) return;
     if (REGB) {

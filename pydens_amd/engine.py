@@ -18,7 +18,7 @@ MAX_OPS, MAX_CONSTS, MAX_REGS = 64, 32, 40
 MAX_STREAMS, MAX_AUX, MAX_VARS = 7, 8, 8
 SAMPLE_UNIFORM, SAMPLE_NORMAL, SAMPLE_CONST = 0, 1, 2
 RES_PROGRAM, RES_AFFINE = 0, 1
-ACT_CODES = {'tanh': 0, 'sigmoid': 1, 'sin': 2, 'identity': 3}
+ACT_CODES = {'tanh': 0, 'sigmoid': 1, 'sin': 2, 'identity': 3, 'softplus': 4, 'silu': 5, 'swish': 5, 'gelu': 6}
 
 OPS = dict(CONST=0, ADD=1, SUB=2, MUL=3, DIV=4, NEG=5, SIN=6, COS=7, EXP=8, LOG=9, TANH=10, SQRT=11, POW=12,
            ABS=13, SIGMOID=14, RECIP=15, COPY=16, STORE=17)
@@ -187,7 +187,7 @@ class Net:
         codes = [ACT_CODES.get(str(name).lower()) for name in names]
         if None in codes:
             raise NotImplementedError(f'activation {names[codes.index(None)]!r}: the HIP kernels implement Tanh, Sigmoid '
-                                      'and Sin (and the identity)')
+                                      'Sin, Softplus, SiLU and GELU (and the identity)')
         skips = sorted(skips)
         domain = list(domain) if domain is not None else [(0.0, 1.0)] * ndims
         dims = (ctypes.c_int * len(layer_dims))(*layer_dims)

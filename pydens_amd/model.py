@@ -91,6 +91,11 @@ def _activation_name(act):
     if isinstance(act, type):
         return act.__name__
     if isinstance(act, nn.Module):
+        # the kernels implement the DEFAULT form of each activation
+        if isinstance(act, nn.Softplus) and (act.beta != 1 or act.threshold != 20):
+            raise NotImplementedError('nn.Softplus with beta != 1 or threshold != 20 is not implemented by the HIP kernels')
+        if isinstance(act, nn.GELU) and getattr(act, 'approximate', 'none') != 'none':
+            raise NotImplementedError("nn.GELU(approximate='tanh') is not implemented by the HIP kernels (erf form only)")
         return type(act).__name__
     if act is torch.sin:
         return 'Sin'
@@ -98,7 +103,13 @@ def _activation_name(act):
         return 'Tanh'
     if act is torch.sigmoid:
         return 'Sigmoid'
-    raise NotImplementedError(f'activation {act!r}: the HIP kernels implement Tanh, Sigmoid and Sin')
+    if act is torch.nn.functional.softplus:
+        return 'Softplus'
+    if act is torch.nn.functional.silu:
+        return 'SiLU'
+    if act is torch.nn.functional.gelu:
+        return 'GELU'
+    raise NotImplementedError(f'activation {act!r}: the HIP kernels implement Tanh, Sigmoid, Sin, Softplus, SiLU and GELU')
 
 
 def parse_fc_layout(layout, features, activation):

@@ -459,6 +459,8 @@ LAYOUTS = {
     # a hidden dense layer without activation
     'identity': dict(layout='fa f fa f', features=[16, 16, 16, 1], activation='Tanh'),
     'skip_to_top_wide': dict(layout='fa R fa fa + f', features=[40, 40, 40, 1], activation='Sigmoid'),
+    # smooth activations whose derivatives are functions of the pre-activation (kept in the slab instead of the value)
+    'softplus_silu_gelu': dict(layout='fa fa fa f', features=[12, 16, 12, 1], activation=['Softplus', 'SiLU', 'GELU']),
     # every unit of a 64-wide net real (no zero padding to hide a wrong lane / K quad)
     'full64': dict(layout='fa R fa fa + f', features=[64, 64, 64, 1], activation=['Sin', 'Tanh', 'Sigmoid']),
 }

@@ -299,7 +299,7 @@ def test_every_width_and_depth_uses_all_its_units(pa, width, depth):
                 assert rel_l2(got, want) < 2e-4, path
 
 
-@pytest.mark.parametrize('net', ['skip', 'two_skips', 'sin', 'identity', 'skip_to_top_wide', 'full64'])
+@pytest.mark.parametrize('net', ['skip', 'two_skips', 'sin', 'identity', 'skip_to_top_wide', 'full64', 'softplus_silu_gelu'])
 @pytest.mark.parametrize('which', ['poisson', 'burgers'])
 def test_layout_breadth_matches_the_oracle(pa, net, which):
     """ skip connections 'R ... +', per-layer activation lists, Sin, activation-free dense layers (reference
