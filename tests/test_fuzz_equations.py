@@ -8,7 +8,7 @@ import numpy as np
 import pytest
 import torch
 
-from conftest import rel_l2
+from conftest import params_close, rel_l2
 from helpers import FixedBatches, export_params, load_params
 
 LEAVES = ['u', 'ux', 'ut', 'uxx', 'x', 't', 'c']
@@ -16,16 +16,17 @@ UNARY = ['sin', 'cos', 'tanh', 'neg', 'sq', 'cube', 'sigmoid', 'abs', 'exps']
 BINARY = ['add', 'sub', 'mul', 'divc', 'mulc']
 
 
-def _gen(rng, depth):
+def _gen(rng, depth, leaves=None):
+    leaves = leaves or LEAVES
     if depth == 0 or rng.rand() < 0.25:
-        leaf = LEAVES[rng.randint(len(LEAVES))]
+        leaf = leaves[rng.randint(len(leaves))]
         return ('c', float(np.round(rng.uniform(-2, 2), 3))) if leaf == 'c' else (leaf,)
     if rng.rand() < 0.4:
-        return (UNARY[rng.randint(len(UNARY))], _gen(rng, depth - 1))
+        return (UNARY[rng.randint(len(UNARY))], _gen(rng, depth - 1, leaves))
     op = BINARY[rng.randint(len(BINARY))]
     if op in ('divc', 'mulc'):
-        return (op, _gen(rng, depth - 1), float(np.round(rng.uniform(0.5, 3), 3)))
-    return (op, _gen(rng, depth - 1), _gen(rng, depth - 1))
+        return (op, _gen(rng, depth - 1, leaves), float(np.round(rng.uniform(0.5, 3), 3)))
+    return (op, _gen(rng, depth - 1, leaves), _gen(rng, depth - 1, leaves))
 
 
 def _ev(tree, env):
@@ -62,28 +63,38 @@ def _uses(tree, name):
 def _equation(tree, D):
     def equation(u, x, t):
         env = {'u': u, 'x': x, 't': t}
-        if _uses(tree, 'ux') or _uses(tree, 'uxx'):
+        if _uses(tree, 'ux') or _uses(tree, 'uxx') or _uses(tree, 'uxxx'):
             env['ux'] = D(u, x)
-        if _uses(tree, 'uxx'):
+        if _uses(tree, 'uxx') or _uses(tree, 'uxxx'):
             env['uxx'] = D(env['ux'], x)
+        if _uses(tree, 'uxxx'):
+            env['uxxx'] = D(env['uxx'], x)
         if _uses(tree, 'ut'):
             env['ut'] = D(u, t)
         return _ev(tree, env) + 0.0 * u + 0.37                  # keeps the field in and the residual away from zero
     return equation
 
 
-def _run(pa, extra, n_trees, batch, fused=True):
+def _run(pa, extra, n_trees, batch, fused=True, third=False):
+    """ third: u_xxx joins the leaves and every tree uses it. Three nested fp32 autograd sweeps are noisy, so the oracle runs in
+    fp64 from the same fp32 start (the arbiter of SURVEY 8c item 5) and the tolerances are those of an fp32 computation against
+    the exact one. """
     from oracle import pinn_oracle as po
-    rng = np.random.RandomState(1)
+    rng = np.random.RandomState(11 if third else 1)
+    leaves = LEAVES + ['uxxx', 'uxxx'] if third else LEAVES
     kw = dict(ndims=2, initial_condition=lambda x: torch.sin(np.pi * x), boundary_condition=0.0, layout='fafaf',
               features=[16, 16, 1], activation='Tanh')
     kinds = {'program': 0, 'affine': 0}
     for trial in range(n_trees):
-        tree = _gen(rng, 3)
-        if not any(_uses(tree, name) for name in ('u', 'ux', 'ut', 'uxx')):
+        tree = _gen(rng, 3, leaves)
+        if not any(_uses(tree, name) for name in (('uxxx',) if third else ('u', 'ux', 'ut', 'uxx'))):
             continue
         torch.manual_seed(trial)
         oracle = po.OracleSolver(_equation(tree, po.D), **kw)
+        if third:
+            start = oracle.export_params()
+            oracle = po.OracleSolver(_equation(tree, po.D), dtype=torch.float64, **kw)
+            oracle.import_params(start)
         solver = pa.Solver(_equation(tree, pa.D), **kw, **extra)
         solver.use_fused = fused
         load_params(solver, oracle.export_params())
@@ -94,11 +105,13 @@ def _run(pa, extra, n_trees, batch, fused=True):
         if not np.all(np.isfinite(want)):
             continue
         assert solver.last_fit_path == ('fused' if fused else 'generic'), (tree, solver.program_error)
-        np.testing.assert_allclose([float(v) for v in solver.losses], want, rtol=5e-5, err_msg=str(tree))
+        if third:
+            assert solver.spec.n3 == 1, tree
+        np.testing.assert_allclose([float(v) for v in solver.losses], want, rtol=1e-4 if third else 5e-5, err_msg=str(tree))
         for got, ref in zip(export_params(solver), oracle.export_params()):
-            assert rel_l2(got, ref) < 2e-4, tree
+            assert params_close(got, ref, 2e-4, atol=1e-5) if third else rel_l2(got, ref) < 2e-4, tree
         kinds['program' if solver.residual_plan.kind == 0 else 'affine'] += 1
-    assert kinds['program'] >= 5 and kinds['affine'] >= 5, kinds
+    assert (kinds['program'] >= 5 and kinds['affine'] >= 5) or (third and sum(kinds.values()) >= 10), kinds
 
 
 @pytest.mark.parametrize('path', ['fused', 'generic'])
@@ -119,13 +132,32 @@ def test_random_equations_on_the_gpu():
     _run(pa, {}, n_trees=40, batch=523)
 
 
+@pytest.mark.parametrize('path', ['fused', 'generic'])
+def test_random_third_order_equations_on_the_emulated_kernels(path):
+    import ctypes
+    import os
+    import sys
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), 'emu'))
+    import build_emu
+    import pydens_amd as pa
+    from pydens_amd import engine
+    _run(pa, dict(lib=engine.bind(ctypes.CDLL(build_emu.build())), device='cpu'), n_trees=40, batch=23, fused=path == 'fused', third=True)
+
+
+@pytest.mark.gpu
+def test_random_third_order_equations_on_the_gpu():
+    import pydens_amd as pa
+    _run(pa, {}, n_trees=40, batch=523, third=True)
+
+
 def _random_net(rng):
     """ a random fully connected layout of the reference's Block vocabulary: 1-5 hidden layers of 5-40 units (padded to
-    16 / 32 / 64 inside), Tanh / Sigmoid / Sin per layer (or one name), sometimes a hidden layer without activation,
+    16 / 32 / 64 inside), Tanh / Sigmoid / Sin / Softplus / SiLU / GELU per layer (or one name), sometimes a hidden layer without activation,
     sometimes one skip connection 'R ... +' over layers of equal width """
     depth = rng.randint(1, 6)
     widths = [int(rng.randint(5, 41)) for _ in range(depth)]
-    acts = [['Tanh', 'Sigmoid', 'Sin'][rng.randint(3)] for _ in range(depth)]
+    names = ['Tanh', 'Sigmoid', 'Sin', 'Softplus', 'SiLU', 'GELU']
+    acts = [names[rng.randint(len(names))] for _ in range(depth)]
     letters = ['fa'] * depth
     no_act = depth >= 3 and rng.rand() < 0.3
     skip = depth >= 3 and not no_act and rng.rand() < 0.5
@@ -166,7 +198,7 @@ def test_random_layouts_on_the_emulated_kernels():
             (lambda u, x, e: D(u, x) - e * torch.cos(e * x), dict(ndims=1, nparams=1, initial_condition=1.0)),
         ]
     seen = set()
-    for trial in range(14):
+    for trial in range(20):
         net = _random_net(rng)
         which = trial % 3
         eq_o, kw = problems(po.D)[which]
