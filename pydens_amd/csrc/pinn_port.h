@@ -19,6 +19,14 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 #define PINN_NBLK ((int)gridDim.x)
 #define PINN_SYNC() __syncthreads()
 #define PINN_FENCE_BLOCK() __threadfence_block()
+// LDS exchange between the lanes of ONE wave: LDS instructions of a wave execute in issue order, so nothing has to be
+// waited for -- the fences only pin the program order of the stores in front and the loads behind
+#define PINN_WAVE_SYNC()                                          \
+    do {                                                          \
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");    \
+        __builtin_amdgcn_wave_barrier();                          \
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");    \
+    } while (0)
 #define PINN_SMEM(name) extern __shared__ __attribute__((aligned(16))) float name[]
 #define PINN_LAUNCH_BOUNDS(n) __launch_bounds__(n)
 
@@ -27,6 +35,22 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 PINN_DEVICE f32x4 pinn_mfma16(float a, float b, f32x4 c) {
     return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0);
 }
+// lane-private f32x4 rows of a wave-owned block of global memory through buffer instructions: ONE vector register of offsets
+// (lane * 16) for every row, the row offset in a scalar register -- with plain pointers hipcc keeps a 64-bit address pair
+// per row alive across the whole tile loop (several dozen VGPRs, spilled)
+struct PinnRows { __amdgpu_buffer_rsrc_t r; };
+PINN_DEVICE PinnRows pinn_rows(const void* base /*wave-uniform*/, unsigned bytes) {
+    return PinnRows{__builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(base), 0, (int)bytes, 0x00020000)};
+}
+typedef unsigned int pinn_u32x4 __attribute__((ext_vector_type(4)));
+PINN_DEVICE f32x4 pinn_rows_ld4(const PinnRows& b, int lane_bytes, int row_bytes) {
+    return __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(b.r, lane_bytes, row_bytes, 0));
+}
+PINN_DEVICE void pinn_rows_st4(const PinnRows& b, int lane_bytes, int row_bytes, f32x4 v) {
+    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(pinn_u32x4, v), b.r, lane_bytes, row_bytes, 0);
+}
+// a value the whole wave agrees on, moved to a scalar register (addresses built from it use the scalar-base forms)
+PINN_DEVICE int pinn_wave_uniform(int v) { return __builtin_amdgcn_readfirstlane(v); }
 PINN_DEVICE float pinn_shfl_xor(float v, int mask) { return __shfl_xor(v, mask, 64); }
 // lane-wise sum over the four 16-lane rows of the wave (every lane gets x[l] + x[l^16] + x[l^32] + x[l^48]) with the
 // gfx950 row swaps: v_permlane16_swap exchanges the odd rows of its first operand with the even rows of the second,
@@ -51,6 +75,19 @@ PINN_DEVICE float pinn_row_sum16(float v) {
     v += __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, v), 0x141, 0xF, 0xF, true));
     v += __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, v), 0x140, 0xF, 0xF, true));
     return v;
+}
+// the same for N values at once, step-major: N independent adds per DPP step (a lone chain pays two wait states between its
+// dependent DPP steps)
+template <int N>
+PINN_DEVICE void pinn_row_sum16_n(float (&v)[N]) {
+#pragma unroll
+    for (int i = 0; i < N; ++i) v[i] += __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, v[i]), 0xB1, 0xF, 0xF, true));
+#pragma unroll
+    for (int i = 0; i < N; ++i) v[i] += __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, v[i]), 0x4E, 0xF, 0xF, true));
+#pragma unroll
+    for (int i = 0; i < N; ++i) v[i] += __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, v[i]), 0x141, 0xF, 0xF, true));
+#pragma unroll
+    for (int i = 0; i < N; ++i) v[i] += __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, v[i]), 0x140, 0xF, 0xF, true));
 }
 // 2^x and 1/x at hardware precision (v_exp_f32 / v_rcp_f32, ~1 ulp)
 PINN_DEVICE float pinn_exp2(float x) { return __builtin_amdgcn_exp2f(x); }

@@ -59,6 +59,8 @@ void sync_block() {
     while (g_barrier_gen == my) yield();
 }
 
+void sync_wave() { wave_sync(g_waves[g_cur >> 6]); }
+
 f32x4 mfma16(float a, float b, f32x4 c) {
     Wave& w = g_waves[g_cur >> 6];
     const int l = g_cur & 63;

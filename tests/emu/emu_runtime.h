@@ -19,6 +19,7 @@ int bid();
 int nblk();
 float* smem();
 void sync_block();
+void sync_wave();
 f32x4 mfma16(float a, float b, f32x4 c);
 float shfl_xor(float v, int mask);
 float row_sum16(float v);
@@ -32,10 +33,16 @@ void launch(int grid, int block, size_t smem_bytes, const std::function<void()>&
 #define PINN_NBLK (emu::nblk())
 #define PINN_SYNC() emu::sync_block()
 #define PINN_FENCE_BLOCK()
+#define PINN_WAVE_SYNC() emu::sync_wave()
 #define PINN_SMEM(name) float* name = emu::smem()
 #define PINN_LAUNCH_BOUNDS(n)
 
 static inline f32x4 pinn_mfma16(float a, float b, f32x4 c) { return emu::mfma16(a, b, c); }
+struct PinnRows { char* p; };
+static inline PinnRows pinn_rows(const void* base, unsigned) { return PinnRows{(char*)const_cast<void*>(base)}; }
+static inline f32x4 pinn_rows_ld4(const PinnRows& b, int lane_bytes, int row_bytes) { return *reinterpret_cast<const f32x4*>(b.p + lane_bytes + row_bytes); }
+static inline void pinn_rows_st4(const PinnRows& b, int lane_bytes, int row_bytes, f32x4 v) { *reinterpret_cast<f32x4*>(b.p + lane_bytes + row_bytes) = v; }
+static inline int pinn_wave_uniform(int v) { return v; }
 static inline float pinn_shfl_xor(float v, int mask) { return emu::shfl_xor(v, mask); }
 static inline float pinn_rows_sum(float x) {
     x += emu::shfl_xor(x, 16);
@@ -43,6 +50,9 @@ static inline float pinn_rows_sum(float x) {
     return x;
 }
 static inline float pinn_row_sum16(float v) { return emu::row_sum16(v); }
+template <int N> static inline void pinn_row_sum16_n(float (&v)[N]) {
+    for (int i = 0; i < N; ++i) v[i] = emu::row_sum16(v[i]);
+}
 static inline float pinn_exp2(float x) { return exp2f(x); }
 static inline float pinn_rcp(float x) { return 1.0f / x; }
 #define PINN_LAUNCH_BOUNDS2(n, w)

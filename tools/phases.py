@@ -14,6 +14,9 @@ lib_path, cfg_name = sys.argv[1], (sys.argv[2] if len(sys.argv) > 2 else 'cfg2')
 DUO = len(sys.argv) > 3 and sys.argv[3] == 'duo'
 if DUO:
     NAMES = [f'phase {i}' for i in range(14)] + ['idle slot', 'barrier wait']
+if len(sys.argv) > 3 and sys.argv[3] == 'chain':      # pinn_chain_kernel
+    NAMES = ['0 tile top', '1 first layer', '2 fwd MFMA', '3 fwd activation', '4 head dot', '5 point stage', '6 top reverse',
+             '7 act reverse', '8 dgrad MFMA', '9 wgrad stage+MFMA', '10 layer0 reverse', '11 prologue', '12 epilogue', '-', '-', '-']
 lib = engine.bind(ctypes.CDLL(lib_path))
 lib.pinn_debug_phase_buffer.argtypes = [ctypes.c_void_p]
 torch.manual_seed(0)
