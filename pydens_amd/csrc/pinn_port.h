@@ -35,6 +35,16 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 PINN_DEVICE f32x4 pinn_mfma16(float a, float b, f32x4 c) {
     return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0);
 }
+// flags between two waves of a workgroup in LDS (a producer / consumer pair): LDS instructions of a CU execute in issue order, so
+// "data, then flag" on one side and "flag, then data" on the other need no waiting -- only the program order, which the
+// wavefront-scope fences pin (a workgroup-scope release would wait for every outstanding GLOBAL access of the wave as well)
+PINN_DEVICE int pinn_flag_load(const int* p) { return *reinterpret_cast<const volatile int*>(p); }
+PINN_DEVICE void pinn_flag_publish(int* p, int v, bool leader) {
+    PINN_WAVE_SYNC();
+    if (leader) *reinterpret_cast<volatile int*>(p) = v;
+    PINN_WAVE_SYNC();
+}
+#define PINN_SPIN_PAUSE() __builtin_amdgcn_s_sleep(1)
 // lane-private f32x4 rows of a wave-owned block of global memory through buffer instructions: ONE vector register of offsets
 // (lane * 16) for every row, the row offset in a scalar register -- with plain pointers hipcc keeps a 64-bit address pair
 // per row alive across the whole tile loop (several dozen VGPRs, spilled)

@@ -16,7 +16,15 @@ FLAGS = ['-x', 'c++', '-DPINN_EMU', '-O1', '-std=c++17', '-fPIC', '-I', HERE, '-
 WIDTHS = (16, 32, 64, 128, 256)
 
 
-def build(force=False):
+def build(force=False, extra_flags=(), tag=''):
+    """ extra_flags / tag: a second library with other build knobs (e.g. -DPINN_CHAIN=1), kept beside the default one """
+    global BUILD, OUT
+    if tag:
+        BUILD = os.path.join(HERE, '_build_' + tag)
+        OUT = os.path.join(BUILD, 'libpinn_emu.so')
+    else:
+        BUILD = os.path.join(HERE, '_build')
+        OUT = os.path.join(BUILD, 'libpinn_emu.so')
     deps = [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith(('.h', '.inc', '.cpp'))]
     deps += [os.path.join(HERE, f) for f in ('emu_runtime.h', 'emu_runtime.cpp')]
     deps.append(os.path.join(ROOT, 'include', 'pinn.h'))
@@ -25,7 +33,7 @@ def build(force=False):
     os.makedirs(BUILD, exist_ok=True)
     jobs = []
     for hp in WIDTHS:
-        jobs.append([CXX, *FLAGS, f'-DPINN_INST_HP={hp}', '-c', os.path.join(CSRC, 'pinn_inst.inc'), '-o',
+        jobs.append([CXX, *FLAGS, *extra_flags, f'-DPINN_INST_HP={hp}', '-c', os.path.join(CSRC, 'pinn_inst.inc'), '-o',
                      os.path.join(BUILD, f'inst_hp{hp}.o')])
     jobs.append([CXX, *FLAGS, '-c', os.path.join(CSRC, 'pinn_abi.cpp'), '-o', os.path.join(BUILD, 'abi.o')])
     jobs.append([CXX, *FLAGS, '-c', os.path.join(HERE, 'emu_runtime.cpp'), '-o', os.path.join(BUILD, 'emu_runtime.o')])

@@ -60,6 +60,7 @@ void sync_block() {
 }
 
 void sync_wave() { wave_sync(g_waves[g_cur >> 6]); }
+void yield_fiber() { yield(); }
 
 f32x4 mfma16(float a, float b, f32x4 c) {
     Wave& w = g_waves[g_cur >> 6];

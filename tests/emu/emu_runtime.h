@@ -20,6 +20,7 @@ int nblk();
 float* smem();
 void sync_block();
 void sync_wave();
+void yield_fiber();
 f32x4 mfma16(float a, float b, f32x4 c);
 float shfl_xor(float v, int mask);
 float row_sum16(float v);
@@ -38,6 +39,13 @@ void launch(int grid, int block, size_t smem_bytes, const std::function<void()>&
 #define PINN_LAUNCH_BOUNDS(n)
 
 static inline f32x4 pinn_mfma16(float a, float b, f32x4 c) { return emu::mfma16(a, b, c); }
+static inline int pinn_flag_load(const int* p) { return *reinterpret_cast<const volatile int*>(p); }
+static inline void pinn_flag_publish(int* p, int v, bool leader) {
+    emu::sync_wave();                       // every lane's data is in place before the leader raises the flag
+    if (leader) *reinterpret_cast<volatile int*>(p) = v;
+    emu::sync_wave();
+}
+#define PINN_SPIN_PAUSE() emu::yield_fiber()
 struct PinnRows { char* p; };
 static inline PinnRows pinn_rows(const void* base, unsigned) { return PinnRows{(char*)const_cast<void*>(base)}; }
 static inline f32x4 pinn_rows_ld4(const PinnRows& b, int lane_bytes, int row_bytes) { return *reinterpret_cast<const f32x4*>(b.p + lane_bytes + row_bytes); }

@@ -1,0 +1,45 @@
+""" The experimental chain kernel (pydens_amd/csrc/pinn_chain_kernel.h, build knob -DPINN_CHAIN=1: wave-private points, layers
+chained through the MFMA accumulators, a weight-gradient wave beside every chain wave, LDS flags instead of barriers) on the
+emulated kernels against the oracle: BASELINE configs 2 and 4 (the two shapes it is built for), ragged batches, several
+workgroup rounds. The product keeps pinn_tile_kernel for these shapes (measured slower on MI355X); the test
+keeps the experiment honest. """
+import ctypes
+import os
+import sys
+
+import numpy as np
+import pytest
+import torch
+
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), 'emu'))
+import pinn_configs as pc
+from conftest import params_close
+from helpers import FixedBatches, export_params, load_params
+
+
+@pytest.fixture(scope='module')
+def chain_lib():
+    import build_emu
+    from pydens_amd import engine
+    path = build_emu.build(extra_flags=['-DPINN_CHAIN=1'], tag='chain')
+    build_emu.build()                 # leave the module's paths on the default library for the other tests
+    return engine.bind(ctypes.CDLL(path))
+
+
+@pytest.mark.parametrize('name,n', [('cfg2', 200), ('cfg4', 333), ('cfg2', 16 * 4 * 3 + 5)])
+def test_chain_kernel_matches_the_oracle(chain_lib, name, n):
+    import pydens_amd as pa
+    from oracle import pinn_oracle as po
+    torch.manual_seed(0)
+    co, cp = pc.make_config(name, po.D, torch), pc.make_config(name, pa.D, torch)
+    oracle = po.OracleSolver(co['equation'], **co['solver_kwargs'])
+    solver = pa.Solver(cp['equation'], **cp['solver_kwargs'], lib=chain_lib, device='cpu')
+    load_params(solver, oracle.export_params())
+    pts = pc.sample_points(co, n, seed=3, steps=3)
+    oracle.fit(niters=3, batch_size=n, points=pts, lr=0.01)
+    solver.fit(niters=3, batch_size=n, sampler=FixedBatches(pts), lr=0.01)
+    assert solver.last_fit_path == 'fused'
+    assert chain_lib.pinn_last_kernel_name().decode().startswith('pinn_chain_kernel<')
+    np.testing.assert_allclose([float(v) for v in solver.losses], [float(v) for v in oracle.losses], rtol=2e-6)
+    for got, want in zip(export_params(solver), oracle.export_params()):
+        assert params_close(got, want, 2e-6)

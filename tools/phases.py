@@ -36,6 +36,8 @@ torch.cuda.synchronize()
 lib.pinn_debug_phase_buffer(None)
 b = buf.cpu().numpy().reshape(-1, 16)
 b = b[b.sum(axis=1) > 0]
+if len(sys.argv) > 3 and sys.argv[3] == 'chain':
+    b = b[b[:, 2] > 0]          # chain waves only (the wgrad waves report their total under 'epilogue')
 nw = b.shape[0]
 tot = b.sum(axis=1).mean()
 print(f'{cfg_name}: {nw} waves reported, mean total cycles/wave {tot:.0f}')
