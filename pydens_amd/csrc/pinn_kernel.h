@@ -888,6 +888,22 @@ template <bool NT> PINN_DEVICE f32x4 pinn_ld4_stream(const f32x4* p) {
     return *p;
 }
 PINN_DEVICE void pinn_st4(float* p, f32x4 v) { *reinterpret_cast<f32x4*>(p) = v; }
+// the four components of v summed over the 16 lanes of a DPP row, step-major (four independent adds per DPP step: a lone
+// chain pays two wait states between its dependent steps; pinn_port.h)
+#ifndef PINN_ROWSUM_BATCH
+#define PINN_ROWSUM_BATCH 0      // (measured on the tile kernels: no difference -- the second wave per SIMD already covers the wait states)
+#endif
+PINN_DEVICE f32x4 pinn_row_sum16_v4(f32x4 v) {
+#if PINN_ROWSUM_BATCH
+    float w[4] = {v[0], v[1], v[2], v[3]};
+    pinn_row_sum16_n<4>(w);
+    return f32x4{w[0], w[1], w[2], w[3]};
+#else
+#pragma unroll
+    for (int r = 0; r < 4; ++r) v[r] = pinn_row_sum16(v[r]);
+    return v;
+#endif
+}
 
 // VAR (experiment bits): 1 = accumulate dW in the partial buffer although the layer count is static, 2 = two waves per
 // SIMD (two workgroups per CU), 4 = no whole-layer weight prefetch; 8 = layout breadth: Sin / identity activations and
@@ -1509,8 +1525,7 @@ pinn_tile_kernel(const PinnKArgs A) {
                 if (REGB) {
                     bacc[j] += bsum;
                 } else {
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) bsum[r] = pinn_row_sum16(bsum[r]);
+                    bsum = pinn_row_sum16_v4(bsum);
                     if (lr == 0) {
                         float* dst = accB + a * HP + unit0(j);
                         pinn_st4(dst, pinn_ld4(dst) + bsum);
@@ -1842,10 +1857,14 @@ pinn_tile_kernel(const PinnKArgs A) {
                         for (int k = 0; k < ND; ++k)
                             if (pinn_dir_has(SH::dir(A, k), c)) v += gz[j][mt][1 + k];
                     }
+                    v = pinn_row_sum16_v4(v);
+                    if (lr == 0) {
+                        // (all four reads first: written element by element these are four LDS round trips in a row)
+                        float old[4];
 #pragma unroll
-                    for (int r = 0; r < 4; ++r) {
-                        const float t = pinn_row_sum16(v[r]);
-                        if (lr == 0) accW1[(unit0(j) + r) * PINN_XS_LD + c] += t;
+                        for (int r = 0; r < 4; ++r) old[r] = accW1[(unit0(j) + r) * PINN_XS_LD + c];
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) accW1[(unit0(j) + r) * PINN_XS_LD + c] = old[r] + v[r];
                     }
                 }
             }
