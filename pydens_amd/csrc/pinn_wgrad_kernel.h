@@ -24,7 +24,9 @@ template <int HP, int ND, int N2, int MT = 1>
 struct PinnWgCfg {
     using C = PinnCfg<HP, ND, N2, MT>;
     static constexpr int S = C::S, NW = C::NW, NTW = C::NTW, NTHREADS = C::NTHREADS;
+#ifndef PINN_WG_SKIP_NW_ASSERT      // (timing experiments on the tile kernel alone: -DPINN_NW_MAX=4 builds, wrong weight gradients)
     static_assert(NW == 8, "the streamed weight-gradient kernel is built for the 8-wave widths (HP >= 128)");
+#endif
     static constexpr int KC = 16;                    // K rows per stage: the 16 points of one (tile, mt, stream)
     static constexpr int LDK = KC + 4;               // row stride of the unit-major operand buffers: rows 4 units apart land
                                                      // 16 banks apart (ds_write_b32 of lanes lq, lq + 1), b128 rows stay aligned
