@@ -4,6 +4,8 @@ pydens equation callable under an IC + BC ansatz; two Adam iterations must agree
 tracer, both residual kinds, the in-kernel interpreter with its reverse sweep and the pre-pass on shapes nobody wrote by
 hand -- and, with use_fused = False, the generic path (kernel streams, the user's torch code, D's stream chain rule).
 CPU: emulated kernels; -m gpu: the HIP library. """
+import os
+
 import numpy as np
 import pytest
 import torch
@@ -11,6 +13,7 @@ import torch
 from conftest import params_close, rel_l2
 from helpers import FixedBatches, export_params, load_params
 
+SCALE = int(os.environ.get('PINN_FUZZ_SCALE', '1'))       # soak runs: PINN_FUZZ_SCALE=8 pytest tests/test_fuzz_equations.py -m gpu
 LEAVES = ['u', 'ux', 'ut', 'uxx', 'x', 't', 'c']
 UNARY = ['sin', 'cos', 'tanh', 'neg', 'sq', 'cube', 'sigmoid', 'abs', 'exps']
 BINARY = ['add', 'sub', 'mul', 'divc', 'mulc']
@@ -132,7 +135,7 @@ def test_random_equations_on_the_emulated_kernels(path):
 @pytest.mark.gpu
 def test_random_equations_on_the_gpu():
     import pydens_amd as pa
-    _run(pa, {}, n_trees=40, batch=523)
+    _run(pa, {}, n_trees=40 * SCALE, batch=523)
 
 
 @pytest.mark.parametrize('path', ['fused', 'generic'])
@@ -150,15 +153,15 @@ def test_random_third_order_equations_on_the_emulated_kernels(path):
 @pytest.mark.gpu
 def test_random_third_order_equations_on_the_gpu():
     import pydens_amd as pa
-    _run(pa, {}, n_trees=40, batch=523, third=True)
+    _run(pa, {}, n_trees=40 * SCALE, batch=523, third=True)
 
 
-def _random_net(rng):
+def _random_net(rng, wmax=41):
     """ a random fully connected layout of the reference's Block vocabulary: 1-5 hidden layers of 5-40 units (padded to
     16 / 32 / 64 inside), Tanh / Sigmoid / Sin / Softplus / SiLU / GELU per layer (or one name), sometimes a hidden layer without activation,
     sometimes one skip connection 'R ... +' over layers of equal width """
     depth = rng.randint(1, 6)
-    widths = [int(rng.randint(5, 41)) for _ in range(depth)]
+    widths = [int(rng.randint(5, wmax)) for _ in range(depth)]
     names = ['Tanh', 'Sigmoid', 'Sin', 'Softplus', 'SiLU', 'GELU']
     acts = [names[rng.randint(len(names))] for _ in range(depth)]
     letters = ['fa'] * depth
@@ -181,16 +184,9 @@ def _random_net(rng):
     return dict(layout=' '.join(letters) + ' f', features=widths + [1], activation=activation if isinstance(activation, str) else acts)
 
 
-def test_random_layouts_on_the_emulated_kernels():
-    import ctypes
-    import os
-    import sys
-    sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), 'emu'))
-    import build_emu
-    import pydens_amd as pa
-    from pydens_amd import engine
+def _run_layouts(pa, extra, n_nets, batch, wide=False):
+    """ wide: widths up to 200 (the 128- and 256-wide kernels with the streamed weight gradient; the device only) """
     from oracle import pinn_oracle as po
-    extra = dict(lib=engine.bind(ctypes.CDLL(build_emu.build())), device='cpu')
     rng = np.random.RandomState(4)
 
     def problems(D):
@@ -201,8 +197,8 @@ def test_random_layouts_on_the_emulated_kernels():
             (lambda u, x, e: D(u, x) - e * torch.cos(e * x), dict(ndims=1, nparams=1, initial_condition=1.0)),
         ]
     seen = set()
-    for trial in range(20):
-        net = _random_net(rng)
+    for trial in range(n_nets):
+        net = _random_net(rng, 201 if wide and trial % 4 == 3 else 41)
         which = trial % 3
         eq_o, kw = problems(po.D)[which]
         eq_p, _ = problems(pa.D)[which]
@@ -210,14 +206,113 @@ def test_random_layouts_on_the_emulated_kernels():
         oracle = po.OracleSolver(eq_o, **kw, **net)
         solver = pa.Solver(eq_p, **kw, **net, **extra)
         load_params(solver, oracle.export_params())
-        pts = np.random.RandomState(trial).rand(2, 21, 2).astype(np.float32)
-        oracle.fit(niters=2, batch_size=21, points=pts, lr=0.01)
-        solver.fit(niters=2, batch_size=21, sampler=FixedBatches(pts), lr=0.01)
+        pts = np.random.RandomState(trial).rand(2, batch, 2).astype(np.float32)
+        oracle.fit(niters=2, batch_size=batch, points=pts, lr=0.01)
+        solver.fit(niters=2, batch_size=batch, sampler=FixedBatches(pts), lr=0.01)
         assert solver.last_fit_path == 'fused', (net, solver.program_error)
         np.testing.assert_allclose([float(v) for v in solver.losses], [float(v) for v in oracle.losses], rtol=5e-5, err_msg=str(net))
         for got, ref in zip(export_params(solver), oracle.export_params()):
-            assert rel_l2(got, ref) < 2e-4, net
+            assert params_close(got, ref, 2e-4, atol=2e-6), net
         grid = [np.linspace(0.1, 0.9, 5).astype(np.float32)] * 2
         assert np.abs(solver.predict(*grid) - oracle.predict(*grid)).max() < 2e-5, net
         seen.add(('R' in net['layout'], isinstance(net['activation'], list)))
     assert len(seen) >= 3                                          # with / without skips, one name / per-layer lists
+
+
+def test_random_layouts_on_the_emulated_kernels():
+    import ctypes
+    import os
+    import sys
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), 'emu'))
+    import build_emu
+    import pydens_amd as pa
+    from pydens_amd import engine
+    _run_layouts(pa, dict(lib=engine.bind(ctypes.CDLL(build_emu.build())), device='cpu'), n_nets=20, batch=21)
+
+
+@pytest.mark.gpu
+def test_random_layouts_on_the_gpu():
+    import pydens_amd as pa
+    _run_layouts(pa, {}, n_nets=24 * SCALE, batch=311, wide=True)
+
+
+
+def _random_problem(rng, D):
+    """ a random problem SHAPE: 1-3 differentiated variables, with / without time, box or no boundary binding, constant or
+    callable initial condition, 0-2 extra parameters, a random domain, a random net, a ragged batch size """
+    ndims = int(rng.randint(1, 4))
+    nparams = int(rng.randint(0, 3)) if ndims < 3 else 0
+    has_ic = bool(rng.rand() < 0.6)
+    has_bc = bool(rng.rand() < 0.6) and (ndims > 1 or not has_ic)
+    lo = [float(np.round(rng.uniform(-1, 0.5), 2)) for _ in range(ndims)]
+    hi = [float(np.round(l + rng.uniform(0.5, 2.0), 2)) for l in lo]
+    kw = dict(ndims=ndims, nparams=nparams, domain=list(zip(lo, hi)) if ndims > 1 else (lo[0], hi[0]))
+    if has_bc:
+        kw['boundary_condition'] = float(np.round(rng.uniform(-1, 1), 2))
+    if has_ic:
+        nsp = ndims - 1
+        if nsp >= 1 and rng.rand() < 0.5:
+            kw['initial_condition'] = (lambda x: torch.sin(2.0 * x) + 0.3) if nsp == 1 else (lambda x, y: x * y + torch.cos(x))
+        else:
+            kw['initial_condition'] = float(np.round(rng.uniform(-1, 1), 2))
+    order2 = bool(rng.rand() < 0.6)
+    c = float(np.round(rng.uniform(0.1, 1.5), 2))
+
+    def equation(u, *args):
+        xs, ps = args[:ndims], args[ndims:]
+        r = 0.37 + 0.1 * u
+        for i, x in enumerate(xs):
+            ux = D(u, x)
+            r = r + (1.0 + 0.5 * i) * ux * (u if i == 0 else 1.0)
+            if order2 and (i < ndims - 1 or not has_ic):
+                r = r - c * D(ux, x)
+            r = r + torch.sin(x)
+        for p in ps:
+            r = r + p * u
+        return r
+    depth = int(rng.randint(1, 5))
+    net = dict(layout='fa' * depth + 'f', features=[int(rng.randint(4, 70)) for _ in range(depth)] + [1],
+               activation=['Tanh', 'Sigmoid', 'Sin'][rng.randint(3)])
+    batch = int(rng.choice([1, 7, 16, 17, 63, 64, 65, 200, 513, 1500, 2999]))
+    return equation, {**kw, **net}, batch, ndims + nparams, lo + [0.5] * nparams, hi + [1.5] * nparams
+
+
+def _run_problems(pa, extra, n_problems, max_batch):
+    from oracle import pinn_oracle as po
+    paths = set()
+    for trial in range(n_problems):
+        eq_o, kw, batch, d, lo, hi = _random_problem(np.random.RandomState(100 + trial), po.D)
+        eq_p = _random_problem(np.random.RandomState(100 + trial), pa.D)[0]
+        batch = min(batch, max_batch)
+        torch.manual_seed(trial)
+        oracle = po.OracleSolver(eq_o, **kw)
+        solver = pa.Solver(eq_p, **kw, **extra)
+        load_params(solver, oracle.export_params())
+        u = np.random.RandomState(trial).rand(2, batch, d)
+        pts = (np.asarray(lo) + (np.asarray(hi) - np.asarray(lo)) * u).astype(np.float32)
+        oracle.fit(niters=2, batch_size=batch, points=pts, lr=0.01)
+        solver.fit(niters=2, batch_size=batch, sampler=FixedBatches(pts), lr=0.01)
+        want = [float(v) for v in oracle.losses]
+        if not np.all(np.isfinite(want)):
+            continue
+        np.testing.assert_allclose([float(v) for v in solver.losses], want, rtol=5e-5, err_msg=str((trial, kw, batch)))
+        for got, ref in zip(export_params(solver), oracle.export_params()):
+            assert params_close(got, ref, 2e-4, atol=2e-6), (trial, kw, batch)
+        paths.add(solver.last_fit_path)
+    assert 'fused' in paths
+
+
+def test_random_problem_shapes_on_the_emulated_kernels():
+    import ctypes
+    import sys
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), 'emu'))
+    import build_emu
+    import pydens_amd as pa
+    from pydens_amd import engine
+    _run_problems(pa, dict(lib=engine.bind(ctypes.CDLL(build_emu.build())), device='cpu'), n_problems=10, max_batch=65)
+
+
+@pytest.mark.gpu
+def test_random_problem_shapes_on_the_gpu():
+    import pydens_amd as pa
+    _run_problems(pa, {}, n_problems=40 * SCALE, max_batch=3000)
