@@ -133,9 +133,10 @@ def test_random_equations_on_the_emulated_kernels(path):
 
 
 @pytest.mark.gpu
-def test_random_equations_on_the_gpu():
+@pytest.mark.parametrize('path', ['fused', 'generic'])
+def test_random_equations_on_the_gpu(path):
     import pydens_amd as pa
-    _run(pa, {}, n_trees=40 * SCALE, batch=523)
+    _run(pa, {}, n_trees=40 * SCALE, batch=523, fused=path == 'fused')
 
 
 @pytest.mark.parametrize('path', ['fused', 'generic'])
