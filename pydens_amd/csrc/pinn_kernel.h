@@ -1280,23 +1280,36 @@ pinn_tile_kernel(const PinnKArgs A) {
                 // of quad q issue, accumulators interleaved (an accumulator is re-used every S*MT*NTW issues, far
                 // beyond the 40-cycle dependent latency). sched_barrier pins that order (the register-pressured
                 // scheduler otherwise sinks every load next to its first use).
-                f32x4 wf[2][NTW], hf[2][MT][S];
-                auto load_q = [&](int q, f32x4 (&w)[NTW], f32x4 (&h)[MT][S]) {
+                // (weights that come from global memory / L2 -- widths >= 128 -- may run PINN_W_AHEAD quads ahead instead of one:
+                //  20 MFMAs per quad at width 128 are 640 cycles, about one L2 round trip under load)
+#ifndef PINN_W_AHEAD
+#define PINN_W_AHEAD 1
+#endif
+                constexpr int WA = (!WPF && PINN_W_AHEAD > 1) ? PINN_W_AHEAD : 1;
+                constexpr int NQF = HP / 16;
+                f32x4 wf[WA + 1][NTW], hf[2][MT][S];
+                auto load_w = [&](int q, f32x4 (&w)[NTW]) {
 #pragma unroll
                     for (int j = 0; j < NTW; ++j)
                         w[j] = WPF ? wall[WPF ? q : 0][j]
                                    : pinn_ld4(Wl + ((wave * NTW + j) * 16 + lr) * HP + 16 * q + 4 * lq);
+                };
+                auto load_h = [&](int q, f32x4 (&h)[MT][S]) {
 #pragma unroll
                     for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
                         for (int s = 0; s < S; ++s)
                             h[mt][s] = pinn_ld4(cur + (s * T + mt * 16 + lr) * LDA + 16 * q + 4 * lq);
                 };
-                load_q(0, wf[0], hf[0]);
 #pragma unroll
-                for (int q = 0; q < HP / 16; ++q) {
+                for (int i = 0; i < WA; ++i)
+                    if (i < NQF) load_w(i, wf[i]);
+                load_h(0, hf[0]);
+#pragma unroll
+                for (int q = 0; q < NQF; ++q) {
                     PINN_SCHED_BARRIER();
-                    if (q + 1 < HP / 16) load_q(q + 1, wf[(q + 1) & 1], hf[(q + 1) & 1]);
+                    if (q + WA < NQF) load_w(q + WA, wf[(q + WA) % (WA + 1)]);
+                    if (q + 1 < NQF) load_h(q + 1, hf[(q + 1) & 1]);
                     if (!PINN_SCHED_IL) PINN_SCHED_BARRIER();
 #pragma unroll
                     for (int m = 0; m < 4; ++m)
@@ -1306,8 +1319,8 @@ pinn_tile_kernel(const PinnKArgs A) {
                             for (int s = 0; s < S; ++s)
 #pragma unroll
                                 for (int j = 0; j < NTW; ++j)
-                                    acc[j][mt][s] = pinn_mfma16(wf[q & 1][j][m], hf[q & 1][mt][s][m], acc[j][mt][s]);
-                    if (q + 1 < HP / 16) pinn_sched_interleave<4 * MT * S * NTW, MT * S + (WPF ? 0 : NTW)>();
+                                    acc[j][mt][s] = pinn_mfma16(wf[q % (WA + 1)][j][m], hf[q & 1][mt][s][m], acc[j][mt][s]);
+                    if (q + 1 < NQF) pinn_sched_interleave<4 * MT * S * NTW, MT * S + (WPF ? 0 : NTW)>();
                     PINN_SCHED_BARRIER();
                 }
             }
@@ -1767,9 +1780,11 @@ pinn_tile_kernel(const PinnKArgs A) {
 #pragma unroll
                     for (int s = 0; s < S; ++s) g[j][mt][s] = f32x4{0.f, 0.f, 0.f, 0.f};
             {
-                float wq[2][NTW][4];
+                constexpr int WAD = (WTG && PINN_W_AHEAD > 1) ? PINN_W_AHEAD : 1;     // (global weights: quads ahead, see the forward GEMM)
+                constexpr int NQD = HP / 16;
+                float wq[WAD + 1][NTW][4];
                 f32x4 gf[2][MT][S];
-                auto load_q = [&](int q, float (&w)[NTW][4], f32x4 (&gfr)[MT][S]) {
+                auto load_w = [&](int q, float (&w)[NTW][4]) {
 #pragma unroll
                     for (int j = 0; j < NTW; ++j)
 #pragma unroll
@@ -1789,17 +1804,23 @@ pinn_tile_kernel(const PinnKArgs A) {
                                               : Wl[(16 * q + 4 * lq + m) * HP + (wave * NTW + j) * 16 + lr];
                             }
                         }
+                };
+                auto load_g = [&](int q, f32x4 (&gfr)[MT][S]) {
 #pragma unroll
                     for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
                         for (int s = 0; s < S; ++s)
                             gfr[mt][s] = pinn_ld4(nxt + (s * T + mt * 16 + lr) * LDA + 16 * q + 4 * lq);
                 };
-                load_q(0, wq[0], gf[0]);
 #pragma unroll
-                for (int q = 0; q < HP / 16; ++q) {
+                for (int i = 0; i < WAD; ++i)
+                    if (i < NQD) load_w(i, wq[i]);
+                load_g(0, gf[0]);
+#pragma unroll
+                for (int q = 0; q < NQD; ++q) {
                     PINN_SCHED_BARRIER();
-                    if (q + 1 < HP / 16) load_q(q + 1, wq[(q + 1) & 1], gf[(q + 1) & 1]);
+                    if (q + WAD < NQD) load_w(q + WAD, wq[(q + WAD) % (WAD + 1)]);
+                    if (q + 1 < NQD) load_g(q + 1, gf[(q + 1) & 1]);
                     if (!PINN_SCHED_IL) PINN_SCHED_BARRIER();
 #pragma unroll
                     for (int m = 0; m < 4; ++m)
@@ -1809,8 +1830,8 @@ pinn_tile_kernel(const PinnKArgs A) {
                             for (int s = 0; s < S; ++s)
 #pragma unroll
                                 for (int j = 0; j < NTW; ++j)
-                                    g[j][mt][s] = pinn_mfma16(wq[q & 1][j][m], gf[q & 1][mt][s][m], g[j][mt][s]);
-                    if (q + 1 < HP / 16)
+                                    g[j][mt][s] = pinn_mfma16(wq[q % (WAD + 1)][j][m], gf[q & 1][mt][s][m], g[j][mt][s]);
+                    if (q + 1 < NQD)
                         pinn_sched_interleave<4 * MT * S * NTW, MT * S + ((WTL || WTG) ? NTW : (WPF ? 0 : 4 * NTW))>();
                     PINN_SCHED_BARRIER();
                 }
