@@ -240,6 +240,8 @@ const char* pinn_last_kernel_name(void);
  *   pinn_debug_set_flags          experiment bits handed to the kernels (PinnKArgs::debug_flags; 0 = off, the default):
  *                                 2 / 4 slab reads / writes of the widths >= 128 pinned to one tile (L2-resident),
  *                                 8 / 16 / 32 weight-gradient kernel without barrier / LDS staging / HBM loads
+ *                                 (-DPINN_CHAIN=1 experiment builds, pinn_chain_kernel: 8 stages consumed but not multiplied,
+ *                                 16 no ring wait, 32 no weight gradient, 64 / 128 no slab reads / writes)
  *   pinn_debug_prepass_in_kernel  0: x-only pre-pass as its own launch (pinn_aux_kernel) instead of the tile kernel's prologue
  *   pinn_debug_phase_buffer       device buffer for per-phase cycle counters (-DPINN_PROFILE_PHASES builds, tools/phases.py)
  *   pinn_debug_wgx_chunk_bytes    slab budget per pass of the widths >= 128 (default 6.5 GB; <= 0 restores it): tests force
