@@ -16,40 +16,52 @@ FLAGS = ['-x', 'c++', '-DPINN_EMU', '-O1', '-std=c++17', '-fPIC', '-I', HERE, '-
 WIDTHS = (16, 32, 64, 128, 256)
 
 
-def build(force=False, extra_flags=(), tag=''):
-    """ extra_flags / tag: a second library with other build knobs (e.g. -DPINN_CHAIN=1), kept beside the default one """
-    global BUILD, OUT
-    if tag:
-        BUILD = os.path.join(HERE, '_build_' + tag)
-        OUT = os.path.join(BUILD, 'libpinn_emu.so')
-    else:
-        BUILD = os.path.join(HERE, '_build')
-        OUT = os.path.join(BUILD, 'libpinn_emu.so')
+def _deps():
     deps = [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith(('.h', '.inc', '.cpp'))]
     deps += [os.path.join(HERE, f) for f in ('emu_runtime.h', 'emu_runtime.cpp')]
     deps.append(os.path.join(ROOT, 'include', 'pinn.h'))
-    if not force and os.path.exists(OUT) and all(os.path.getmtime(d) <= os.path.getmtime(OUT) for d in deps):
-        return OUT
-    os.makedirs(BUILD, exist_ok=True)
-    jobs = []
-    for hp in WIDTHS:
-        jobs.append([CXX, *FLAGS, *extra_flags, f'-DPINN_INST_HP={hp}', '-c', os.path.join(CSRC, 'pinn_inst.inc'), '-o',
-                     os.path.join(BUILD, f'inst_hp{hp}.o')])
-    jobs.append([CXX, *FLAGS, '-c', os.path.join(CSRC, 'pinn_abi.cpp'), '-o', os.path.join(BUILD, 'abi.o')])
-    jobs.append([CXX, *FLAGS, '-c', os.path.join(HERE, 'emu_runtime.cpp'), '-o', os.path.join(BUILD, 'emu_runtime.o')])
+    return deps
 
-    def run(cmd):
-        res = subprocess.run(cmd, capture_output=True, text=True)
-        if res.returncode != 0:
-            raise RuntimeError(' '.join(cmd) + '\n' + res.stdout + res.stderr)
-        return cmd[-1]
 
-    with ThreadPoolExecutor(max_workers=os.cpu_count() or 4) as pool:
-        objs = list(pool.map(run, jobs))
-    res = subprocess.run([CXX, '-shared', '-fPIC', '-o', OUT, *objs], capture_output=True, text=True)
+def _run(cmd):
+    res = subprocess.run(cmd, capture_output=True, text=True)
     if res.returncode != 0:
-        raise RuntimeError(res.stdout + res.stderr)
-    return OUT
+        raise RuntimeError(' '.join(cmd) + '\n' + res.stdout + res.stderr)
+    return cmd[-1]
+
+
+def _fresh(out, deps):
+    return os.path.exists(out) and all(os.path.getmtime(d) <= os.path.getmtime(out) for d in deps)
+
+
+def build(force=False, extra_flags=(), tag='', widths=(64,)):
+    """ extra_flags / tag: a second library with other build knobs (e.g. -DPINN_CHAIN=1) for the kernel instantiations of
+    `widths`, kept beside the default one and sharing every other object with it """
+    deps = _deps()
+    if not (not force and _fresh(OUT, deps)):
+        os.makedirs(BUILD, exist_ok=True)
+        jobs = [[CXX, *FLAGS, f'-DPINN_INST_HP={hp}', '-c', os.path.join(CSRC, 'pinn_inst.inc'), '-o',
+                 os.path.join(BUILD, f'inst_hp{hp}.o')] for hp in WIDTHS]
+        jobs.append([CXX, *FLAGS, '-c', os.path.join(CSRC, 'pinn_abi.cpp'), '-o', os.path.join(BUILD, 'abi.o')])
+        jobs.append([CXX, *FLAGS, '-c', os.path.join(HERE, 'emu_runtime.cpp'), '-o', os.path.join(BUILD, 'emu_runtime.o')])
+        with ThreadPoolExecutor(max_workers=os.cpu_count() or 4) as pool:
+            objs = list(pool.map(_run, jobs))
+        _run([CXX, '-shared', '-fPIC', *objs, '-o', OUT])
+    if not tag:
+        return OUT
+    tbuild = os.path.join(HERE, '_build_' + tag)
+    tout = os.path.join(tbuild, 'libpinn_emu.so')
+    if not force and _fresh(tout, deps + [OUT]):
+        return tout
+    os.makedirs(tbuild, exist_ok=True)
+    jobs = [[CXX, *FLAGS, *extra_flags, f'-DPINN_INST_HP={hp}', '-c', os.path.join(CSRC, 'pinn_inst.inc'), '-o',
+             os.path.join(tbuild, f'inst_hp{hp}.o')] for hp in widths]
+    with ThreadPoolExecutor(max_workers=os.cpu_count() or 4) as pool:
+        objs = list(pool.map(_run, jobs))
+    objs += [os.path.join(BUILD, f'inst_hp{hp}.o') for hp in WIDTHS if hp not in widths]
+    objs += [os.path.join(BUILD, 'abi.o'), os.path.join(BUILD, 'emu_runtime.o')]
+    _run([CXX, '-shared', '-fPIC', *objs, '-o', tout])
+    return tout
 
 
 if __name__ == '__main__':

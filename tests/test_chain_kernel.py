@@ -21,8 +21,7 @@ from helpers import FixedBatches, export_params, load_params
 def chain_lib():
     import build_emu
     from pydens_amd import engine
-    path = build_emu.build(extra_flags=['-DPINN_CHAIN=1'], tag='chain')
-    build_emu.build()                 # leave the module's paths on the default library for the other tests
+    path = build_emu.build(extra_flags=['-DPINN_CHAIN=1'], tag='chain')     # (only the width-64 instantiations differ)
     return engine.bind(ctypes.CDLL(path))
 
 

@@ -310,7 +310,7 @@ def test_random_problem_shapes_on_the_emulated_kernels():
     import build_emu
     import pydens_amd as pa
     from pydens_amd import engine
-    _run_problems(pa, dict(lib=engine.bind(ctypes.CDLL(build_emu.build())), device='cpu'), n_problems=10, max_batch=65)
+    _run_problems(pa, dict(lib=engine.bind(ctypes.CDLL(build_emu.build())), device='cpu'), n_problems=6, max_batch=65)
 
 
 @pytest.mark.gpu
