@@ -1011,18 +1011,32 @@ pinn_tile_kernel(const PinnKArgs A) {
             wtw[((size_t)l * HP + k) * HP + n] = A.params[A.off_wh + (size_t)l * A.hidden_stride + n * HP + k];
         }
     }
-    if (WTL && train) {
-        // WTs[l][k][n] = W_l[n][k]: coalesced global reads along k, one-time strided LDS writes. ALL loads of a thread are
-        // issued before the first LDS write (the registers are free here): the weights were last written by another
-        // launch's Adam on other XCDs, so every batch of loads pays a full L2-miss round trip -- one instead of six or more
-        // (prologue phase counters: 9.4 K -> cycles of one round trip on cfg2)
-        constexpr int WT_TOTAL = (LHC > 0 ? LHC : 0) * HP * HP;
-        constexpr int NTH_ALL = NTHREADS * TEAMS;               // both teams stage the shared copy together
-        constexpr int WT_PER = (WT_TOTAL + NTH_ALL - 1) / NTH_ALL;
+    // WTs[l][k][n] = W_l[n][k]: coalesced global reads along k, one-time strided LDS writes. ALL loads of a thread are
+    // issued before the first LDS write (the registers are free here): the weights were last written by another
+    // launch's Adam on other XCDs, so every batch of loads pays a full L2-miss round trip -- one instead of six or more
+    // (prologue phase counters: 9.4 K -> cycles of one round trip on cfg2). When one batch holds everything (PINN_WT_SPLIT),
+    // the LDS writes wait until the x-only pre-pass below is through: the round trip runs behind it.
+    constexpr int WT_TOTAL = (LHC > 0 ? LHC : 0) * HP * HP;
+    constexpr int NTH_ALL = NTHREADS * TEAMS;               // both teams stage the shared copy together
+    constexpr int WT_PER = (WT_TOTAL + NTH_ALL - 1) / NTH_ALL;
 #ifndef PINN_WT_STAGE_BATCH
 #define PINN_WT_STAGE_BATCH 64
 #endif
-        constexpr int WT_B = WT_PER < 1 ? 1 : (WT_PER < PINN_WT_STAGE_BATCH ? WT_PER : PINN_WT_STAGE_BATCH);
+#ifndef PINN_WT_SPLIT
+#define PINN_WT_SPLIT 0      // (measured with Adam in the loop: cfg2 +0.8 %, cfg4 +-0: the pre-pass does not cover more than the loads already overlapped)
+#endif
+    constexpr int WT_B = WT_PER < 1 ? 1 : (WT_PER < PINN_WT_STAGE_BATCH ? WT_PER : PINN_WT_STAGE_BATCH);
+    constexpr bool WT_SPLIT = WTL && PINN_WT_SPLIT && WT_PER >= 1 && WT_PER <= WT_B;
+    float wreg_split[WT_SPLIT ? WT_B : 1];
+    auto wt_write = [&](int e0, const float* wreg) {
+#pragma unroll
+        for (int e = 0; e < WT_B; ++e) {
+            const int i = gtid + (e0 + e) * NTH_ALL;
+            const int l = i / (HP * HP), n = (i / HP) % HP, k = i % HP;
+            if (i < WT_TOTAL) WTs[(l * HP + k) * C::WT_LD + n] = wreg[e];
+        }
+    };
+    if (WTL && train) {
         for (int e0 = 0; e0 < WT_PER; e0 += WT_B) {
             float wreg[WT_B];
 #pragma unroll
@@ -1031,11 +1045,11 @@ pinn_tile_kernel(const PinnKArgs A) {
                 const int l = i / (HP * HP), n = (i / HP) % HP, k = i % HP;
                 wreg[e] = (i < WT_TOTAL) ? A.params[A.off_wh + (size_t)l * A.hidden_stride + n * HP + k] : 0.0f;
             }
+            if (WT_SPLIT) {
 #pragma unroll
-            for (int e = 0; e < WT_B; ++e) {
-                const int i = gtid + (e0 + e) * NTH_ALL;
-                const int l = i / (HP * HP), n = (i / HP) % HP, k = i % HP;
-                if (i < WT_TOTAL) WTs[(l * HP + k) * C::WT_LD + n] = wreg[e];
+                for (int e = 0; e < WT_B; ++e) wreg_split[WT_SPLIT ? e : 0] = wreg[e];
+            } else {
+                wt_write(e0, wreg);
             }
         }
     }
@@ -1149,6 +1163,7 @@ pinn_tile_kernel(const PinnKArgs A) {
         }
         PINN_FENCE_BLOCK();
     }
+    if (WT_SPLIT && train) wt_write(0, wreg_split);
     fetch_points(A.tile_begin + vbid);
     store_points(xs_base);
     fetch_points(A.tile_begin + vbid + vnblk);
