@@ -42,3 +42,28 @@ def test_chain_kernel_matches_the_oracle(chain_lib, name, n):
     np.testing.assert_allclose([float(v) for v in solver.losses], [float(v) for v in oracle.losses], rtol=2e-6)
     for got, want in zip(export_params(solver), oracle.export_params()):
         assert params_close(got, want, 2e-6)
+
+
+def test_experiment_build_knobs_keep_parity():
+    """ the measured-and-rejected build options of the tile kernel (batched DPP row sums, weight
+    fragments two K quads ahead, W^T staging split around the pre-pass) still produce the oracle's step """
+    import build_emu
+    import pydens_amd as pa
+    from pydens_amd import engine
+    from oracle import pinn_oracle as po
+    path = build_emu.build(extra_flags=['-DPINN_ROWSUM_BATCH=1', '-DPINN_W_AHEAD=2', '-DPINN_WT_SPLIT=1'], tag='knobs',
+                           widths=(64, 128))
+    lib = engine.bind(ctypes.CDLL(path))
+    for name, n in (('cfg2', 70), ('cfg3', 40)):
+        torch.manual_seed(0)
+        co, cp = pc.make_config(name, po.D, torch), pc.make_config(name, pa.D, torch)
+        oracle = po.OracleSolver(co['equation'], **co['solver_kwargs'])
+        solver = pa.Solver(cp['equation'], **cp['solver_kwargs'], lib=lib, device='cpu')
+        load_params(solver, oracle.export_params())
+        pts = pc.sample_points(co, n, seed=5, steps=2)
+        oracle.fit(niters=2, batch_size=n, points=pts, lr=0.01)
+        solver.fit(niters=2, batch_size=n, sampler=FixedBatches(pts), lr=0.01)
+        assert solver.last_fit_path == 'fused'
+        np.testing.assert_allclose([float(v) for v in solver.losses], [float(v) for v in oracle.losses], rtol=3e-6)
+        for got, want in zip(export_params(solver), oracle.export_params()):
+            assert params_close(got, want, 3e-5, atol=2e-6)
