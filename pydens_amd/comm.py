@@ -40,6 +40,9 @@ def _rccl():
         lib.ncclAllReduce.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_size_t, ctypes.c_int, ctypes.c_int,
                                       ctypes.c_void_p, ctypes.c_void_p]
         lib.ncclCommDestroy.argtypes = [ctypes.c_void_p]
+        if hasattr(lib, 'ncclCommCount'):
+            lib.ncclCommCount.argtypes = [ctypes.c_void_p, ctypes.POINTER(ctypes.c_int)]
+            lib.ncclCommCount.restype = ctypes.c_int
         lib.ncclGetErrorString.argtypes = [ctypes.c_int]
         lib.ncclGetErrorString.restype = ctypes.c_char_p
         for name in ('ncclGetUniqueId', 'ncclCommInitRank', 'ncclAllReduce', 'ncclCommDestroy'):
@@ -59,37 +62,80 @@ class Communicator:
         self.device = torch.device(device)
         self.rank, self.world = dist.get_rank(), dist.get_world_size()
         self.comm = None
-        self.direct = (self.device.type == 'cuda' and dist.get_backend() == 'nccl'
+        self.n_ranks = self.world                 # RCCL's own count once the direct communicator exists (ncclCommCount)
+        self.fallback_reason = None
+        want_direct = (self.device.type == 'cuda' and dist.get_backend() == 'nccl'
                        and os.environ.get('PYDENS_AMD_COMM', 'rccl') != 'torch')
-        if self.direct:
+        self.direct = False
+        if not want_direct:
+            self.fallback_reason = 'CPU tensors / gloo' if self.device.type != 'cuda' else 'PYDENS_AMD_COMM=torch'
+            return
+        # Every rank must take the same path, and no rank may enter ncclCommInitRank alone (its peers would wait in it for
+        # ever): the ranks agree (MIN all-reduce over the torch group) after each step that can fail locally -- loading the
+        # library, creating the communicator, a known-answer all-reduce through it.
+        lib, err = None, None
+        try:
             lib = _rccl()
-            uid = _UniqueId()
-            if self.rank == 0:
-                _check(lib, lib.ncclGetUniqueId(ctypes.byref(uid)), 'ncclGetUniqueId')
-            box = torch.tensor(list(uid.internal), dtype=torch.uint8, device=self.device)      # all 128 bytes, zeros included
-            dist.broadcast(box, src=0)
-            raw = bytes(box.cpu().tolist())
-            assert len(raw) == NCCL_UNIQUE_ID_BYTES
-            ctypes.memmove(ctypes.byref(uid), raw, NCCL_UNIQUE_ID_BYTES)
-            comm = ctypes.c_void_p()
-            err = None
+        except (OSError, AttributeError) as exc:
+            err = exc
+        if not self._agree(err is None):
+            return self._fall_back(f'librccl not loadable on every rank ({err})')
+        uid = _UniqueId()
+        if self.rank == 0:
             try:
-                with torch.cuda.device(self.device):
-                    _check(lib, lib.ncclCommInitRank(ctypes.byref(comm), self.world, uid, self.rank), 'ncclCommInitRank')
+                _check(lib, lib.ncclGetUniqueId(ctypes.byref(uid)), 'ncclGetUniqueId')
             except RuntimeError as exc:
                 err = exc
-            # every rank must take the same path: agree on the outcome over the torch group
-            ok = torch.tensor([0 if err is not None else 1], dtype=torch.int32, device=self.device)
-            dist.all_reduce(ok, op=dist.ReduceOp.MIN)
-            if int(ok.item()) == 1:
-                self.comm = comm
-            else:
-                import warnings
-                warnings.warn(f'pydens_amd.comm: direct RCCL communicator unavailable ({err}); gradient all-reduce goes '
-                              'through torch.distributed (ProcessGroupNCCL, side stream)')
-                if err is None:
-                    lib.ncclCommDestroy(comm)
-                self.direct = False
+        box = torch.tensor(list(uid.internal) + [0 if err is None else 1], dtype=torch.uint8, device=self.device)
+        dist.broadcast(box, src=0)                # all 128 bytes, zeros included, + rank 0's verdict
+        raw = bytes(box.cpu().tolist())
+        if raw[NCCL_UNIQUE_ID_BYTES]:
+            return self._fall_back(f'ncclGetUniqueId failed on rank 0 ({err})')
+        ctypes.memmove(ctypes.byref(uid), raw[:NCCL_UNIQUE_ID_BYTES], NCCL_UNIQUE_ID_BYTES)
+        torch.cuda.synchronize(self.device)       # nothing of ProcessGroupNCCL's in flight while the second communicator boots
+        comm = ctypes.c_void_p()
+        try:
+            with torch.cuda.device(self.device):
+                _check(lib, lib.ncclCommInitRank(ctypes.byref(comm), self.world, uid, self.rank), 'ncclCommInitRank')
+        except RuntimeError as exc:
+            err = exc
+        if not self._agree(err is None):
+            if err is None:
+                lib.ncclCommDestroy(comm)
+            return self._fall_back(f'ncclCommInitRank failed on some rank ({err})')
+        self.comm, self.direct = comm, True
+        count = ctypes.c_int(0)
+        if hasattr(lib, 'ncclCommCount') and lib.ncclCommCount(comm, ctypes.byref(count)) == 0:
+            self.n_ranks = int(count.value)
+        # known answer through the direct path: rank r contributes r + 1 in every slot
+        probe = torch.full((64,), float(self.rank + 1), dtype=torch.float32, device=self.device)
+        try:
+            self.all_reduce_(probe)
+            torch.cuda.synchronize(self.device)
+            good = bool((probe == self.world * (self.world + 1) / 2).all().item()) and self.n_ranks == self.world
+        except RuntimeError as exc:
+            good, err = False, exc
+        if not self._agree(good):
+            self.close()
+            return self._fall_back(f'direct all-reduce failed its known-answer check ({err})')
+
+    def _agree(self, ok):
+        flag = torch.tensor([1 if ok else 0], dtype=torch.int32, device=self.device)
+        dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+        return int(flag.item()) == 1
+
+    def _fall_back(self, reason):
+        import warnings
+        self.direct, self.comm, self.fallback_reason, self.n_ranks = False, None, reason, self.world
+        warnings.warn(f'pydens_amd.comm: direct RCCL communicator unavailable: {reason}; the gradient all-reduce goes through '
+                      'torch.distributed (ProcessGroupNCCL, side stream)')
+
+    def describe(self):
+        """ which all-reduce runs, for logs and bench lines """
+        if self.direct:
+            return {'all_reduce': 'RCCL ncclAllReduce called directly on the compute stream', 'n_ranks': self.n_ranks}
+        return {'all_reduce': f'torch.distributed.all_reduce ({dist.get_backend()}; fallback: {self.fallback_reason})',
+                'n_ranks': self.world}
 
     def all_reduce_(self, tensor, stream=None):
         if not self.direct:
@@ -109,6 +155,7 @@ class Communicator:
             torch.cuda.synchronize(self.device)
             _rccl().ncclCommDestroy(self.comm)
             self.comm = None
+            self.direct = False
 
     def __del__(self):
         try:

@@ -191,6 +191,11 @@ int make_plan(const pinn_net* net, int64_t n_points, int nd, int n2, Plan* plan,
         int64_t grid2 = (int64_t)device_cus(net) * winfo[3];
         if (grid2 > wg_tiles) grid2 = wg_tiles;
         plan->grid2 = (int)(grid2 < 1 ? 1 : grid2);
+        // the hidden->hidden blocks of a partial row are written by pinn_wgrad_kernel alone (rows < grid2; the tile kernel leaves
+        // them untouched in WGX mode), and the reduction sums max(grid, grid2) rows: a tile-kernel grid beyond grid2 would add
+        // rows whose blocks nobody wrote -- the occupancy query may answer more workgroups per CU for the tile
+        // kernel than WGS_PER_CU of the weight-gradient kernel, so the tile grid is capped here
+        if (plan->grid > plan->grid2) plan->grid = plan->grid2;
         plan->gz_vec4_per_tile = (size_t)info[7];
         // whole sweeps of the persistent workgroups per chunk
         const size_t per_tile = (plan->slab_vec4_per_wg + plan->gz_vec4_per_tile) * 16;

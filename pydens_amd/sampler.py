@@ -99,7 +99,14 @@ class ConstantSampler(Sampler):
 
 
 class NumpySampler(Sampler):
-    """ sampler named after a `numpy.random` distribution ('uniform'/'u', 'normal'/'n', ...). """
+    """ sampler named after a `numpy.random` distribution ('uniform'/'u', 'normal'/'n', ...).
+
+    `seed=`: `sample()` (host numpy) replays numpy's own stream, as batchflow's sampler does. Inside `Solver.fit` products of
+    uniform / normal / constant columns are drawn ON THE DEVICE by a counter-based Philox generator keyed with the seeds
+    (`device_key`): runs are reproducible for a given seed, rank and batch count, but the points are NOT numpy's -- two
+    leaves with the same seed give independent columns there, every rank draws its own points -- so a seeded run does not
+    reproduce the reference's point sets bit for bit. For that, hand `fit` a sampler object without `columns()` (e.g. a
+    thin wrapper exposing only `sample`): it then takes the host path of the reference (model_torch.py:433). """
     def __init__(self, name, dim=1, seed=None, **kwargs):
         self.name = _ALIASES.get(name, name)
         self.dim = dim

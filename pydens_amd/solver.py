@@ -147,7 +147,9 @@ class Solver:
             self._trace_equation()
         elif self.program is not None and self.residual_plan is not None:
             try:
-                ok = self._plan_matches(self.residual_plan)
+                # (a callable initial condition lowered into the pre-pass is part of the cached lowering: the reference calls
+                #  it in every iteration too, model_torch.py:125)
+                ok = self._plan_matches(self.residual_plan) and self._ic_matches(self.residual_plan)
             except (trace.TraceUnsupported, NotImplementedError, RuntimeError, TypeError, ValueError):
                 ok = False
             if not ok:
@@ -157,11 +159,20 @@ class Solver:
                 if num < len(self.constraint_plans) and num not in nums_constraints and \
                         num < len(self._traced_constraints) and constraint is self._traced_constraints[num]:
                     continue
+                known = num < len(self._traced_constraints) and constraint is self._traced_constraints[num]
+                before = set(self.model.variables)
                 plan, err = self._try_compile_constraint(constraint)
                 if num < len(self.constraint_plans):
                     self.constraint_plans[num], self.constraint_errors[num] = plan, err
                 else:
                     self.constraint_plans.append(plan); self.constraint_errors.append(err)
+                if not known:
+                    # a constraint appended after construction: variables its tracing brings to life are dormant until a fit
+                    # call has evaluated it, exactly as for the constraints __init__ saw (reference :420 vs :457)
+                    born = set(self.model.variables) - before
+                    self._born_in_constraint[num] = self._born_in_constraint.get(num, set()) | born
+                    if num not in self._constraints_seen:
+                        self.model.dormant_variables |= born
             self._traced_constraints = tuple(self.constraints)
 
     # ---- tracing ---------------------------------------------------------------------------------------------------
@@ -195,6 +206,15 @@ class Solver:
         var_values = self.model.flat[lay.off_extra:lay.off_extra + plan.n_vars].detach().cpu().numpy()
         got = trace.run_residual_numpy(plan, streams.cpu().numpy(), pts.cpu().numpy(), var_values)
         return bool(np.allclose(got, want, rtol=1e-4, atol=1e-5))
+
+    def _ic_matches(self, plan):
+        """ the initial-condition rows of the pre-pass against torch autograd over the live callable on random points """
+        if plan.ic_row is None:
+            return True
+        pts = torch.rand((17, self.model.total), device=self.device) + 0.25
+        want = self._ic_stream_tensor(pts, plan.comb_w)
+        got = trace.run_ic_numpy(plan, pts.cpu().numpy().astype(np.float64))
+        return got.shape == tuple(want.shape) and bool(np.allclose(got, want.double().cpu().numpy(), rtol=1e-4, atol=1e-5))
 
     def _try_compile(self):
         """ lower the equation to a residual program and cross-check it numerically against the callable. """
@@ -238,10 +258,7 @@ class Solver:
             if plan.ic_row is None:
                 raise trace.TraceUnsupported('initial condition does not fit the pre-pass')
             # validation against torch autograd over the callable on random points
-            pts = torch.rand((17, self.model.total), device=self.device) + 0.25
-            want = self._ic_stream_tensor(pts, plan.comb_w)
-            got = trace.run_ic_numpy(plan, pts.cpu().numpy().astype(np.float64))
-            if got.shape != tuple(want.shape) or not np.allclose(got, want.double().cpu().numpy(), rtol=1e-4, atol=1e-5):
+            if not self._ic_matches(plan):
                 raise trace.TraceUnsupported('lowered initial condition disagrees with the callable')
         except (trace.TraceUnsupported, NotImplementedError) as err:
             plan.ic_row, plan.ic_const = None, None          # (unused rows stay in the pre-pass: harmless)
@@ -538,6 +555,11 @@ class Solver:
         rank, world = self._world()
         if world > 1:
             self.begin_data_parallel()
+            # every rank must run the same step path (the validation of a lowering is a float comparison on random points and
+            # may come out differently on one rank): fused only if fused everywhere
+            flag = torch.tensor([1 if fused else 0], dtype=torch.int32, device=self.device)
+            torch.distributed.all_reduce(flag, op=torch.distributed.ReduceOp.MIN)
+            fused = bool(int(flag.item()))
         local_batch = batch_size // world + (1 if rank < batch_size % world else 0)
         self._global_batch = batch_size
         self._new_sample_seed()

@@ -669,6 +669,34 @@ def test_closure_constants_and_reassigned_equations_take_effect_in_the_next_fit(
     np.testing.assert_allclose([float(v) for v in solver.losses], [float(v) for v in oracle.losses], rtol=3e-5)
 
 
+def test_closure_constant_inside_a_callable_initial_condition(pa, emu_lib):
+    """ a callable IC lowered into the x-only pre-pass is part of the cached lowering -- the reference calls
+    it in every iteration (model_torch.py:125), so an amplitude changed between two fit calls must train against the new IC. """
+    from oracle import pinn_oracle as po
+    amp = {'a': 1.0}
+
+    def problem(D):
+        def pde(f, x, t):
+            return D(f, t) - 0.1 * D(D(f, x), x)
+        return pde, dict(ndims=2, boundary_condition=0, initial_condition=lambda x: amp['a'] * torch.sin(np.pi * x),
+                         layout='fa fa f', features=[10, 12, 1], activation='Tanh')
+    eq_o, kw_o = problem(po.D)
+    oracle = po.OracleSolver(eq_o, **kw_o)
+    eq_p, kw_p = problem(pa.D)
+    solver = pa.Solver(eq_p, **kw_p, **emu_kwargs(emu_lib))
+    assert solver.residual_plan.ic_row is not None            # the IC sits in the pre-pass
+    load_params(solver, oracle.export_params())
+    pts = np.random.RandomState(5).rand(4, 48, 2).astype(np.float32)
+    for a, sl in ((1.0, slice(0, 2)), (3.0, slice(2, 4))):
+        amp['a'] = a
+        oracle.fit(niters=2, batch_size=48, points=pts[sl], lr=0.01)
+        solver.fit(niters=2, batch_size=48, sampler=FixedBatches(pts[sl]), lr=0.01)
+        assert solver.last_fit_path == 'fused' and solver.residual_plan.ic_row is not None
+    np.testing.assert_allclose([float(v) for v in solver.losses], [float(v) for v in oracle.losses], rtol=3e-5)
+    x = np.linspace(0.1, 0.9, 5)
+    np.testing.assert_allclose(solver.predict(x, 0.0)[:, 0], 3.0 * np.sin(np.pi * x), rtol=1e-5)
+
+
 def test_interrupted_fit_keeps_the_losses_it_reached(pa, emu_lib):
     """ the reference appends a loss per iteration (model_torch.py:464); a sampler that raises in iteration 3
     leaves three applied steps AND three recorded losses """
