@@ -223,6 +223,19 @@ int pinn_adam_step_at(float* params, const float* grads, float* exp_avg, float* 
                       int64_t n, int32_t* step_ptr, int32_t step, float lr, float beta1, float beta2, float eps,
                       float* loss_out, int32_t off_loss, void* stream);
 
+/* Arithmetic of the hidden-layer GEMMs (forward, data gradient, weight gradient) of the fused step -- what ATen's `addmm` /
+ * `mm` calls do in the reference (pydens/model_torch.py:170-178, :460), per net:
+ *   PINN_GEMM_FP32    (default) v_mfma_f32_16x16x4_f32: exact fp32, bitwise an fmaf chain
+ *   PINN_GEMM_BF16X3  every fp32 operand split EXACTLY into three bf16 (hi + mid + lo), the six partial products
+ *                     a_i b_j with i + j <= 2 on v_mfma_f32_16x16x32_bf16, fp32 accumulate: the dropped products are below
+ *                     2^-24 of |a b| (measured: at or below the rounding error of the fp32 chain). Used by the kernels
+ *                     built with it (width-64 nets of static depth 3 on the Dirichlet-box / ODE-family training shapes);
+ *                     every other call keeps the fp32 kernels. pinn_last_kernel_name() tells which one ran.
+ * Returns non-zero for an unknown mode. */
+#define PINN_GEMM_FP32   0
+#define PINN_GEMM_BF16X3 1
+int pinn_set_gemm_mode(pinn_t* net, int mode);
+
 /* Measurement hook (bench.py `roofline`): with enable != 0 the step/backward entry points bracket their TILE
  * kernel launch with hipEvents on the launch stream; pinn_last_tile_ms() waits for the last bracket and returns
  * its duration in milliseconds (negative if none). Off by default; never used on the training path. */
@@ -234,23 +247,27 @@ float pinn_last_wgrad_ms(void);
  * "pinn_tile_kernel<64,2,1,2,3,0,true,16>" (the symbol rocprofv3 shows): bench.py names the kernel it prices with it. */
 const char* pinn_last_kernel_name(void);
 
-/* Diagnostics (tests, tools/): never used on the training path. All but pinn_debug_set_flags leave results untouched;
- * the flag bits are TIMING experiments (kernels skip loads / stores / barriers: results of such a call are meaningless).
+/* Diagnostics (tests, tools/): never used on the training path; they leave results untouched.
  *   pinn_debug_last_kernel        0 = general tile kernel, 2 = shape-specialised tile kernel took the last launch
- *   pinn_debug_set_flags          experiment bits handed to the kernels (PinnKArgs::debug_flags; 0 = off, the default):
- *                                 2 / 4 slab reads / writes of the widths >= 128 pinned to one tile (L2-resident),
- *                                 8 / 16 / 32 weight-gradient kernel without barrier / LDS staging / HBM loads
- *                                 (-DPINN_CHAIN=1 experiment builds, pinn_chain_kernel: 8 stages consumed but not multiplied,
- *                                 16 no ring wait, 32 no weight gradient, 64 / 128 no slab reads / writes)
  *   pinn_debug_prepass_in_kernel  0: x-only pre-pass as its own launch (pinn_aux_kernel) instead of the tile kernel's prologue
- *   pinn_debug_phase_buffer       device buffer for per-phase cycle counters (-DPINN_PROFILE_PHASES builds, tools/phases.py)
  *   pinn_debug_wgx_chunk_bytes    slab budget per pass of the widths >= 128 (default 6.5 GB; <= 0 restores it): tests force
  *                                 multi-chunk steps with a tiny budget; affects pinn_workspace_bytes, so set it first */
 int pinn_debug_last_kernel(void);
-int pinn_debug_set_flags(int flags);
 int pinn_debug_prepass_in_kernel(int enable);
-int pinn_debug_phase_buffer(void* buf);
 int pinn_debug_wgx_chunk_bytes(long long bytes);
+#ifdef PINN_DEBUG_ABI
+/* EXPERIMENT BUILDS ONLY (-DPINN_DEBUG_ABI, tools/variant.sh): the product library neither exports these nor compiles the
+ * kernel paths behind them. The flag bits are TIMING experiments -- kernels skip loads / stores / barriers, the results of
+ * such a call are meaningless:
+ *   pinn_debug_set_flags          bits handed to the kernels (PinnKArgs::debug_flags; 0 = off):
+ *                                 2 / 4 slab reads / writes of the widths >= 128 pinned to one tile (L2-resident),
+ *                                 8 / 16 / 32 weight-gradient kernel without barrier / LDS staging / HBM loads
+ *                                 (-DPINN_CHAIN=1 builds, tools/experiments/pinn_chain_kernel.h: 8 stages consumed but not
+ *                                 multiplied, 16 no ring wait, 32 no weight gradient, 64 / 128 no slab reads / writes)
+ *   pinn_debug_phase_buffer       device buffer for per-phase cycle counters (-DPINN_PROFILE_PHASES builds, tools/phases.py) */
+int pinn_debug_set_flags(int flags);
+int pinn_debug_phase_buffer(void* buf);
+#endif
 
 /* Collocation points drawn on the device: replaces the host-side sampling of model_torch.py:430-434 (d independent
  * `torch.rand((N,1))` columns, or `sampler.sample(N)` of a NumpySampler product `a & b & ...`, README.md:82) with ONE

@@ -15,7 +15,7 @@ PKG = os.path.dirname(HERE)
 OUT = os.path.join(PKG, 'libpinn_hip.so')
 OBJ = os.path.join(HERE, '_obj')
 WIDTHS = (16, 32, 64, 128, 256)
-FLAGS = ['--offload-arch=gfx950', '-O3', '-std=c++17', '-fPIC', '-x', 'hip', '-Wno-unused-result']
+FLAGS = ['--offload-arch=gfx950', '-O3', '-std=c++17', '-fPIC', '-x', 'hip', '-Wno-unused-result', '-I', HERE]
 # per-width scheduler choice (same-box A/B of hipcc's -amdgpu-sched-strategy values on the BASELINE kernels, DESIGN.md
 # section 6): the width-256 kernels (256 VGPRs, spilling) run 4.9 % faster under `iterative-maxocc` (4.1 % under
 # `iterative-ilp`, 10 % slower under `iterative-minreg` / `max-memory-clause`); the other widths are within 1 % of the
@@ -24,6 +24,12 @@ FLAGS = ['--offload-arch=gfx950', '-O3', '-std=c++17', '-fPIC', '-x', 'hip', '-W
 # width 256 is within 0.3 % between the default and `iterative-maxocc` now (`iterative-ilp` costs its weight-gradient kernel 27 %);
 # width 128 is within 1 % everywhere
 WIDTH_FLAGS = {256: ['-mllvm', '-amdgpu-sched-strategy=iterative-maxocc'], 64: ['-mllvm', '-amdgpu-sched-strategy=iterative-ilp']}
+# split-bf16 twins of the two BASELINE width-64 kernels (same-box A/B, round 3): 1 = the S = 4 Poisson-box kernel, fastest with the
+# SLP vectoriser on (packed fp32 ops: fewer instructions to issue), 2 = the S = 2 ODE-family kernel, fastest without it
+SPLIT_FLAGS = {1: [], 2: ['-fno-slp-vectorize']}
+if os.environ.get('PINN_SPLIT_FLAGS'):
+    import json
+    SPLIT_FLAGS = {int(k): v for k, v in json.loads(os.environ['PINN_SPLIT_FLAGS']).items()}
 if os.environ.get('PINN_WIDTH_FLAGS'):          # experiment builds: JSON {width: [flags]} replaces the table above
     import json
     WIDTH_FLAGS = {int(k): v for k, v in json.loads(os.environ['PINN_WIDTH_FLAGS']).items()}
@@ -72,6 +78,11 @@ def _build(force, verbose, extra_flags, widths):
         else:
             extra = []
         jobs.append((obj, [hipcc, *FLAGS, *WIDTH_FLAGS.get(hp, []), *extra_flags, *extra, f'-DPINN_INST_HP={hp}', '-c',
+                           os.path.join(HERE, 'pinn_inst.inc'), '-o', obj]))
+    # split-bf16 kernels of width 64 (pinn_inst.inc, PINN_INST_SPLIT): their own translation units and flags
+    for which, flags in SPLIT_FLAGS.items():
+        obj = os.path.join(OBJ, f'inst_hp64_split{which}.o')
+        jobs.append((obj, [hipcc, *FLAGS, *flags, *extra_flags, '-DPINN_INST_HP=64', f'-DPINN_INST_SPLIT={which}', '-c',
                            os.path.join(HERE, 'pinn_inst.inc'), '-o', obj]))
     obj = os.path.join(OBJ, 'abi.o')
     jobs.append((obj, [hipcc, *FLAGS, *extra_flags, '-c', os.path.join(HERE, 'pinn_abi.cpp'), '-o', obj]))

@@ -49,10 +49,14 @@ float prof_elapsed(hipEvent_t a, hipEvent_t b) {
 #endif
 }  // namespace
 
-int g_pinn_last_kernel = -1;
-char g_pinn_last_kernel_name[96] = "";
+// (shared with the per-width translation units, not exported)
+#define PINN_HIDDEN __attribute__((visibility("hidden")))
+PINN_HIDDEN int g_pinn_last_kernel = -1;
+PINN_HIDDEN char g_pinn_last_kernel_name[96] = "";
+namespace {
 int g_pinn_prepass_in_kernel = 1;   // debug switch: 0 = x-only pre-pass as its own launch (pinn_aux_kernel)
-int g_pinn_debug_flags = 0;
+int g_pinn_debug_flags = 0;         // -DPINN_DEBUG_ABI builds: pinn_debug_set_flags
+}
 
 struct pinn_net {
     pinn_layout_t lay;
@@ -62,6 +66,7 @@ struct pinn_net {
     int dims[PINN_MAX_LAYERS + 1];
     float lo[PINN_MAX_INPUTS], hi[PINN_MAX_INPUTS], bc_value;
     int n_cu;
+    int gemm_mode;                  // PINN_GEMM_FP32 / PINN_GEMM_BF16X3 (pinn_set_gemm_mode)
 };
 
 namespace {
@@ -130,6 +135,7 @@ struct Plan {
     // WGX (widths >= 128): hidden->hidden weight gradients by pinn_wgrad_kernel from per-tile slabs in HBM
     int wgx, grid2;                 // grid2: workgroups of the weight-gradient kernel
     int wt_global;                  // the kernel reads the transposed global copy of the hidden weights (pinn_transpose_kernel)
+    int split;                      // split-bf16 kernel: reads the bf16 fragment copy of the hidden weights (pinn_wsplit_kernel)
     wgrad_fn wfn;
     size_t gz_vec4_per_tile;
     int64_t chunk_tiles;            // tiles per pass through the two kernels
@@ -160,10 +166,11 @@ int make_plan(const pinn_net* net, int64_t n_points, int nd, int n2, Plan* plan,
         probe.act_codes = net->act_codes;
         probe.n_skips = net->n_skips;
     }
+    probe.gemm_mode = net->gemm_mode;
     probe.mode = mode;
     probe.res_kind = res_kind;
     probe.comb = comb;
-    long long info[11] = {0, 0, 0, 1, 1, 0, 0, 0, 0, 0, 1};
+    long long info[12] = {0, 0, 0, 1, 1, 0, 0, 0, 0, 0, 1, 0};
     if (plan->fn(nd, plan->n2k, &probe, 0, nullptr, 1, info))
         return fail("no kernel instantiation for width %d with nd=%d n2=%d%s", net->lay.hp, nd, plan->n2k, comb ? " (combined)" : "");
     plan->smem = (size_t)info[0];
@@ -182,10 +189,11 @@ int make_plan(const pinn_net* net, int64_t n_points, int nd, int n2, Plan* plan,
     plan->comb = comb;
     plan->wgx = (mode != PINN_MODE_FORWARD && info[6]) ? 1 : 0;
     plan->wt_global = (int)info[9];
+    plan->split = (int)info[11];
     plan->grid2 = 0; plan->wfn = nullptr; plan->gz_vec4_per_tile = 0; plan->chunk_tiles = wg_tiles;
     if (plan->wgx) {
         plan->wfn = wgrad_launcher_for(net->lay.hp);
-        long long winfo[11] = {0, 0, 0, 1, 1, 0, 0, 0, 0, 0, 1};
+        long long winfo[12] = {0, 0, 0, 1, 1, 0, 0, 0, 0, 0, 1, 0};
         if (!plan->wfn || plan->wfn(nd, plan->n2k, comb, plan->mt, &probe, 0, nullptr, 1, winfo))
             return fail("no weight-gradient kernel for width %d with nd=%d n2=%d%s", net->lay.hp, nd, plan->n2k, comb ? " (combined)" : "");
         int64_t grid2 = (int64_t)device_cus(net) * winfo[3];
@@ -227,6 +235,7 @@ void fill_args(const pinn_net* net, PinnKArgs* a, const float* params, const flo
     }
     for (int k = 0; k < PINN_MAX_DIRS; ++k) a->dir_cols[k] = (k < nd) ? dir_cols[k] : 0;
     a->s_user = pinn_ns(nd, n2);
+    a->gemm_mode = net->gemm_mode;
     a->tile_begin = 0;
     a->tile_end = 0;                // set from the plan (set_tile_range) before every launch
 }
@@ -293,6 +302,11 @@ size_t align256(size_t v) { return (v + 255) / 256 * 256; }
 size_t wt_workspace_bytes(const pinn_net* net) {
     return net->lay.lh > 0 ? align256((size_t)net->lay.lh * net->lay.hp * net->lay.hp * sizeof(float)) : 0;
 }
+
+// split-bf16 kernels: the bf16 fragment copy of the hidden weights (PinnCfg::wsp_bytes: 2 directions x 3 planes x 2 bytes)
+size_t wsp_workspace_bytes(const pinn_net* net) {
+    return net->lay.lh > 0 ? align256((size_t)net->lay.lh * 2 * 3 * net->lay.hp * net->lay.hp * 2) : 0;
+}
 }  // namespace
 
 extern "C" {
@@ -324,9 +338,18 @@ int pinn_sample_points(float* xs, int64_t n_points, int d, const int* kind, cons
     return 0;
 }
 
+#ifdef PINN_DEBUG_ABI
 int pinn_debug_set_flags(int flags) { g_pinn_debug_flags = flags; return 0; }
+#endif
 
 int pinn_debug_last_kernel(void) { return g_pinn_last_kernel; }
+
+int pinn_set_gemm_mode(pinn_t* net, int mode) {
+    if (!net) return fail("null argument");
+    if (mode != PINN_GEMM_FP32 && mode != PINN_GEMM_BF16X3) return fail("unknown GEMM mode %d", mode);
+    net->gemm_mode = mode;
+    return 0;
+}
 
 const char* pinn_last_kernel_name(void) { return g_pinn_last_kernel_name; }
 
@@ -340,10 +363,12 @@ int pinn_debug_wgx_chunk_bytes(long long bytes) {
     return 0;
 }
 
+#ifdef PINN_DEBUG_ABI
 int pinn_debug_phase_buffer(void* buf) {
     g_phase_prof = reinterpret_cast<long long*>(buf);
     return 0;
 }
+#endif
 
 int pinn_profile_tile(int enable) {
     g_profile = enable ? 1 : 0;
@@ -501,7 +526,8 @@ size_t pinn_workspace_bytes(const pinn_t* net, int64_t n_points, int nd, int n2)
         if (v > need) need = v;
     }
     if (!any) return 0;
-    return need + align256((size_t)PINN_MAX_AUX * (size_t)n_points * sizeof(float)) + wt_workspace_bytes(net) + 256;
+    return need + align256((size_t)PINN_MAX_AUX * (size_t)n_points * sizeof(float)) + wt_workspace_bytes(net) +
+           wsp_workspace_bytes(net) + 256;
 }
 
 int pinn_jet_forward(pinn_t* net, const float* params, const float* xs, int64_t n_points, const int* dir_cols, int nd,
@@ -531,7 +557,8 @@ static int run_train(pinn_t* net, PinnKArgs* a, const Plan& plan, int nd, float*
     const size_t wt_bytes = plan.wt_floats_per_wg ? align256((size_t)plan.grid * plan.wt_floats_per_wg * sizeof(float))
                                                   : (plan.wt_global ? wt_workspace_bytes(net) : 0);
     const size_t gz_bytes = align256(plan.gz_bytes());
-    const size_t need = part_bytes + slab_bytes + aux_bytes + wt_bytes + gz_bytes;
+    const size_t wsp_bytes = plan.split ? wsp_workspace_bytes(net) : 0;
+    const size_t need = part_bytes + slab_bytes + aux_bytes + wt_bytes + gz_bytes + wsp_bytes;
     if (!workspace || workspace_bytes < need)
         return fail("workspace too small: need %zu bytes, got %zu", need, workspace_bytes);
     if (((uintptr_t)workspace & 15) != 0) return fail("workspace must be 16-byte aligned");
@@ -580,6 +607,21 @@ static int run_train(pinn_t* net, PinnKArgs* a, const Plan& plan, int nd, float*
         hipLaunchKernelGGL(pinn_transpose_kernel, dim3(blocks), dim3(256), 32 * 33 * sizeof(float), (hipStream_t)stream, wh,
                            stride, hp, wt);
         if (hipGetLastError() != hipSuccess) return fail("transpose kernel launch failed");
+#endif
+    }
+    if (wsp_bytes && net->lay.lh > 0) {
+        // split-bf16 kernels: hidden weights -> hi / mid / lo bf16 MFMA fragments (the weights change every step)
+        pinn_s16x8* wsp = reinterpret_cast<pinn_s16x8*>(ws + part_bytes + slab_bytes + aux_bytes + wt_bytes + gz_bytes);
+        a->wsp = wsp;
+        const int hp = net->lay.hp, lh = net->lay.lh;
+        const int blocks = (lh * 2 * (hp / 32) * (hp / 16) * 64 + 255) / 256;
+        const float* wh = a->params + net->lay.off_wh;
+        const int stride = net->lay.hidden_stride;
+#ifdef PINN_EMU
+        emu::launch(blocks, 256, 0, [&] { pinn_wsplit_kernel(wh, stride, hp, lh, wsp); });
+#else
+        hipLaunchKernelGGL(pinn_wsplit_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, wh, stride, hp, lh, wsp);
+        if (hipGetLastError() != hipSuccess) return fail("weight-split kernel launch failed");
 #endif
     }
 #ifndef PINN_EMU

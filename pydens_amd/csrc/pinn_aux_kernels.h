@@ -110,6 +110,40 @@ PINN_GLOBAL void PINN_LAUNCH_BOUNDS(256) pinn_transpose_kernel(const float* wh, 
     for (int y = y0; y < 32; y += 8) dst[(size_t)(tc * 32 + y) * hp + tr * 32 + x] = tile[x * 33 + y];
 }
 
+// ------------------------------------------------------------------------------------------------------------
+// split-bf16 kernels (pinn_tile_kernel VAR 512): the hidden->hidden weights as MFMA A-operand fragments of three bf16 planes,
+// w = hi + mid + lo exactly (pinn_split4's arithmetic), in the order the waves load them -- PinnCfg::wsp_frag:
+// [layer][direction][K block of 32][16-unit tile j][plane][lane] x 16 bytes. Direction 0 (forward GEMM): lane (lr, lq) holds
+// W[16 j + lr][32 kb + 8 lq + e], e = 0..7; direction 1 (data gradient): W[32 kb + 8 lq + e][16 j + lr]. One thread per
+// (layer, direction, K block, tile, lane); rewritten before every step (the weights change every step), 147 KB at 3 x 64 x 64.
+// ------------------------------------------------------------------------------------------------------------
+PINN_GLOBAL void PINN_LAUNCH_BOUNDS(256) pinn_wsplit_kernel(const float* wh, int hidden_stride, int hp, int lh, pinn_s16x8* out) {
+    const int kbs = hp / 32, nt = hp / 16;
+    const int idx = PINN_BID * 256 + PINN_TID;
+    if (idx >= lh * 2 * kbs * nt * 64) return;
+    const int lane = idx & 63, j = (idx >> 6) % nt, kb = (idx >> 6) / nt % kbs, dir = (idx >> 6) / nt / kbs % 2, l = (idx >> 6) / nt / kbs / 2;
+    const int lr = lane & 15, lq = lane >> 4;
+    const float* W = wh + (size_t)l * hidden_stride;
+    unsigned b[3][8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+        const int unit = 16 * j + lr, k = 32 * kb + 8 * lq + e;
+        const float x = dir == 0 ? W[(size_t)unit * hp + k] : W[(size_t)k * hp + unit];
+        b[0][e] = pinn_fbits(x);
+        const float r1 = x - pinn_bitsf(b[0][e] & 0xffff0000u);
+        b[1][e] = pinn_fbits(r1);
+        const float r2 = r1 - pinn_bitsf(b[1][e] & 0xffff0000u);
+        b[2][e] = pinn_fbits(r2);
+    }
+#pragma unroll
+    for (int p = 0; p < 3; ++p) {
+        pinn_s16x8 f;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) f[e] = (short)(b[p][e] >> 16);
+        out[((((size_t)(l * 2 + dir) * kbs + kb) * nt + j) * 3 + p) * 64 + lane] = f;
+    }
+}
+
 PINN_GLOBAL void PINN_LAUNCH_BOUNDS(64) pinn_tick_kernel(int* step_ptr) {
     if (PINN_TID == 0 && PINN_BID == 0) step_ptr[0] += 1;
 }

@@ -25,6 +25,7 @@
 //   PINN_WAVES_PER_SIMD (1), PINN_SCHED_IL (1, pinn_port.h)   blocking / prefetch / occupancy / scheduling thresholds
 //   PINN_FAST_MT_S5 / _S2 / _COMB, PINN_FAST_VAR_COMB, PINN_WIDE_MT (pinn_inst.inc)   tile heights of the fast kernels
 //   PINN_ONLY_BASELINE            experiment builds: only the BASELINE kernels (seconds to compile)
+//   PINN_DEBUG_ABI                experiment builds: pinn_debug_set_flags / pinn_debug_phase_buffer and the kernel paths behind them
 //   PINN_PROFILE_PHASES           per-phase cycle counters (tools/phases.py)
 #pragma once
 #include "pinn_port.h"
@@ -38,6 +39,14 @@
 #endif
 
 enum { PINN_MODE_FORWARD = 0, PINN_MODE_STEP = 1, PINN_MODE_BACKWARD = 2 };
+
+// timing-experiment bits (kernels skip loads / stores / barriers; include/pinn.h): compiled into -DPINN_DEBUG_ABI builds only
+// (tools/variant.sh), the product kernels carry none of these paths
+#ifdef PINN_DEBUG_ABI
+#define PINN_DBG(A, bit) (((A).debug_flags & (bit)) != 0)
+#else
+#define PINN_DBG(A, bit) false
+#endif
 
 // Higher-order stream counts travel PACKED in one integer wherever the interface says "n2" (template parameter N2P, the
 // n2 argument of the C-ABI): low three bits = directions with a second derivative, bits 3.. = how many of THOSE (the
@@ -61,8 +70,10 @@ struct PinnKArgs {
     long long tile_begin, tile_end;   // tiles [tile_begin, tile_end) of the batch belong to this launch (WGX launches go chunk by chunk)
     int partial_row0;            // pinn_wgrad_kernel: partial rows >= this one belong to no tile-kernel workgroup (zeroed there)
     const float* wt;             // widths >= 128: transposed copy of the hidden weights, [lh][in][out] (pinn_transpose_kernel)
+    const void* wsp;             // split-bf16 kernels (VAR 512): hidden weights as hi / mid / lo bf16 MFMA fragments (pinn_wsplit_kernel)
+    int gemm_mode;               // PINN_GEMM_FP32 / PINN_GEMM_BF16X3 (pinn_set_gemm_mode): which instantiation the launcher picks
     long long* prof;             // optional per-phase cycle counters (PINN_PROFILE_PHASES builds only)
-    int debug_flags;             // bit 0: two-team kernel runs team 0 only (experiments)
+    int debug_flags;             // timing-experiment bits (PINN_DBG; -DPINN_DEBUG_ABI builds only)
     long long n_points;
     int lh, d, act, mode;        // act: the activation code shared by every layer, or -1 when they differ (act_codes)
     unsigned long long act_codes;   // 4 bits per activation index a = 0..lh (a = 0: first layer)
@@ -95,9 +106,10 @@ struct PinnKArgs {
                                  // (kernel prologue) instead of a separate launch in front of it
 };
 
-template <int HP_, int ND_, int N2_, int MT_ = 1>
+template <int HP_, int ND_, int N2_, int MT_ = 1, bool SPLIT_ = false>
 struct PinnCfg {
     static constexpr int HP = HP_, ND = ND_, N2 = pinn_n2(N2_), N3 = pinn_n3(N2_), MT = MT_;
+    static constexpr bool SPLIT = SPLIT_;                    // split-bf16 GEMM operands (VAR 512; below)
     static constexpr int S = pinn_ns(ND_, N2_);
     static constexpr int NT = HP / 16;                       // 16-wide unit tiles
 #ifndef PINN_NW_MAX
@@ -127,8 +139,14 @@ struct PinnCfg {
     static constexpr int O_B1 = O_W1 + HP * PINN_XS_LD;
     static constexpr int O_WL = O_B1 + HP;
     static constexpr int O_BUFA = O_WL + HP;
-    static constexpr int O_BUFB = ONEBUF ? O_BUFA : O_BUFA + S * T * LDA;
-    static constexpr int O_NET = O_BUFB + S * T * LDA;          // [NW][S][T] per-wave partial dot products
+    // split-bf16 kernels keep an activation buffer as THREE bf16 planes (hi, mid, lo) of [S*T rows][HP units]: rows of
+    // 2 HP bytes without padding, the 16-byte chunk index XORed with (row & 7) instead (tools/layout/lds_banks.py:
+    // ds_read_b128 along K and ds_read_b64_tr_b16 along the points are conflict-free, ds_write_b64 two-way)
+    static constexpr int SP_ROW_BYTES = 2 * HP;
+    static constexpr int SP_PLANE_BYTES = S * T * SP_ROW_BYTES;
+    static constexpr int BUF_FLOATS = SPLIT ? 3 * SP_PLANE_BYTES / 4 : S * T * LDA;
+    static constexpr int O_BUFB = ONEBUF ? O_BUFA : O_BUFA + BUF_FLOATS;
+    static constexpr int O_NET = O_BUFB + BUF_FLOATS;           // [NW][S][T] per-wave partial dot products
     static constexpr int O_GNET = O_NET + NW * S * T;
     static constexpr int O_ACCB = O_GNET + S * T;
     static constexpr int O_ACCW1 = O_ACCB + PINN_MAX_LAYERS * HP;   // bias-gradient rows for any depth
@@ -148,7 +166,8 @@ struct PinnCfg {
     // two-team kernels (VAR 256): each team owns a block [0, O_PREG) of this carve (shape-specialised: no program registers),
     // W^T of the static-depth net sits once behind both blocks
     static constexpr int TEAM_FLOATS = O_PREG;
-    PINN_HOST_DEVICE static constexpr int smem_floats_teams(int lh) { return 2 * TEAM_FLOATS + (lh > 0 ? lh : 0) * HP * WT_LD; }
+    // (split-bf16 kernels take their weight fragments from global memory / L2: no W^T block)
+    PINN_HOST_DEVICE static constexpr int smem_floats_teams(int lh) { return 2 * TEAM_FLOATS + (SPLIT ? 0 : (lh > 0 ? lh : 0) * HP * WT_LD); }
     PINN_HOST_DEVICE static constexpr bool wt_fits_teams(int lh) { return lh > 0 && HP <= 64 && smem_floats_teams(lh) * 4 <= 160 * 1024; }
     // "slab in LDS" kernels (shape-specialised, affine residual: no program registers): the saved jets take the LDS
     // from O_PREG on -- one value per layer-0 unit, S jets per further activation below the top one (which stays in
@@ -157,6 +176,13 @@ struct PinnCfg {
     PINN_HOST_DEVICE static constexpr int slabl_smem_floats(int lh) { return O_PREG + 4 * slabl_vec4(lh); }
     PINN_HOST_DEVICE static constexpr bool slabl_fits(int lh) {
         return lh >= 1 && HP <= 64 && slabl_smem_floats(lh) * 4 <= 160 * 1024;
+    }
+    // split-bf16 weight fragments (PinnKArgs::wsp): [layer][direction: 0 forward W, 1 data gradient W^T][K block of 32][16-unit
+    // tile j][plane][lane] x 16 bytes -- a wave's A operand of one K block is three coalesced 1-KB loads
+    static constexpr int SP_KB = HP / 32;
+    PINN_HOST_DEVICE static constexpr size_t wsp_bytes(int lh) { return (size_t)(lh > 0 ? lh : 0) * 2 * SP_KB * NT * 3 * 1024; }
+    PINN_HOST_DEVICE static constexpr size_t wsp_frag(int l, int dir, int kb, int j, int p) {      // index in 16-byte units, + lane
+        return ((((size_t)(l * 2 + dir) * SP_KB + kb) * NT + j) * 3 + p) * 64;
     }
     // WGX kernels: gz_a, a = 1 .. lh, of one tile (S jets per hidden->hidden layer)
     PINN_HOST_DEVICE static constexpr size_t gz_vec4_per_tile(int lh) { return (size_t)lh * S * NTW * MT * NTHREADS; }
@@ -888,6 +914,44 @@ template <bool NT> PINN_DEVICE f32x4 pinn_ld4_stream(const f32x4* p) {
     return *p;
 }
 PINN_DEVICE void pinn_st4(float* p, f32x4 v) { *reinterpret_cast<f32x4*>(p) = v; }
+// ---- split-bf16 operands -----------------------------------------------------------------------------------------------
+// x = hi + mid + lo EXACTLY, each a bf16: hi = x truncated to its upper 16 bits, mid = (x - hi) truncated, lo = x - hi - mid
+// (the subtractions are exact: 24 = 8 + 8 + 8 mantissa bits). Four VALU operations per value, then one v_perm_b32 per PAIR of
+// values and plane packs the upper halves (the pack is the truncation of mid and lo).
+PINN_DEVICE unsigned pinn_fbits(float x) { return __builtin_bit_cast(unsigned, x); }
+PINN_DEVICE float pinn_bitsf(unsigned x) { return __builtin_bit_cast(float, x); }
+struct PinnSplit4 { pinn_u32x2 hi, mid, lo; };            // four consecutive units of one (point, stream): 8 bytes per plane
+PINN_DEVICE PinnSplit4 pinn_split4(f32x4 v) {
+    unsigned b0[4], b1[4], b2[4];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        b0[r] = pinn_fbits(v[r]);
+        const float r1 = v[r] - pinn_bitsf(b0[r] & 0xffff0000u);
+        b1[r] = pinn_fbits(r1);
+        const float r2 = r1 - pinn_bitsf(b1[r] & 0xffff0000u);
+        b2[r] = pinn_fbits(r2);
+    }
+    PinnSplit4 o;
+    o.hi = pinn_u32x2{pinn_pack_hi16(b0[0], b0[1]), pinn_pack_hi16(b0[2], b0[3])};
+    o.mid = pinn_u32x2{pinn_pack_hi16(b1[0], b1[1]), pinn_pack_hi16(b1[2], b1[3])};
+    o.lo = pinn_u32x2{pinn_pack_hi16(b2[0], b2[1]), pinn_pack_hi16(b2[2], b2[3])};
+    return o;
+}
+// byte offset, inside one plane, of the 16-byte chunk `chunk` (8 units) of row `row`: rows of ROWB bytes, chunk index swizzled
+template <int ROWB>
+PINN_DEVICE int pinn_sp_off(int row, int chunk) { return row * ROWB + ((chunk ^ (row & 7)) << 4); }
+// the six products of a split-bf16 GEMM step that matter (a_i b_j with i + j <= 2; the three dropped ones are below
+// 2^-24 of |a b|), SMALL TERMS FIRST: measured against fp64, tools/ubench/split_bf16.cpp (K = 64: max error 9e-8 of
+// sum |a b| against 2e-7 for the exact-fp32 MFMA chain; large terms first: 3.6e-7)
+PINN_DEVICE f32x4 pinn_mfma_split6(const pinn_s16x8 (&a)[3], const pinn_s16x8 (&b)[3], f32x4 c) {
+    c = pinn_mfma16_bf16(a[2], b[0], c);
+    c = pinn_mfma16_bf16(a[0], b[2], c);
+    c = pinn_mfma16_bf16(a[1], b[1], c);
+    c = pinn_mfma16_bf16(a[1], b[0], c);
+    c = pinn_mfma16_bf16(a[0], b[1], c);
+    c = pinn_mfma16_bf16(a[0], b[0], c);
+    return c;
+}
 // the four components of v summed over the 16 lanes of a DPP row, step-major (four independent adds per DPP step: a lone
 // chain pays two wait states between its dependent steps; pinn_port.h)
 #ifndef PINN_ROWSUM_BATCH
@@ -925,7 +989,7 @@ template <int HP, int ND, int N2, int MT, int LHC, int ACTC, bool COMB = false, 
 PINN_GLOBAL void PINN_LAUNCH_BOUNDS2((PinnCfg<HP, ND, N2, MT>::NTHREADS * ((VAR & 256) ? 2 : 1)),
                                     (PinnCfg<HP, ND, N2, MT>::NW < 4 || (VAR & (2 | 256)) ? 2 : PINN_WAVES_PER_SIMD))
 pinn_tile_kernel(const PinnKArgs A) {
-    using C = PinnCfg<HP, ND, N2, MT>;
+    using C = PinnCfg<HP, ND, N2, MT, (VAR & 512) != 0>;
     constexpr int S = C::S, NT = C::NT, NTW = C::NTW, NW = C::NW, T = C::T, LDA = C::LDA, NTHREADS = C::NTHREADS;
     constexpr bool DWG = (LHC < 0) || (VAR & 1), ONEBUF = C::ONEBUF, SKIPS = (VAR & 8) != 0;
     constexpr int LHREG = DWG ? 1 : PINN_LHMAX;            // layers with register-resident dW accumulators
@@ -935,17 +999,28 @@ pinn_tile_kernel(const PinnKArgs A) {
     constexpr bool WGX = (VAR & 128) != 0;
     constexpr bool TEAMS2 = (VAR & 256) != 0;
     constexpr int TEAMS = TEAMS2 ? 2 : 1;
+    // VAR 512: split-bf16 GEMMs. Every hidden-layer GEMM (forward, data gradient, weight gradient) runs on
+    // v_mfma_f32_16x16x32_bf16 with both operands split exactly into hi + mid + lo bf16 and the six products a_i b_j,
+    // i + j <= 2, accumulated in fp32 (pinn_mfma_split6): 6 x 16 cycles of the matrix pipe per K = 32 instead of 8 x 32 cycles
+    // of the fp32 vector lanes, and the jets' VALU work co-executes. The activations cross the LDS as three bf16 planes
+    // (PinnCfg::SP_*), split where they are written; the weight fragments come pre-split from global memory (A.wsp,
+    // pinn_wsplit_kernel, L2-resident); the weight-gradient operands are read point-contiguous out of the same planes with
+    // ds_read_b64_tr_b16. Accumulator layouts, jets, point stage, slab and reductions are those of the exact kernel.
+    constexpr bool SPLIT = C::SPLIT;
+    static_assert(!SPLIT || (HP == 64 && NTW == 1 && LHC >= 1 && !(VAR & (1 | 2 | 8 | 64 | 128)) && ((S * T) % 32) == 0 &&
+                             ((T == 16 && S % 2 == 0) || T == 32)),
+                  "split-bf16 kernels: width 64, static depth, register-resident dW, K = S * T a multiple of 32");
     static_assert(!TEAMS2 || (((VAR >> 4) & 3) != 0 && LHC >= 1 && !(VAR & (1 | 2 | 8 | 64 | 128)) && NW == 4 && C::wt_fits_teams(LHC)),
                   "two-team kernels: shape-specialised, static depth, 4 waves per team, W^T of all layers in LDS");
     constexpr bool SNT = HP >= PINN_SLAB_NT_MIN_HP;        // streaming (non-temporal) slab stores
     static_assert(!WGX || (DWG && !SKIPS && !SLABL), "WGX kernels: generic depth, no skips, global slab");
     static_assert(!SLABL || (((VAR >> 4) & 3) != 0 && LHC >= 1 && !(VAR & 8) && !(VAR & 1) && C::slabl_fits(LHC)),
                   "slab-in-LDS kernels: shape-specialised, static depth, no skips, and the jets must fit");
-    constexpr bool WTL = (C::wt_fits(LHC) && !SLABL && !(VAR & 2)) || TEAMS2;        // transposed hidden weights staged in LDS
+    constexpr bool WTL = !SPLIT && ((C::wt_fits(LHC) && !SLABL && !(VAR & 2)) || TEAMS2);        // transposed hidden weights staged in LDS
     // widths >= 128: the data-gradient A operand comes from a transposed copy of the weights in global memory (one b128 per
     // K quad like the forward GEMM) instead of four strided global_load_dword per quad
     // (VAR 2, two workgroups per CU: W^T of both does not fit the LDS beside the activation buffers)
-    constexpr bool WTG = C::WTG || SLABL || (VAR & 2) != 0;
+    constexpr bool WTG = !SPLIT && (C::WTG || SLABL || (VAR & 2) != 0);
     constexpr int SPEC = (VAR >> 4) & 3;                   // VAR 16/32/48: training shape 1/2/3 fixed at compile time
     using SH = PinnShape<SPEC, ND>;
     // two teams: everything below is written in TEAM-local terms (tid, wave, LDS block, virtual block index); the teams meet
@@ -1120,6 +1195,86 @@ pinn_tile_kernel(const PinnKArgs A) {
         return slab + ((slot * NTW + j) * MT + mt) * NTHREADS + tid;
     };
     auto unit0 = [&](int j) { return (wave * NTW + j) * 16 + 4 * lq; };     // first of this lane's 4 units
+    // split-bf16 kernels: four consecutive units [n0, n0 + 4) of row `row` (= s * T + point) into the three planes of `buf`
+    auto sp_store = [&](float* buf, int row, int n0, f32x4 v) {
+        char* b = reinterpret_cast<char*>(buf) + pinn_sp_off<C::SP_ROW_BYTES>(row, n0 >> 3) + ((n0 >> 2) & 1) * 8;
+        const PinnSplit4 sp = pinn_split4(v);
+        *reinterpret_cast<pinn_u32x2*>(b) = sp.hi;
+        *reinterpret_cast<pinn_u32x2*>(b + C::SP_PLANE_BYTES) = sp.mid;
+        *reinterpret_cast<pinn_u32x2*>(b + 2 * C::SP_PLANE_BYTES) = sp.lo;
+    };
+    // ... and the fragment of 8 units (chunk = K block * 4 + lq) of row `row`, all three planes: the B operand of a GEMM step
+    auto sp_frag = [&](const float* buf, int row, int chunk, pinn_s16x8 (&f)[3]) {
+        const char* b = reinterpret_cast<const char*>(buf) + pinn_sp_off<C::SP_ROW_BYTES>(row, chunk);
+#pragma unroll
+        for (int p = 0; p < 3; ++p) f[p] = *reinterpret_cast<const pinn_s16x8*>(b + p * C::SP_PLANE_BYTES);
+    };
+    // weight fragments of hidden layer l, direction dir (0: W for the forward GEMM, 1: W^T for the data gradient), this wave's tile
+    // (buffer loads: ONE vector register of offsets, lane * 16, for all 36 fragments of the net, the fragment's offset in a scalar
+    //  register -- with plain pointers hipcc hoists a 64-bit VGPR address pair per fragment out of the tile loop, spills them, and
+    //  every load then waits for the scratch reload of its own address)
+    const PinnRows wsp_rows = pinn_rows(A.wsp, SPLIT ? (unsigned)C::wsp_bytes(LHC > 0 ? LHC : 1) : 0u);
+    const int wave_s = pinn_wave_uniform(wave);
+    auto sp_weights = [&](int l, int dir, pinn_s16x8 (&w)[C::SP_KB][3]) {
+#pragma unroll
+        for (int kb = 0; kb < C::SP_KB; ++kb)
+#pragma unroll
+            for (int p = 0; p < 3; ++p)
+                w[kb][p] = __builtin_bit_cast(pinn_s16x8, pinn_rows_ld4(wsp_rows, lane * 16, (int)(C::wsp_frag(l, dir, kb, 0, p) * 16) + wave_s * 3 * 1024));
+    };
+    // out^T[16 units of this wave][points] += W-fragments . rows of `bbuf` (forward: h_{l-1}, data gradient: gz_a), all S * MT
+    // (row tile, stream) rows of the tile: two rows per step, their B fragments (three planes each) fetched one step ahead,
+    // the twelve MFMAs of a step alternating between the two accumulators, small products first (pinn_mfma_split6's order)
+#ifndef PINN_SP_PIPE
+#define PINN_SP_PIPE 1          // split-bf16 GEMMs: operand fragments of step n + 1 in flight during the MFMAs of step n (0: fetched at the step's start)
+#endif
+#ifndef PINN_SP_PIPE_W
+#define PINN_SP_PIPE_W PINN_SP_PIPE     // ... of the weight-gradient GEMM
+#endif
+#ifndef PINN_SP_FRONT
+#define PINN_SP_FRONT 0         // K > 0: the prefetch reads of a step K at a time behind its FIRST MFMAs (pinn_sched_front) instead of spread evenly
+#endif
+#ifndef PINN_SP_G
+#define PINN_SP_G 2             // (row tile, stream) rows per step of the forward / data-gradient GEMMs
+#endif
+#ifndef PINN_SP_OG
+#define PINN_SP_OG 2            // output tile rows per step of the weight-gradient GEMM
+#endif
+    auto sp_gemm = [&](const float* bbuf, const pinn_s16x8 (&w)[SPLIT ? C::SP_KB : 1][3], f32x4 (&out)[NTW][MT][S]) {
+        constexpr int NR = MT * S, G = (NR % PINN_SP_G == 0) ? PINN_SP_G : 1, NG = NR / G, STEPS = C::SP_KB * NG;
+        constexpr int NB = PINN_SP_PIPE ? 2 : 1;
+        constexpr int pa[6] = {2, 0, 1, 1, 0, 0}, pb[6] = {0, 2, 1, 0, 1, 0};
+        pinn_s16x8 bf[NB][G][3];
+        auto load = [&](int step, pinn_s16x8 (&f)[G][3]) {
+            const int kb = step / NG, g0 = (step % NG) * G;
+#pragma unroll
+            for (int i = 0; i < G; ++i) {
+                const int r = g0 + i, mt = r / S, sidx = r % S;
+                sp_frag(bbuf, sidx * T + mt * 16 + lr, 4 * kb + lq, f[i]);
+            }
+        };
+        if (PINN_SP_PIPE) load(0, bf[0]);
+#pragma unroll
+        for (int step = 0; step < STEPS; ++step) {
+            PINN_SCHED_BARRIER();
+            if (PINN_SP_PIPE) { if (step + 1 < STEPS) load(step + 1, bf[(step + 1) % NB]); }
+            else load(step, bf[0]);
+            if (!PINN_SCHED_IL) PINN_SCHED_BARRIER();
+            const int kb = step / NG, g0 = (step % NG) * G;
+#pragma unroll
+            for (int t = 0; t < 6; ++t)
+#pragma unroll
+                for (int i = 0; i < G; ++i) {
+                    const int r = g0 + i;
+                    out[0][r / S][r % S] = pinn_mfma16_bf16(w[SPLIT ? kb : 0][pa[t]], bf[step % NB][i][pb[t]], out[0][r / S][r % S]);
+                }
+            if (PINN_SP_PIPE && step + 1 < STEPS) {
+                if (PINN_SP_FRONT) pinn_sched_front<6 * G, 3 * G, PINN_SP_FRONT ? PINN_SP_FRONT : 1>();
+                else pinn_sched_interleave<6 * G, 3 * G>();
+            }
+            PINN_SCHED_BARRIER();
+        }
+    };
     // weight-gradient GEMM: MFMA k-slot (lq, m) -> point of the tile. Any bijection works (K is a sum index); this one
     // puts lanes lq and lq+1 two rows (2*LDA = 16 mod 32 banks) apart, so the ds_read_b32 column reads are conflict-free.
     auto wg_pt = [&](int m) { return 2 * lq + (m & 1) + 8 * (m >> 1); };
@@ -1182,7 +1337,7 @@ pinn_tile_kernel(const PinnKArgs A) {
         const long long base = tile * T;
         if (WGX && train) {
             // (debug flag 4, timing experiments only: every tile writes the first tile's slab -- stores stay in L2)
-            const size_t tl = (A.debug_flags & 4) ? 0 : (size_t)(tile - A.tile_begin);
+            const size_t tl = PINN_DBG(A, 4) ? 0 : (size_t)(tile - A.tile_begin);
             slab = A.slab + tl * C::slab_vec4_per_wg(lh);
             gzs = A.gzslab + tl * C::gz_vec4_per_tile(lh);
         }
@@ -1200,7 +1355,7 @@ pinn_tile_kernel(const PinnKArgs A) {
         // (not in the VAR 8 kernels: with the four-way activation code between the prefetch and its first use, hipcc
         //  7.2 produced a width-64 kernel whose last prefetched K quad arrived wrong on gfx950 -- reproducible, cured by
         //  -amdgpu-waitcnt-forcezero, by dropping the prefetch, or by the two-way activation)
-        constexpr bool WPF = (HP <= 64) && !(VAR & 4) && !(VAR & 8);
+        constexpr bool WPF = (HP <= 64) && !(VAR & 4) && !(VAR & 8) && !SPLIT;
         constexpr int NQ = HP / 16;
         f32x4 wall[WPF ? NQ : 1][NTW];
         f32x4 biasn[NTW];              // bias of the NEXT hidden layer, fetched with its weights
@@ -1214,6 +1369,15 @@ pinn_tile_kernel(const PinnKArgs A) {
                     wall[q][j] = pinn_ld4(Wl + ((wave * NTW + j) * 16 + lr) * HP + 16 * q + 4 * lq);
         };
         if (WPF && lh > 0) load_wall(A.params + A.off_wh);
+        pinn_s16x8 wsf[SPLIT ? C::SP_KB : 1][3];       // split-bf16: forward weight fragments of the NEXT hidden layer, one phase ahead
+#ifndef PINN_SP_WPF
+#define PINN_SP_WPF 1           // split-bf16: forward weight fragments one phase ahead (0: fetched at the start of their GEMM)
+#endif
+        if constexpr (SPLIT) {
+            if (PINN_SP_WPF) sp_weights(0, 0, wsf);
+#pragma unroll
+            for (int j = 0; j < NTW; ++j) biasn[j] = pinn_ld4(A.params + A.off_wh + HP * HP + unit0(j));
+        }
         f32x4 hskip[SKIPS ? NTW : 1][SKIPS ? MT : 1][S];      // activations carried by the open skip connection
         const int act0 = act_at(0);
         // ---- (1) first layer on the VALU: z0 = W1 x + b1, z_k = W1[:, col_k], z_kk = 0 ------------------------
@@ -1258,7 +1422,10 @@ pinn_tile_kernel(const PinnKArgs A) {
                     for (int s = 0; s < S; ++s) hskip[SKIPS ? j : 0][SKIPS ? mt : 0][s] = hv[s];
                 }
 #pragma unroll
-                for (int s = 0; s < S; ++s) pinn_st4(cur + (s * T + pt) * LDA + n0, hv[s]);
+                for (int s = 0; s < S; ++s) {
+                    if constexpr (SPLIT) sp_store(cur, s * T + pt, n0, hv[s]);
+                    else pinn_st4(cur + (s * T + pt) * LDA + n0, hv[s]);
+                }
                 if (lh == 0) {
 #pragma unroll
                     for (int s = 0; s < S; ++s) htop[j][mt][s] = hv[s];
@@ -1290,7 +1457,10 @@ pinn_tile_kernel(const PinnKArgs A) {
                 for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
                     for (int s = 0; s < S; ++s) acc[j][mt][s] = f32x4{0.f, 0.f, 0.f, 0.f};
-            {
+            if constexpr (SPLIT) {
+                if (!PINN_SP_WPF) sp_weights(li, 0, wsf);
+                sp_gemm(cur, wsf, acc);
+            } else {
                 // software pipeline over the K quads: the operands of quad q+1 are in flight while the S*MT*NTW*4 MFMAs
                 // of quad q issue, accumulators interleaved (an accumulator is re-used every S*MT*NTW issues, far
                 // beyond the 40-cycle dependent latency). sched_barrier pins that order (the register-pressured
@@ -1343,9 +1513,16 @@ pinn_tile_kernel(const PinnKArgs A) {
             if (ONEBUF) PINN_SYNC();                       // in place: every wave must be done reading h_{l-1}
             f32x4 biasv[NTW];
 #pragma unroll
-            for (int j = 0; j < NTW; ++j) biasv[j] = WPF ? biasn[j] : pinn_ld4(bl + unit0(j));
+            for (int j = 0; j < NTW; ++j) biasv[j] = (WPF || SPLIT) ? biasn[j] : pinn_ld4(bl + unit0(j));
             PINN_SCHED_BARRIER();
             if (WPF && li + 1 < lh) load_wall(Wl + A.hidden_stride);
+            if constexpr (SPLIT) {
+                if (li + 1 < lh) {
+                    if (PINN_SP_WPF) sp_weights(li + 1, 0, wsf);
+#pragma unroll
+                    for (int j = 0; j < NTW; ++j) biasn[j] = pinn_ld4(Wl + A.hidden_stride + HP * HP + unit0(j));
+                }
+            }
 #pragma unroll
             for (int j = 0; j < NTW; ++j) {
                 const int n0 = unit0(j);
@@ -1382,7 +1559,10 @@ pinn_tile_kernel(const PinnKArgs A) {
                         for (int s = 0; s < S; ++s) htop[j][mt][s] = hv[s];
                     } else {
 #pragma unroll
-                        for (int s = 0; s < S; ++s) pinn_st4(nxt + (s * T + pt) * LDA + n0, hv[s]);
+                        for (int s = 0; s < S; ++s) {
+                            if constexpr (SPLIT) sp_store(nxt, s * T + pt, n0, hv[s]);
+                            else pinn_st4(nxt + (s * T + pt) * LDA + n0, hv[s]);
+                        }
                     }
                     if (train) {
                         if (li + 1 == lh) {
@@ -1603,7 +1783,10 @@ pinn_tile_kernel(const PinnKArgs A) {
 #pragma unroll
                     for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
-                        for (int s = 0; s < S; ++s) pinn_st4(buf + (s * T + mt * 16 + lr) * LDA + unit0(j), v[j][mt][s]);
+                        for (int s = 0; s < S; ++s) {
+                            if constexpr (SPLIT) sp_store(buf, s * T + mt * 16 + lr, unit0(j), v[j][mt][s]);
+                            else pinn_st4(buf + (s * T + mt * 16 + lr) * LDA + unit0(j), v[j][mt][s]);
+                        }
             };
             // B fragments of the weight-gradient GEMM (h_{a-1}): lane (lr, lq) needs h[pt = wg_pt(m)][its unit column]
             float hfrag[(ONEBUF && !WGX) ? MT * S : 1][NTW][4];
@@ -1646,6 +1829,8 @@ pinn_tile_kernel(const PinnKArgs A) {
             PH(11)
             if (SVPF && a >= 2) load_saved(a - 2, svn);    // in flight during the two GEMMs below
             const int li = a - 1;
+            pinn_s16x8 wsb[SPLIT ? C::SP_KB : 1][3];       // split-bf16: W^T fragments of this layer (L2 round trip behind the weight-gradient GEMM)
+            if constexpr (SPLIT) sp_weights(li, 1, wsb);
             const float* Wl = A.params + A.off_wh + (size_t)li * A.hidden_stride;
             float wqall[WPF ? NQ : 1][NTW][4];
             if (WPF && !WTL) {
@@ -1660,6 +1845,78 @@ pinn_tile_kernel(const PinnKArgs A) {
             // weight gradient: dW_li[out][in] += sum_{s,pt} gz_s[pt][out] * h_s[pt][in]   (A = gz^T, B = h)
             if constexpr (WGX) {
                 // pinn_wgrad_kernel
+            } else if constexpr (SPLIT) {
+                // K = the S * T (stream, point) pairs of the tile in blocks of 32; k slot (lq, e) of block kb:
+                //   T = 16: stream 2 kb + (lq >> 1), point 4 (lq & 1) + e (e < 4) / 8 + 4 (lq & 1) + e - 4
+                //   T = 32: stream kb,               point 4 lq + e (e < 4)       / 16 + 4 lq + e - 4
+                // (any bijection works as long as both operands use it; this one keeps the transpose reads conflict-free).
+                // ds_read_b64_tr_b16: lane i of a 16-lane group addresses (row p0 + i / 4, units 16 o + 4 (i % 4) ..) and receives
+                // the four points of unit 16 o + i -- two reads per plane make one 8-slot fragment.
+                const char* gb = reinterpret_cast<const char*>(nxt);
+                const char* hb = reinterpret_cast<const char*>(cur);
+                auto tr_frag = [&](const char* base, int row0, int row1, int ucol, pinn_s16x8 (&f)[3]) {
+                    // ucol = first unit of the 16-unit column block; this lane's 8 bytes: units ucol + 4 (lr & 3) .. + 3
+                    const int r0 = row0 + (lr >> 2), r1 = row1 + (lr >> 2), u = ucol + 4 * (lr & 3);
+                    const int o0 = pinn_sp_off<C::SP_ROW_BYTES>(r0, u >> 3) + ((u >> 2) & 1) * 8;
+                    const int o1 = pinn_sp_off<C::SP_ROW_BYTES>(r1, u >> 3) + ((u >> 2) & 1) * 8;
+#pragma unroll
+                    for (int p = 0; p < 3; ++p) {
+                        const pinn_s16x4 x = pinn_lds_tr16(base + p * C::SP_PLANE_BYTES + o0);
+                        const pinn_s16x4 y = pinn_lds_tr16(base + p * C::SP_PLANE_BYTES + o1);
+                        f[p] = pinn_s16x8{x[0], x[1], x[2], x[3], y[0], y[1], y[2], y[3]};
+                    }
+                };
+                constexpr int KBW = (S * T) / 32, OG = PINN_SP_OG, NOG = NT / OG, STEPS = KBW * NOG, NB = PINN_SP_PIPE_W ? 2 : 1;
+                constexpr int pa[6] = {2, 0, 1, 1, 0, 0}, pb[6] = {0, 2, 1, 0, 1, 0};
+                auto rows_of = [&](int kb, int& r0, int& r1) {
+                    const int srow = (T == 16) ? (2 * kb + (lq >> 1)) * T : kb * T;
+                    r0 = srow + ((T == 16) ? 4 * (lq & 1) : 4 * lq);
+                    r1 = srow + ((T == 16) ? 8 + 4 * (lq & 1) : 16 + 4 * lq);
+                };
+                // B fragments (h_{a-1}, this wave's 16 input units) of every K block up front; the A fragments (gz_a, 16 output
+                // units per tile row o) two tile rows per step, one step ahead of their twelve MFMAs
+                pinn_s16x8 bfr[PINN_SP_PIPE_W ? KBW : 1][3], afr[NB][OG][3];
+                if (PINN_SP_PIPE_W) {
+#pragma unroll
+                    for (int kb = 0; kb < KBW; ++kb) {
+                        int r0, r1;
+                        rows_of(kb, r0, r1);
+                        tr_frag(hb, r0, r1, wave * 16, bfr[PINN_SP_PIPE_W ? kb : 0]);
+                    }
+                }
+                auto load_a = [&](int step, pinn_s16x8 (&f)[OG][3]) {
+                    int r0, r1;
+                    rows_of(step / NOG, r0, r1);
+#pragma unroll
+                    for (int i = 0; i < OG; ++i) tr_frag(gb, r0, r1, ((step % NOG) * OG + i) * 16, f[i]);
+                };
+                if (PINN_SP_PIPE_W) load_a(0, afr[0]);
+#pragma unroll
+                for (int step = 0; step < STEPS; ++step) {
+                    PINN_SCHED_BARRIER();
+                    const int kb = step / NOG, o0 = (step % NOG) * OG;
+                    if (PINN_SP_PIPE_W) {
+                        if (step + 1 < STEPS) load_a(step + 1, afr[(step + 1) % NB]);
+                    } else {
+                        if (step % NOG == 0) {
+                            int r0, r1;
+                            rows_of(kb, r0, r1);
+                            tr_frag(hb, r0, r1, wave * 16, bfr[0]);
+                        }
+                        load_a(step, afr[0]);
+                    }
+                    if (!PINN_SCHED_IL) PINN_SCHED_BARRIER();
+#pragma unroll
+                    for (int t = 0; t < 6; ++t)
+#pragma unroll
+                        for (int i = 0; i < OG; ++i)
+                            dw[o0 + i][0] = pinn_mfma16_bf16(afr[step % NB][i][pa[t]], bfr[PINN_SP_PIPE_W ? kb : 0][pb[t]], dw[o0 + i][0]);
+                    if (PINN_SP_PIPE_W && step + 1 < STEPS) {
+                        if (PINN_SP_FRONT) pinn_sched_front<6 * OG, 6 * OG, PINN_SP_FRONT ? PINN_SP_FRONT : 1>();
+                        else pinn_sched_interleave<6 * OG, 6 * OG>();
+                    }
+                    PINN_SCHED_BARRIER();
+                }
             } else if constexpr (!DWG) {
                 // register accumulators, software pipeline over the (mt, s) row tiles, NT*NTW accumulators interleaved
                 float bq[2][NTW][4], aq[2][NT][4];
@@ -1794,7 +2051,9 @@ pinn_tile_kernel(const PinnKArgs A) {
                 for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
                     for (int s = 0; s < S; ++s) g[j][mt][s] = f32x4{0.f, 0.f, 0.f, 0.f};
-            {
+            if constexpr (SPLIT) {
+                sp_gemm(nxt, wsb, g);
+            } else {
                 constexpr int WAD = (WTG && PINN_W_AHEAD > 1) ? PINN_W_AHEAD : 1;     // (global weights: quads ahead, see the forward GEMM)
                 constexpr int NQD = HP / 16;
                 float wq[WAD + 1][NTW][4];

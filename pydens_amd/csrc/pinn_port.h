@@ -35,6 +35,27 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 PINN_DEVICE f32x4 pinn_mfma16(float a, float b, f32x4 c) {
     return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0);
 }
+// ---- split-bf16 GEMM operands (round 3): an fp32 value is EXACTLY hi + mid + lo with three bf16 (8 + 8 + 8 mantissa bits), and
+// v_mfma_f32_16x16x32_bf16 multiplies such parts exactly and accumulates in fp32 -- on the matrix pipe proper (16 cycles per
+// K = 32 against 8 x 32 cycles of v_mfma_f32_16x16x4_f32, which runs on the fp32 vector lanes) and beside the VALU, not instead of it
+// (tools/ubench/split_bf16.cpp: accuracy, issue rates, the transpose read).
+typedef short pinn_s16x8 __attribute__((ext_vector_type(8)));   // 8 bf16 bit patterns = 4 VGPRs: one MFMA operand fragment
+typedef short pinn_s16x4 __attribute__((ext_vector_type(4)));
+typedef unsigned int pinn_u32x2 __attribute__((ext_vector_type(2)));
+// D[16x16] += A[16x32] * B[32x16]: lane l supplies A[l&15][8*(l>>4) + e] and B[8*(l>>4) + e][l&15], e = 0..7 (element e in
+// bits 16*(e&1) of register e>>1); c[r] is D[(l>>4)*4 + r][l&15] as for pinn_mfma16.
+PINN_DEVICE f32x4 pinn_mfma16_bf16(pinn_s16x8 a, pinn_s16x8 b, f32x4 c) {
+    typedef __bf16 pinn_bf16x8 __attribute__((ext_vector_type(8)));
+    return __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(pinn_bf16x8, a), __builtin_bit_cast(pinn_bf16x8, b), c, 0, 0, 0);
+}
+// ds_read_b64_tr_b16: within each group of 16 lanes, lane i supplies the (8-byte aligned) address of 4 consecutive 16-bit
+// elements -- read them as row i/4, columns 4*(i%4) .. +3 of a [4][16] block whose row stride is whatever the addresses say --
+// and lane n receives column n of the block: elements (row 0..3, column n). Checked on the device by tools/ubench/split_bf16.cpp.
+PINN_DEVICE pinn_s16x4 pinn_lds_tr16(const void* p) {
+    return __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) pinn_s16x4*)(p));
+}
+// (a >> 16) | (b & 0xffff0000): the bf16 truncations of two fp32 bit patterns in one register (v_perm_b32)
+PINN_DEVICE unsigned pinn_pack_hi16(unsigned a, unsigned b) { return __builtin_amdgcn_perm(b, a, 0x07060302u); }
 // flags between two waves of a workgroup in LDS (a producer / consumer pair): LDS instructions of a CU execute in issue order, so
 // "data, then flag" on one side and "flag, then data" on the other need no waiting -- only the program order, which the
 // wavefront-scope fences pin (a workgroup-scope release would wait for every outstanding GLOBAL access of the wave as well)
@@ -123,6 +144,24 @@ PINN_DEVICE void pinn_sched_interleave() {
         __builtin_amdgcn_sched_group_barrier(0x120, 1, 0);        // one DS read or VMEM read
     }
     if (N_MFMA - USED > 0) __builtin_amdgcn_sched_group_barrier(0x008, N_MFMA - USED > 0 ? N_MFMA - USED : 1, 0);
+#endif
+}
+// N_MEM reads in the shadow of the FIRST MFMAs of the region, K reads behind each of them, then the remaining MFMAs: a prefetch
+// spread evenly over the region (pinn_sched_interleave) issues its last reads right in front of the wait that opens the next region
+template <int N_MFMA, int N_MEM, int K>
+PINN_DEVICE void pinn_sched_front(){
+#if PINN_SCHED_IL
+    constexpr int FULL = N_MEM / K, REST = N_MEM % K, SLOTS = FULL + (REST ? 1 : 0);
+#pragma unroll
+    for (int i = 0; i < FULL; ++i) {
+        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+        __builtin_amdgcn_sched_group_barrier(0x120, K, 0);
+    }
+    if constexpr (REST > 0) {
+        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+        __builtin_amdgcn_sched_group_barrier(0x120, REST, 0);
+    }
+    if (N_MFMA - SLOTS > 0) __builtin_amdgcn_sched_group_barrier(0x008, N_MFMA - SLOTS > 0 ? N_MFMA - SLOTS : 1, 0);
 #endif
 }
 // issue order inside one scheduling region: the next N_DS LDS reads FIRST, then N_MFMA matrix instructions (a fragment

@@ -85,7 +85,7 @@ pinn_wgrad_kernel(const PinnKArgs A) {
         auto load_raw = [&](long long tile, int mt, int s, f32x4 (&gzr)[NTW], f32x4 (&svr)[NTW]) {
             // (uniform 64-bit base per slot + this thread's 32-bit index: scalar address arithmetic, one VGPR of offset)
             // (debug flag 2, timing experiments only: every stage re-reads the first tile -- operands from L2 instead of HBM)
-            const size_t tl = (A.debug_flags & 2) ? 0 : (size_t)(tile - A.tile_begin);
+            const size_t tl = PINN_DBG(A, 2) ? 0 : (size_t)(tile - A.tile_begin);
             const f32x4* gzp = A.gzslab + tl * gz_tile + (((size_t)(li * S + s) * NTW) * MT + mt) * NTHREADS;
             const f32x4* svp = A.slab + tl * sv_tile + (((size_t)(li * S + s) * NTW) * MT + mt) * NTHREADS;
             const unsigned t = (unsigned)tid;
@@ -196,13 +196,13 @@ pinn_wgrad_kernel(const PinnKArgs A) {
                     const int nmt = (k + 1 == S) ? (mt + 1) % MT : mt;
                     const long long ntile = (k + 1 == S && mt + 1 == MT) ? tile + t_step : tile;
                     // (debug flags 8 / 16 / 32, timing experiments only: no barrier / no LDS staging / no HBM loads)
-                    if (has_next && !(A.debug_flags & 32)) load_raw(ntile, nmt, ns, gzr, svr);
+                    if (has_next && !PINN_DBG(A, 32)) load_raw(ntile, nmt, ns, gzr, svr);
                     mfma_stage(smem + p * 2 * OPER);
-                    if (has_next && !(A.debug_flags & 16)) {
+                    if (has_next && !PINN_DBG(A, 16)) {
                         transform(ns, svr, hv);
                         write_stage(smem + (p ^ 1) * 2 * OPER, gzr, hv);
                     }
-                    if (!(A.debug_flags & 8)) PINN_SYNC();
+                    if (!PINN_DBG(A, 8)) PINN_SYNC();
                     p ^= 1;
                 }
             }

@@ -102,12 +102,15 @@ def bind(lib):
                                             vp, i32, f32, f32, f32, f32, vp, vp, ctypes.c_size_t, vp]
     lib.pinn_sample_points.argtypes = [vp, i64, i32, ip, ctypes.POINTER(f32), ctypes.POINTER(f32), ctypes.c_uint64,
                                        ctypes.c_uint64, vp]
+    lib.pinn_set_gemm_mode.argtypes = [vp, i32]
+    lib.pinn_set_gemm_mode.restype = i32
     lib.pinn_profile_tile.argtypes = [i32]
     lib.pinn_profile_tile.restype = i32
     lib.pinn_last_tile_ms.restype = f32
     lib.pinn_last_wgrad_ms.restype = f32
     lib.pinn_last_kernel_name.restype = ctypes.c_char_p
-    lib.pinn_debug_phase_buffer.argtypes = [vp]
+    if hasattr(lib, 'pinn_debug_phase_buffer'):                  # -DPINN_DEBUG_ABI experiment builds only
+        lib.pinn_debug_phase_buffer.argtypes = [vp]
     lib.pinn_debug_wgx_chunk_bytes.argtypes = [ctypes.c_longlong]
     for name in ('pinn_create', 'pinn_create_ex', 'pinn_destroy', 'pinn_layout', 'pinn_jet_forward', 'pinn_jet_backward',
                  'pinn_residual_step', 'pinn_residual_adam_step', 'pinn_adam_step', 'pinn_adam_step_at'):
@@ -116,9 +119,9 @@ def bind(lib):
 
 
 ABI_SYMBOLS = ('pinn_create', 'pinn_create_ex', 'pinn_destroy', 'pinn_layout', 'pinn_workspace_bytes', 'pinn_jet_forward',
-               'pinn_jet_backward', 'pinn_residual_step', 'pinn_residual_step_add', 'pinn_residual_adam_step', 'pinn_adam_step', 'pinn_adam_step_at', 'pinn_sample_points', 'pinn_profile_tile',
-               'pinn_last_tile_ms', 'pinn_last_wgrad_ms', 'pinn_last_kernel_name', 'pinn_debug_last_kernel', 'pinn_debug_set_flags',
-               'pinn_debug_prepass_in_kernel', 'pinn_debug_phase_buffer', 'pinn_debug_wgx_chunk_bytes',
+               'pinn_jet_backward', 'pinn_residual_step', 'pinn_residual_step_add', 'pinn_residual_adam_step', 'pinn_adam_step', 'pinn_adam_step_at', 'pinn_sample_points', 'pinn_set_gemm_mode', 'pinn_profile_tile',
+               'pinn_last_tile_ms', 'pinn_last_wgrad_ms', 'pinn_last_kernel_name', 'pinn_debug_last_kernel',
+               'pinn_debug_prepass_in_kernel', 'pinn_debug_wgx_chunk_bytes',
                'pinn_last_error', 'pinn_backend')
 
 _LIB = None
@@ -206,6 +209,18 @@ class Net:
         self.layout = lay
         self.layer_dims = list(layer_dims)
         self.ndims, self.nparams = ndims, nparams
+        self.gemm_mode = 'fp32'
+        if os.environ.get('PYDENS_AMD_GEMM'):
+            self.set_gemm_mode(os.environ['PYDENS_AMD_GEMM'])
+
+    def set_gemm_mode(self, mode):
+        """ 'fp32' (default: exact-fp32 MFMA) or 'bf16x3' (fp32 operands as three bf16, six products, fp32 accumulate: the
+        split-bf16 kernels where they exist, include/pinn.h pinn_set_gemm_mode) """
+        codes = {'fp32': 0, 'bf16x3': 1}
+        if mode not in codes:
+            raise ValueError(f'gemm mode {mode!r}: expected one of {sorted(codes)}')
+        self._raise(self.lib.pinn_set_gemm_mode(self.handle, codes[mode]))
+        self.gemm_mode = mode
 
     def _raise(self, rc):
         if rc != 0:

@@ -121,6 +121,12 @@ class Solver:
             self.model.dormant_variables |= self._born_in_constraint[num]
         self._traced_constraints = tuple(self.constraints)
 
+    def set_gemm_mode(self, mode):
+        """ arithmetic of the hidden-layer GEMMs of the fused step: 'fp32' (default; exact-fp32 MFMA) or 'bf16x3' (every fp32
+        operand as three bf16, six partial products, fp32 accumulate -- the split-bf16 kernels where they are built, the fp32
+        kernels elsewhere; include/pinn.h pinn_set_gemm_mode). Also settable for a whole process with PYDENS_AMD_GEMM. """
+        self.model.net.set_gemm_mode(mode)
+
     def _trace_equation(self):
         """ which streams does the equation need, and can it be lowered to a residual program? (construction, and again at
         the start of a fit call whenever the cached lowering no longer reproduces the live callable) """

@@ -20,6 +20,7 @@ def _deps():
     deps = [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith(('.h', '.inc', '.cpp'))]
     deps += [os.path.join(HERE, f) for f in ('emu_runtime.h', 'emu_runtime.cpp')]
     deps.append(os.path.join(ROOT, 'include', 'pinn.h'))
+    deps.append(os.path.join(ROOT, 'tools', 'experiments', 'pinn_chain_kernel.h'))       # (-DPINN_CHAIN=1 builds)
     return deps
 
 
@@ -42,6 +43,8 @@ def build(force=False, extra_flags=(), tag='', widths=(64,)):
         os.makedirs(BUILD, exist_ok=True)
         jobs = [[CXX, *FLAGS, f'-DPINN_INST_HP={hp}', '-c', os.path.join(CSRC, 'pinn_inst.inc'), '-o',
                  os.path.join(BUILD, f'inst_hp{hp}.o')] for hp in WIDTHS]
+        jobs += [[CXX, *FLAGS, '-DPINN_INST_HP=64', f'-DPINN_INST_SPLIT={n}', '-c', os.path.join(CSRC, 'pinn_inst.inc'), '-o',
+                  os.path.join(BUILD, f'inst_hp64_split{n}.o')] for n in (1, 2)]
         jobs.append([CXX, *FLAGS, '-c', os.path.join(CSRC, 'pinn_abi.cpp'), '-o', os.path.join(BUILD, 'abi.o')])
         jobs.append([CXX, *FLAGS, '-c', os.path.join(HERE, 'emu_runtime.cpp'), '-o', os.path.join(BUILD, 'emu_runtime.o')])
         with ThreadPoolExecutor(max_workers=os.cpu_count() or 4) as pool:
@@ -59,6 +62,7 @@ def build(force=False, extra_flags=(), tag='', widths=(64,)):
     with ThreadPoolExecutor(max_workers=os.cpu_count() or 4) as pool:
         objs = list(pool.map(_run, jobs))
     objs += [os.path.join(BUILD, f'inst_hp{hp}.o') for hp in WIDTHS if hp not in widths]
+    objs += [os.path.join(BUILD, f'inst_hp64_split{n}.o') for n in (1, 2)]
     objs += [os.path.join(BUILD, 'abi.o'), os.path.join(BUILD, 'emu_runtime.o')]
     _run([CXX, '-shared', '-fPIC', *objs, '-o', tout])
     return tout

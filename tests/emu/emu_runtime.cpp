@@ -5,6 +5,7 @@
 
 #include <cstdio>
 #include <cstdlib>
+#include <cstring>
 #include <vector>
 
 namespace emu {
@@ -19,6 +20,8 @@ struct Fiber {
 
 struct Wave {
     float a[64], b[64];
+    unsigned short a16[64][8], b16[64][8];
+    unsigned short t16[64][4];
     int arrived = 0;
     unsigned gen = 0;
 };
@@ -77,6 +80,41 @@ f32x4 mfma16(float a, float b, f32x4 c) {
     }
     wave_sync(w);      // nobody overwrites a/b before everyone has read them
     return d;
+}
+
+static inline double bf16_value(unsigned short h) {
+    const unsigned bits = (unsigned)h << 16;
+    float f;
+    memcpy(&f, &bits, 4);
+    return (double)f;
+}
+
+f32x4 mfma16_bf16(const unsigned short* a8, const unsigned short* b8, f32x4 c) {
+    Wave& w = g_waves[g_cur >> 6];
+    const int l = g_cur & 63;
+    for (int e = 0; e < 8; ++e) { w.a16[l][e] = a8[e]; w.b16[l][e] = b8[e]; }
+    wave_sync(w);
+    const int col = l & 15, rq = l >> 4;
+    f32x4 d = c;
+    for (int r = 0; r < 4; ++r) {
+        const int row = rq * 4 + r;
+        double acc = (double)c[r];
+        for (int g = 0; g < 4; ++g)                 // k slot 8 g + e: lane (row, g) of A, lane (col, g) of B
+            for (int e = 0; e < 8; ++e) acc += bf16_value(w.a16[g * 16 + row][e]) * bf16_value(w.b16[g * 16 + col][e]);
+        d[r] = (float)acc;
+    }
+    wave_sync(w);
+    return d;
+}
+
+void lds_tr16(const void* p, unsigned short* out4) {
+    Wave& w = g_waves[g_cur >> 6];
+    const int l = g_cur & 63, grp = l & ~15, n = l & 15;
+    if (((uintptr_t)p & 7) != 0) { fprintf(stderr, "emu: ds_read_b64_tr_b16 address not 8-byte aligned\n"); abort(); }
+    memcpy(w.t16[l], p, 8);
+    wave_sync(w);
+    for (int j = 0; j < 4; ++j) out4[j] = w.t16[grp + 4 * j + n / 4][n % 4];     // element (row j, column n) of the group's block
+    wave_sync(w);
 }
 
 float shfl_xor(float v, int mask) {

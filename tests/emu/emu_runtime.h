@@ -23,6 +23,8 @@ void sync_wave();
 void yield_fiber();
 f32x4 mfma16(float a, float b, f32x4 c);
 float shfl_xor(float v, int mask);
+f32x4 mfma16_bf16(const unsigned short* a8, const unsigned short* b8, f32x4 c);
+void lds_tr16(const void* p, unsigned short* out4);
 float row_sum16(float v);
 void launch(int grid, int block, size_t smem_bytes, const std::function<void()>& body);
 }
@@ -39,6 +41,23 @@ void launch(int grid, int block, size_t smem_bytes, const std::function<void()>&
 #define PINN_LAUNCH_BOUNDS(n)
 
 static inline f32x4 pinn_mfma16(float a, float b, f32x4 c) { return emu::mfma16(a, b, c); }
+typedef short pinn_s16x8 __attribute__((ext_vector_type(8)));
+typedef short pinn_s16x4 __attribute__((ext_vector_type(4)));
+typedef unsigned int pinn_u32x2 __attribute__((ext_vector_type(2)));
+// v_mfma_f32_16x16x32_bf16: products of bf16 values are exact; the sum over the 32 k slots and the accumulator is taken in
+// double here and rounded once (the hardware's internal order is not documented; tools/ubench/split_bf16.cpp measures it
+// at or below the error of an fp32 fmaf chain)
+static inline f32x4 pinn_mfma16_bf16(pinn_s16x8 a, pinn_s16x8 b, f32x4 c) {
+    unsigned short aa[8], bb[8];
+    for (int e = 0; e < 8; ++e) { aa[e] = (unsigned short)a[e]; bb[e] = (unsigned short)b[e]; }
+    return emu::mfma16_bf16(aa, bb, c);
+}
+static inline pinn_s16x4 pinn_lds_tr16(const void* p) {
+    unsigned short o[4];
+    emu::lds_tr16(p, o);
+    return pinn_s16x4{(short)o[0], (short)o[1], (short)o[2], (short)o[3]};
+}
+static inline unsigned pinn_pack_hi16(unsigned a, unsigned b) { return (a >> 16) | (b & 0xffff0000u); }
 static inline int pinn_flag_load(const int* p) { return *reinterpret_cast<const volatile int*>(p); }
 static inline void pinn_flag_publish(int* p, int v, bool leader) {
     emu::sync_wave();                       // every lane's data is in place before the leader raises the flag
@@ -68,5 +87,6 @@ static inline float pinn_rcp(float x) { return 1.0f / x; }
 #define PINN_SCHED_IL 0
 template <int N_MFMA, int N_MEM> static inline void pinn_sched_interleave() {}
 template <int N_DS, int N_MFMA> static inline void pinn_sched_reads_first() {}
+template <int N_MFMA, int N_MEM, int K> static inline void pinn_sched_front() {}
 #define PINN_INLINE_LAMBDA
 #define PINN_SETPRIO(n)

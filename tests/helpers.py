@@ -48,9 +48,19 @@ def export_grads(solver):
     return out
 
 
-def make_solver(name, pa, **kwargs):
+def make_solver(name, pa, gemm=None, **kwargs):
+    """ gemm: 'fp32' / 'bf16x3' (Solver.set_gemm_mode); None keeps the default (fp32, or PYDENS_AMD_GEMM) """
     cfg = pc.make_config(name, pa.D, torch)
-    return cfg, pa.Solver(cfg['equation'], **cfg['solver_kwargs'], **kwargs)
+    solver = pa.Solver(cfg['equation'], **cfg['solver_kwargs'], **kwargs)
+    if gemm is not None:
+        solver.set_gemm_mode(gemm)
+    return cfg, solver
+
+
+def ran_split_kernel(solver):
+    """ did the last launch take a split-bf16 instantiation (VAR bit 512 of pinn_tile_kernel<...>)? """
+    name = solver.model.net.lib.pinn_last_kernel_name().decode()
+    return bool(int(name.rstrip('>').split(',')[-1]) & 512)
 
 
 def fit_rtol(name):

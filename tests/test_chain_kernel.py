@@ -1,4 +1,4 @@
-""" The experimental chain kernel (pydens_amd/csrc/pinn_chain_kernel.h, build knob -DPINN_CHAIN=1: wave-private points, layers
+""" The experimental chain kernel (tools/experiments/pinn_chain_kernel.h, build knob -DPINN_CHAIN=1: wave-private points, layers
 chained through the MFMA accumulators, a weight-gradient wave beside every chain wave, LDS flags instead of barriers) on the
 emulated kernels against the oracle: BASELINE configs 2 and 4 (the two shapes it is built for), ragged batches, several
 workgroup rounds. The product keeps pinn_tile_kernel for these shapes (measured slower on MI355X); the test

@@ -21,12 +21,13 @@ def bench(cfg_name, lib_path, n=None, reps=None, rounds=3):
     solver = pa.Solver(cfg['equation'], **cfg['solver_kwargs'], lib=lib)
     n = n or (cfg['n_points'] if cfg_name == 'cfg3' else min(cfg['n_points'], 131072))
     xs = torch.from_numpy(pc.sample_points(cfg, n, seed=1)).cuda()
-    for _ in range(5):
+    for _ in range(300 if cfg_name in ('cfg2', 'cfg4') else 10):     # (also brings a fresh process's GPU to its clocks)
         solver._fused_step(xs, 1)
     torch.cuda.synchronize()
     lay = solver.model.net.layout
     out = []
-    lib.pinn_debug_set_flags(FLAGS)
+    if FLAGS:
+        lib.pinn_debug_set_flags(FLAGS)            # (-DPINN_DEBUG_ABI builds: tools/variant.sh)
     lib.pinn_profile_tile(1)
     wg = []
     for _ in range(rounds):
@@ -40,7 +41,8 @@ def bench(cfg_name, lib_path, n=None, reps=None, rounds=3):
     if max(wg) > 0:
         out = [f'{a:.4f}+{b:.4f}={a + b:.4f}' for a, b in zip(out, wg)]
     lib.pinn_profile_tile(0)
-    lib.pinn_debug_set_flags(0)
+    if FLAGS:
+        lib.pinn_debug_set_flags(0)
     loss = float(solver.grads[lay.off_loss])
     gsum = float(solver.grads[:lay.p_core].double().abs().sum())
     return out, loss, gsum, n
