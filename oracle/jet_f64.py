@@ -8,34 +8,38 @@ section 3). This file is the plain-numpy, double-precision statement of exactly 
 (b) as the fp64 arbiter for the fp32 kernels.
 
 Stream order (shared with the kernels): index 0 = value; 1..ND = first derivative along direction k;
-1+ND..ND+N2 = second derivative along direction k < N2 (directions that need a second derivative come first).
+1+ND..ND+N2 = second derivative along direction k < N2 (directions that need a second derivative come first);
+then N3 third derivatives along the first N3 of those (single columns only: D(D(D(f, x), x), x), KdV-type equations).
 `dir_cols[k]` is the input column that direction k differentiates, or a pair (a, b) for the diagonal direction
 e_a + e_b (mixed partials: u_ab = (u_vv - u_aa - u_bb) / 2).
 """
 import numpy as np
 
 
-def act_derivs(z, act):
-    """ activation value and its first three derivatives. """
+def act_derivs(z, act, fourth=False):
+    """ activation value and its first three (four) derivatives. """
     if act == 'tanh':
         t = np.tanh(z)
         d1 = 1.0 - t * t
         d2 = -2.0 * t * d1
         d3 = d1 * (6.0 * t * t - 2.0)
-        return t, d1, d2, d3
-    if act == 'sigmoid':
-        s = 1.0 / (1.0 + np.exp(-z))
-        d1 = s * (1.0 - s)
-        d2 = d1 * (1.0 - 2.0 * s)
-        d3 = d1 * ((1.0 - 2.0 * s) ** 2 - 2.0 * d1)
-        return s, d1, d2, d3
-    raise ValueError(act)
+        d4 = d1 * t * (16.0 - 24.0 * t * t)
+    elif act == 'sigmoid':
+        t = 1.0 / (1.0 + np.exp(-z))
+        d1 = t * (1.0 - t)
+        q = 1.0 - 2.0 * t
+        d2 = d1 * q
+        d3 = d1 * (q * q - 2.0 * d1)
+        d4 = d1 * q * (q * q - 8.0 * d1)
+    else:
+        raise ValueError(act)
+    return (t, d1, d2, d3, d4) if fourth else (t, d1, d2, d3)
 
 
 class Spec:
     """ Problem descriptor: network, ansatz and requested derivative streams. """
     def __init__(self, weights, biases, act, ndims, nparams=0, has_bc=False, bc_value=0.0, has_ic=False,
-                 domain=None, log_scale=0.0, dir_cols=(), n2=0):
+                 domain=None, log_scale=0.0, dir_cols=(), n2=0, n3=0):
         self.W = [np.asarray(w, dtype=np.float64) for w in weights]     # [out, in] per layer (nn.Linear layout)
         self.b = [np.asarray(b, dtype=np.float64) for b in biases]
         self.act = act.lower()
@@ -44,8 +48,13 @@ class Spec:
         self.nsp = ndims - 1 if has_ic else ndims
         self.domain = [tuple(map(float, d)) for d in (domain or [(0.0, 1.0)] * ndims)]
         self.log_scale = float(log_scale)
-        self.dir_cols, self.nd, self.n2 = list(dir_cols), len(dir_cols), n2
-        self.S = 1 + self.nd + self.n2
+        self.dir_cols, self.nd, self.n2, self.n3 = list(dir_cols), len(dir_cols), n2, n3
+        assert n3 <= n2 <= self.nd
+        self.S = 1 + self.nd + self.n2 + self.n3
+
+    def i3(self, k):
+        """ stream index of the third derivative along direction k < n3 """
+        return 1 + self.nd + self.n2 + k
 
 
 def _cols(direction):
@@ -70,14 +79,17 @@ def mlp_jet_forward(sp, xs):
             W, b = sp.W[l], sp.b[l]
             z = np.einsum('snk,ok->sno', h_prev, W)
             z[0] += b
-        t, d1, d2, d3 = act_derivs(z[0], sp.act)
+        t, d1, d2, d3, d4 = act_derivs(z[0], sp.act, fourth=True)
         h = np.zeros_like(z)
         h[0] = t
         for k in range(sp.nd):
             h[1 + k] = d1 * z[1 + k]
         for k in range(sp.n2):
             h[1 + sp.nd + k] = d2 * z[1 + k] ** 2 + d1 * z[1 + sp.nd + k]
-        cache.append((h_prev, z, d1, d2, d3))
+        for k in range(sp.n3):                                         # h''' = s' z''' + 3 s'' z' z'' + s''' z'^3
+            z1, z2 = z[1 + k], z[1 + sp.nd + k]
+            h[sp.i3(k)] = d1 * z[sp.i3(k)] + 3.0 * d2 * z1 * z2 + d3 * z1 ** 3
+        cache.append((h_prev, z, d1, d2, d3, d4))
         h_prev = h
     W, b = sp.W[L - 1], sp.b[L - 1]
     net = np.einsum('snk,ok->sno', h_prev, W)[:, :, 0]
@@ -95,7 +107,7 @@ def mlp_jet_backward(sp, gnet, fwd_cache):
     db[L - 1] = np.array([gnet[0].sum()])
     gh = gnet[:, :, None] * sp.W[L - 1][0][None, None, :]
     for l in range(L - 2, -1, -1):
-        h_prev, z, d1, d2, d3 = cache[l]
+        h_prev, z, d1, d2, d3, d4 = cache[l]
         gz = np.zeros_like(gh)
         acc = d1 * gh[0]
         for k in range(sp.nd):
@@ -107,6 +119,12 @@ def mlp_jet_backward(sp, gnet, fwd_cache):
                 gz[1 + sp.nd + k] = d1 * ghkk
                 gz[1 + k] += 2.0 * d2 * zk * ghkk
                 acc = acc + (d3 * zk * zk + d2 * zkk) * ghkk
+        for k in range(sp.n3):                                          # adjoint of the third-order jet (the derivatives of
+            z1, z2, z3, g3 = z[1 + k], z[1 + sp.nd + k], z[sp.i3(k)], gh[sp.i3(k)]     # the activation depend on z0 as well)
+            gz[sp.i3(k)] = d1 * g3
+            gz[1 + sp.nd + k] += 3.0 * d2 * z1 * g3
+            gz[1 + k] += (3.0 * d3 * z1 * z1 + 3.0 * d2 * z2) * g3
+            acc = acc + (d4 * z1 ** 3 + 3.0 * d3 * z1 * z2 + d2 * z3) * g3
         gz[0] = acc
         db[l] = gz[0].sum(axis=0)
         if l > 0:
@@ -156,23 +174,25 @@ def _ic_gate(sp, xs):
     t0 = sp.domain[-1][0]
     es = np.exp(-sp.log_scale)
     tau = (xs[:, tcol] - t0) * es
-    s, d1, d2, d3 = act_derivs(tau, 'sigmoid')
+    s, d1, d2, d3, d4 = act_derivs(tau, 'sigmoid', fourth=True)
     G = s - 0.5
-    Gk = np.zeros((sp.nd, N)); Gkk = np.zeros((sp.nd, N))
+    Gk = np.zeros((sp.nd, N)); Gkk = np.zeros((sp.nd, N)); Gkkk = np.zeros((sp.nd, N))
     dG_ds = -tau * d1
-    dGk_ds = np.zeros((sp.nd, N)); dGkk_ds = np.zeros((sp.nd, N))
+    dGk_ds = np.zeros((sp.nd, N)); dGkk_ds = np.zeros((sp.nd, N)); dGkkk_ds = np.zeros((sp.nd, N))
     for k, c in enumerate(sp.dir_cols):
         if tcol in _cols(c):
             Gk[k] = d1 * es
             Gkk[k] = d2 * es * es
+            Gkkk[k] = d3 * es ** 3
             dGk_ds[k] = es * (-tau * d2 - d1)
             dGkk_ds[k] = es * es * (-tau * d3 - 2.0 * d2)
-    return G, Gk, Gkk, dG_ds, dGk_ds, dGkk_ds
+            dGkkk_ds[k] = es ** 3 * (-tau * d4 - 3.0 * d3)          # d tau / ds = -tau, d es / ds = -es
+    return G, Gk, Gkk, dG_ds, dGk_ds, dGkk_ds, Gkkk, dGkkk_ds
 
 
 def ansatz_forward(sp, net, xs, ic_streams=None):
     """ net streams [S,N] -> u streams [S,N] (reference model_torch.py:107-128 + product rule). """
-    nd, n2 = sp.nd, sp.n2
+    nd, n2, n3 = sp.nd, sp.n2, sp.n3
     Q = net.copy()
     bc = None
     if sp.has_bc:
@@ -183,16 +203,21 @@ def ansatz_forward(sp, net, xs, ic_streams=None):
             Q[1 + k] = net[1 + k] * P + net[0] * Pk[k]
         for k in range(n2):
             Q[1 + nd + k] = net[1 + nd + k] * P + 2.0 * net[1 + k] * Pk[k] + net[0] * Pkk[k]
+        for k in range(n3):                          # single columns: every factor of P is quadratic, P''' = 0
+            Q[sp.i3(k)] = net[sp.i3(k)] * P + 3.0 * (net[1 + nd + k] * Pk[k] + net[1 + k] * Pkk[k])
     u = Q.copy()
     gate = None
     if sp.has_ic:
         gate = _ic_gate(sp, xs)
         G, Gk, Gkk = gate[:3]
+        Gkkk = gate[6]
         u[0] = G * Q[0]
         for k in range(nd):
             u[1 + k] = Gk[k] * Q[0] + G * Q[1 + k]
         for k in range(n2):
             u[1 + nd + k] = Gkk[k] * Q[0] + 2.0 * Gk[k] * Q[1 + k] + G * Q[1 + nd + k]
+        for k in range(n3):                          # u''' = G Q''' + 3 G' Q'' + 3 G'' Q' + G''' Q
+            u[sp.i3(k)] = G * Q[sp.i3(k)] + 3.0 * (Gk[k] * Q[1 + nd + k] + Gkk[k] * Q[1 + k]) + Gkkk[k] * Q[0]
         if ic_streams is not None:
             u = u + ic_streams
     return u, (net, Q, bc, gate)
@@ -201,11 +226,11 @@ def ansatz_forward(sp, net, xs, ic_streams=None):
 def ansatz_backward(sp, gu, cache):
     """ gu [S,N] -> (gnet [S,N], d log_scale). """
     net, Q, bc, gate = cache
-    nd, n2 = sp.nd, sp.n2
+    nd, n2, n3 = sp.nd, sp.n2, sp.n3
     gQ = gu.copy()
     g_ls = 0.0
     if sp.has_ic:
-        G, Gk, Gkk, dG, dGk, dGkk = gate
+        G, Gk, Gkk, dG, dGk, dGkk, Gkkk, dGkkk = gate
         gG = gu[0] * Q[0]
         gQ[0] = gu[0] * G
         for k in range(nd):
@@ -222,6 +247,14 @@ def ansatz_backward(sp, gu, cache):
                 gQ[1 + k] = gQ[1 + k] + 2.0 * gkk * Gk[k]
                 gQ[1 + nd + k] = gkk * G
             g_ls += np.sum(gGk * dGk[k])
+        for k in range(n3):
+            g3 = gu[sp.i3(k)]
+            gQ[sp.i3(k)] = g3 * G
+            gQ[1 + nd + k] = gQ[1 + nd + k] + 3.0 * g3 * Gk[k]
+            gQ[1 + k] = gQ[1 + k] + 3.0 * g3 * Gkk[k]
+            gQ[0] = gQ[0] + g3 * Gkkk[k]
+            gG = gG + g3 * Q[sp.i3(k)]
+            g_ls += np.sum(g3 * (3.0 * (Q[1 + nd + k] * dGk[k] + Q[1 + k] * dGkk[k]) + Q[0] * dGkkk[k]))
         g_ls += np.sum(gG * dG)
     gnet = gQ.copy()
     if sp.has_bc:
@@ -235,6 +268,11 @@ def ansatz_backward(sp, gu, cache):
                 gnet[0] = gnet[0] + gkk * Pkk[k]
                 gnet[1 + k] = gnet[1 + k] + 2.0 * gkk * Pk[k]
                 gnet[1 + nd + k] = gkk * P
+        for k in range(n3):
+            g3 = gQ[sp.i3(k)]
+            gnet[sp.i3(k)] = g3 * P
+            gnet[1 + nd + k] = gnet[1 + nd + k] + 3.0 * g3 * Pk[k]
+            gnet[1 + k] = gnet[1 + k] + 3.0 * g3 * Pkk[k]
     return gnet, g_ls
 
 

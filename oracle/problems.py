@@ -47,15 +47,29 @@ def stream_form(name):
             d = np.zeros_like(u); d[5] = 1.0; d[6] = 1.0; d[7] = 1.0; d[4] = -1.0
             return r, d
         return dict(dir_cols=[0, 1, 2, 3], n2=3, residual=residual)
+    if name == 'kdv':                                # u_t + 6 u u_x + u_xxx; dirs x (3rd order), t (1st):
+        def residual(u, xs):                         # streams u, ux, ut, uxx, uxxx
+            r = u[2] + 6.0 * u[0] * u[1] + u[4]
+            d = np.zeros_like(u); d[2] = 1.0; d[0] = 6.0 * u[1]; d[1] = 6.0 * u[0]; d[4] = 1.0
+            return r, d
+        return dict(dir_cols=[0, 1], n2=1, n3=1, residual=residual)
     raise KeyError(name)
 
 
-def ic_streams_f64(name, xs, dir_cols, n2):
+def ic_streams_f64(name, xs, dir_cols, n2, n3=0):
     """ IC(x_spatial) and its derivative streams in fp64 (analytic, per config); None when IC is constant-free. """
     xs = np.asarray(xs, dtype=np.float64)
     nd = len(dir_cols)
-    S = 1 + nd + n2
+    S = 1 + nd + n2 + n3
     out = np.zeros((S, xs.shape[0]))
+    if name == 'kdv':                                # x sin(pi x): streams u, ux, ut, uxx, uxxx
+        x = xs[:, 0]
+        sn, cs = np.sin(PI * x), np.cos(PI * x)
+        out[0] = x * sn
+        out[1] = sn + PI * x * cs
+        out[3] = 2 * PI * cs - PI * PI * x * sn
+        out[4] = -3 * PI * PI * sn - PI ** 3 * x * cs
+        return out
     if name == 'cfg3':                               # 10 x y (1-x)(1-y)
         x, y = xs[:, 0], xs[:, 1]
         fx, fy = x * (1 - x), y * (1 - y)

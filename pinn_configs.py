@@ -14,8 +14,9 @@ def mlp(depth, width):
     return dict(layout='fa' * depth + 'f', features=[width] * depth + [1], activation='Tanh')
 
 
-def make_config(name, D, torch):
-    """ -> dict(equation, solver_kwargs, n_points, low, high, dir_cols, n2) """
+def make_config(name, D, torch, V=None):
+    """ -> dict(equation, solver_kwargs, n_points, low, high, dir_cols, n2); V: the framework's trainable-variable token (the
+    'program' breadth workload only) """
     if name in ('cfg1', 'cfg2'):
         def equation(f, x, y):                                   # reference README.md:36-37
             return D(D(f, x), x) + D(D(f, y), y) - 5 * torch.sin(PI * (x + y))
@@ -69,6 +70,27 @@ def make_config(name, D, torch):
                     solver_kwargs=dict(ndims=2, boundary_condition=0.2, initial_condition=lambda x: torch.sin(PI * x) * x,
                                        layout='fa fa fa f', features=[24, 24, 24, 1], activation='Tanh'),
                     n_points=4096, low=[0, 0], high=[1, 1])
+    # ---- breadth workloads: timed by `bench.py --workload ...`, not BASELINE configs -----------------------
+    if name in ('skip128', 'sin64', 'program', 'generic'):
+        def poisson(f, x, y):
+            return D(D(f, x), x) + D(D(f, y), y) - 5 * torch.sin(PI * (x + y))
+        if name == 'skip128':                                    # skip connection 'R ... +' (reference model_torch.py:142-156), width 128
+            net = dict(layout='faR fa fa+ fa f', features=[128, 128, 128, 128, 1], activation='Tanh')
+            return dict(equation=poisson, solver_kwargs=dict(ndims=2, boundary_condition=1, **net), n_points=65536,
+                        low=[0, 0], high=[1, 1])
+        if name == 'sin64':                                      # 4 x 64 with activation 'Sin'
+            net = dict(layout='fa fa fa fa f', features=[64, 64, 64, 64, 1], activation='Sin')
+            return dict(equation=poisson, solver_kwargs=dict(ndims=2, boundary_condition=1, **net), n_points=65536,
+                        low=[0, 0], high=[1, 1])
+        if name == 'program':                                    # non-affine equation with a trainable coefficient: residual program
+            def reaction(f, x, y):
+                k = V('k', data=torch.Tensor([1.5]))
+                return D(D(f, x), x) + D(D(f, y), y) + k * f * f - 5 * torch.sin(PI * (x + y))
+            return dict(equation=reaction, solver_kwargs=dict(ndims=2, boundary_condition=1, **mlp(4, 64)), n_points=65536,
+                        low=[0, 0], high=[1, 1])
+        # 'generic': BASELINE config 2 forced onto the generic step path (pinn_jet_forward -> torch -> pinn_jet_backward)
+        return dict(equation=poisson, solver_kwargs=dict(ndims=2, boundary_condition=1, **mlp(4, 64)), n_points=65536,
+                    low=[0, 0], high=[1, 1])
     raise KeyError(name)
 
 

@@ -25,8 +25,10 @@ FLAGS = ['--offload-arch=gfx950', '-O3', '-std=c++17', '-fPIC', '-x', 'hip', '-W
 # width 128 is within 1 % everywhere
 WIDTH_FLAGS = {256: ['-mllvm', '-amdgpu-sched-strategy=iterative-maxocc'], 64: ['-mllvm', '-amdgpu-sched-strategy=iterative-ilp']}
 # split-bf16 twins of the two BASELINE width-64 kernels (same-box A/B, round 3): 1 = the S = 4 Poisson-box kernel, fastest with the
-# SLP vectoriser on (packed fp32 ops: fewer instructions to issue), 2 = the S = 2 ODE-family kernel, fastest without it
-SPLIT_FLAGS = {1: [], 2: ['-fno-slp-vectorize']}
+# SLP vectoriser on (packed fp32 ops: fewer instructions to issue) and -- it sits at the 256-register limit of two waves per SIMD --
+# without operand prefetch in its forward / data-gradient GEMMs (40 spilled registers otherwise), 2 = the S = 2 ODE-family kernel,
+# fastest without the SLP vectoriser
+SPLIT_FLAGS = {1: ['-DPINN_SP_PIPE=0', '-DPINN_SP_PIPE_W=1'], 2: ['-fno-slp-vectorize']}
 if os.environ.get('PINN_SPLIT_FLAGS'):
     import json
     SPLIT_FLAGS = {int(k): v for k, v in json.loads(os.environ['PINN_SPLIT_FLAGS']).items()}

@@ -129,11 +129,7 @@ PINN_GLOBAL void PINN_LAUNCH_BOUNDS(256) pinn_wsplit_kernel(const float* wh, int
     for (int e = 0; e < 8; ++e) {
         const int unit = 16 * j + lr, k = 32 * kb + 8 * lq + e;
         const float x = dir == 0 ? W[(size_t)unit * hp + k] : W[(size_t)k * hp + unit];
-        b[0][e] = pinn_fbits(x);
-        const float r1 = x - pinn_bitsf(b[0][e] & 0xffff0000u);
-        b[1][e] = pinn_fbits(r1);
-        const float r2 = r1 - pinn_bitsf(b[1][e] & 0xffff0000u);
-        b[2][e] = pinn_fbits(r2);
+        pinn_split3(x, b[0][e], b[1][e], b[2][e]);
     }
 #pragma unroll
     for (int p = 0; p < 3; ++p) {

@@ -920,17 +920,30 @@ PINN_DEVICE void pinn_st4(float* p, f32x4 v) { *reinterpret_cast<f32x4*>(p) = v;
 // values and plane packs the upper halves (the pack is the truncation of mid and lo).
 PINN_DEVICE unsigned pinn_fbits(float x) { return __builtin_bit_cast(unsigned, x); }
 PINN_DEVICE float pinn_bitsf(unsigned x) { return __builtin_bit_cast(float, x); }
+// hi and mid are ROUNDED to nearest (+0x8000 on the bit pattern before the mask), lo takes the rest exactly. Truncation would be
+// two instructions per value cheaper and just as exact a split, but then every part of a value carries the value's sign and
+// the matrix pipe's internal accumulation (which does not round to nearest) drifts one way: on TRAINED models, arbitrated in
+// fp64, the gradient error came out at 2.18x the fp32 reference's own (cfg4) with truncation, 1.34x with mid alone rounded,
+// 1.18x with both -- the exact-fp32 kernel's 1.19x (profiles/r03_arbiter_split.txt; all nine products with truncation: 1.53x).
+#ifndef PINN_SP_ROUND
+#define PINN_SP_ROUND 2         // 0: hi and mid by truncation; 1: mid rounded to nearest; 2: hi and mid rounded
+#endif
+#ifndef PINN_SP_NPROD
+#define PINN_SP_NPROD 6         // partial products per GEMM step: 6 (i + j <= 2) or all 9
+#endif
+// bit patterns whose UPPER halves are the three bf16 parts of x (b0: hi, b1: mid, b2: lo); x = hi + mid + lo exactly
+PINN_DEVICE void pinn_split3(float x, unsigned& b0, unsigned& b1, unsigned& b2) {
+    b0 = pinn_fbits(x) + (PINN_SP_ROUND >= 2 ? 0x8000u : 0u);
+    const float r1 = x - pinn_bitsf(b0 & 0xffff0000u);
+    b1 = pinn_fbits(r1) + (PINN_SP_ROUND >= 1 ? 0x8000u : 0u);
+    const float r2 = r1 - pinn_bitsf(b1 & 0xffff0000u);
+    b2 = pinn_fbits(r2);
+}
 struct PinnSplit4 { pinn_u32x2 hi, mid, lo; };            // four consecutive units of one (point, stream): 8 bytes per plane
 PINN_DEVICE PinnSplit4 pinn_split4(f32x4 v) {
     unsigned b0[4], b1[4], b2[4];
 #pragma unroll
-    for (int r = 0; r < 4; ++r) {
-        b0[r] = pinn_fbits(v[r]);
-        const float r1 = v[r] - pinn_bitsf(b0[r] & 0xffff0000u);
-        b1[r] = pinn_fbits(r1);
-        const float r2 = r1 - pinn_bitsf(b1[r] & 0xffff0000u);
-        b2[r] = pinn_fbits(r2);
-    }
+    for (int r = 0; r < 4; ++r) pinn_split3(v[r], b0[r], b1[r], b2[r]);
     PinnSplit4 o;
     o.hi = pinn_u32x2{pinn_pack_hi16(b0[0], b0[1]), pinn_pack_hi16(b0[2], b0[3])};
     o.mid = pinn_u32x2{pinn_pack_hi16(b1[0], b1[1]), pinn_pack_hi16(b1[2], b1[3])};
@@ -1007,6 +1020,10 @@ pinn_tile_kernel(const PinnKArgs A) {
     // pinn_wsplit_kernel, L2-resident); the weight-gradient operands are read point-contiguous out of the same planes with
     // ds_read_b64_tr_b16. Accumulator layouts, jets, point stage, slab and reductions are those of the exact kernel.
     constexpr bool SPLIT = C::SPLIT;
+    // (VAR 2, two independent workgroups per CU, is NOT allowed: measured 2 - 5 % faster than two teams, but with a second
+    //  workgroup resident on the CU every build that spills even two registers returned slightly wrong, run-to-run different
+    //  gradients on MI355X (1e-5 .. 1e-3; exact with one workgroup per CU, with -amdgpu-waitcnt-forcezero, and for the two-team
+    //  form at every size) -- DESIGN.md section 6b; tests/test_gpu_parity.py holds the shipped kernels to bitwise repeatability)
     static_assert(!SPLIT || (HP == 64 && NTW == 1 && LHC >= 1 && !(VAR & (1 | 2 | 8 | 64 | 128)) && ((S * T) % 32) == 0 &&
                              ((T == 16 && S % 2 == 0) || T == 32)),
                   "split-bf16 kernels: width 64, static depth, register-resident dW, K = S * T a multiple of 32");
@@ -1220,7 +1237,11 @@ pinn_tile_kernel(const PinnKArgs A) {
         for (int kb = 0; kb < C::SP_KB; ++kb)
 #pragma unroll
             for (int p = 0; p < 3; ++p)
-                w[kb][p] = __builtin_bit_cast(pinn_s16x8, pinn_rows_ld4(wsp_rows, lane * 16, (int)(C::wsp_frag(l, dir, kb, 0, p) * 16) + wave_s * 3 * 1024));
+#ifndef PINN_SP_WBUF
+#define PINN_SP_WBUF 1
+#endif
+                if (PINN_SP_WBUF) w[kb][p] = __builtin_bit_cast(pinn_s16x8, pinn_rows_ld4(wsp_rows, lane * 16, (int)(C::wsp_frag(l, dir, kb, 0, p) * 16) + wave_s * 3 * 1024));
+                else w[kb][p] = reinterpret_cast<const pinn_s16x8*>(A.wsp)[C::wsp_frag(l, dir, kb, wave, p) + lane];
     };
     // out^T[16 units of this wave][points] += W-fragments . rows of `bbuf` (forward: h_{l-1}, data gradient: gz_a), all S * MT
     // (row tile, stream) rows of the tile: two rows per step, their B fragments (three planes each) fetched one step ahead,
@@ -1243,7 +1264,7 @@ pinn_tile_kernel(const PinnKArgs A) {
     auto sp_gemm = [&](const float* bbuf, const pinn_s16x8 (&w)[SPLIT ? C::SP_KB : 1][3], f32x4 (&out)[NTW][MT][S]) {
         constexpr int NR = MT * S, G = (NR % PINN_SP_G == 0) ? PINN_SP_G : 1, NG = NR / G, STEPS = C::SP_KB * NG;
         constexpr int NB = PINN_SP_PIPE ? 2 : 1;
-        constexpr int pa[6] = {2, 0, 1, 1, 0, 0}, pb[6] = {0, 2, 1, 0, 1, 0};
+        constexpr int pa[9] = {2, 2, 1, 2, 0, 1, 1, 0, 0}, pb[9] = {2, 1, 2, 0, 2, 1, 0, 1, 0};     // (a part, b part), small products first
         pinn_s16x8 bf[NB][G][3];
         auto load = [&](int step, pinn_s16x8 (&f)[G][3]) {
             const int kb = step / NG, g0 = (step % NG) * G;
@@ -1262,7 +1283,7 @@ pinn_tile_kernel(const PinnKArgs A) {
             if (!PINN_SCHED_IL) PINN_SCHED_BARRIER();
             const int kb = step / NG, g0 = (step % NG) * G;
 #pragma unroll
-            for (int t = 0; t < 6; ++t)
+            for (int t = 9 - PINN_SP_NPROD; t < 9; ++t)
 #pragma unroll
                 for (int i = 0; i < G; ++i) {
                     const int r = g0 + i;
@@ -1460,6 +1481,10 @@ pinn_tile_kernel(const PinnKArgs A) {
             if constexpr (SPLIT) {
                 if (!PINN_SP_WPF) sp_weights(li, 0, wsf);
                 sp_gemm(cur, wsf, acc);
+#ifndef PINN_SP_FWD_BARRIER
+#define PINN_SP_FWD_BARRIER 0   // a barrier between a forward GEMM and its jet epilogue: with PINN_TEAM_SKEW the GEMM interval of one team then faces a vector interval of the other
+#endif
+                if (PINN_SP_FWD_BARRIER) PINN_SYNC();
             } else {
                 // software pipeline over the K quads: the operands of quad q+1 are in flight while the S*MT*NTW*4 MFMAs
                 // of quad q issue, accumulators interleaved (an accumulator is re-used every S*MT*NTW issues, far
@@ -1867,7 +1892,7 @@ pinn_tile_kernel(const PinnKArgs A) {
                     }
                 };
                 constexpr int KBW = (S * T) / 32, OG = PINN_SP_OG, NOG = NT / OG, STEPS = KBW * NOG, NB = PINN_SP_PIPE_W ? 2 : 1;
-                constexpr int pa[6] = {2, 0, 1, 1, 0, 0}, pb[6] = {0, 2, 1, 0, 1, 0};
+                constexpr int pa[9] = {2, 2, 1, 2, 0, 1, 1, 0, 0}, pb[9] = {2, 1, 2, 0, 2, 1, 0, 1, 0};     // (a part, b part), small products first
                 auto rows_of = [&](int kb, int& r0, int& r1) {
                     const int srow = (T == 16) ? (2 * kb + (lq >> 1)) * T : kb * T;
                     r0 = srow + ((T == 16) ? 4 * (lq & 1) : 4 * lq);
@@ -1907,7 +1932,7 @@ pinn_tile_kernel(const PinnKArgs A) {
                     }
                     if (!PINN_SCHED_IL) PINN_SCHED_BARRIER();
 #pragma unroll
-                    for (int t = 0; t < 6; ++t)
+                    for (int t = 9 - PINN_SP_NPROD; t < 9; ++t)
 #pragma unroll
                         for (int i = 0; i < OG; ++i)
                             dw[o0 + i][0] = pinn_mfma16_bf16(afr[step % NB][i][pa[t]], bfr[PINN_SP_PIPE_W ? kb : 0][pb[t]], dw[o0 + i][0]);

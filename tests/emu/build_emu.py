@@ -59,10 +59,15 @@ def build(force=False, extra_flags=(), tag='', widths=(64,)):
     os.makedirs(tbuild, exist_ok=True)
     jobs = [[CXX, *FLAGS, *extra_flags, f'-DPINN_INST_HP={hp}', '-c', os.path.join(CSRC, 'pinn_inst.inc'), '-o',
              os.path.join(tbuild, f'inst_hp{hp}.o')] for hp in widths]
+    split_here = 64 in widths                  # the split-bf16 translation units belong to width 64
+    if split_here:
+        jobs += [[CXX, *FLAGS, *extra_flags, '-DPINN_INST_HP=64', f'-DPINN_INST_SPLIT={n}', '-c', os.path.join(CSRC, 'pinn_inst.inc'),
+                  '-o', os.path.join(tbuild, f'inst_hp64_split{n}.o')] for n in (1, 2)]
     with ThreadPoolExecutor(max_workers=os.cpu_count() or 4) as pool:
         objs = list(pool.map(_run, jobs))
     objs += [os.path.join(BUILD, f'inst_hp{hp}.o') for hp in WIDTHS if hp not in widths]
-    objs += [os.path.join(BUILD, f'inst_hp64_split{n}.o') for n in (1, 2)]
+    if not split_here:
+        objs += [os.path.join(BUILD, f'inst_hp64_split{n}.o') for n in (1, 2)]
     objs += [os.path.join(BUILD, 'abi.o'), os.path.join(BUILD, 'emu_runtime.o')]
     _run([CXX, '-shared', '-fPIC', *objs, '-o', tout])
     return tout

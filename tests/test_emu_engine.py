@@ -13,7 +13,7 @@ import torch
 
 import pinn_configs as pc
 from conftest import Golden, params_close, rel_l2
-from helpers import FixedBatches, export_grads, export_params, fit_rtol, load_params, make_solver
+from helpers import FixedBatches, export_grads, export_params, fit_rtol, grad_close, load_params, make_solver
 
 sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), 'emu'))
 
@@ -83,7 +83,7 @@ def test_gradients_match_reference_golden(pa, emu_lib, name):
         if want is None:
             assert float(np.abs(got).max()) == 0.0
         else:
-            assert rel_l2(got, want) < 1e-4
+            assert grad_close(got, want)
 
 
 @pytest.mark.parametrize('n', [1, 15, 17, 50])
