@@ -223,6 +223,18 @@ int pinn_adam_step_at(float* params, const float* grads, float* exp_avg, float* 
                       int64_t n, int32_t* step_ptr, int32_t step, float lr, float beta1, float beta2, float eps,
                       float* loss_out, int32_t off_loss, void* stream);
 
+/* The reference's fit loop (model_torch.py:426-464) for the common case -- on-device column sampler, one equation term on the
+ * fused path, Adam -- as ONE call that enqueues `k_steps` iterations: iteration k draws batch `call_index0 + k` into `xs`
+ * (pinn_sample_points with kind / a / b / seed), runs pinn_residual_adam_step with Adam step `step0 + k` and leaves the
+ * iteration's loss in loss_history[k] (device memory). Asynchronous like every entry point; at 100-point batches the host
+ * loop is what bounds Solver.fit (three launches per iteration), and this keeps it out of the interpreter. Problems with
+ * ic_streams (an initial condition the tracer could not lower) do not take this path. */
+int pinn_fit_steps(pinn_t* net, const pinn_residual_t* residual, float* params, float* xs, int64_t n_points,
+                   const int* kind, const float* a, const float* b, uint64_t seed, uint64_t call_index0,
+                   const int* dir_cols, int nd, int n2, float ic_const, float* grads, float* exp_avg, float* exp_avg_sq,
+                   const uint8_t* mask, int32_t* step_ptr, int32_t step0, float lr, float beta1, float beta2, float eps,
+                   float* loss_history, int32_t k_steps, void* workspace, size_t workspace_bytes, void* stream);
+
 /* Arithmetic of the hidden-layer GEMMs (forward, data gradient, weight gradient) of the fused step -- what ATen's `addmm` /
  * `mm` calls do in the reference (pydens/model_torch.py:170-178, :460), per net:
  *   PINN_GEMM_FP32    (default) v_mfma_f32_16x16x4_f32: exact fp32, bitwise an fmaf chain

@@ -798,6 +798,25 @@ int pinn_residual_adam_step(pinn_t* net, const pinn_residual_t* residual, float*
                               1.0f / (float)n_points, grads, workspace, workspace_bytes, stream, &adam);
 }
 
+int pinn_fit_steps(pinn_t* net, const pinn_residual_t* residual, float* params, float* xs, int64_t n_points,
+                   const int* kind, const float* a, const float* b, uint64_t seed, uint64_t call_index0,
+                   const int* dir_cols, int nd, int n2, float ic_const, float* grads, float* exp_avg, float* exp_avg_sq,
+                   const uint8_t* mask, int32_t* step_ptr, int32_t step0, float lr, float beta1, float beta2, float eps,
+                   float* loss_history, int32_t k_steps, void* workspace, size_t workspace_bytes, void* stream) {
+    if (!net || !xs || !loss_history) return fail("null argument");
+    if (k_steps < 0 || step0 < 1) return fail("k_steps must be >= 0 and step0 >= 1");
+    // K iterations of the reference's fit loop (model_torch.py:426-464) enqueued by ONE call: sample, fused step, Adam. Nothing
+    // here waits for the device; the arguments that change from one iteration to the next (Philox batch counter, Adam step,
+    // slot of the loss history) travel by value, so a launch graph would have to be re-instantiated per iteration anyway
+    for (int32_t k = 0; k < k_steps; ++k) {
+        if (pinn_sample_points(xs, n_points, net->lay.d, kind, a, b, seed, call_index0 + (uint64_t)k, stream)) return 1;
+        if (pinn_residual_adam_step(net, residual, params, xs, n_points, dir_cols, nd, n2, nullptr, ic_const, grads, exp_avg,
+                                    exp_avg_sq, mask, step_ptr, step0 + k, lr, beta1, beta2, eps, loss_history + k, workspace,
+                                    workspace_bytes, stream)) return 1;
+    }
+    return 0;
+}
+
 static int adam_launch(float* params, const float* grads, float* exp_avg, float* exp_avg_sq, const uint8_t* mask, int64_t n,
                        int32_t* step_ptr, int32_t step, float lr, float beta1, float beta2, float eps, void* stream,
                        float* loss_out = nullptr, int off_loss = -1) {

@@ -197,6 +197,25 @@ struct PinnCfg {
 // ------------------------------------------------------------------------------------------------------------
 // tanh(z) = sign(z) (1 - t)/(1 + t) with t = e^{-2|z|}, sigmoid(z) = 1/(1 + e^{-z}) on v_exp_f32 / v_rcp_f32 (about 1 ulp
 // each): absolute error <= ~1.5e-7 over the whole range, saturates cleanly, no branches.
+// sin and cos of one argument together (activation 'Sin': value and derivatives come from both): k = nearest integer to
+// x * 2/pi, r = x - k * pi/2 by three-constant Cody-Waite steps (exact products for |k| < 2^15, i.e. |x| < 5e4), minimax
+// polynomials on [-pi/4, pi/4] (cephes sinf / cosf), quadrant fix-up: ~25 instructions and ~1 ulp, against two to three ocml
+// sinf / cosf calls per use (each with its own range reduction and a branch to the large-argument path): the Sin breadth
+// workload of bench.py went 0.644 -> see DESIGN.md section 6b.
+PINN_DEVICE void pinn_sincos(float x, float& sn, float& cs) {
+    const float kf = rintf(x * 0.63661977236758134f);
+    float r = fmaf(kf, -1.5703125f, x);
+    r = fmaf(kf, -4.837512969970703125e-4f, r);
+    r = fmaf(kf, -7.54978995489188216e-8f, r);
+    const int k = (int)kf;
+    const float r2 = r * r;
+    const float sp = fmaf(fmaf(fmaf(-1.9515295891e-4f, r2, 8.3321608736e-3f), r2, -1.6666654611e-1f) * r2, r, r);
+    const float cp = fmaf(fmaf(fmaf(2.443315711809948e-5f, r2, -1.388731625493765e-3f), r2, 4.166664568298827e-2f) * r2, r2,
+                          fmaf(-0.5f, r2, 1.0f));
+    const float a = (k & 1) ? cp : sp, b = (k & 1) ? sp : cp;
+    sn = (k & 2) ? -a : a;
+    cs = ((k + 1) & 2) ? -b : b;
+}
 PINN_DEVICE float pinn_act(float z, int act) {
     if (act == PINN_ACT_TANH) {
         // Forms measured on trained models against the fp64 oracle (tools/arbiter.py; gradient error
@@ -245,7 +264,7 @@ PINN_DEVICE float pinn_act(float z, int act) {
 #endif
     }
     if (act == PINN_ACT_SIGMOID) return pinn_rcp(1.0f + pinn_exp2(z * -1.4426950408889634f));
-    if (act == PINN_ACT_SIN) return sinf(z);
+    if (act == PINN_ACT_SIN) { float sn, cs; pinn_sincos(z, sn, cs); return sn; }
     if (act == PINN_ACT_SOFTPLUS) return z > 20.0f ? z : log1pf(expf(z));           // torch.nn.Softplus (beta 1, threshold 20)
     if (act == PINN_ACT_SILU) return z / (1.0f + expf(-z));
     if (act == PINN_ACT_GELU) return 0.5f * z * (1.0f + erff(z * 0.70710678118654752f));   // torch.nn.GELU (erf form)
@@ -276,7 +295,7 @@ PINN_DEVICE void pinn_act_zderivs(float z, int act, float& d1, float& d2, float&
 PINN_DEVICE void pinn_act_d12(float sv, int act, float& d1, float& d2) {
     if (act == PINN_ACT_TANH) { d1 = 1.0f - sv * sv; d2 = -2.0f * sv * d1; }
     else if (act == PINN_ACT_SIGMOID) { d1 = sv * (1.0f - sv); d2 = d1 * (1.0f - 2.0f * sv); }
-    else if (act == PINN_ACT_SIN) { d1 = cosf(sv); d2 = -sinf(sv); }
+    else if (act == PINN_ACT_SIN) { float sn; pinn_sincos(sv, sn, d1); d2 = -sn; }
     else if (act >= PINN_ACT_SOFTPLUS) { float d3, d4; pinn_act_zderivs(sv, act, d1, d2, d3, d4); }
     else { d1 = 1.0f; d2 = 0.0f; }
 }
@@ -298,7 +317,7 @@ PINN_DEVICE float pinn_act_d4(float sv, float d1, float d2, int act) {
         const float q = 1.0f - 2.0f * sv;                        // with a = s(1 - s): s2 = a q, s3 = a (q^2 - 2 a), s4 = a q (q^2 - 8 a)
         return d1 * q * (q * q - 8.0f * d1);
     }
-    if (act == PINN_ACT_SIN) return sinf(sv);
+    if (act == PINN_ACT_SIN) return -d2;                          // sin(z) = -(second derivative)
     if (act >= PINN_ACT_SOFTPLUS) { float e1, e2, e3, d4; pinn_act_zderivs(sv, act, e1, e2, e3, d4); return d4; }
     return 0.0f;
 }

@@ -102,6 +102,10 @@ def bind(lib):
                                             vp, i32, f32, f32, f32, f32, vp, vp, ctypes.c_size_t, vp]
     lib.pinn_sample_points.argtypes = [vp, i64, i32, ip, ctypes.POINTER(f32), ctypes.POINTER(f32), ctypes.c_uint64,
                                        ctypes.c_uint64, vp]
+    lib.pinn_fit_steps.argtypes = [vp, ctypes.POINTER(Residual), vp, vp, i64, ip, ctypes.POINTER(f32), ctypes.POINTER(f32),
+                                   ctypes.c_uint64, ctypes.c_uint64, ip, i32, i32, f32, vp, vp, vp, vp, vp, i32, f32, f32, f32, f32,
+                                   vp, i32, vp, ctypes.c_size_t, vp]
+    lib.pinn_fit_steps.restype = i32
     lib.pinn_set_gemm_mode.argtypes = [vp, i32]
     lib.pinn_set_gemm_mode.restype = i32
     lib.pinn_profile_tile.argtypes = [i32]
@@ -119,7 +123,7 @@ def bind(lib):
 
 
 ABI_SYMBOLS = ('pinn_create', 'pinn_create_ex', 'pinn_destroy', 'pinn_layout', 'pinn_workspace_bytes', 'pinn_jet_forward',
-               'pinn_jet_backward', 'pinn_residual_step', 'pinn_residual_step_add', 'pinn_residual_adam_step', 'pinn_adam_step', 'pinn_adam_step_at', 'pinn_sample_points', 'pinn_set_gemm_mode', 'pinn_profile_tile',
+               'pinn_jet_backward', 'pinn_residual_step', 'pinn_residual_step_add', 'pinn_residual_adam_step', 'pinn_adam_step', 'pinn_adam_step_at', 'pinn_sample_points', 'pinn_fit_steps', 'pinn_set_gemm_mode', 'pinn_profile_tile',
                'pinn_last_tile_ms', 'pinn_last_wgrad_ms', 'pinn_last_kernel_name', 'pinn_debug_last_kernel',
                'pinn_debug_prepass_in_kernel', 'pinn_debug_wgx_chunk_bytes',
                'pinn_last_error', 'pinn_backend')
@@ -317,6 +321,31 @@ class Net:
                 float(lr), float(betas[0]), float(betas[1]), float(eps),
                 None if loss_out is None else ctypes.c_void_p(loss_out), _ptr(workspace),
                 workspace.numel() * workspace.element_size(), _stream(xs) if stream is None else stream))
+
+    def fit_steps(self, residual, params, xs, columns, seed, call_index0, grads, workspace, exp_avg, exp_avg_sq, mask,
+                  step_tensor, step0, lr, betas, eps, loss_history, k_steps, dir_cols=(), n2=0, ic_const=0.0, stream=None):
+        """ `k_steps` iterations of the fit loop (sample -> fused step -> Adam) enqueued by one call (include/pinn.h
+        pinn_fit_steps); `xs` is the [N, d] batch buffer every iteration overwrites, `loss_history` a float32 device tensor
+        with at least k_steps entries. """
+        for t, name in ((params, 'params'), (xs, 'xs'), (grads, 'grads'), (exp_avg, 'exp_avg'), (exp_avg_sq, 'exp_avg_sq'),
+                        (loss_history, 'loss_history')):
+            _check(t, name)
+        _check(mask, 'mask', torch.uint8)
+        _check(step_tensor, 'step', torch.int32)
+        d = len(columns)
+        if xs.dim() != 2 or xs.shape[1] != d or loss_history.numel() < k_steps:
+            raise ValueError(f'xs must be [N, {d}] and loss_history hold {k_steps} entries')
+        kind = (ctypes.c_int * d)(*[int(c[0]) for c in columns])
+        a = (ctypes.c_float * d)(*[float(c[1]) for c in columns])
+        b = (ctypes.c_float * d)(*[float(c[2]) for c in columns])
+        dirs, nd = self._dirs(dir_cols)
+        with _on_device(params):
+            self._raise(self.lib.pinn_fit_steps(
+                self.handle, ctypes.byref(residual), _ptr(params), _ptr(xs), xs.shape[0], kind, a, b,
+                int(seed) & (2 ** 64 - 1), int(call_index0), dirs, nd, n2, float(ic_const), _ptr(grads), _ptr(exp_avg),
+                _ptr(exp_avg_sq), _ptr(mask), _ptr(step_tensor), int(step0), float(lr), float(betas[0]), float(betas[1]),
+                float(eps), _ptr(loss_history), int(k_steps), _ptr(workspace), workspace.numel() * workspace.element_size(),
+                _stream(xs) if stream is None else stream))
 
     def sample_points(self, xs, columns, seed, call_index, stream=None):
         """ fill xs [N, d] on the device: columns = [(kind, a, b), ...] with kind SAMPLE_UNIFORM (a + (b - a) u),

@@ -52,10 +52,11 @@ class Sampler:
             return None
         return key
 
-    def next_device_call(self):
-        """ batches this sampler object has drawn on the device so far (its own call counter, like its own numpy state) """
+    def next_device_call(self, count=1):
+        """ batches this sampler object has drawn on the device so far (its own call counter, like its own numpy state);
+        reserves `count` consecutive batch numbers and returns the first """
         n = getattr(self, '_device_calls', 0)
-        self._device_calls = n + 1
+        self._device_calls = n + count
         return n
 
     def __and__(self, other):

@@ -587,6 +587,11 @@ class Solver:
     def _fit_loop(self, niters, local_batch, sampler, loss_terms, nums_constraints, criterion, world, fused, one_launch,
                   flat_adam, stream, history, history_ptr, done):
         lay = self.model.net.layout
+        columns = self._device_columns(sampler) if one_launch else None
+        if columns is not None and not self._needs_ic_streams():
+            # the common case end to end on the device: chunks of iterations enqueued by ONE library call each
+            # (pinn_fit_steps: sample, fused step, Adam per iteration; the interpreter is out of the per-iteration path)
+            return self._fit_chunks(niters, local_batch, sampler, columns, stream, history, done)
         for it in tqdm(range(niters), disable=None):
             xs = self._sample(local_batch, sampler, stream)
             if one_launch:
@@ -613,6 +618,50 @@ class Solver:
                 self.optimizer.step(self.grads)
                 history[it:it + 1].copy_(self.grads[lay.off_loss:lay.off_loss + 1])
             done[0] = it + 1
+
+    FIT_CHUNK = 128             # iterations per pinn_fit_steps call (progress bar / KeyboardInterrupt granularity)
+
+    def _device_columns(self, sampler):
+        """ (kind, a, b) per input column if the Philox kernel can draw this sampler's batches, else None """
+        total = self.model.total
+        columns = [(engine.SAMPLE_UNIFORM, 0.0, 1.0)] * total if sampler is None else \
+            (sampler.columns() if hasattr(sampler, 'columns') else None)
+        if columns is not None and len(columns) == total and total <= engine.MAX_INPUTS:
+            return columns
+        return None
+
+    def _needs_ic_streams(self):
+        model = self.model
+        lowered_ic = self.residual_plan is not None and self.residual_plan.ic_row is not None
+        return (model.initial_condition is not None and model.ic_constant is None and self.ic_var_slot is None
+                and not lowered_ic)
+
+    def _fit_chunks(self, niters, batch, sampler, columns, stream, history, done):
+        model, spec, adam = self.model, self.spec, self.optimizer
+        comb_w = self.residual_plan.comb_w if self.residual_plan is not None else None
+        n2 = spec.n2p if comb_w is None else 1
+        ws = model.workspace(batch, spec.nd, spec.n2p)
+        xs = torch.empty((batch, model.total), dtype=torch.float32, device=self.device)
+        own = sampler.device_key() if (sampler is not None and hasattr(sampler, 'device_key')) else None
+        rank, _ = self._world()
+        with tqdm(total=niters, disable=None) as bar:
+            it = 0
+            while it < niters:
+                k = min(self.FIT_CHUNK, niters - it)
+                if own is not None:         # `NumpySampler(..., seed=k)`: the sampler's own key and batch counter (see _sample)
+                    seed = (own + 7919 * rank) & (2 ** 64 - 1)
+                    call0 = sampler.next_device_call(k)
+                else:
+                    seed, call0 = self._sample_seed, self._sample_calls
+                model.net.fit_steps(self.program, model.flat, xs, columns, seed, call0, self.grads, ws, adam.exp_avg,
+                                    adam.exp_avg_sq, adam.mask, adam.step_count, adam.t + 1, adam.lr, adam.betas, adam.eps,
+                                    history[it:it + k], k, dir_cols=spec.dir_cols, n2=n2, ic_const=model.kernel_ic_const(),
+                                    stream=stream)
+                adam.t += k
+                self._sample_calls += k
+                it += k
+                done[0] = it
+                bar.update(k)
 
     def _fused_step(self, xs, world, adam=None, loss_out=None, stream=None):
         model, spec = self.model, self.spec

@@ -821,3 +821,55 @@ def test_third_order_streams_match_the_oracle(pa, emu_lib, which):
             assert params_close(got, want, 1e-4, atol=1e-5)
     xs = [pts[0][:, i] for i in range(d)]
     assert np.abs(solver.predict(*xs) - oracle.predict(*xs)).max() < 2e-5
+
+
+def test_chunked_fit_equals_the_per_iteration_loop(pa, emu_lib):
+    """ Solver.fit on the common path -- device sampler, one equation term, Adam -- enqueues chunks of iterations through ONE
+    library call (pinn_fit_steps; reference loop model_torch.py:426-464). Same Philox batches, same Adam steps, same loss
+    history as the per-iteration loop, bit for bit; a seeded NumpySampler keeps counting its own batches across the chunks. """
+    def run(chunk, per_iteration, sampler_of):
+        torch.manual_seed(77)
+        cfg, solver = make_solver('cfg4', pa, **emu_kwargs(emu_lib))
+        solver.FIT_CHUNK = chunk
+        if per_iteration:
+            solver._device_columns = lambda sampler: None
+        sampler = sampler_of()
+        solver.fit(niters=7, batch_size=48, sampler=sampler, lr=0.01)
+        solver.fit(niters=3, batch_size=48, sampler=sampler, lr=0.01, optimizer=None)
+        return np.array([float(v) for v in solver.losses]), export_params(solver)
+    for sampler_of in (lambda: None, lambda: pa.NumpySampler('uniform', seed=5) & pa.NumpySampler('uniform', low=1, high=5, seed=6)):
+        want_l, want_p = run(128, True, sampler_of)
+        for chunk in (128, 3, 1):
+            got_l, got_p = run(chunk, False, sampler_of)
+            assert np.array_equal(got_l, want_l), chunk
+            for a, b in zip(got_p, want_p):
+                assert np.array_equal(a, b), chunk
+
+
+@pytest.mark.parametrize('bc', [1, None])
+def test_sin_net_of_depth_four_takes_the_static_kernel(pa, emu_lib, bc):
+    """ 4 x 64 'Sin' nets (reference model_torch.py:158-168 takes any activation name) run on instantiations with the depth and
+    the activation fixed -- register-resident weight gradients instead of read-modify-write rows (round 3, the worst breadth
+    workload) -- with the Dirichlet-box shape facts fixed where they apply (bc = 1) and without (no boundary condition). """
+    from oracle import pinn_oracle as po
+
+    def problem(D):
+        eq = lambda f, x, y: D(D(f, x), x) + D(D(f, y), y) - 5 * torch.sin(np.pi * (x + y))
+        kw = dict(ndims=2, layout='fa fa fa fa f', features=[64, 64, 64, 64, 1], activation='Sin')
+        if bc is not None:
+            kw['boundary_condition'] = bc
+        return eq, kw
+    torch.manual_seed(4)
+    eq_o, kw = problem(po.D)
+    oracle = po.OracleSolver(eq_o, **kw)
+    eq_p, kw = problem(pa.D)
+    solver = pa.Solver(eq_p, **kw, **emu_kwargs(emu_lib))
+    load_params(solver, oracle.export_params())
+    pts = np.random.RandomState(8).rand(2, 50, 2).astype(np.float32)
+    oracle.fit(niters=2, batch_size=50, points=pts, lr=0.005)
+    solver.fit(niters=2, batch_size=50, sampler=FixedBatches(pts), lr=0.005)
+    name = emu_lib.pinn_last_kernel_name().decode()
+    assert name == ('pinn_tile_kernel<64,2,1,1,3,2,true,24>' if bc is not None else 'pinn_tile_kernel<64,2,1,1,3,2,true,8>'), name
+    np.testing.assert_allclose([float(v) for v in solver.losses], [float(v) for v in oracle.losses], rtol=2e-5)
+    for got, want in zip(export_params(solver), oracle.export_params()):
+        assert params_close(got, want, 2e-5)

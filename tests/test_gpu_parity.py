@@ -858,3 +858,20 @@ def test_split_kernels_are_bitwise_repeatable(pa, name, n):
     for _ in range(3):
         solver._fused_step(pts, 1)
         assert torch.equal(solver.grads, first)
+
+
+def test_sin_net_of_depth_four_on_the_static_kernel(pa):
+    """ the 4 x 64 'Sin' breadth workload of bench.py (static-depth kernel with the Dirichlet-box facts fixed) against the oracle """
+    from oracle import pinn_oracle as po
+    torch.manual_seed(4)
+    ocfg = pc.make_config('sin64', po.D, torch)
+    oracle = po.OracleSolver(ocfg['equation'], **ocfg['solver_kwargs'])
+    cfg, solver = make_solver('sin64', pa)
+    load_params(solver, oracle.export_params())
+    pts = pc.sample_points(cfg, 3000, seed=9, steps=2)
+    oracle.fit(niters=2, batch_size=3000, points=pts, lr=0.005)
+    solver.fit(niters=2, batch_size=3000, sampler=FixedBatches(pts), lr=0.005)
+    assert solver.model.net.lib.pinn_last_kernel_name().decode() == 'pinn_tile_kernel<64,2,1,1,3,2,true,24>'
+    np.testing.assert_allclose([float(v) for v in solver.losses], [float(v) for v in oracle.losses], rtol=2e-5)
+    for got, want in zip(export_params(solver), oracle.export_params()):
+        assert params_close(got, want, 2e-5)
