@@ -258,6 +258,9 @@ float pinn_last_wgrad_ms(void);
 /* Instantiation of the tile kernel the last step / forward / backward call launched on this thread's library, e.g.
  * "pinn_tile_kernel<64,2,1,2,3,0,true,16>" (the symbol rocprofv3 shows): bench.py names the kernel it prices with it. */
 const char* pinn_last_kernel_name(void);
+/* ... and of the streamed weight-gradient kernel of widths >= 128 ("" before the first such launch); the last template argument
+ * says whether it was the split-bf16 form (pinn_set_gemm_mode) */
+const char* pinn_last_wgrad_kernel_name(void);
 
 /* Diagnostics (tests, tools/): never used on the training path; they leave results untouched.
  *   pinn_debug_last_kernel        0 = general tile kernel, 2 = shape-specialised tile kernel took the last launch

@@ -29,6 +29,10 @@ WIDTH_FLAGS = {256: ['-mllvm', '-amdgpu-sched-strategy=iterative-maxocc'], 64: [
 # without operand prefetch in its forward / data-gradient GEMMs (40 spilled registers otherwise), 2 = the S = 2 ODE-family kernel,
 # fastest without the SLP vectoriser
 SPLIT_FLAGS = {1: ['-DPINN_SP_PIPE=0', '-DPINN_SP_PIPE_W=1'], 2: ['-fno-slp-vectorize']}
+WIDE_SPLIT_FLAGS = {}
+if os.environ.get('PINN_WIDE_SPLIT_FLAGS'):
+    import json
+    WIDE_SPLIT_FLAGS = {int(k): v for k, v in json.loads(os.environ['PINN_WIDE_SPLIT_FLAGS']).items()}
 if os.environ.get('PINN_SPLIT_FLAGS'):
     import json
     SPLIT_FLAGS = {int(k): v for k, v in json.loads(os.environ['PINN_SPLIT_FLAGS']).items()}
@@ -86,6 +90,10 @@ def _build(force, verbose, extra_flags, widths):
         obj = os.path.join(OBJ, f'inst_hp64_split{which}.o')
         jobs.append((obj, [hipcc, *FLAGS, *flags, *extra_flags, '-DPINN_INST_HP=64', f'-DPINN_INST_SPLIT={which}', '-c',
                            os.path.join(HERE, 'pinn_inst.inc'), '-o', obj]))
+    for hp in (128, 256):                 # the split-bf16 WGX tile kernels of BASELINE configs 3 / 5
+        obj = os.path.join(OBJ, f'inst_hp{hp}_split.o')
+        jobs.append((obj, [hipcc, *FLAGS, *WIDE_SPLIT_FLAGS.get(hp, []), *extra_flags, f'-DPINN_INST_HP={hp}', '-DPINN_INST_SPLIT=1',
+                           '-c', os.path.join(HERE, 'pinn_inst.inc'), '-o', obj]))
     obj = os.path.join(OBJ, 'abi.o')
     jobs.append((obj, [hipcc, *FLAGS, *extra_flags, '-c', os.path.join(HERE, 'pinn_abi.cpp'), '-o', obj]))
 

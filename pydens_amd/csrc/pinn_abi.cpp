@@ -53,6 +53,7 @@ float prof_elapsed(hipEvent_t a, hipEvent_t b) {
 #define PINN_HIDDEN __attribute__((visibility("hidden")))
 PINN_HIDDEN int g_pinn_last_kernel = -1;
 PINN_HIDDEN char g_pinn_last_kernel_name[96] = "";
+PINN_HIDDEN char g_pinn_last_wgrad_name[96] = "";
 namespace {
 int g_pinn_prepass_in_kernel = 1;   // debug switch: 0 = x-only pre-pass as its own launch (pinn_aux_kernel)
 int g_pinn_debug_flags = 0;         // -DPINN_DEBUG_ABI builds: pinn_debug_set_flags
@@ -352,6 +353,8 @@ int pinn_set_gemm_mode(pinn_t* net, int mode) {
 }
 
 const char* pinn_last_kernel_name(void) { return g_pinn_last_kernel_name; }
+
+const char* pinn_last_wgrad_kernel_name(void) { return g_pinn_last_wgrad_name; }
 
 int pinn_debug_prepass_in_kernel(int enable) {
     g_pinn_prepass_in_kernel = enable ? 1 : 0;

@@ -971,7 +971,12 @@ PINN_DEVICE PinnSplit4 pinn_split4(f32x4 v) {
 }
 // byte offset, inside one plane, of the 16-byte chunk `chunk` (8 units) of row `row`: rows of ROWB bytes, chunk index swizzled
 template <int ROWB>
-PINN_DEVICE int pinn_sp_off(int row, int chunk) { return row * ROWB + ((chunk ^ (row & 7)) << 4); }
+PINN_DEVICE int pinn_sp_off(int row, int chunk) {
+    // (rows of 128 bytes hold 8 chunks: XOR with row & 7; longer rows XOR the low four chunk bits with row & 15, so that the
+    //  16 rows a ds_read_b128 lane group touches land in 16 different 16-byte slots of the 256-byte bank row)
+    constexpr int M = (ROWB / 16 >= 16) ? 15 : 7;
+    return row * ROWB + ((chunk ^ (row & M)) << 4);
+}
 // the six products of a split-bf16 GEMM step that matter (a_i b_j with i + j <= 2; the three dropped ones are below
 // 2^-24 of |a b|), SMALL TERMS FIRST: measured against fp64, tools/ubench/split_bf16.cpp (K = 64: max error 9e-8 of
 // sum |a b| against 2e-7 for the exact-fp32 MFMA chain; large terms first: 3.6e-7)
@@ -1043,9 +1048,14 @@ pinn_tile_kernel(const PinnKArgs A) {
     //  workgroup resident on the CU every build that spills even two registers returned slightly wrong, run-to-run different
     //  gradients on MI355X (1e-5 .. 1e-3; exact with one workgroup per CU, with -amdgpu-waitcnt-forcezero, and for the two-team
     //  form at every size) -- DESIGN.md section 6b; tests/test_gpu_parity.py holds the shipped kernels to bitwise repeatability)
+    // Widths >= 128 (round 3, later): the WGX form -- forward and data-gradient GEMMs here, weight fragments streamed K block by
+    // K block (they do not fit the registers), weight gradients in pinn_wgrad_kernel's own split form.
     static_assert(!SPLIT || (HP == 64 && NTW == 1 && LHC >= 1 && !(VAR & (1 | 2 | 8 | 64 | 128)) && ((S * T) % 32) == 0 &&
-                             ((T == 16 && S % 2 == 0) || T == 32)),
-                  "split-bf16 kernels: width 64, static depth, register-resident dW, K = S * T a multiple of 32");
+                             ((T == 16 && S % 2 == 0) || T == 32)) ||
+                            (HP >= 128 && (VAR & 128) && !(VAR & (1 | 2 | 8 | 64 | 256))),
+                  "split-bf16 kernels: width 64 with static depth and register-resident dW (K = S * T a multiple of 32), or the WGX kernels of widths >= 128");
+    constexpr bool SPW = SPLIT && HP >= 128;               // wide form: weights streamed inside the GEMM
+    constexpr int SPK = (SPLIT && !SPW) ? C::SP_KB : 1;    // K blocks whose weight fragments a wave holds at once (width 64: all)
     static_assert(!TEAMS2 || (((VAR >> 4) & 3) != 0 && LHC >= 1 && !(VAR & (1 | 2 | 8 | 64 | 128)) && NW == 4 && C::wt_fits_teams(LHC)),
                   "two-team kernels: shape-specialised, static depth, 4 waves per team, W^T of all layers in LDS");
     constexpr bool SNT = HP >= PINN_SLAB_NT_MIN_HP;        // streaming (non-temporal) slab stores
@@ -1249,18 +1259,19 @@ pinn_tile_kernel(const PinnKArgs A) {
     // (buffer loads: ONE vector register of offsets, lane * 16, for all 36 fragments of the net, the fragment's offset in a scalar
     //  register -- with plain pointers hipcc hoists a 64-bit VGPR address pair per fragment out of the tile loop, spills them, and
     //  every load then waits for the scratch reload of its own address)
-    const PinnRows wsp_rows = pinn_rows(A.wsp, SPLIT ? (unsigned)C::wsp_bytes(LHC > 0 ? LHC : 1) : 0u);
+    const PinnRows wsp_rows = pinn_rows(A.wsp, SPLIT ? (unsigned)C::wsp_bytes(lh > 0 ? lh : 1) : 0u);
     const int wave_s = pinn_wave_uniform(wave);
-    auto sp_weights = [&](int l, int dir, pinn_s16x8 (&w)[C::SP_KB][3]) {
+    // fragment (l, dir, kb, tile j of this wave, plane p)
+    auto sp_wfrag = [&](int l, int dir, int kb, int j, int p) -> pinn_s16x8 {
+        return __builtin_bit_cast(pinn_s16x8, pinn_rows_ld4(wsp_rows, lane * 16, (int)(C::wsp_frag(l, dir, kb, 0, p) * 16) + (wave_s * NTW + j) * 3 * 1024));
+    };
+    auto sp_weights = [&](int l, int dir, pinn_s16x8 (&w)[SPK][3]) {
+        if constexpr (SPLIT && !SPW) {
 #pragma unroll
-        for (int kb = 0; kb < C::SP_KB; ++kb)
+            for (int kb = 0; kb < SPK; ++kb)
 #pragma unroll
-            for (int p = 0; p < 3; ++p)
-#ifndef PINN_SP_WBUF
-#define PINN_SP_WBUF 1
-#endif
-                if (PINN_SP_WBUF) w[kb][p] = __builtin_bit_cast(pinn_s16x8, pinn_rows_ld4(wsp_rows, lane * 16, (int)(C::wsp_frag(l, dir, kb, 0, p) * 16) + wave_s * 3 * 1024));
-                else w[kb][p] = reinterpret_cast<const pinn_s16x8*>(A.wsp)[C::wsp_frag(l, dir, kb, wave, p) + lane];
+                for (int p = 0; p < 3; ++p) w[kb][p] = sp_wfrag(l, dir, kb, 0, p);
+        }
     };
     // out^T[16 units of this wave][points] += W-fragments . rows of `bbuf` (forward: h_{l-1}, data gradient: gz_a), all S * MT
     // (row tile, stream) rows of the tile: two rows per step, their B fragments (three planes each) fetched one step ahead,
@@ -1280,7 +1291,7 @@ pinn_tile_kernel(const PinnKArgs A) {
 #ifndef PINN_SP_OG
 #define PINN_SP_OG 2            // output tile rows per step of the weight-gradient GEMM
 #endif
-    auto sp_gemm = [&](const float* bbuf, const pinn_s16x8 (&w)[SPLIT ? C::SP_KB : 1][3], f32x4 (&out)[NTW][MT][S]) {
+    auto sp_gemm = [&](const float* bbuf, const pinn_s16x8 (&w)[SPK][3], f32x4 (&out)[NTW][MT][S]) {
         constexpr int NR = MT * S, G = (NR % PINN_SP_G == 0) ? PINN_SP_G : 1, NG = NR / G, STEPS = C::SP_KB * NG;
         constexpr int NB = PINN_SP_PIPE ? 2 : 1;
         constexpr int pa[9] = {2, 2, 1, 2, 0, 1, 1, 0, 0}, pb[9] = {2, 1, 2, 0, 2, 1, 0, 1, 0};     // (a part, b part), small products first
@@ -1306,12 +1317,55 @@ pinn_tile_kernel(const PinnKArgs A) {
 #pragma unroll
                 for (int i = 0; i < G; ++i) {
                     const int r = g0 + i;
-                    out[0][r / S][r % S] = pinn_mfma16_bf16(w[SPLIT ? kb : 0][pa[t]], bf[step % NB][i][pb[t]], out[0][r / S][r % S]);
+                    out[0][r / S][r % S] = pinn_mfma16_bf16(w[SPK > 1 ? kb : 0][pa[t]], bf[step % NB][i][pb[t]], out[0][r / S][r % S]);
                 }
             if (PINN_SP_PIPE && step + 1 < STEPS) {
                 if (PINN_SP_FRONT) pinn_sched_front<6 * G, 3 * G, PINN_SP_FRONT ? PINN_SP_FRONT : 1>();
                 else pinn_sched_interleave<6 * G, 3 * G>();
             }
+            PINN_SCHED_BARRIER();
+        }
+    };
+    // the same GEMM for widths >= 128 (SPW): NTW output tiles per wave, the weight fragments of a K block (NTW x three planes)
+    // arrive from global memory / L2 one K block ahead (all K blocks of a layer do not fit the registers: 2 x 8 x 3 fragments at
+    // width 256), the B fragments of a step's rows one step ahead
+    auto sp_gemm_wide = [&](const float* bbuf, int l, int dir, f32x4 (&out)[NTW][MT][S]) {
+        constexpr int NR = MT * S, G = (NR % 2 == 0) ? 2 : 1, NG = NR / G, KB = C::SP_KB, STEPS = KB * NG;
+        constexpr int pa[9] = {2, 2, 1, 2, 0, 1, 1, 0, 0}, pb[9] = {2, 1, 2, 0, 2, 1, 0, 1, 0};
+        pinn_s16x8 wa[2][NTW][3], bf[2][G][3];
+        auto load_w = [&](int kb, pinn_s16x8 (&w)[NTW][3]) {
+#pragma unroll
+            for (int j = 0; j < NTW; ++j)
+#pragma unroll
+                for (int p = 0; p < 3; ++p) w[j][p] = sp_wfrag(l, dir, kb, j, p);
+        };
+        auto load_b = [&](int step, pinn_s16x8 (&f)[G][3]) {
+            const int kb = step / NG, g0 = (step % NG) * G;
+#pragma unroll
+            for (int i = 0; i < G; ++i) {
+                const int r = g0 + i, mt = r / S, sidx = r % S;
+                sp_frag(bbuf, sidx * T + mt * 16 + lr, 4 * kb + lq, f[i]);
+            }
+        };
+        load_w(0, wa[0]);
+        load_b(0, bf[0]);
+#pragma unroll
+        for (int step = 0; step < STEPS; ++step) {
+            const int kb = step / NG, g0 = (step % NG) * G;
+            PINN_SCHED_BARRIER();
+            if (step % NG == 0 && kb + 1 < KB) load_w(kb + 1, wa[(kb + 1) & 1]);
+            if (step + 1 < STEPS) load_b(step + 1, bf[(step + 1) & 1]);
+            if (!PINN_SCHED_IL) PINN_SCHED_BARRIER();
+#pragma unroll
+            for (int t = 9 - PINN_SP_NPROD; t < 9; ++t)
+#pragma unroll
+                for (int i = 0; i < G; ++i)
+#pragma unroll
+                    for (int j = 0; j < NTW; ++j) {
+                        const int r = g0 + i;
+                        out[j][r / S][r % S] = pinn_mfma16_bf16(wa[kb & 1][j][pa[t]], bf[step & 1][i][pb[t]], out[j][r / S][r % S]);
+                    }
+            if (step + 1 < STEPS) pinn_sched_interleave<PINN_SP_NPROD * G * NTW, 3 * G>();
             PINN_SCHED_BARRIER();
         }
     };
@@ -1409,7 +1463,7 @@ pinn_tile_kernel(const PinnKArgs A) {
                     wall[q][j] = pinn_ld4(Wl + ((wave * NTW + j) * 16 + lr) * HP + 16 * q + 4 * lq);
         };
         if (WPF && lh > 0) load_wall(A.params + A.off_wh);
-        pinn_s16x8 wsf[SPLIT ? C::SP_KB : 1][3];       // split-bf16: forward weight fragments of the NEXT hidden layer, one phase ahead
+        pinn_s16x8 wsf[SPK][3];       // split-bf16: forward weight fragments of the NEXT hidden layer, one phase ahead
 #ifndef PINN_SP_WPF
 #define PINN_SP_WPF 1           // split-bf16: forward weight fragments one phase ahead (0: fetched at the start of their GEMM)
 #endif
@@ -1498,8 +1552,12 @@ pinn_tile_kernel(const PinnKArgs A) {
 #pragma unroll
                     for (int s = 0; s < S; ++s) acc[j][mt][s] = f32x4{0.f, 0.f, 0.f, 0.f};
             if constexpr (SPLIT) {
-                if (!PINN_SP_WPF) sp_weights(li, 0, wsf);
-                sp_gemm(cur, wsf, acc);
+                if constexpr (SPW) {
+                    sp_gemm_wide(cur, li, 0, acc);
+                } else {
+                    if (!PINN_SP_WPF) sp_weights(li, 0, wsf);
+                    sp_gemm(cur, wsf, acc);
+                }
 #ifndef PINN_SP_FWD_BARRIER
 #define PINN_SP_FWD_BARRIER 0   // a barrier between a forward GEMM and its jet epilogue: with PINN_TEAM_SKEW the GEMM interval of one team then faces a vector interval of the other
 #endif
@@ -1873,7 +1931,7 @@ pinn_tile_kernel(const PinnKArgs A) {
             PH(11)
             if (SVPF && a >= 2) load_saved(a - 2, svn);    // in flight during the two GEMMs below
             const int li = a - 1;
-            pinn_s16x8 wsb[SPLIT ? C::SP_KB : 1][3];       // split-bf16: W^T fragments of this layer (L2 round trip behind the weight-gradient GEMM)
+            pinn_s16x8 wsb[SPK][3];       // split-bf16: W^T fragments of this layer (L2 round trip behind the weight-gradient GEMM)
             if constexpr (SPLIT) sp_weights(li, 1, wsb);
             const float* Wl = A.params + A.off_wh + (size_t)li * A.hidden_stride;
             float wqall[WPF ? NQ : 1][NTW][4];
@@ -2096,7 +2154,8 @@ pinn_tile_kernel(const PinnKArgs A) {
 #pragma unroll
                     for (int s = 0; s < S; ++s) g[j][mt][s] = f32x4{0.f, 0.f, 0.f, 0.f};
             if constexpr (SPLIT) {
-                sp_gemm(nxt, wsb, g);
+                if constexpr (SPW) sp_gemm_wide(nxt, li, 1, g);
+                else sp_gemm(nxt, wsb, g);
             } else {
                 constexpr int WAD = (WTG && PINN_W_AHEAD > 1) ? PINN_W_AHEAD : 1;     // (global weights: quads ahead, see the forward GEMM)
                 constexpr int NQD = HP / 16;

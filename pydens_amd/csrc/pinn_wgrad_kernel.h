@@ -20,9 +20,10 @@
 #pragma once
 #include "pinn_kernel.h"
 
-template <int HP, int ND, int N2, int MT = 1>
+template <int HP, int ND, int N2, int MT = 1, bool SPLIT_ = false>
 struct PinnWgCfg {
     using C = PinnCfg<HP, ND, N2, MT>;
+    static constexpr bool SPLIT = SPLIT_;
     static constexpr int S = C::S, NW = C::NW, NTW = C::NTW, NTHREADS = C::NTHREADS;
 #ifndef PINN_WG_SKIP_NW_ASSERT      // (timing experiments on the tile kernel alone: -DPINN_NW_MAX=4 builds, wrong weight gradients)
     static_assert(NW == 8, "the streamed weight-gradient kernel is built for the 8-wave widths (HP >= 128)");
@@ -33,15 +34,23 @@ struct PinnWgCfg {
     static constexpr int WM = 2, WN = 4;             // wave grid over the output
     static constexpr int AM = HP / 16 / WM, BN = HP / 16 / WN;    // 16 x 16 output tiles per wave (8 x 4 at 256, 4 x 2 at 128)
     static constexpr int OPER = HP * LDK;            // one operand buffer (floats)
-    static constexpr int O_W1 = 4 * OPER;            // [2 buffers][gz, h], then the first-layer weights
+    // split-bf16 form (round 3): TWO stages (K = 32 (stream, point) slots) per MFMA step; an operand buffer = three bf16 planes
+    // of [HP units][32 k] = rows of 64 bytes, k slot 2 * point + stage: the two stages' values of a thread share one dword,
+    // written by one ds_write_b32 per plane; 16-byte chunk index XORed with 3 * ((unit >> 2) & 1): ds_read_b128 of the fragments
+    // conflict-free, the writes two-way (free for ds_write_b32). Two such buffer pairs (double buffering) fit at width 128
+    // (96 KB), one at width 256 (96 KB: the staging of the next pair then waits for the MFMAs of this one).
+    static constexpr int SP_PLANE_F = HP * 16;       // floats of one plane
+    static constexpr int SP_OPER_F = 3 * SP_PLANE_F; // one operand (hi, mid, lo)
+    static constexpr int SP_NBUF = (2 * 2 * SP_OPER_F * 4 + HP * PINN_XS_LD * 4 <= 160 * 1024) ? 2 : 1;
+    static constexpr int O_W1 = SPLIT ? SP_NBUF * 2 * SP_OPER_F : 4 * OPER;      // [2 buffers][gz, h], then the first-layer weights
     static constexpr int SMEM_FLOATS = O_W1 + HP * PINN_XS_LD;
-    static constexpr int WGS_PER_CU = (SMEM_FLOATS * 4 <= 75 * 1024 && AM * BN * 4 <= 64) ? 2 : 1;
+    static constexpr int WGS_PER_CU = (!SPLIT && SMEM_FLOATS * 4 <= 75 * 1024 && AM * BN * 4 <= 64) ? 2 : 1;
 };
 
-template <int HP, int ND, int N2, bool COMB, int MT>
-PINN_GLOBAL void PINN_LAUNCH_BOUNDS2((PinnWgCfg<HP, ND, N2, MT>::NTHREADS), (2 * PinnWgCfg<HP, ND, N2, MT>::WGS_PER_CU))
+template <int HP, int ND, int N2, bool COMB, int MT, bool SPLIT = false>
+PINN_GLOBAL void PINN_LAUNCH_BOUNDS2((PinnWgCfg<HP, ND, N2, MT, SPLIT>::NTHREADS), (2 * PinnWgCfg<HP, ND, N2, MT, SPLIT>::WGS_PER_CU))
 pinn_wgrad_kernel(const PinnKArgs A) {
-    using W = PinnWgCfg<HP, ND, N2, MT>;
+    using W = PinnWgCfg<HP, ND, N2, MT, SPLIT>;
     using C = typename W::C;
     constexpr int N2n = pinn_n2(N2), N3n = pinn_n3(N2);           // (N2 is the packed count, pinn_kernel.h)
     constexpr int S = W::S, NTW = W::NTW, NTHREADS = W::NTHREADS, LDK = W::LDK, AM = W::AM, BN = W::BN, OPER = W::OPER;
@@ -173,6 +182,121 @@ pinn_wgrad_kernel(const PinnKArgs A) {
                 af = afn;
             }
         };
+        if constexpr (SPLIT) {
+            // ---- split-bf16 form: stages in PAIRS (K = 32), operands split exactly into hi + mid + lo bf16 (pinn_split3), six
+            //      partial products per MFMA step on v_mfma_f32_16x16x32_bf16 (pinn_kernel.h, VAR 512 of the tile kernel) ----
+            long long n_tiles_wg = 0;
+            if (t_first < A.tile_end) n_tiles_wg = (A.tile_end - t_first + t_step - 1) / t_step;
+            const long long n_stages = n_tiles_wg * MT * S;
+            constexpr int GROUP = (S % 2 == 0) ? S : 2 * S;          // stages per unrolled group (even; the stream index of every stage a compile-time fact)
+            constexpr int NB = W::SP_NBUF;
+            char* lds = reinterpret_cast<char*>(smem);
+            auto buf_of = [&](int b) { return lds + (size_t)b * 2 * W::SP_OPER_F * 4; };
+            // dword of (unit row, k pair lr) inside a plane
+            auto sp_dword = [&](int row, int kd) { return row * 64 + ((((kd >> 2) ^ (3 * ((row >> 2) & 1))) & 3) << 4) + (kd & 3) * 4; };
+            f32x4 gz0[NTW], h0[NTW];                                 // first stage of the pair under construction
+            auto write_pair = [&](char* buf, const f32x4 (&g0)[NTW], const f32x4 (&hh0)[NTW], const f32x4 (&g1)[NTW], const f32x4 (&hh1)[NTW]) {
+#pragma unroll
+                for (int j = 0; j < NTW; ++j)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        unsigned a0[3], a1[3], b0[3], b1[3];
+                        pinn_split3(g0[j][r], a0[0], a0[1], a0[2]);
+                        pinn_split3(g1[j][r], a1[0], a1[1], a1[2]);
+                        pinn_split3(hh0[j][r], b0[0], b0[1], b0[2]);
+                        pinn_split3(hh1[j][r], b1[0], b1[1], b1[2]);
+                        const int off = sp_dword(unit0(j) + r, lr);
+#pragma unroll
+                        for (int p = 0; p < 3; ++p) {
+                            *reinterpret_cast<unsigned*>(buf + p * W::SP_PLANE_F * 4 + off) = pinn_pack_hi16(a0[p], a1[p]);
+                            *reinterpret_cast<unsigned*>(buf + (W::SP_OPER_F + p * W::SP_PLANE_F) * 4 + off) = pinn_pack_hi16(b0[p], b1[p]);
+                        }
+                    }
+            };
+            auto frag = [&](const char* oper, int row, pinn_s16x8 (&f)[3]) {
+                const int off = row * 64 + (((lq ^ (3 * ((row >> 2) & 1))) & 3) << 4);
+#pragma unroll
+                for (int p = 0; p < 3; ++p) f[p] = *reinterpret_cast<const pinn_s16x8*>(oper + p * W::SP_PLANE_F * 4 + off);
+            };
+            auto mfma_pair = [&](const char* buf) {
+                constexpr int pa[9] = {2, 2, 1, 2, 0, 1, 1, 0, 0}, pb[9] = {2, 1, 2, 0, 2, 1, 0, 1, 0};
+                constexpr int BH = (BN > 2) ? 2 : BN;               // B fragments two output columns at a time (registers)
+                const char* bh = buf + W::SP_OPER_F * 4;
+#pragma unroll
+                for (int jb = 0; jb < BN; jb += BH) {
+                    pinn_s16x8 bf[BH][3], af[3];
+#pragma unroll
+                    for (int jn = 0; jn < BH; ++jn) frag(bh, n0 + 16 * (jb + jn) + lr, bf[jn]);
+                    frag(buf, m0 + lr, af);
+#pragma unroll
+                    for (int i = 0; i < AM; ++i) {
+                        PINN_SCHED_BARRIER();
+                        pinn_s16x8 afn[3];
+                        if (i + 1 < AM) frag(buf, m0 + 16 * (i + 1) + lr, afn);
+#pragma unroll
+                        for (int t = 9 - PINN_SP_NPROD; t < 9; ++t)
+#pragma unroll
+                            for (int jn = 0; jn < BH; ++jn) acc[i][jb + jn] = pinn_mfma16_bf16(af[pa[t]], bf[jn][pb[t]], acc[i][jb + jn]);
+                        if (i + 1 < AM) pinn_sched_reads_first<3, PINN_SP_NPROD * BH>();
+                        PINN_SCHED_BARRIER();
+                        if (i + 1 < AM) {
+#pragma unroll
+                            for (int p = 0; p < 3; ++p) af[p] = afn[p];
+                        }
+                    }
+                }
+            };
+            auto stage_pos = [&](long long i, long long& tile, int& mt) {
+                const long long g = i / S;
+                tile = t_first + (g / MT) * t_step;
+                mt = (int)(g % MT);
+            };
+            // raw operands of the NEXT pair are requested from HBM before the MFMAs of the current one
+            f32x4 gzr[2][NTW], svr[2][NTW];
+            auto load_pair = [&](long long i0, int s_a, int s_b) {
+                long long tile; int mt;
+                if (i0 < n_stages) { stage_pos(i0, tile, mt); load_raw(tile, mt, s_a, gzr[0], svr[0]); }
+                if (i0 + 1 < n_stages) { stage_pos(i0 + 1, tile, mt); load_raw(tile, mt, s_b, gzr[1], svr[1]); }
+            };
+            auto build_pair = [&](char* buf, long long i0, int s_a, int s_b) {
+                f32x4 ha[NTW], hb[NTW], ga[NTW], gb[NTW];
+#pragma unroll
+                for (int j = 0; j < NTW; ++j) { ga[j] = gzr[0][j]; gb[j] = f32x4{0.f, 0.f, 0.f, 0.f}; hb[j] = f32x4{0.f, 0.f, 0.f, 0.f}; ha[j] = f32x4{0.f, 0.f, 0.f, 0.f}; }
+                if (i0 < n_stages) transform(s_a, svr[0], ha);
+                else {
+#pragma unroll
+                    for (int j = 0; j < NTW; ++j) ga[j] = f32x4{0.f, 0.f, 0.f, 0.f};
+                }
+                if (i0 + 1 < n_stages) {
+                    transform(s_b, svr[1], hb);
+#pragma unroll
+                    for (int j = 0; j < NTW; ++j) gb[j] = gzr[1][j];
+                }
+                write_pair(buf, ga, ha, gb, hb);
+            };
+            int pbuf = 0;
+            if (n_stages > 0) {
+                load_pair(0, 0, 1 % S);
+                build_pair(buf_of(0), 0, 0, 1 % S);
+            }
+            PINN_SYNC();
+            for (long long g0 = 0; g0 < n_stages; g0 += GROUP) {
+#pragma unroll
+                for (int u = 0; u < GROUP; u += 2) {
+                    const long long i = g0 + u;                      // first stage of this pair
+                    if (i < n_stages) {
+                        const int s_na = (u + 2) % S, s_nb = (u + 3) % S;       // streams of the next pair (compile time)
+                        const bool has_next = i + 2 < n_stages;
+                        if (has_next) load_pair(i + 2, s_na, s_nb);
+                        mfma_pair(buf_of(pbuf));
+                        if (NB == 1) PINN_SYNC();                     // one buffer: everybody is done reading it
+                        if (has_next) build_pair(buf_of(NB == 2 ? pbuf ^ 1 : 0), i + 2, s_na, s_nb);
+                        PINN_SYNC();
+                        if (NB == 2) pbuf ^= 1;
+                    }
+                }
+            }
+        } else {
 #ifndef PINN_WG_PF
 #define PINN_WG_PF 1          // stages the HBM loads run ahead of the MFMAs (1: one register set, 2: two -- measured 1-5 %
                               // SLOWER on MI355X: the loads are not what the waves wait for)
@@ -256,6 +380,7 @@ pinn_wgrad_kernel(const PinnKArgs A) {
             }
         }
 #endif
+        }
         // this workgroup's dW_li: D[(l >> 4) * 4 + r][l & 15] of tile (i, jn) -> row (out) m0 + 16 i + 4 lq + r, column (in) n0 + 16 jn + lr
         float* dst = part + A.off_wh + (size_t)li * A.hidden_stride;
 #pragma unroll

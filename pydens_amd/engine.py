@@ -113,6 +113,7 @@ def bind(lib):
     lib.pinn_last_tile_ms.restype = f32
     lib.pinn_last_wgrad_ms.restype = f32
     lib.pinn_last_kernel_name.restype = ctypes.c_char_p
+    lib.pinn_last_wgrad_kernel_name.restype = ctypes.c_char_p
     if hasattr(lib, 'pinn_debug_phase_buffer'):                  # -DPINN_DEBUG_ABI experiment builds only
         lib.pinn_debug_phase_buffer.argtypes = [vp]
     lib.pinn_debug_wgx_chunk_bytes.argtypes = [ctypes.c_longlong]
@@ -124,7 +125,7 @@ def bind(lib):
 
 ABI_SYMBOLS = ('pinn_create', 'pinn_create_ex', 'pinn_destroy', 'pinn_layout', 'pinn_workspace_bytes', 'pinn_jet_forward',
                'pinn_jet_backward', 'pinn_residual_step', 'pinn_residual_step_add', 'pinn_residual_adam_step', 'pinn_adam_step', 'pinn_adam_step_at', 'pinn_sample_points', 'pinn_fit_steps', 'pinn_set_gemm_mode', 'pinn_profile_tile',
-               'pinn_last_tile_ms', 'pinn_last_wgrad_ms', 'pinn_last_kernel_name', 'pinn_debug_last_kernel',
+               'pinn_last_tile_ms', 'pinn_last_wgrad_ms', 'pinn_last_kernel_name', 'pinn_last_wgrad_kernel_name', 'pinn_debug_last_kernel',
                'pinn_debug_prepass_in_kernel', 'pinn_debug_wgx_chunk_bytes',
                'pinn_last_error', 'pinn_backend')
 

@@ -27,7 +27,7 @@ def pa():
     return pydens_amd
 
 
-SPLIT_SHAPES = ('cfg2', 'cfg4')          # the shapes the split-bf16 kernels are built for
+SPLIT_SHAPES = ('cfg2', 'cfg3', 'cfg4', 'cfg5')          # the shapes the split-bf16 kernels are built for
 WITH_GEMM = [(n, 'fp32') for n in SUPPORTED] + [(n, 'bf16x3') for n in SPLIT_SHAPES]
 
 
@@ -182,7 +182,7 @@ def test_baseline_full_sizes_through_size_independent_properties(pa, name, n_ful
 
 
 @pytest.mark.parametrize('name,iters,batch,gemm', [('cfg2', 600, 4096, 'fp32'), ('cfg4', 400, 4096, 'fp32'), ('cfg3', 150, 2048, 'fp32'),
-                                                   ('cfg2', 600, 4096, 'bf16x3'), ('cfg4', 400, 4096, 'bf16x3')])
+                                                   ('cfg2', 600, 4096, 'bf16x3'), ('cfg4', 400, 4096, 'bf16x3'), ('cfg3', 150, 2048, 'bf16x3')])
 def test_trained_models_against_the_fp64_arbiter(pa, name, iters, batch, gemm):
     """ on a TRAINED model the residual is a small difference of large terms and the reference's own
     fp32 result is only good to 1e-5 .. 1e-2 (gradients of cfg3!) of the fp64 value, so neither engine can be held to 1e-5
@@ -824,14 +824,15 @@ def test_two_ranks_over_rccl_follow_the_single_process_trajectory(pa):
                 assert rel_l2(z[f'p{i}'], want) < fit_rtol('cfg4'), (rank, i)
 
 
+@pytest.mark.parametrize('gemm', ['fp32', 'bf16x3'])
 @pytest.mark.parametrize('name,n', [('cfg3', 262144), ('cfg5', 131072)])
-def test_wide_nets_at_their_full_batch_against_the_chunked_oracle(pa, name, n):
+def test_wide_nets_at_their_full_batch_against_the_chunked_oracle(pa, name, n, gemm):
     """ BASELINE config 3 at its full batch (262 144 points) and config 5 at the per-GPU batch of its 8-GPU step
     (131 072 points) -- the streamed weight-gradient path -- against the oracle evaluated in chunks of 16 384 points: loss and every
     gradient tensor, not only a prefix plus shard / permutation invariants. """
     from oracle import pinn_oracle as po
     torch.manual_seed(5)
-    cfg, solver = make_solver(name, pa)
+    cfg, solver = make_solver(name, pa, gemm=gemm)
     ocfg = pc.make_config(name, po.D, torch)
     oracle = po.OracleSolver(ocfg['equation'], **ocfg['solver_kwargs'])
     oracle.import_params(export_params(solver))
@@ -845,7 +846,7 @@ def test_wide_nets_at_their_full_batch_against_the_chunked_oracle(pa, name, n):
             assert grad_close(got, want)
 
 
-@pytest.mark.parametrize('name,n', [('cfg2', 16384), ('cfg2', 65536), ('cfg4', 131072)])
+@pytest.mark.parametrize('name,n', [('cfg2', 16384), ('cfg2', 65536), ('cfg4', 131072), ('cfg3', 65536), ('cfg5', 32768)])
 def test_split_kernels_are_bitwise_repeatable(pa, name, n):
     """ the same step twice gives the same bits (fixed summation order, no atomics) -- and a guard: while the split kernels were
     developed, builds that ran two workgroups per CU returned run-to-run different gradients """

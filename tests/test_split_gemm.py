@@ -30,7 +30,7 @@ def pa():
     return pydens_amd
 
 
-@pytest.mark.parametrize('name', ['cfg2', 'cfg4'])
+@pytest.mark.parametrize('name', ['cfg2', 'cfg4', 'cfg3', 'cfg5'])
 def test_split_kernels_follow_the_reference_goldens(pa, emu_lib, name):
     g = Golden(name)
     _, solver = make_solver(name, pa, gemm='bf16x3', lib=emu_lib, device='cpu')
@@ -38,6 +38,8 @@ def test_split_kernels_follow_the_reference_goldens(pa, emu_lib, name):
     xs = torch.from_numpy(g.points[0].copy())
     solver._fused_step(xs, 1)
     assert ran_split_kernel(solver)
+    if name in ('cfg3', 'cfg5'):                    # widths >= 128: the streamed weight-gradient kernel in its split form as well
+        assert emu_lib.pinn_last_wgrad_kernel_name().decode().endswith(',true>')
     lay = solver.model.net.layout
     assert abs(float(solver.grads[lay.off_loss]) - g.loss0) <= 1e-5 * g.loss0
     for got, want in zip(export_grads(solver), g.grads):
