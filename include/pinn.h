@@ -52,6 +52,7 @@ extern "C" {
 #define PINN_MAX_VARS     8    /* trainable V(...) scalars a residual program may read (user slots 0..n_vars-1) */
 
 #define PINN_MAX_SKIPS    4    /* skip connections ('R ... +') per net */
+#define PINN_SKIP_PRE     0x100 /* ORed into skip_dst[k]: the skip ends IN FRONT of that activation ('faR fa f+ a') */
 
 #define PINN_ACT_TANH     0
 #define PINN_ACT_SIGMOID  1
@@ -149,7 +150,9 @@ int pinn_create(const int* layer_dims, int n_layers, int act, int ndims, int npa
 /* General form of the descriptor: per-layer activations and skip connections of the reference's layout strings
  * ('faR fa fa+ f', model_torch.py:143-156).  acts[a], a = 0 .. n_layers-2, is the activation after hidden layer a
  * (PINN_ACT_*).  Skip k adds the output of activation skip_src[k] to the output of activation skip_dst[k]
- * (0 <= src < dst <= n_layers-2, equal widths, intervals not overlapping: dst[k] <= src[k+1]). */
+ * (0 <= src < dst <= n_layers-2, equal widths, intervals not overlapping: dst[k] <= src[k+1]) -- or, with
+ * PINN_SKIP_PRE ORed into skip_dst[k], to the pre-activation of hidden layer dst ('+' between 'f' and 'a': the
+ * usual residual block act(W h + skip)). */
 int pinn_create_ex(const int* layer_dims, int n_layers, const int* acts, int n_skips, const int* skip_src,
                    const int* skip_dst, int ndims, int nparams, int has_bc, int has_ic, const float* dom_lo,
                    const float* dom_hi, float bc_value, pinn_t** out);
@@ -241,8 +244,9 @@ int pinn_fit_steps(pinn_t* net, const pinn_residual_t* residual, float* params, 
  *   PINN_GEMM_BF16X3  every fp32 operand split EXACTLY into three bf16 (hi + mid + lo), the six partial products
  *                     a_i b_j with i + j <= 2 on v_mfma_f32_16x16x32_bf16, fp32 accumulate: the dropped products are below
  *                     2^-24 of |a b| (measured: at or below the rounding error of the fp32 chain). Used by the kernels
- *                     built with it (width-64 nets of static depth 3 on the Dirichlet-box / ODE-family training shapes);
- *                     every other call keeps the fp32 kernels. pinn_last_kernel_name() tells which one ran.
+ *                     built with it (the BASELINE training shapes: width-64 nets of static depth 3 on the Dirichlet-box /
+ *                     ODE-family shapes, widths 128 / 256 of any depth on the heat / wave shapes incl. their streamed
+ *                     weight-gradient kernel); every other call keeps the fp32 kernels. pinn_last_kernel_name() tells which one ran.
  * Returns non-zero for an unknown mode. */
 #define PINN_GEMM_FP32   0
 #define PINN_GEMM_BF16X3 1

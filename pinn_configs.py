@@ -70,6 +70,16 @@ def make_config(name, D, torch, V=None):
                     solver_kwargs=dict(ndims=2, boundary_condition=0.2, initial_condition=lambda x: torch.sin(PI * x) * x,
                                        layout='fa fa fa f', features=[24, 24, 24, 1], activation='Tanh'),
                     n_points=4096, low=[0, 0], high=[1, 1])
+    if name == 'resnet3':
+        # breadth fixture (round 3): dispersive Burgers equation (third derivative in x) on a net with two residual blocks -- one
+        # joining IN FRONT of its activation ('f+a': act(W h + skip)), one behind ('fa+') -- and activations outside Tanh / Sigmoid
+        def equation(f, x, t):
+            return D(f, t) + f * D(f, x) + 0.05 * D(D(D(f, x), x), x) - 0.1 * D(D(f, x), x)
+        return dict(equation=equation,
+                    solver_kwargs=dict(ndims=2, boundary_condition=0.1, initial_condition=lambda x: torch.sin(PI * x) * x,
+                                       layout='faR fa f+a R fa fa+ f', features=[24, 24, 24, 24, 24, 1],
+                                       activation=['Sin', 'Tanh', 'SiLU', 'Tanh', 'Sigmoid']),
+                    n_points=4096, low=[0, 0], high=[1, 1])
     # ---- breadth workloads: timed by `bench.py --workload ...`, not BASELINE configs -----------------------
     if name in ('skip128', 'sin64', 'program', 'generic'):
         def poisson(f, x, y):

@@ -29,7 +29,8 @@ WIDTH_FLAGS = {256: ['-mllvm', '-amdgpu-sched-strategy=iterative-maxocc'], 64: [
 # without operand prefetch in its forward / data-gradient GEMMs (40 spilled registers otherwise), 2 = the S = 2 ODE-family kernel,
 # fastest without the SLP vectoriser
 SPLIT_FLAGS = {1: ['-DPINN_SP_PIPE=0', '-DPINN_SP_PIPE_W=1'], 2: ['-fno-slp-vectorize']}
-WIDE_SPLIT_FLAGS = {}
+# (same-box A/B, round 3: width 128 gains 3 % without the SLP vectoriser, width 256 is within 1 % of every flag set tried)
+WIDE_SPLIT_FLAGS = {128: ['-fno-slp-vectorize']}
 if os.environ.get('PINN_WIDE_SPLIT_FLAGS'):
     import json
     WIDE_SPLIT_FLAGS = {int(k): v for k, v in json.loads(os.environ['PINN_WIDE_SPLIT_FLAGS']).items()}

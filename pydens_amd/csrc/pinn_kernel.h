@@ -79,6 +79,7 @@ struct PinnKArgs {
     unsigned long long act_codes;   // 4 bits per activation index a = 0..lh (a = 0: first layer)
     int n_skips;                 // skip connections 'R ... +': h_out[skip_dst] += h_out[skip_src] (activation indices)
     int skip_src[PINN_MAX_SKIPS], skip_dst[PINN_MAX_SKIPS];
+    int skip_pre;                // bit k: skip k ends IN FRONT of the activation ('R fa f+ a': z[skip_dst] += h_out[skip_src])
     int off_b1, off_wh, hidden_stride, off_wl, off_bl, off_ls, off_loss;
     int p_core;                  // row stride of `partials` = length of the gradient buffer (user slots included)
     int off_extra, n_vars;       // first user slot; V(...) scalars a residual program reads (registers S+d+n_aux+k)
@@ -151,6 +152,8 @@ struct PinnCfg {
     static constexpr int O_ACCB = O_GNET + S * T;
     static constexpr int O_ACCW1 = O_ACCB + PINN_MAX_LAYERS * HP;   // bias-gradient rows for any depth
     static constexpr int O_SCAL = O_ACCW1 + HP * PINN_XS_LD;
+    static constexpr int O_TBAR = O_SCAL;                       // arrival counter of the team-local barrier (PINN_TEAM_FLAGS builds): shares
+                                                                // the first slot of `scal`, which is written behind the tile loop only
     static constexpr int O_PREG = O_SCAL + T * 4;
     static constexpr int O_PADJ = O_PREG + PINN_MAX_REGS * T;
     static constexpr int SMEM_FLOATS = O_PADJ + PINN_MAX_REGS * T;
@@ -1110,6 +1113,7 @@ pinn_tile_kernel(const PinnKArgs A) {
     float* accB = smem + C::O_ACCB;
     float* accW1 = smem + C::O_ACCW1;
     float* scal = smem + C::O_SCAL;
+    int* tbar = reinterpret_cast<int*>(smem + C::O_TBAR);
     float* pregs = smem + C::O_PREG;
     float* padj = smem + C::O_PADJ;
 
@@ -1120,6 +1124,7 @@ pinn_tile_kernel(const PinnKArgs A) {
         accW1[i] = 0.0f;
     }
     for (int i = tid; i < HP; i += NTHREADS) { b1s[i] = A.params[A.off_b1 + i]; WLs[i] = A.params[A.off_wl + i]; }
+    if (tid == 0) tbar[0] = 0;
     for (int i = tid; i < PINN_MAX_LAYERS * HP; i += NTHREADS) accB[i] = 0.0f;
     float* WTs = TEAMS2 ? smem_all + 2 * C::TEAM_FLOATS : smem + C::O_WT;
     const float* wtg = A.wt + (SLABL ? (size_t)PINN_BID * (size_t)lh * HP * HP : (size_t)0);
@@ -1424,6 +1429,25 @@ pinn_tile_kernel(const PinnKArgs A) {
 #define PINN_TEAM_SKEW 0       // two-team kernels: team 1 runs one barrier behind team 0 (its vector phases then meet team 0's GEMM phases)
 #endif
     if (TEAMS2 && PINN_TEAM_SKEW && team == 1) PINN_SYNC();
+    // barriers INSIDE the tile loop. Two-team kernels share nothing between the teams in there (each team its own LDS block and
+    // slab; W^T / the split fragments are read-only), so a team's barrier need not hold the other team: PINN_TEAM_FLAGS replaces
+    // s_barrier by an arrival counter in the team's LDS block and the teams drift apart -- one team's vector phases then run
+    // under the other's GEMM phases on every SIMD they share (they were lock-stepped phase by phase before: section 6b)
+#ifndef PINN_TEAM_FLAGS
+#define PINN_TEAM_FLAGS 0
+#endif
+    constexpr bool TEAM_FLAGS = TEAMS2 && ((PINN_TEAM_FLAGS & (SPLIT ? 1 : 2)) != 0);
+    int tb_round = 0;
+    auto tsync = [&]() {
+        if constexpr (TEAM_FLAGS) {
+            tb_round += NW;
+            pinn_flag_arrive(tbar, lane == 0);
+            while (pinn_flag_load(tbar) < tb_round) PINN_SPIN_PAUSE();
+            PINN_WAVE_SYNC();
+        } else {
+            PINN_SYNC();
+        }
+    };
     // (two teams: both run as many rounds as team 0 has tiles -- a team without a tile in the last round works on an empty
     //  one: zero points, every sample invalid, contributions zero -- so that the barriers match)
     for (long long tile0 = A.tile_begin + (long long)PINN_BID * TEAMS; tile0 < ntiles; tile0 += vnblk, tile_parity ^= 1) {
@@ -1536,7 +1560,7 @@ pinn_tile_kernel(const PinnKArgs A) {
             }
         }
         PH(1)
-        PINN_SYNC();
+        tsync();
         PH(2)
 
         // ---- (2) hidden layers: Z^T = W H^T (MFMA: A = weight fragment, B = activations), jets on accumulators --------
@@ -1561,7 +1585,7 @@ pinn_tile_kernel(const PinnKArgs A) {
 #ifndef PINN_SP_FWD_BARRIER
 #define PINN_SP_FWD_BARRIER 0   // a barrier between a forward GEMM and its jet epilogue: with PINN_TEAM_SKEW the GEMM interval of one team then faces a vector interval of the other
 #endif
-                if (PINN_SP_FWD_BARRIER) PINN_SYNC();
+                if (PINN_SP_FWD_BARRIER) tsync();
             } else {
                 // software pipeline over the K quads: the operands of quad q+1 are in flight while the S*MT*NTW*4 MFMAs
                 // of quad q issue, accumulators interleaved (an accumulator is re-used every S*MT*NTW issues, far
@@ -1612,7 +1636,7 @@ pinn_tile_kernel(const PinnKArgs A) {
                 }
             }
             PH(3)
-            if (ONEBUF) PINN_SYNC();                       // in place: every wave must be done reading h_{l-1}
+            if (ONEBUF) tsync();                       // in place: every wave must be done reading h_{l-1}
             f32x4 biasv[NTW];
 #pragma unroll
             for (int j = 0; j < NTW; ++j) biasv[j] = (WPF || SPLIT) ? biasn[j] : pinn_ld4(bl + unit0(j));
@@ -1633,18 +1657,24 @@ pinn_tile_kernel(const PinnKArgs A) {
                 for (int mt = 0; mt < MT; ++mt) {
                     const int pt = mt * 16 + lr;
                     f32x4 hv[S], sv[S];
+                    // '+' in front of the activation: the jets of the skipped activations join the pre-activation jets
+                    const bool pre_in = SKIPS && sk_in >= 0 && ((A.skip_pre >> sk_in) & 1);
 #pragma unroll
                     for (int r = 0; r < 4; ++r) {
                         float z[S], h[S];
 #pragma unroll
                         for (int s = 0; s < S; ++s) z[s] = acc[j][mt][s][r];
                         z[0] += bias[r];
+                        if (SKIPS && pre_in) {
+#pragma unroll
+                            for (int s = 0; s < S; ++s) z[s] += hskip[SKIPS ? j : 0][SKIPS ? mt : 0][s][r];
+                        }
                         pinn_jet_fwd<ND, N2, COMB>(z, act, h, cw);
 #pragma unroll
                         for (int s = 0; s < S; ++s) { hv[s][r] = h[s]; sv[s][r] = (s == 0) ? pinn_act_saved(h[0], z[0], act) : z[s]; }
                     }
-                    if (SKIPS && sk_in >= 0) {
-                        // '+': add the activations saved at 'R'; the reverse half needs them again (slab slot of the skip)
+                    if (SKIPS && sk_in >= 0 && !pre_in) {
+                        // '+' behind the activation: add the activations saved at 'R'; the reverse half needs them again (slab slot of the skip)
 #pragma unroll
                         for (int s = 0; s < S; ++s) {
                             const f32x4 hs = hskip[SKIPS ? j : 0][SKIPS ? mt : 0][s];
@@ -1681,7 +1711,7 @@ pinn_tile_kernel(const PinnKArgs A) {
                 }
             }
             PH(4)
-            PINN_SYNC();
+            tsync();
             PH(5)
             float* tmp = cur; cur = nxt; nxt = tmp;
         }
@@ -1720,7 +1750,7 @@ pinn_tile_kernel(const PinnKArgs A) {
             }
         }
         PH(6)
-        PINN_SYNC();
+        tsync();
         PH(7)
 
         // ---- (4) ansatz + residual + their reverse, one thread per point; all threads: stage the NEXT tile's points ------
@@ -1745,7 +1775,7 @@ pinn_tile_kernel(const PinnKArgs A) {
             if (SPEC == 0) sum_ic += po.g_ic;
         }
         PH(8)
-        PINN_SYNC();
+        tsync();
         PH(9)
         if (!train) continue;
 
@@ -1806,7 +1836,9 @@ pinn_tile_kernel(const PinnKArgs A) {
             if (SKIPS) {
                 // h_out(a) feeds a later '+': its gradient arrives through the skip slot; h_out(a) = act(z_a) + skipped
                 // activations: the whole gradient is handed down the skip (slot re-used: its activations are consumed)
+                // (a '+' in front of the activation hands down gz_a instead, below)
                 const int k_out = skip_from(a), k_in = skip_into(a);
+                const bool post_in = k_in >= 0 && !((A.skip_pre >> k_in) & 1);
 #pragma unroll
                 for (int j = 0; j < NTW; ++j)
 #pragma unroll
@@ -1814,7 +1846,7 @@ pinn_tile_kernel(const PinnKArgs A) {
 #pragma unroll
                         for (int s = 0; s < S; ++s) {
                             if (k_out >= 0) g[j][mt][s] += *slab_at(lh + 1 + k_out, s, j, mt);
-                            if (k_in >= 0) *slab_at(lh + 1 + k_in, s, j, mt) = g[j][mt][s];
+                            if (post_in) *slab_at(lh + 1 + k_in, s, j, mt) = g[j][mt][s];
                         }
             }
 #pragma unroll
@@ -1842,6 +1874,17 @@ pinn_tile_kernel(const PinnKArgs A) {
                     }
                 }
             }
+            if (SKIPS) {
+                const int k_in = skip_into(a);
+                if (k_in >= 0 && ((A.skip_pre >> k_in) & 1)) {
+#pragma unroll
+                    for (int j = 0; j < NTW; ++j)
+#pragma unroll
+                        for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+                            for (int s = 0; s < S; ++s) *slab_at(lh + 1 + k_in, s, j, mt) = gz[j][mt][s];
+                }
+            }
         };
         // after the forward half `nxt` still holds h_{lh-1} (the input of the last hidden layer): the top reverse step
         // uses it in place and stages only gz
@@ -1855,7 +1898,9 @@ pinn_tile_kernel(const PinnKArgs A) {
             //  the data-gradient GEMM and to HBM for that kernel)
             f32x4 hv[NTW][MT][S];               // (WGX: never touched)
             if (!SVPF) load_saved(a - 1, svn);
-            const int act = act_at(a - 1), sk_prev = skip_into(a - 1);
+            const int act = act_at(a - 1);
+            int sk_prev = skip_into(a - 1);
+            if (SKIPS && sk_prev >= 0 && ((A.skip_pre >> sk_prev) & 1)) sk_prev = -1;      // (joined in front of the activation: h_out = act(z))
 #pragma unroll
             for (int j = 0; j < NTW; ++j) {
 #pragma unroll
@@ -1911,7 +1956,7 @@ pinn_tile_kernel(const PinnKArgs A) {
                 if (!GZ_LATE) store_gz();
             } else if constexpr (ONEBUF) {
                 // one LDS buffer: h_{a-1} -> LDS -> fragments in registers, then gz_a takes its place
-                if (!top) { stage(cur, hv); PINN_SYNC(); }
+                if (!top) { stage(cur, hv); tsync(); }
 #pragma unroll
                 for (int ms = 0; ms < MT * S; ++ms)
 #pragma unroll
@@ -1920,14 +1965,14 @@ pinn_tile_kernel(const PinnKArgs A) {
                         for (int m = 0; m < 4; ++m)
                             hfrag[ONEBUF ? ms : 0][j][m] =
                                 cur[((ms % S) * T + (ms / S) * 16 + wg_pt(m)) * LDA + (wave * NTW + j) * 16 + lr];
-                PINN_SYNC();
+                tsync();
                 stage(nxt, gz);
             } else {
                 if (!top) stage(cur, hv);
                 stage(nxt, gz);
             }
             PH(10)
-            PINN_SYNC();
+            tsync();
             PH(11)
             if (SVPF && a >= 2) load_saved(a - 2, svn);    // in flight during the two GEMMs below
             const int li = a - 1;
@@ -2215,7 +2260,7 @@ pinn_tile_kernel(const PinnKArgs A) {
             }
             if (WGX && GZ_LATE) store_gz();
             PH(13)
-            PINN_SYNC();
+            tsync();
             PH(14)
         };
         if constexpr (DWG) {
@@ -2269,6 +2314,7 @@ pinn_tile_kernel(const PinnKArgs A) {
         }
         PH(15)
     }
+    if (TEAM_FLAGS) PINN_SYNC();       // (the arrival counter shares its LDS slot with `scal`, written below)
     PH_FLUSH
     if (TEAMS2 && PINN_TEAM_SKEW && team == 0) PINN_SYNC();
 

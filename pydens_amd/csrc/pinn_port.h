@@ -66,6 +66,13 @@ PINN_DEVICE void pinn_flag_publish(int* p, int v, bool leader) {
     PINN_WAVE_SYNC();
 }
 #define PINN_SPIN_PAUSE() __builtin_amdgcn_s_sleep(1)
+// arrival counter of a barrier among SOME waves of a workgroup (a team), in LDS: every wave adds one after its own LDS accesses
+// (program order + in-order LDS = the same guarantee s_barrier gives for LDS data) and polls for the round's total
+PINN_DEVICE void pinn_flag_arrive(int* p, bool leader) {
+    PINN_WAVE_SYNC();
+    if (leader) __hip_atomic_fetch_add(p, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    PINN_WAVE_SYNC();
+}
 // lane-private f32x4 rows of a wave-owned block of global memory through buffer instructions: ONE vector register of offsets
 // (lane * 16) for every row, the row offset in a scalar register -- with plain pointers hipcc keeps a 64-bit address pair
 // per row alive across the whole tile loop (several dozen VGPRs, spilled)

@@ -18,6 +18,7 @@ MAX_OPS, MAX_CONSTS, MAX_REGS = 64, 32, 40
 MAX_STREAMS, MAX_AUX, MAX_VARS = 7, 8, 8
 SAMPLE_UNIFORM, SAMPLE_NORMAL, SAMPLE_CONST = 0, 1, 2
 RES_PROGRAM, RES_AFFINE = 0, 1
+SKIP_PRE = 0x100         # include/pinn.h PINN_SKIP_PRE
 ACT_CODES = {'tanh': 0, 'sigmoid': 1, 'sin': 2, 'identity': 3, 'softplus': 4, 'silu': 5, 'swish': 5, 'gelu': 6}
 
 OPS = dict(CONST=0, ADD=1, SUB=2, MUL=3, DIV=4, NEG=5, SIN=6, COS=7, EXP=8, LOG=9, TANH=10, SQRT=11, POW=12,
@@ -186,7 +187,8 @@ class Net:
     def __init__(self, layer_dims, activation, ndims, nparams=0, has_bc=False, bc_value=0.0, has_ic=False,
                  domain=None, lib=None, skips=()):
         """ activation: one name for every hidden layer or a sequence with one name per hidden layer;
-        skips: (src, dst) hidden-layer indices, output of dst += output of src ('R ... +' layouts). """
+        skips: (src, dst) or (src, dst, pre) hidden-layer indices: output of dst += output of src ('R ... +' layouts); pre: the
+        sum enters in front of the activation of dst ('faR fa f+ a'). """
         self.lib = lib if lib is not None else load_library()
         n_hidden = len(layer_dims) - 2
         names = [activation] * n_hidden if isinstance(activation, str) else list(activation)
@@ -196,15 +198,15 @@ class Net:
         if None in codes:
             raise NotImplementedError(f'activation {names[codes.index(None)]!r}: the HIP kernels implement Tanh, Sigmoid '
                                       'Sin, Softplus, SiLU and GELU (and the identity)')
-        skips = sorted(skips)
+        skips = sorted((s[0], s[1], bool(s[2]) if len(s) > 2 else False) for s in skips)
         domain = list(domain) if domain is not None else [(0.0, 1.0)] * ndims
         dims = (ctypes.c_int * len(layer_dims))(*layer_dims)
         lo = (ctypes.c_float * ndims)(*[float(d[0]) for d in domain])
         hi = (ctypes.c_float * ndims)(*[float(d[1]) for d in domain])
         handle = ctypes.c_void_p()
         acts = (ctypes.c_int * max(1, n_hidden))(*codes)
-        src = (ctypes.c_int * max(1, len(skips)))(*[s for s, _ in skips])
-        dst = (ctypes.c_int * max(1, len(skips)))(*[d for _, d in skips])
+        src = (ctypes.c_int * max(1, len(skips)))(*[s for s, _, _ in skips])
+        dst = (ctypes.c_int * max(1, len(skips)))(*[d | (SKIP_PRE if pre else 0) for _, d, pre in skips])
         rc = self.lib.pinn_create_ex(dims, len(layer_dims) - 1, acts, len(skips), src, dst, ndims, nparams, int(has_bc),
                                      int(has_ic), lo, hi, float(bc_value), ctypes.byref(handle))
         self._raise(rc)

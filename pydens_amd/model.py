@@ -117,9 +117,11 @@ def parse_fc_layout(layout, features, activation):
 
     Letters (reference model_torch.py:142-156): 'f' dense layer, 'a' activation (a shared one or a sequence with one
     entry per 'a'), 'R' start / '+' end of a skip connection; spaces are ignored. The net must end in a 1-unit dense
-    layer. A hidden 'f' without an 'a' gets the identity. 'R' and '+' must sit right behind an activation (or a '+'),
-    skips join layers of equal width and do not nest; conv letters are out of scope. Skips are returned as
-    (src, dst) hidden-layer indices: the output of layer dst gets the output of layer src added. """
+    layer. A hidden 'f' without an 'a' gets the identity. 'R' must sit right behind an activation (or a '+'); '+' either
+    right behind an activation ('faR fa fa+': sum of activation outputs) or between a dense layer and its activation
+    ('faR fa f+a': the usual residual block act(W h + skip)). Skips join layers of equal width and do not nest; conv
+    letters are out of scope. Skips are returned as (src, dst, pre) hidden-layer indices: the output of layer dst
+    -- its pre-activation if `pre` -- gets the output of layer src added. """
     letters = layout.replace(' ', '')
     features = list(features)
     if set(letters) - set('faR+'):
@@ -146,9 +148,10 @@ def parse_fc_layout(layout, features, activation):
                 raise NotImplementedError(f"layout {layout!r}: every 'a' must follow its own dense layer")
             acts.append(_activation_name(act_list.pop(0) if act_list is not None else activation))
         else:
-            if layer < 0 or len(acts) != layer + 1:
-                raise NotImplementedError(f"layout {layout!r}: {letter!r} must come right after an activation "
-                                          '(skips join activation outputs)')
+            pre = letter == '+' and layer >= 0 and len(acts) == layer          # '+' between 'f' and its 'a'
+            if layer < 0 or (len(acts) != layer + 1 and not pre):
+                raise NotImplementedError(f"layout {layout!r}: 'R' must come right after an activation; '+' after an "
+                                          "activation or between a dense layer and its activation")
             if letter == 'R':
                 if open_skip is not None:
                     raise NotImplementedError(f'layout {layout!r}: nested skip connections are not supported')
@@ -158,7 +161,7 @@ def parse_fc_layout(layout, features, activation):
                     raise NotImplementedError(f"layout {layout!r}: '+' needs an open 'R' with a layer in between")
                 if features[open_skip] != features[layer]:
                     raise ValueError(f"layout {layout!r}: skip connection joins widths {features[open_skip]} and {features[layer]}")
-                skips.append((open_skip, layer))
+                skips.append((open_skip, layer, pre))
                 open_skip = None
     if open_skip is not None:
         raise ValueError(f"layout {layout!r}: 'R' without a closing '+'")

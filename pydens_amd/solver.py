@@ -132,9 +132,6 @@ class Solver:
         the start of a fit call whenever the cached lowering no longer reproduces the live callable) """
         self.spec, self.needs_x_grad = trace.discover(self.equation, self.ctx.run, self.model.total, self.device,
                                                       hp=self.model.net.layout.hp)
-        if self.spec.n3 and (self.model.skips or any(str(a).lower() not in ('tanh', 'sigmoid') for a in self.model.activation_names)):
-            raise NotImplementedError('third derivatives are built for Tanh / Sigmoid nets without skip connections '
-                                      f'(got activations {self.model.activation_names}, skips {self.model.skips})')
         # a callable initial condition that IS one scalar trainable variable (`lambda *a: V('init', ...)`, reference
         # examples notebook cells 80-88) stays on the fused path: the kernels read it from its user slot and return its
         # gradient there (pinn_residual_t::ic_var1); any other dependence on variables needs torch autograd (generic path)

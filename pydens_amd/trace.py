@@ -66,8 +66,8 @@ class StreamSpec:
             elif len(alpha) > 2:
                 raise NotImplementedError(
                     f'derivative multi-index {alpha}: the HIP kernels provide first and second derivatives incl. mixed '
-                    'partials, and third derivatives along single columns (u_xxx); mixed third-order partials and orders '
-                    'above three are not built')
+                    'partials, and third derivatives along single columns (u_xxx, any number of such columns); mixed '
+                    'third-order partials and orders above three are not built')
         firsts |= seconds
         # directions: third-order columns first, then the other second-order ones, the diagonals, the first-order rest
         self.dirs = ([(c,) for c in sorted(thirds)] + [(c,) for c in sorted(seconds - thirds)] + sorted(mixed)
@@ -92,12 +92,10 @@ class StreamSpec:
                       for ab in sorted(mixed)}
         # can ONE kernel call produce all of it as separate streams?
         if self.n3 > 0:
-            # third order: one such direction, at most two directions in all, nothing else of second order (u_xxx-type
-            # equations: KdV in (x, t), third-order ODEs); anything else with a third derivative is not built
-            if not (self.n3 == 1 and self.n2 == 1 and self.nd <= 2):
-                raise NotImplementedError(f'{self.dirs} with third derivatives: the kernels are built for one third-order '
-                                          'column plus at most one first-order column (u_xxx-type equations)')
-            self.single_call = True
+            # third order in ONE call: one such direction, at most two directions in all, nothing else of second order (u_xxx-type
+            # equations: KdV in (x, t), third-order ODEs). Anything else with third derivatives along single columns (two
+            # third-order columns, a third-order column beside other second-order ones) goes through the groups below
+            self.single_call = self.n3 == 1 and self.n2 == 1 and self.nd <= 2
         else:
             self.single_call = (self.nd <= 3 and not (self.nd == 3 and self.n2 == 3 and hp == 256)) or \
                                (self.nd == 4 and self.n2 == 0)
@@ -105,9 +103,13 @@ class StreamSpec:
         self.combinable = self.nd <= MAX_DIRS and self.n2 >= 2 and self.n3 == 0
         # groups for the generic path: (direction codes, packed n2 of the group, stream index of each of the group's streams)
         self.groups = []
-        step = self.nd if self.single_call else 2
-        for g0 in range(0, max(self.nd, 1), max(step, 1)):
-            ks = list(range(g0, min(g0 + step, self.nd)))
+        if self.single_call:
+            chunks = [list(range(self.nd))] if self.nd else [[]]
+        else:
+            # every third-order column in a call of its own (the third-order kernels carry one such column), the rest in pairs
+            rest = list(range(self.n3, self.nd))
+            chunks = [[k] for k in range(self.n3)] + [rest[i:i + 2] for i in range(0, len(rest), 2)]
+        for ks in chunks:
             n2g = sum(1 for k in ks if k < self.n2)
             n3g = sum(1 for k in ks if k < self.n3)
             idx = ([0] + [1 + k for k in ks] + [1 + self.nd + k for k in ks if k < self.n2]

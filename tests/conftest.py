@@ -9,7 +9,7 @@ if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
 GOLDEN_DIR = os.path.join(ROOT, 'tests', 'golden')
-GOLDEN_NAMES = ('cfg1', 'cfg2', 'cfg3', 'cfg4', 'cfg5', 'ode_sigmoid', 'mixed', 'heat3d', 'kdv')
+GOLDEN_NAMES = ('cfg1', 'cfg2', 'cfg3', 'cfg4', 'cfg5', 'ode_sigmoid', 'mixed', 'heat3d', 'kdv', 'resnet3')
 
 
 def pytest_configure(config):

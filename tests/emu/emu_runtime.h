@@ -65,6 +65,11 @@ static inline void pinn_flag_publish(int* p, int v, bool leader) {
     emu::sync_wave();
 }
 #define PINN_SPIN_PAUSE() emu::yield_fiber()
+static inline void pinn_flag_arrive(int* p, bool leader) {
+    emu::sync_wave();
+    if (leader) *reinterpret_cast<volatile int*>(p) += 1;
+    emu::sync_wave();
+}
 struct PinnRows { char* p; };
 static inline PinnRows pinn_rows(const void* base, unsigned) { return PinnRows{(char*)const_cast<void*>(base)}; }
 static inline f32x4 pinn_rows_ld4(const PinnRows& b, int lane_bytes, int row_bytes) { return *reinterpret_cast<const f32x4*>(b.p + lane_bytes + row_bytes); }

@@ -37,7 +37,7 @@ def emu_kwargs(lib):
     return dict(lib=lib, device='cpu')
 
 
-@pytest.mark.parametrize('name', ['cfg1', 'cfg2', 'cfg3', 'cfg4', 'ode_sigmoid', 'mixed', 'heat3d', 'kdv'])
+@pytest.mark.parametrize('name', ['cfg1', 'cfg2', 'cfg3', 'cfg4', 'ode_sigmoid', 'mixed', 'heat3d', 'kdv', 'resnet3'])
 def test_fused_fit_matches_reference_golden(pa, emu_lib, name):
     g = Golden(name)
     _, solver = make_solver(name, pa, **emu_kwargs(emu_lib))
@@ -58,7 +58,7 @@ def test_fused_fit_matches_reference_golden(pa, emu_lib, name):
             assert rel_l2(got, want) < fit_rtol(name)
 
 
-@pytest.mark.parametrize('name', ['cfg1', 'ode_sigmoid', 'mixed', 'heat3d', 'kdv'])
+@pytest.mark.parametrize('name', ['cfg1', 'ode_sigmoid', 'mixed', 'heat3d', 'kdv', 'resnet3'])
 def test_generic_fit_matches_reference_golden(pa, emu_lib, name):
     g = Golden(name)
     _, solver = make_solver(name, pa, **emu_kwargs(emu_lib))
@@ -463,6 +463,11 @@ LAYOUTS = {
     'softplus_silu_gelu': dict(layout='fa fa fa f', features=[12, 16, 12, 1], activation=['Softplus', 'SiLU', 'GELU']),
     # every unit of a 64-wide net real (no zero padding to hide a wrong lane / K quad)
     'full64': dict(layout='fa R fa fa + f', features=[64, 64, 64, 1], activation=['Sin', 'Tanh', 'Sigmoid']),
+    # the usual residual block act(W h + skip): '+' between the dense layer and its activation (PINN_SKIP_PRE); two blocks, the
+    # second one starting where the first ends, and one joining in front of an identity
+    'pre_activation_blocks': dict(layout='fa R fa f+a R fa f+a f', features=[16, 16, 16, 16, 16, 1],
+                                  activation=['Tanh', 'Sin', 'Tanh', 'SiLU', 'Sigmoid']),
+    'pre_activation_mixed': dict(layout='faR f+a R fa fa+ f', features=[24, 24, 24, 24, 1], activation='Tanh'),
 }
 
 
@@ -508,7 +513,7 @@ def test_layout_errors_are_loud(pa, emu_lib):
                                   ('fa R fa + f', [8, 12, 1], ValueError),                # widths differ
                                   ('fa R fa R fa + + f', [8, 8, 8, 1], NotImplementedError),   # nested
                                   ('R fa fa + f', [8, 8, 1], NotImplementedError),        # skip from the inputs
-                                  ('fa R f + a f', [8, 8, 1], NotImplementedError),       # pre-activation add
+                                  ('fa f R a fa + f', [8, 8, 8, 1], NotImplementedError),  # skip from a pre-activation
                                   ('ca f', [8, 1], NotImplementedError)]:
         with pytest.raises(exc):
             pa.Solver(lambda f, x: pa.D(f, x), ndims=1, layout=layout, features=features, **emu_kwargs(emu_lib))
@@ -768,6 +773,13 @@ def _third_order_problems(D, torch, which):
     elif which == 'ode_time':       # ... along the time column: the gate sigmoid((t - t0) e^{-s}) enters to third order
         eq = lambda f, t: D(D(D(f, t), t), t) - 0.5 * D(D(f, t), t) + f
         kw = dict(ndims=1, initial_condition=0.7, domain=(0.5, 2.0), layout='fa fa f', features=[16, 24, 1], activation='Sigmoid')
+    elif which == 'sin_skip':       # third order through a skip connection and the activations outside Tanh / Sigmoid
+        eq = lambda f, x, t: D(f, t) + 0.05 * D(D(D(f, x), x), x) + f * D(f, x)
+        kw = dict(ndims=2, boundary_condition=0.1, initial_condition=lambda x: 0.1 + x * (1 - x),
+                  layout='faR fa fa+ fa f', features=[24, 24, 24, 24, 1], activation=['Sin', 'SiLU', 'Sin', 'Softplus'])
+    elif which == 'gelu':
+        eq = lambda f, x: D(D(D(f, x), x), x) - D(D(f, x), x) + f * f
+        kw = dict(ndims=1, boundary_condition=0.3, layout='fa fa f', features=[20, 20, 1], activation='GELU')
     else:                           # dispersive wave in (x, t): u_t + u u_x + 0.1 u_xxx, callable IC, BC, wide enough for WGX
         eq = lambda f, x, t: D(f, t) + f * D(f, x) + 0.1 * D(D(D(f, x), x), x)
         kw = dict(ndims=2, boundary_condition=0.0, initial_condition=lambda x: torch.sin(3.0 * x) * x * x,
@@ -775,7 +787,7 @@ def _third_order_problems(D, torch, which):
     return eq, kw
 
 
-@pytest.mark.parametrize('which', ['ode_space', 'ode_time', 'wide_wgx'])
+@pytest.mark.parametrize('which', ['ode_space', 'ode_time', 'wide_wgx', 'sin_skip', 'gelu'])
 def test_third_order_streams_match_the_oracle(pa, emu_lib, which):
     """ u_xxx-type equations (the reference nests D three times, model_torch.py:174-178): third Taylor coefficient per
     direction in the jets, the ansatz product rules to third order (incl. the IC gate and its log_scale adjoint) and
@@ -821,6 +833,53 @@ def test_third_order_streams_match_the_oracle(pa, emu_lib, which):
             assert params_close(got, want, 1e-4, atol=1e-5)
     xs = [pts[0][:, i] for i in range(d)]
     assert np.abs(solver.predict(*xs) - oracle.predict(*xs)).max() < 2e-5
+
+
+@pytest.mark.parametrize('which', ['two_third_order_columns', 'third_beside_second'])
+def test_third_order_beyond_one_call_runs_in_direction_groups(pa, emu_lib, which):
+    _direction_groups_case(pa, which, emu_kwargs(emu_lib))
+
+
+def _direction_groups_case(pa, which, solver_kwargs):
+    """ the reference nests D to any order over any inputs (model_torch.py:174-178); the third-order kernels carry ONE third-order
+    column per call, so equations with two of them (u_xxx + u_yyy) or with other second-order columns beside one run on the
+    generic path in direction groups (StreamSpec.groups: every third-order column a call of its own). fp64 oracle arbitrates. """
+    from oracle import pinn_oracle as po
+
+    def problem(D):
+        if which == 'two_third_order_columns':
+            eq = lambda f, x, y, t: D(f, t) + 0.1 * D(D(D(f, x), x), x) - 0.2 * D(D(D(f, y), y), y) + f * D(f, x)
+        else:
+            eq = lambda f, x, y, t: D(f, t) + 0.1 * D(D(D(f, x), x), x) - D(D(f, y), y) + f * D(f, y)
+        return eq, dict(ndims=3, boundary_condition=0.1, initial_condition=lambda x, y: x * y * (1 - x),
+                        layout='fa fa f', features=[24, 24, 1], activation='Tanh')
+    eq_o, kw = problem(po.D)
+    oracle32 = po.OracleSolver(eq_o, **kw)
+    oracle = po.OracleSolver(eq_o, dtype=torch.float64, **kw)
+    start = oracle32.export_params()
+    oracle.import_params(start)
+    pts = np.random.RandomState(11).rand(3, 40, 3).astype(np.float32)
+    ev32, g32 = oracle32.evaluate(pts[0]), oracle32.export_grads()
+    ev, g_want = oracle.evaluate(pts[0]), oracle.export_grads()
+    oracle.fit(niters=3, batch_size=40, points=pts, lr=0.01)
+    eq_p, kw = problem(pa.D)
+    solver = pa.Solver(eq_p, **kw, **solver_kwargs)
+    assert solver.program is None and not solver.spec.single_call
+    assert [g[1] for g in solver.spec.groups] == ([9, 9, 0] if which == 'two_third_order_columns' else [9, 1])
+    load_params(solver, start)
+    solver._generic_step(torch.from_numpy(pts[0].copy()).to(solver.device), ('equation',), [], torch.nn.MSELoss(), 1)
+    lay = solver.model.net.layout
+    loss = float(solver.grads[lay.off_loss])
+    assert abs(loss - ev['loss']) <= max(2 * abs(ev32['loss'] - ev['loss']), 1e-5 * ev['loss'])
+    for got, want, w32 in zip(export_grads(solver), g_want, g32):
+        if want is not None:
+            err = np.linalg.norm(np.asarray(got, dtype=np.float64) - want)
+            assert err <= max(2 * np.linalg.norm(np.asarray(w32, dtype=np.float64) - want), 1e-4 * np.linalg.norm(want))
+    solver.fit(niters=3, batch_size=40, sampler=FixedBatches(pts), lr=0.01)
+    assert solver.last_fit_path == 'generic'
+    np.testing.assert_allclose([float(v) for v in solver.losses], [float(v) for v in oracle.losses], rtol=5e-5)
+    for got, want in zip(export_params(solver), oracle.export_params()):
+        assert params_close(got, want, 1e-4, atol=1e-5)
 
 
 def test_chunked_fit_equals_the_per_iteration_loop(pa, emu_lib):

@@ -160,7 +160,7 @@ def test_random_third_order_equations_on_the_gpu():
 def _random_net(rng, wmax=41):
     """ a random fully connected layout of the reference's Block vocabulary: 1-5 hidden layers of 5-40 units (padded to
     16 / 32 / 64 inside), Tanh / Sigmoid / Sin / Softplus / SiLU / GELU per layer (or one name), sometimes a hidden layer without activation,
-    sometimes one skip connection 'R ... +' over layers of equal width """
+    sometimes one skip connection 'R ... +' over layers of equal width (joining behind or in front of the activation) """
     depth = rng.randint(1, 6)
     widths = [int(rng.randint(5, wmax)) for _ in range(depth)]
     names = ['Tanh', 'Sigmoid', 'Sin', 'Softplus', 'SiLU', 'GELU']
@@ -178,7 +178,7 @@ def _random_net(rng, wmax=41):
         for i in range(a, b + 1):
             widths[i] = widths[a]
         letters[a] = 'faR'
-        letters[b] = 'fa+'
+        letters[b] = 'fa+' if rng.rand() < 0.5 else 'f+a'      # sum behind the activation, or the residual block act(W h + skip)
     activation = acts[0] if rng.rand() < 0.4 and not no_act else acts
     if isinstance(activation, str):
         acts = [activation] * len(acts)

@@ -15,7 +15,7 @@ from helpers import FixedBatches, export_grads, export_params, fit_rtol, grad_cl
 
 pytestmark = pytest.mark.gpu
 
-SUPPORTED = ('cfg1', 'cfg2', 'cfg3', 'cfg4', 'cfg5', 'ode_sigmoid', 'mixed', 'heat3d', 'kdv')
+SUPPORTED = ('cfg1', 'cfg2', 'cfg3', 'cfg4', 'cfg5', 'ode_sigmoid', 'mixed', 'heat3d', 'kdv', 'resnet3')
 
 
 @pytest.fixture(scope='module')
@@ -735,7 +735,14 @@ def test_known_answers_of_the_tutorial(pa):
     assert abs(v - 2.0) < 0.05 and err < 0.1, (v, err)              # (reference: V = 1.997 .. 2.004, error 0.006 .. 0.02)
 
 
-@pytest.mark.parametrize('which', ['ode_space', 'ode_time', 'wide_wgx'])
+@pytest.mark.parametrize('which', ['two_third_order_columns', 'third_beside_second'])
+def test_third_order_direction_groups_on_the_gpu(pa, which):
+    """ equations with more third-order content than one kernel call carries: generic path, one call per third-order column """
+    import test_emu_engine as te
+    te._direction_groups_case(pa, which, {})
+
+
+@pytest.mark.parametrize('which', ['ode_space', 'ode_time', 'wide_wgx', 'sin_skip', 'gelu'])
 def test_third_order_streams_on_the_gpu(pa, which):
     """ u_xxx-type equations: third-order jets, ansatz product rules and reverse sweep on the device (fused and generic
     paths, widths 32 and 128 -- the latter through the streamed weight-gradient kernel), arbitrated by the fp64 oracle: three

@@ -6,7 +6,7 @@
 CFG=${1:-cfg2}; TAG=${2:-prof}; SUF=${3:-}; shift 3 2>/dev/null; EXTRA="$@"; OUT=/root/repo/gpurun_out/$TAG/prof_$CFG$SUF; mkdir -p $OUT
 export TMPDIR=/tmp; cd /tmp
 STEPS=30; WARM=5; case $CFG in cfg3|cfg5) STEPS=8; WARM=2;; esac
-CMD="python /root/repo/bench.py --workload $CFG --no-cpu-baseline --no-strong --steps $STEPS --warmup $WARM $EXTRA"
+CMD="python /root/repo/bench.py --workload $CFG --no-cpu-baseline --no-strong --no-side --steps $STEPS --warmup $WARM $EXTRA"
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -- $CMD > $OUT/trace.log 2>&1
 rocprofv3 --kernel-trace --output-format csv --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_MFMA SQ_INSTS_VALU SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY GRBM_GUI_ACTIVE -d $OUT/pmc1 -- $CMD > $OUT/pmc1.log 2>&1
 rocprofv3 --kernel-trace --output-format csv --pmc FETCH_SIZE -d $OUT/pmc2 -- $CMD > $OUT/pmc2.log 2>&1
