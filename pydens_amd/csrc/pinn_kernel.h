@@ -219,7 +219,14 @@ PINN_DEVICE void pinn_sincos(float x, float& sn, float& cs) {
     sn = (k & 2) ? -a : a;
     cs = ((k + 1) & 2) ? -b : b;
 }
+// TIMING ablations of experiment builds (tools/variant.sh -DPINN_ABL=bits; results of such a build are meaningless): 1 the split
+// without its arithmetic, 2 no slab stores, 4 no slab loads, 8 no LDS writes of the split planes, 16 no barriers in the tile loop,
+// 32 activation derivatives without transcendental functions -- what each piece of the vector phases costs
+#ifndef PINN_ABL
+#define PINN_ABL 0
+#endif
 PINN_DEVICE float pinn_act(float z, int act) {
+    if (PINN_ABL & 32) return 0.5f * z;
     if (act == PINN_ACT_TANH) {
         // Forms measured on trained models against the fp64 oracle (tools/arbiter.py; gradient error
         // relative to the fp32 reference's own, cfg4 / time on cfg2, cfg4):
@@ -955,6 +962,7 @@ PINN_DEVICE float pinn_bitsf(unsigned x) { return __builtin_bit_cast(float, x); 
 #endif
 // bit patterns whose UPPER halves are the three bf16 parts of x (b0: hi, b1: mid, b2: lo); x = hi + mid + lo exactly
 PINN_DEVICE void pinn_split3(float x, unsigned& b0, unsigned& b1, unsigned& b2) {
+    if (PINN_ABL & 1) { b0 = b1 = b2 = pinn_fbits(x); return; }
     b0 = pinn_fbits(x) + (PINN_SP_ROUND >= 2 ? 0x8000u : 0u);
     const float r1 = x - pinn_bitsf(b0 & 0xffff0000u);
     b1 = pinn_fbits(r1) + (PINN_SP_ROUND >= 1 ? 0x8000u : 0u);
@@ -1250,6 +1258,9 @@ pinn_tile_kernel(const PinnKArgs A) {
     auto sp_store = [&](float* buf, int row, int n0, f32x4 v) {
         char* b = reinterpret_cast<char*>(buf) + pinn_sp_off<C::SP_ROW_BYTES>(row, n0 >> 3) + ((n0 >> 2) & 1) * 8;
         const PinnSplit4 sp = pinn_split4(v);
+#ifndef PINN_EMU
+        if (PINN_ABL & 8) { asm volatile("" :: "v"(sp.hi), "v"(sp.mid), "v"(sp.lo), "v"(b)); return; }
+#endif
         *reinterpret_cast<pinn_u32x2*>(b) = sp.hi;
         *reinterpret_cast<pinn_u32x2*>(b + C::SP_PLANE_BYTES) = sp.mid;
         *reinterpret_cast<pinn_u32x2*>(b + 2 * C::SP_PLANE_BYTES) = sp.lo;
@@ -1444,7 +1455,7 @@ pinn_tile_kernel(const PinnKArgs A) {
             pinn_flag_arrive(tbar, lane == 0);
             while (pinn_flag_load(tbar) < tb_round) PINN_SPIN_PAUSE();
             PINN_WAVE_SYNC();
-        } else {
+        } else if (!(PINN_ABL & 16)) {
             PINN_SYNC();
         }
     };
@@ -1554,7 +1565,7 @@ pinn_tile_kernel(const PinnKArgs A) {
                         for (int s = 0; s < S; ++s) svtop[j][mt][s] = sv[s];
                     } else {
                         if (WGX) pinn_st4_stream<SNT>(slab_at(0, 0, j, mt), sv[0]);
-                        else *slab_at(0, 0, j, mt) = sv[0];     // z_k = W1[:, col_k] and z_kk = 0 are rebuilt in the reverse half
+                        else if (!(PINN_ABL & 2)) *slab_at(0, 0, j, mt) = sv[0];     // z_k = W1[:, col_k] and z_kk = 0 are rebuilt in the reverse half
                     }
                 }
             }
@@ -1704,7 +1715,7 @@ pinn_tile_kernel(const PinnKArgs A) {
 #pragma unroll
                             for (int s = 0; s < S; ++s) {
                                 if (WGX) pinn_st4_stream<SNT>(slab_at(li + 1, s, j, mt), sv[s]);
-                                else *slab_at(li + 1, s, j, mt) = sv[s];
+                                else if (!(PINN_ABL & 2)) *slab_at(li + 1, s, j, mt) = sv[s];
                             }
                         }
                     }
@@ -1790,7 +1801,7 @@ pinn_tile_kernel(const PinnKArgs A) {
 #pragma unroll
                 for (int mt = 0; mt < MT; ++mt) {
                     if (a == 0) {
-                        dst[j][mt][0] = *slab_at(0, 0, j, mt);
+                        dst[j][mt][0] = (PINN_ABL & 4) ? f32x4{0.1f, 0.2f, 0.3f, 0.4f} : *slab_at(0, 0, j, mt);
 #pragma unroll
                         for (int r = 0; r < 4; ++r) {
 #pragma unroll
@@ -1801,7 +1812,7 @@ pinn_tile_kernel(const PinnKArgs A) {
                         }
                     } else {
 #pragma unroll
-                        for (int s = 0; s < S; ++s) dst[j][mt][s] = *slab_at(a, s, j, mt);
+                        for (int s = 0; s < S; ++s) dst[j][mt][s] = (PINN_ABL & 4) ? f32x4{0.1f, 0.2f, 0.3f, 0.4f} * (float)(s + 1) : *slab_at(a, s, j, mt);
                     }
                 }
         };

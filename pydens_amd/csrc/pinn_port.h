@@ -46,6 +46,10 @@ typedef unsigned int pinn_u32x2 __attribute__((ext_vector_type(2)));
 // bits 16*(e&1) of register e>>1); c[r] is D[(l>>4)*4 + r][l&15] as for pinn_mfma16.
 PINN_DEVICE f32x4 pinn_mfma16_bf16(pinn_s16x8 a, pinn_s16x8 b, f32x4 c) {
     typedef __bf16 pinn_bf16x8 __attribute__((ext_vector_type(8)));
+#if defined(PINN_ABL) && (PINN_ABL & 64)          // timing ablation (experiment builds): operands consumed, nothing multiplied
+    asm volatile("" :: "v"(a), "v"(b));
+    return c;
+#endif
     return __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(pinn_bf16x8, a), __builtin_bit_cast(pinn_bf16x8, b), c, 0, 0, 0);
 }
 // ds_read_b64_tr_b16: within each group of 16 lanes, lane i supplies the (8-byte aligned) address of 4 consecutive 16-bit

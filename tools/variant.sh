@@ -6,5 +6,5 @@ python - "$NAME" "$@" <<'PY'
 import sys
 from pydens_amd.csrc import build
 name, flags = sys.argv[1], sys.argv[2:]
-print(build.build(force=True, extra_flags=['-DPINN_ONLY_BASELINE', '-DPINN_DEBUG_ABI', *flags], out=f'/root/repo/gpurun_variants/lib_{name}.so', widths=(64, 128, 256)))
+print(build.build(force=True, extra_flags=['-DPINN_ONLY_BASELINE', '-DPINN_DEBUG_ABI', *flags], out=f'/root/repo/gpurun_variants/lib_{name}.so', widths=tuple(int(w) for w in __import__('os').environ.get('VARIANT_WIDTHS', '64,128,256').split(','))))
 PY
