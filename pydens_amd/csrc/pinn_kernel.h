@@ -13,20 +13,21 @@
 // workgroup; per-workgroup partials are summed by pinn_reduce_kernel.  See DESIGN.md sections 3-5.
 //
 // Build knobs (all have the product's value as default; `tools/variant.sh <name> -D...` builds an A/B library, the
-// measurements behind each default are in DESIGN.md section 6):
-//   PINN_TANH_FORM (4)            tanh formula: 0 / 1 / 4 / 3 / 5 / 2 = increasingly accurate and expensive
+// measurements behind each default are in DESIGN.md section 6; knobs whose experiments were closed as negative are gone,
+// their findings stay as comments where the code was):
 //   PINN_LDA_PAD (8)              padding of the LDS activation rows (bank spread)
-//   PINN_WT_STAGE_BATCH (64)      W^T staging loads issued before the first LDS write
-//   PINN_PREPASS_PRIVATE          pre-pass registers in private memory instead of LDS
-//   PINN_WTG_MIN_HP (128)         from this width on W^T comes from a transposed global copy instead of LDS
+//   PINN_WTG_MIN_HP (128) / PINN_ONEBUF_MIN_HP (256) / PINN_SLAB_NT_MIN_HP (256) / PINN_GZ_LATE_MAX_HP (128) / PINN_WGX_MIN_HP
+//                                 structure thresholds by width: W^T from a global copy, one LDS buffer, non-temporal slabs,
+//                                 gz stores behind the GEMM, streamed weight-gradient kernel (pinn_inst.inc)
 //   PINN_CFG2_SLABL (0)           64: saved jets of the cfg2 kernel in LDS instead of the global slab (pinn_inst.inc)
-//   PINN_EXP_WGRAD (0)            width-256 weight-gradient traffic experiments (1 / 2: timing only, 3: atomics)
-//   PINN_OB_CHAINS (4), PINN_SVPF_MAX (8), PINN_REGB_MAX (6), PINN_REGB_MAX_SPEC (8), PINN_NW_MAX (8),
-//   PINN_WAVES_PER_SIMD (1), PINN_SCHED_IL (1, pinn_port.h)   blocking / prefetch / occupancy / scheduling thresholds
+//   PINN_SVPF_MAX (8), PINN_REGB_MAX (6), PINN_REGB_MAX_SPEC (8), PINN_WAVES_PER_SIMD (1), PINN_SCHED_IL (1, pinn_port.h)
+//                                 prefetch / register-accumulator / occupancy / scheduling thresholds
 //   PINN_FAST_MT_S5 / _S2 / _COMB, PINN_FAST_VAR_COMB, PINN_WIDE_MT (pinn_inst.inc)   tile heights of the fast kernels
+//   PINN_SP_ROUND (2), PINN_SP_PIPE / PINN_SP_PIPE_W (per translation unit: build.py)   split-bf16 kernels
+//   PINN_TEAM_FLAGS (0)           team-local LDS arrival counters instead of s_barrier in the two-team kernels (measured slower)
 //   PINN_ONLY_BASELINE            experiment builds: only the BASELINE kernels (seconds to compile)
 //   PINN_DEBUG_ABI                experiment builds: pinn_debug_set_flags / pinn_debug_phase_buffer and the kernel paths behind them
-//   PINN_PROFILE_PHASES           per-phase cycle counters (tools/phases.py)
+//   PINN_PROFILE_PHASES           per-phase cycle counters (tools/phases.py);  PINN_ABL  timing ablations
 #pragma once
 #include "pinn_port.h"
 
@@ -113,10 +114,8 @@ struct PinnCfg {
     static constexpr bool SPLIT = SPLIT_;                    // split-bf16 GEMM operands (VAR 512; below)
     static constexpr int S = pinn_ns(ND_, N2_);
     static constexpr int NT = HP / 16;                       // 16-wide unit tiles
-#ifndef PINN_NW_MAX
-#define PINN_NW_MAX 8
-#endif
-    static constexpr int NW = (NT <= 4) ? NT : PINN_NW_MAX;  // waves per workgroup
+    static constexpr int NW = (NT <= 4) ? NT : 8;            // waves per workgroup (four waves with twice the unit tiles at widths
+                                                             // >= 128: one wave per SIMD, 12-20 % slower -- DESIGN.md section 6a)
     static constexpr int NTW = NT / NW;                      // unit tiles per wave
     static constexpr int T = 16 * MT;                        // points per tile
 #ifndef PINN_LDA_PAD
@@ -228,50 +227,16 @@ PINN_DEVICE void pinn_sincos(float x, float& sn, float& cs) {
 PINN_DEVICE float pinn_act(float z, int act) {
     if (PINN_ABL & 32) return 0.5f * z;
     if (act == PINN_ACT_TANH) {
-        // Forms measured on trained models against the fp64 oracle (tools/arbiter.py; gradient error
-        // relative to the fp32 reference's own, cfg4 / time on cfg2, cfg4):
-        //   0  1 - 2/(1 + e^{2z})                  2.95x   baseline      absolute error 1.5e-7 everywhere: poor RELATIVE
-        //                                                                accuracy for |z| < 1, where most units live
-        //   1  sign(z) (1 - t)/(1 + t), t = e^{-2|z|}   2.42x   +0 %, +1 %   symmetric, no overflow
-        //   4  form 1, but 1 - 2t/(1 + t) for t < 1/2    1.4x (1.9x for form 1 at that state)   +0.5 %, +1.9 %   (default)
-        //   3  form 1 + odd polynomial for |z| < 0.35   1.82x   +1.1 %, +3.9 %
-        //   2  ocml tanhf                               1.29x   +5 %, +8.5 %
-        //   5  minimax odd polynomial (degree 9, rel. error 9e-8) for |z| < 0.45, 1 - 2t/(1 + t) above
-#ifndef PINN_TANH_FORM
-#define PINN_TANH_FORM 4
-#endif
-#if PINN_TANH_FORM == 0
-        const float e = pinn_exp2(z * 2.8853900817779268f);       // 2 log2(e)
-        return 1.0f - 2.0f * pinn_rcp(1.0f + e);
-#elif PINN_TANH_FORM == 1
-        const float t = pinn_exp2(fabsf(z) * -2.8853900817779268f);   // e^{-2|z|} in (0, 1]: no overflow
-        return copysignf((1.0f - t) * pinn_rcp(1.0f + t), z);
-#elif PINN_TANH_FORM == 4
-        // form 1 for small |z|; 1 - 2t/(1 + t) where the unit saturates (t < 1/2): the subtraction from 1 is then exact and
-        // the error of the small second term does not matter, which is what 1 - v^2 downstream needs
+        // sign(z) (1 - t)/(1 + t) with t = e^{-2|z|} (symmetric, no overflow) for small |z|; 1 - 2t/(1 + t) where the unit saturates
+        // (t < 1/2): the subtraction from 1 is then exact and the error of the small second term does not matter, which is what
+        // 1 - v^2 downstream needs. Measured on trained models against the fp64 oracle (tools/arbiter.py, DESIGN.md section 6a:
+        // gradient error relative to the fp32 reference's own on cfg4 / time on cfg2, cfg4): 1 - 2/(1 + e^{2z}) 2.95x; the first form
+        // alone 2.42x (+0 %, +1 %); THIS 1.4x (+0.5 %, +1.9 %); with an odd polynomial below |z| = 0.35 1.82x (+1.1 %, +3.9 %); a
+        // minimax polynomial below 0.45 1.23x (+0.6 %, +2.7 %); ocml tanhf 1.29x (+5 %, +8.5 %).
         const float t = pinn_exp2(fabsf(z) * -2.8853900817779268f);
         const float r = pinn_rcp(1.0f + t);
         const float lo = (1.0f - t) * r, hi = 1.0f - (t + t) * r;
         return copysignf(t < 0.5f ? hi : lo, z);
-#elif PINN_TANH_FORM == 5
-        // |z| < 0.45: z (1 + w P(w)), w = z^2, P = minimax fit of (tanh(z)/z - 1)/w (no cancellation, no exp error
-        // amplified by 1 - t); above: t < 0.41, so 1 - 2t/(1 + t) subtracts from 1 exactly
-        const float a = fabsf(z);
-        const float t = pinn_exp2(a * -2.8853900817779268f);
-        const float hi = copysignf(1.0f - (t + t) * pinn_rcp(1.0f + t), z);
-        const float w = z * z;
-        const float q = w * (-0.3333321511745453f + w * (0.1332860141992569f + w * (-0.053299661725759506f + w * 0.017926184460520744f)));
-        return a < 0.45f ? fmaf(z, q, z) : hi;
-#elif PINN_TANH_FORM == 3
-        const float a = fabsf(z);
-        const float t = pinn_exp2(a * -2.8853900817779268f);
-        const float big = (1.0f - t) * pinn_rcp(1.0f + t);
-        const float z2 = z * z;
-        const float small = a * (1.0f + z2 * (-0.33333334f + z2 * (0.13333334f + z2 * (-0.053968254f + z2 * 0.021869488f))));
-        return copysignf(a < 0.35f ? small : big, z);
-#else
-        return tanhf(z);
-#endif
     }
     if (act == PINN_ACT_SIGMOID) return pinn_rcp(1.0f + pinn_exp2(z * -1.4426950408889634f));
     if (act == PINN_ACT_SIN) { float sn, cs; pinn_sincos(z, sn, cs); return sn; }
@@ -910,19 +875,6 @@ PINN_DEVICE void pinn_point_stage(const PinnKArgs& A, const float (&net)[pinn_ns
 #define PH_FLUSH
 #endif
 
-// experiments on the partial-buffer weight gradient of the width-256 kernels: 0 = read-modify-write (product),
-// 1 = no read (wrong sums; timing only), 2 = no read, no write (timing only), 3 = fire-and-forget atomic add
-#ifndef PINN_EXP_WGRAD
-#define PINN_EXP_WGRAD 0
-#endif
-#ifndef PINN_EMU
-PINN_DEVICE void pinn_atomic_add_wg(float* p, float v) {
-    (void)__hip_atomic_fetch_add(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-}
-#else
-PINN_DEVICE void pinn_atomic_add_wg(float* p, float v) { *p += v; }
-#endif
-
 PINN_DEVICE f32x4 pinn_ld4(const float* p) { return *reinterpret_cast<const f32x4*>(p); }
 // the per-tile slabs of the WGX kernels are written once and read once, by another launch: streaming (non-temporal) accesses
 // (same-box A/B, MI355X: at width 256 -- 5.9 GB of slab per 131 072 points -- non-temporal stores and loads take 4.8 % off
@@ -957,9 +909,7 @@ PINN_DEVICE float pinn_bitsf(unsigned x) { return __builtin_bit_cast(float, x); 
 #ifndef PINN_SP_ROUND
 #define PINN_SP_ROUND 2         // 0: hi and mid by truncation; 1: mid rounded to nearest; 2: hi and mid rounded
 #endif
-#ifndef PINN_SP_NPROD
-#define PINN_SP_NPROD 6         // partial products per GEMM step: 6 (i + j <= 2) or all 9
-#endif
+#define PINN_SP_NPROD 6         // partial products per GEMM step: those with i + j <= 2 (all nine bought no accuracy: section 6b)
 // bit patterns whose UPPER halves are the three bf16 parts of x (b0: hi, b1: mid, b2: lo); x = hi + mid + lo exactly
 PINN_DEVICE void pinn_split3(float x, unsigned& b0, unsigned& b1, unsigned& b2) {
     if (PINN_ABL & 1) { b0 = b1 = b2 = pinn_fbits(x); return; }
@@ -1002,19 +952,12 @@ PINN_DEVICE f32x4 pinn_mfma_split6(const pinn_s16x8 (&a)[3], const pinn_s16x8 (&
 }
 // the four components of v summed over the 16 lanes of a DPP row, step-major (four independent adds per DPP step: a lone
 // chain pays two wait states between its dependent steps; pinn_port.h)
-#ifndef PINN_ROWSUM_BATCH
-#define PINN_ROWSUM_BATCH 0      // (measured on the tile kernels: no difference -- the second wave per SIMD already covers the wait states)
-#endif
+// (batching the four DPP chains step-major, pinn_row_sum16_n, measured no difference on the tile kernels: the second wave per SIMD
+//  already covers the wait states -- DESIGN.md section 6a)
 PINN_DEVICE f32x4 pinn_row_sum16_v4(f32x4 v) {
-#if PINN_ROWSUM_BATCH
-    float w[4] = {v[0], v[1], v[2], v[3]};
-    pinn_row_sum16_n<4>(w);
-    return f32x4{w[0], w[1], w[2], w[3]};
-#else
 #pragma unroll
     for (int r = 0; r < 4; ++r) v[r] = pinn_row_sum16(v[r]);
     return v;
-#endif
 }
 
 // VAR (experiment bits): 1 = accumulate dW in the partial buffer although the layer count is static, 2 = two waves per
@@ -1148,20 +1091,13 @@ pinn_tile_kernel(const PinnKArgs A) {
     // WTs[l][k][n] = W_l[n][k]: coalesced global reads along k, one-time strided LDS writes. ALL loads of a thread are
     // issued before the first LDS write (the registers are free here): the weights were last written by another
     // launch's Adam on other XCDs, so every batch of loads pays a full L2-miss round trip -- one instead of six or more
-    // (prologue phase counters: 9.4 K -> cycles of one round trip on cfg2). When one batch holds everything (PINN_WT_SPLIT),
-    // the LDS writes wait until the x-only pre-pass below is through: the round trip runs behind it.
+    // (prologue phase counters: 9.4 K -> cycles of one round trip on cfg2). (Holding the LDS writes back until the x-only pre-pass
+    // below is through, so that the round trip runs behind it, measured +0.8 % / +-0 with Adam in the loop: not kept.)
     constexpr int WT_TOTAL = (LHC > 0 ? LHC : 0) * HP * HP;
     constexpr int NTH_ALL = NTHREADS * TEAMS;               // both teams stage the shared copy together
     constexpr int WT_PER = (WT_TOTAL + NTH_ALL - 1) / NTH_ALL;
-#ifndef PINN_WT_STAGE_BATCH
-#define PINN_WT_STAGE_BATCH 64
-#endif
-#ifndef PINN_WT_SPLIT
-#define PINN_WT_SPLIT 0      // (measured with Adam in the loop: cfg2 +0.8 %, cfg4 +-0: the pre-pass does not cover more than the loads already overlapped)
-#endif
-    constexpr int WT_B = WT_PER < 1 ? 1 : (WT_PER < PINN_WT_STAGE_BATCH ? WT_PER : PINN_WT_STAGE_BATCH);
-    constexpr bool WT_SPLIT = WTL && PINN_WT_SPLIT && WT_PER >= 1 && WT_PER <= WT_B;
-    float wreg_split[WT_SPLIT ? WT_B : 1];
+    constexpr int WT_STAGE_BATCH = 64;                      // staging loads issued before the first LDS write
+    constexpr int WT_B = WT_PER < 1 ? 1 : (WT_PER < WT_STAGE_BATCH ? WT_PER : WT_STAGE_BATCH);
     auto wt_write = [&](int e0, const float* wreg) {
 #pragma unroll
         for (int e = 0; e < WT_B; ++e) {
@@ -1179,12 +1115,7 @@ pinn_tile_kernel(const PinnKArgs A) {
                 const int l = i / (HP * HP), n = (i / HP) % HP, k = i % HP;
                 wreg[e] = (i < WT_TOTAL) ? A.params[A.off_wh + (size_t)l * A.hidden_stride + n * HP + k] : 0.0f;
             }
-            if (WT_SPLIT) {
-#pragma unroll
-                for (int e = 0; e < WT_B; ++e) wreg_split[WT_SPLIT ? e : 0] = wreg[e];
-            } else {
-                wt_write(e0, wreg);
-            }
+            wt_write(e0, wreg);
         }
     }
     if (!SLABL && !TEAMS2) for (int i = tid; i < PINN_MAX_REGS * T; i += NTHREADS) padj[i] = 0.0f;   // (team blocks end before the program registers)
@@ -1225,10 +1156,9 @@ pinn_tile_kernel(const PinnKArgs A) {
 #ifndef PINN_REGB_MAX_SPEC
 #define PINN_REGB_MAX_SPEC 8
 #endif
-#ifndef PINN_REGB_V2
-#define PINN_REGB_V2 0      // register accumulators for the bias / first-layer gradients in the two-workgroups-per-CU kernels too
-#endif
-    constexpr bool REGB = !DWG && (PINN_REGB_V2 || !(VAR & (2 | 256))) && (S * MT * NTW <= (SPEC != 0 ? PINN_REGB_MAX_SPEC : PINN_REGB_MAX));
+    // (register accumulators for the bias / first-layer gradients in the two-streams-per-CU kernels as well: 80-160 B per lane of
+    //  scratch, slower -- DESIGN.md section 6a)
+    constexpr bool REGB = !DWG && !(VAR & (2 | 256)) && (S * MT * NTW <= (SPEC != 0 ? PINN_REGB_MAX_SPEC : PINN_REGB_MAX));
     // (two workgroups per CU live on 256 registers: accumulators for the layers that exist and two input columns only)
     constexpr int W1R = (VAR & (2 | 256)) ? 2 : 4;
     constexpr int NBR = (VAR & (2 | 256)) && LHC >= 0 ? LHC + 1 : PINN_LHMAX + 1;
@@ -1298,15 +1228,8 @@ pinn_tile_kernel(const PinnKArgs A) {
 #ifndef PINN_SP_PIPE_W
 #define PINN_SP_PIPE_W PINN_SP_PIPE     // ... of the weight-gradient GEMM
 #endif
-#ifndef PINN_SP_FRONT
-#define PINN_SP_FRONT 0         // K > 0: the prefetch reads of a step K at a time behind its FIRST MFMAs (pinn_sched_front) instead of spread evenly
-#endif
-#ifndef PINN_SP_G
 #define PINN_SP_G 2             // (row tile, stream) rows per step of the forward / data-gradient GEMMs
-#endif
-#ifndef PINN_SP_OG
 #define PINN_SP_OG 2            // output tile rows per step of the weight-gradient GEMM
-#endif
     auto sp_gemm = [&](const float* bbuf, const pinn_s16x8 (&w)[SPK][3], f32x4 (&out)[NTW][MT][S]) {
         constexpr int NR = MT * S, G = (NR % PINN_SP_G == 0) ? PINN_SP_G : 1, NG = NR / G, STEPS = C::SP_KB * NG;
         constexpr int NB = PINN_SP_PIPE ? 2 : 1;
@@ -1335,10 +1258,7 @@ pinn_tile_kernel(const PinnKArgs A) {
                     const int r = g0 + i;
                     out[0][r / S][r % S] = pinn_mfma16_bf16(w[SPK > 1 ? kb : 0][pa[t]], bf[step % NB][i][pb[t]], out[0][r / S][r % S]);
                 }
-            if (PINN_SP_PIPE && step + 1 < STEPS) {
-                if (PINN_SP_FRONT) pinn_sched_front<6 * G, 3 * G, PINN_SP_FRONT ? PINN_SP_FRONT : 1>();
-                else pinn_sched_interleave<6 * G, 3 * G>();
-            }
+            if (PINN_SP_PIPE && step + 1 < STEPS) pinn_sched_interleave<6 * G, 3 * G>();
             PINN_SCHED_BARRIER();
         }
     };
@@ -1417,18 +1337,13 @@ pinn_tile_kernel(const PinnKArgs A) {
         // NTHREADS / T tiles per sweep; the rows land in A.aux and are read back (by the point-stage threads of the same
         // workgroup, hence the fence + the barrier below) at the top of each tile
         // (its registers live in the activation buffers, which nothing uses before the first tile, whenever they fit)
-#ifdef PINN_PREPASS_PRIVATE
-        float* pp_regs = nullptr;               // A/B builds: registers in private memory as before
-#else
         float* pp_regs = (A.pre_nregs * NTHREADS <= C::O_NET - C::O_BUFA) ? smem + C::O_BUFA + tid : nullptr;
-#endif
         for (long long tile = A.tile_begin + vbid + (long long)(tid / T) * vnblk; tile < ntiles; tile += (long long)(NTHREADS / T) * vnblk) {
             const long long gi = tile * T + tid % T;
             if (gi < A.n_points) pinn_prepass_point(A.pre, A.xs + gi * d, d, A.aux, A.n_points, gi, pp_regs, NTHREADS);
         }
         PINN_FENCE_BLOCK();
     }
-    if (WT_SPLIT && train) wt_write(0, wreg_split);
     fetch_points(A.tile_begin + vbid);
     store_points(xs_base);
     fetch_points(A.tile_begin + vbid + vnblk);
@@ -1436,10 +1351,8 @@ pinn_tile_kernel(const PinnKArgs A) {
     PH_DECL
 
     int tile_parity = 0;
-#ifndef PINN_TEAM_SKEW
-#define PINN_TEAM_SKEW 0       // two-team kernels: team 1 runs one barrier behind team 0 (its vector phases then meet team 0's GEMM phases)
-#endif
-    if (TEAMS2 && PINN_TEAM_SKEW && team == 1) PINN_SYNC();
+    // (two-team kernels with team 1 running one barrier behind team 0, so that its vector phases meet team 0's GEMM phases:
+    //  cfg2 -3 %, cfg4 +5 % on the split kernels -- DESIGN.md section 6b; not kept)
     // barriers INSIDE the tile loop. Two-team kernels share nothing between the teams in there (each team its own LDS block and
     // slab; W^T / the split fragments are read-only), so a team's barrier need not hold the other team: PINN_TEAM_FLAGS replaces
     // s_barrier by an arrival counter in the team's LDS block and the teams drift apart -- one team's vector phases then run
@@ -1499,11 +1412,8 @@ pinn_tile_kernel(const PinnKArgs A) {
         };
         if (WPF && lh > 0) load_wall(A.params + A.off_wh);
         pinn_s16x8 wsf[SPK][3];       // split-bf16: forward weight fragments of the NEXT hidden layer, one phase ahead
-#ifndef PINN_SP_WPF
-#define PINN_SP_WPF 1           // split-bf16: forward weight fragments one phase ahead (0: fetched at the start of their GEMM)
-#endif
         if constexpr (SPLIT) {
-            if (PINN_SP_WPF) sp_weights(0, 0, wsf);
+            sp_weights(0, 0, wsf);
 #pragma unroll
             for (int j = 0; j < NTW; ++j) biasn[j] = pinn_ld4(A.params + A.off_wh + HP * HP + unit0(j));
         }
@@ -1590,24 +1500,16 @@ pinn_tile_kernel(const PinnKArgs A) {
                 if constexpr (SPW) {
                     sp_gemm_wide(cur, li, 0, acc);
                 } else {
-                    if (!PINN_SP_WPF) sp_weights(li, 0, wsf);
                     sp_gemm(cur, wsf, acc);
                 }
-#ifndef PINN_SP_FWD_BARRIER
-#define PINN_SP_FWD_BARRIER 0   // a barrier between a forward GEMM and its jet epilogue: with PINN_TEAM_SKEW the GEMM interval of one team then faces a vector interval of the other
-#endif
-                if (PINN_SP_FWD_BARRIER) tsync();
             } else {
                 // software pipeline over the K quads: the operands of quad q+1 are in flight while the S*MT*NTW*4 MFMAs
                 // of quad q issue, accumulators interleaved (an accumulator is re-used every S*MT*NTW issues, far
                 // beyond the 40-cycle dependent latency). sched_barrier pins that order (the register-pressured
                 // scheduler otherwise sinks every load next to its first use).
-                // (weights that come from global memory / L2 -- widths >= 128 -- may run PINN_W_AHEAD quads ahead instead of one:
-                //  20 MFMAs per quad at width 128 are 640 cycles, about one L2 round trip under load)
-#ifndef PINN_W_AHEAD
-#define PINN_W_AHEAD 1
-#endif
-                constexpr int WA = (!WPF && PINN_W_AHEAD > 1) ? PINN_W_AHEAD : 1;
+                // (WA: quads the weight fragments run ahead. Two or three for the weights that come from global memory / L2 -- widths
+                //  >= 128, 20 MFMAs per quad are about one L2 round trip -- measured +-0 / +1.4 %: DESIGN.md section 6a)
+                constexpr int WA = 1;
                 constexpr int NQF = HP / 16;
                 f32x4 wf[WA + 1][NTW], hf[2][MT][S];
                 auto load_w = [&](int q, f32x4 (&w)[NTW]) {
@@ -1655,7 +1557,7 @@ pinn_tile_kernel(const PinnKArgs A) {
             if (WPF && li + 1 < lh) load_wall(Wl + A.hidden_stride);
             if constexpr (SPLIT) {
                 if (li + 1 < lh) {
-                    if (PINN_SP_WPF) sp_weights(li + 1, 0, wsf);
+                    sp_weights(li + 1, 0, wsf);
 #pragma unroll
                     for (int j = 0; j < NTW; ++j) biasn[j] = pinn_ld4(Wl + A.hidden_stride + HP * HP + unit0(j));
                 }
@@ -2069,10 +1971,7 @@ pinn_tile_kernel(const PinnKArgs A) {
 #pragma unroll
                         for (int i = 0; i < OG; ++i)
                             dw[o0 + i][0] = pinn_mfma16_bf16(afr[step % NB][i][pa[t]], bfr[PINN_SP_PIPE_W ? kb : 0][pb[t]], dw[o0 + i][0]);
-                    if (PINN_SP_PIPE_W && step + 1 < STEPS) {
-                        if (PINN_SP_FRONT) pinn_sched_front<6 * OG, 6 * OG, PINN_SP_FRONT ? PINN_SP_FRONT : 1>();
-                        else pinn_sched_interleave<6 * OG, 6 * OG>();
-                    }
+                    if (PINN_SP_PIPE_W && step + 1 < STEPS) pinn_sched_interleave<6 * OG, 6 * OG>();
                     PINN_SCHED_BARRIER();
                 }
             } else if constexpr (!DWG) {
@@ -2116,7 +2015,7 @@ pinn_tile_kernel(const PinnKArgs A) {
 #pragma unroll
                         for (int j = 0; j < NTW; ++j)
 #pragma unroll
-                            for (int r = 0; r < 4; ++r) dwt[j][r] = PINN_EXP_WGRAD ? 0.0f : *dwg_ptr(li, o, j, r);
+                            for (int r = 0; r < 4; ++r) dwt[j][r] = *dwg_ptr(li, o, j, r);
 #pragma unroll
                         for (int ms = 0; ms < MT * S; ++ms) {
                             const int mt = ms / S, s = ms % S;
@@ -2131,21 +2030,15 @@ pinn_tile_kernel(const PinnKArgs A) {
 #pragma unroll
                         for (int j = 0; j < NTW; ++j)
 #pragma unroll
-                            for (int r = 0; r < 4; ++r) {
-                                if (PINN_EXP_WGRAD == 0 || PINN_EXP_WGRAD == 1) *dwg_ptr(li, o, j, r) = dwt[j][r];
-                                if (PINN_EXP_WGRAD == 3) pinn_atomic_add_wg(dwg_ptr(li, o, j, r), dwt[j][r]);
-                                if (PINN_EXP_WGRAD == 2 && dwt[j][r] == 12345.678f) *dwg_ptr(li, o, j, r) = dwt[j][r];
-                            }
+                            for (int r = 0; r < 4; ++r) *dwg_ptr(li, o, j, r) = dwt[j][r];
                     }
                 } else {
                     // accumulators in the workgroup's partial buffer (any depth, any width): OB output tile rows at a time --
                     // OB independent MFMA chains per B fragment (a lone chain stalls on its own 8-pass latency), the tiles of
                     // the NEXT block fetched from the partial buffer (L2) while this block computes, the LDS operands of the
                     // next (mt, s) row tile read between the MFMAs of the current one
-    #ifndef PINN_OB_CHAINS
-#define PINN_OB_CHAINS 4
-#endif
-                constexpr int OB = (NTW >= PINN_OB_CHAINS) ? 1 : ((PINN_OB_CHAINS / NTW < NT) ? PINN_OB_CHAINS / NTW : NT);   // OB * NTW chains
+                constexpr int OB_CHAINS = 4;
+                constexpr int OB = (NTW >= OB_CHAINS) ? 1 : ((OB_CHAINS / NTW < NT) ? OB_CHAINS / NTW : NT);   // OB * NTW chains
                     f32x4 dwn[OB][NTW];
                     auto load_dw = [&](int ob, f32x4 (&dst)[OB][NTW]) {
 #pragma unroll
@@ -2213,7 +2106,7 @@ pinn_tile_kernel(const PinnKArgs A) {
                 if constexpr (SPW) sp_gemm_wide(nxt, li, 1, g);
                 else sp_gemm(nxt, wsb, g);
             } else {
-                constexpr int WAD = (WTG && PINN_W_AHEAD > 1) ? PINN_W_AHEAD : 1;     // (global weights: quads ahead, see the forward GEMM)
+                constexpr int WAD = 1;                     // (quads the weight fragments run ahead, see the forward GEMM)
                 constexpr int NQD = HP / 16;
                 float wq[WAD + 1][NTW][4];
                 f32x4 gf[2][MT][S];
@@ -2327,7 +2220,6 @@ pinn_tile_kernel(const PinnKArgs A) {
     }
     if (TEAM_FLAGS) PINN_SYNC();       // (the arrival counter shares its LDS slot with `scal`, written below)
     PH_FLUSH
-    if (TEAMS2 && PINN_TEAM_SKEW && team == 0) PINN_SYNC();
 
     if (!train) return;
     if (REGB) {

@@ -157,24 +157,6 @@ PINN_DEVICE void pinn_sched_interleave() {
     if (N_MFMA - USED > 0) __builtin_amdgcn_sched_group_barrier(0x008, N_MFMA - USED > 0 ? N_MFMA - USED : 1, 0);
 #endif
 }
-// N_MEM reads in the shadow of the FIRST MFMAs of the region, K reads behind each of them, then the remaining MFMAs: a prefetch
-// spread evenly over the region (pinn_sched_interleave) issues its last reads right in front of the wait that opens the next region
-template <int N_MFMA, int N_MEM, int K>
-PINN_DEVICE void pinn_sched_front(){
-#if PINN_SCHED_IL
-    constexpr int FULL = N_MEM / K, REST = N_MEM % K, SLOTS = FULL + (REST ? 1 : 0);
-#pragma unroll
-    for (int i = 0; i < FULL; ++i) {
-        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-        __builtin_amdgcn_sched_group_barrier(0x120, K, 0);
-    }
-    if constexpr (REST > 0) {
-        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-        __builtin_amdgcn_sched_group_barrier(0x120, REST, 0);
-    }
-    if (N_MFMA - SLOTS > 0) __builtin_amdgcn_sched_group_barrier(0x008, N_MFMA - SLOTS > 0 ? N_MFMA - SLOTS : 1, 0);
-#endif
-}
 // issue order inside one scheduling region: the next N_DS LDS reads FIRST, then N_MFMA matrix instructions (a fragment
 // prefetch must start its round trip before the MFMAs it hides behind; left alone the scheduler sinks it to the end of the
 // region, right in front of its first use)

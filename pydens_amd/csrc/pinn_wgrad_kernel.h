@@ -25,9 +25,7 @@ struct PinnWgCfg {
     using C = PinnCfg<HP, ND, N2, MT>;
     static constexpr bool SPLIT = SPLIT_;
     static constexpr int S = C::S, NW = C::NW, NTW = C::NTW, NTHREADS = C::NTHREADS;
-#ifndef PINN_WG_SKIP_NW_ASSERT      // (timing experiments on the tile kernel alone: -DPINN_NW_MAX=4 builds, wrong weight gradients)
     static_assert(NW == 8, "the streamed weight-gradient kernel is built for the 8-wave widths (HP >= 128)");
-#endif
     static constexpr int KC = 16;                    // K rows per stage: the 16 points of one (tile, mt, stream)
     static constexpr int LDK = KC + 4;               // row stride of the unit-major operand buffers: rows 4 units apart land
                                                      // 16 banks apart (ds_write_b32 of lanes lq, lq + 1), b128 rows stay aligned
@@ -297,11 +295,8 @@ pinn_wgrad_kernel(const PinnKArgs A) {
                 }
             }
         } else {
-#ifndef PINN_WG_PF
-#define PINN_WG_PF 1          // stages the HBM loads run ahead of the MFMAs (1: one register set, 2: two -- measured 1-5 %
-                              // SLOWER on MI355X: the loads are not what the waves wait for)
-#endif
-#if PINN_WG_PF == 1
+        // (the HBM loads of stage i + 1 run during the MFMAs of stage i, one register set. Two sets with the loads two stages ahead
+        //  measured 1-5 % SLOWER on MI355X: the loads are not what the waves wait for -- DESIGN.md section 6a)
         f32x4 gzr[NTW], svr[NTW], hv[NTW];
         int p = 0;
         if (t_first < A.tile_end) {
@@ -331,55 +326,6 @@ pinn_wgrad_kernel(const PinnKArgs A) {
                 }
             }
         }
-#else
-        // Two register sets: while stage i computes from LDS buffer i & 1, the operands of stage i + 1 (loaded during
-        // stage i - 1) are turned into buffer (i + 1) & 1 and those of stage i + 2 are requested from HBM -- a load has
-        // two stage times (about 16 K cycles at width 256) to arrive; with one set it had one, and under the load of 256
-        // workgroups streaming at once that was not always enough (the waves sat in s_waitcnt vmcnt for a quarter of
-        // the kernel) -- that was the hypothesis; measured, the second set costs more than it hides. Stage parity must be a compile-time fact (it selects registers): U groups of S stages are
-        // unrolled so that U * S is even.
-        constexpr int U = (S % 2 == 0) ? 1 : 2;
-        long long n_tiles_wg = 0;
-        if (t_first < A.tile_end) n_tiles_wg = (A.tile_end - t_first + t_step - 1) / t_step;
-        const long long n_stages = n_tiles_wg * MT * S;
-        auto stage_pos = [&](long long j, long long& tile, int& mt) {
-            const long long g = j / S;
-            tile = t_first + (g / MT) * t_step;
-            mt = (int)(g % MT);
-        };
-        f32x4 gz0[NTW], sv0[NTW], gz1[NTW], sv1[NTW], hv[NTW];
-        if (n_stages > 0) {
-            load_raw(t_first, 0, 0, gz0, sv0);
-            if (n_stages > 1) {
-                long long t1; int m1;
-                stage_pos(1, t1, m1);
-                load_raw(t1, m1, 1 % S, gz1, sv1);
-            }
-            transform(0, sv0, hv);
-            write_stage(smem, gz0, hv);
-        }
-        PINN_SYNC();
-        for (long long i0 = 0; i0 < n_stages; i0 += U * S) {
-#pragma unroll
-            for (int u = 0; u < U * S; ++u) {
-                const long long i = i0 + u;
-                if (i < n_stages) {
-                    const int s1 = (u + 1) % S, s2 = (u + 2) % S;       // streams of stages i + 1, i + 2 (compile time)
-                    if (i + 2 < n_stages) {
-                        long long t2; int m2;
-                        stage_pos(i + 2, t2, m2);
-                        if (u % 2 == 0) load_raw(t2, m2, s2, gz0, sv0); else load_raw(t2, m2, s2, gz1, sv1);
-                    }
-                    mfma_stage(smem + (u % 2) * 2 * OPER);
-                    if (i + 1 < n_stages) {
-                        if (u % 2 == 0) { transform(s1, sv1, hv); write_stage(smem + 2 * OPER, gz1, hv); }
-                        else { transform(s1, sv0, hv); write_stage(smem, gz0, hv); }
-                    }
-                    PINN_SYNC();
-                }
-            }
-        }
-#endif
         }
         // this workgroup's dW_li: D[(l >> 4) * 4 + r][l & 15] of tile (i, jn) -> row (out) m0 + 16 i + 4 lq + r, column (in) n0 + 16 jn + lr
         float* dst = part + A.off_wh + (size_t)li * A.hidden_stride;

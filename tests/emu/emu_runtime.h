@@ -92,6 +92,5 @@ static inline float pinn_rcp(float x) { return 1.0f / x; }
 #define PINN_SCHED_IL 0
 template <int N_MFMA, int N_MEM> static inline void pinn_sched_interleave() {}
 template <int N_DS, int N_MFMA> static inline void pinn_sched_reads_first() {}
-template <int N_MFMA, int N_MEM, int K> static inline void pinn_sched_front() {}
 #define PINN_INLINE_LAMBDA
 #define PINN_SETPRIO(n)

@@ -45,14 +45,13 @@ def test_chain_kernel_matches_the_oracle(chain_lib, name, n):
 
 
 def test_experiment_build_knobs_keep_parity():
-    """ the measured-and-rejected build options of the tile kernel (batched DPP row sums, weight
-    fragments two K quads ahead, W^T staging split around the pre-pass) change the order of nothing that is summed: the
-    step equals the default build's (and the oracle's loss) """
+    """ the measured-and-rejected build options that are still in the tree (team-local LDS arrival counters
+    instead of s_barrier in the two-team kernels; section 6a: no prefetch of the saved jets) change the order of nothing that is summed: the step equals the default build's (and the oracle's loss) """
     import build_emu
     import pydens_amd as pa
     from pydens_amd import engine
     from oracle import pinn_oracle as po
-    knobs = build_emu.build(extra_flags=['-DPINN_ROWSUM_BATCH=1', '-DPINN_W_AHEAD=2', '-DPINN_WT_SPLIT=1'], tag='knobs',
+    knobs = build_emu.build(extra_flags=['-DPINN_TEAM_FLAGS=3', '-DPINN_SVPF_MAX=0'], tag='knobs',
                             widths=(64, 128))
     libs = [engine.bind(ctypes.CDLL(build_emu.build())), engine.bind(ctypes.CDLL(knobs))]
     for name, n in (('cfg2', 70), ('cfg3', 40)):
