@@ -1033,8 +1033,10 @@ pinn_tile_kernel(const PinnKArgs A) {
     // activation of index a (0: first layer ... lh: last hidden layer)
     // (plain instantiations only know tanh / sigmoid -- one bit, which lets the compiler drop the sin / identity paths;
     //  the full set runs on the VAR 8 instantiations, see the launcher)
+    // (VAR 8 | 1024: skip connections over Tanh / Sigmoid layers only -- the usual residual PINN -- keep the one-bit code: with the
+    //  sin / softplus / SiLU / GELU paths compiled in, the width-128 breadth kernel spills 283 registers and runs 8 % slower)
     auto act_at = [&](int a) -> int {
-        return (ACTC >= 0) ? ACTC : (int)((A.act_codes >> (4 * a)) & (SKIPS ? 15ull : 1ull));
+        return (ACTC >= 0) ? ACTC : (int)((A.act_codes >> (4 * a)) & ((SKIPS && !(VAR & 1024)) ? 15ull : 1ull));
     };
     // skip connection ending / starting at activation a (or -1); slab slot of skip k
     auto skip_into = [&](int a) -> int {

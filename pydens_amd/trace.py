@@ -581,6 +581,48 @@ def _affine(node, spec, memo):
     return out
 
 
+def _second_order_split(node, spec, memo):
+    """ node as  sum_k c_k * (second-order stream k) + REST  with CONSTANT c_k and REST free of second-order streams:
+    returns ({stream index: float}, REST Sym) or None (a second derivative inside a nonlinear term or under a non-constant
+    factor). What a residual PROGRAM needs in order to run on ONE combined second-order stream (reaction-diffusion, nonlinear
+    Poisson / Helmholtz, Allen-Cahn, viscous Burgers in several space dimensions: the Laplacian part is linear, the rest is not). """
+    key = id(node)
+    if key in memo:
+        return memo[key]
+    first2 = 1 + spec.nd
+    out = None
+    if node.kind == 'stream':
+        if node.alpha not in spec.index:
+            raise TraceUnsupported(f'stream {node.alpha} not in {spec}')
+        idx = spec.index[node.alpha]
+        out = ({idx: 1.0}, Sym('const', value=0.0)) if idx >= first2 else ({}, node)
+    elif node.kind in ('input', 'const', 'var'):
+        out = ({}, node)
+    else:
+        parts = [_second_order_split(a, spec, memo) for a in node.args]
+        if all(p is not None for p in parts):
+            if all(not p[0] for p in parts):
+                out = ({}, node)                                   # no second-order stream below: opaque
+            elif node.op in ('ADD', 'SUB'):
+                (ca, fa), (cb, fb) = parts
+                sign = 1.0 if node.op == 'ADD' else -1.0
+                coefs = dict(ca)
+                for k, v in cb.items():
+                    coefs[k] = coefs.get(k, 0.0) + sign * v
+                out = (coefs, _s_add(fa, fb) if sign > 0 else _s_sub(fa, fb))
+            elif node.op == 'NEG':
+                out = ({k: -v for k, v in parts[0][0].items()}, _s_sub(Sym('const', value=0.0), parts[0][1]))
+            elif node.op == 'MUL' and any(a.kind == 'const' for a in node.args):
+                ci = 0 if node.args[0].kind == 'const' else 1
+                scale, lin = float(node.args[ci].value), parts[1 - ci]
+                out = ({k: v * scale for k, v in lin[0].items()}, _s_mul(Sym('const', value=scale), lin[1]))
+            elif node.op == 'DIV' and node.args[1].kind == 'const' and float(node.args[1].value) != 0.0:
+                scale = 1.0 / float(node.args[1].value)
+                out = ({k: v * scale for k, v in parts[0][0].items()}, _s_mul(Sym('const', value=scale), parts[0][1]))
+    memo[key] = out
+    return out
+
+
 class ResidualPlan:
     """ host-side description of a lowered residual (see pinn_residual_t in include/pinn.h). """
     def __init__(self, kind, n_inputs, n_streams, pre, n_aux, program=None, coef=None, coef_row=None, src_const=0.0,
@@ -757,7 +799,19 @@ def lower_residual(root, spec, n_inputs, ic_root=None):
         plan._pre_emitter, plan._rows = (pre, pre_leaf), rows
         return plan
 
-    # general program: maximal x-only sub-expressions (with at least one op) become pre-pass rows
+    # general program. If its second derivatives enter only as a constant-weighted sum (the Laplacian part of a nonlinear equation),
+    # the kernels propagate that ONE combined stream -- layout [u, firsts (nd), combined], as for affine residuals -- and the
+    # program reads it as a register of its own
+    comb_w = None
+    if spec.n2 >= 2 and spec.n3 == 0 and spec.nd <= MAX_DIRS:
+        split = _second_order_split(root, spec, {})
+        if split is not None:
+            weights = [float(split[0].get(1 + spec.nd + k, 0.0)) if k < spec.n2 else 0.0 for k in range(spec.nd)]
+            if sum(1 for w in weights if w != 0.0) >= 2:
+                comb_w = weights
+                root = _s_add(Sym('stream', alpha=('comb',)), split[1])
+                S = spec.nd + 2
+    # maximal x-only sub-expressions (with at least one op) become pre-pass rows
     uses = {}
     aux_of = {}
 
@@ -774,7 +828,7 @@ def lower_residual(root, spec, n_inputs, ic_root=None):
         # the callable IC joins the pre-pass BEFORE the program numbers its registers (they start behind the rows)
         saved = (list(pre.code), list(pre.consts), dict(pre.memo), dict(pre._cidx), list(rows))
         try:
-            ic_row, ic_const = _emit_ic_rows(pre, pre_leaf, rows, spec, ic_root, None)
+            ic_row, ic_const = _emit_ic_rows(pre, pre_leaf, rows, spec, ic_root, comb_w)
         except TraceUnsupported:
             pre.code[:], pre.consts[:] = saved[0], saved[1]
             pre.memo.clear(); pre.memo.update(saved[2])
@@ -802,8 +856,12 @@ def lower_residual(root, spec, n_inputs, ic_root=None):
         if node.kind == 'var':
             return S + n_inputs + n_aux + node.col
         if node.kind == 'stream':
+            if node.alpha == ('comb',):
+                return 1 + spec.nd
             if node.alpha not in spec.index:
                 raise TraceUnsupported(f'stream {node.alpha} not in {spec}')
+            if comb_w is not None and spec.index[node.alpha] > spec.nd:
+                raise TraceUnsupported('internal: second-order stream beside the combined one')
             return spec.index[node.alpha]
         return S + node.col if node.kind == 'input' else None
 
@@ -813,6 +871,7 @@ def lower_residual(root, spec, n_inputs, ic_root=None):
     plan = ResidualPlan(RES_PROGRAM, n_inputs, S, pre.finish(), n_aux, program=(main.code, main.consts), n_vars=n_vars)
     plan._pre_emitter, plan._rows = (pre, pre_leaf), rows
     plan.ic_row, plan.ic_const = ic_row, ic_const
+    plan.comb_w = comb_w
     return plan
 
 

@@ -882,6 +882,54 @@ def _direction_groups_case(pa, which, solver_kwargs):
         assert params_close(got, want, 1e-4, atol=1e-5)
 
 
+@pytest.mark.parametrize('which', ['reaction_2d', 'allen_cahn', 'not_combinable'])
+def test_residual_programs_run_on_one_combined_second_order_stream(pa, emu_lib, which):
+    _combined_program_case(pa, which, emu_kwargs(emu_lib))
+
+
+def _combined_program_case(pa, which, solver_kwargs):
+    """ a NON-affine equation whose second derivatives enter only as a constant-weighted sum (nonlinear Poisson / reaction-diffusion /
+    Allen-Cahn: the Laplacian part is linear, the rest is not) is lowered to a residual program over [u, firsts, ONE combined
+    second-order stream] -- S = nd + 2 instead of 1 + nd + n2 streams through every GEMM (trace._second_order_split); a second
+    derivative under a non-constant factor keeps the separate streams. The reference evaluates the callable as written
+    (model_torch.py:447); the oracle's trajectory is the reference. """
+    from oracle import pinn_oracle as po
+
+    def problem(D, V):
+        if which == 'reaction_2d':
+            def eq(f, x, y):
+                k = V('k', data=torch.Tensor([1.5]))
+                return 0.5 * D(D(f, x), x) + D(D(f, y), y) * 2 + k * f * f - torch.sin(np.pi * (x + y))
+            return eq, dict(ndims=2, boundary_condition=1)
+        if which == 'allen_cahn':
+            eq = lambda f, x, y, t: D(f, t) - 0.01 * (D(D(f, x), x) + D(D(f, y), y)) + f * f * f - f
+            return eq, dict(ndims=3, boundary_condition=0.0, initial_condition=lambda x, y: torch.sin(np.pi * x) * y * (1 - y))
+        eq = lambda f, x, y: f * D(D(f, x), x) + D(D(f, y), y) - 1.0          # u u_xx: not a constant weight
+        return eq, dict(ndims=2, boundary_condition=1)
+    net = dict(layout='fa fa fa f', features=[24, 24, 24, 1], activation='Tanh')
+    eq_o, kw = problem(po.D, po.V)
+    oracle = po.OracleSolver(eq_o, **kw, **net)
+    eq_p, kw = problem(pa.D, pa.V)
+    solver = pa.Solver(eq_p, **kw, **net, **solver_kwargs)
+    plan, nd = solver.residual_plan, solver.spec.nd
+    assert solver.program is not None, solver.program_error
+    if which == 'not_combinable':
+        assert plan.comb_w is None and plan.n_streams == solver.spec.n_streams
+    else:
+        assert plan.kind == 0 and plan.n_streams == nd + 2                       # PINN_RES_PROGRAM on [u, firsts, combined]
+        assert plan.comb_w == ([0.5, 2.0] if which == 'reaction_2d' else [-0.01, -0.01, 0.0])
+    load_params(solver, oracle.export_params())
+    pts = np.random.RandomState(3).rand(3, 40, kw['ndims']).astype(np.float32)
+    solver.fit(niters=3, batch_size=40, sampler=FixedBatches(pts), lr=0.01)
+    oracle.fit(niters=3, batch_size=40, points=pts, lr=0.01)
+    assert solver.last_fit_path == 'fused'
+    np.testing.assert_allclose([float(v) for v in solver.losses], [float(v) for v in oracle.losses], rtol=2e-5)
+    for got, want in zip(export_params(solver), oracle.export_params()):
+        assert params_close(got, want, 2e-5)
+    if which == 'reaction_2d':
+        assert abs(float(solver.model.k.detach()) - float(oracle.model.k.detach())) < 1e-5
+
+
 def test_chunked_fit_equals_the_per_iteration_loop(pa, emu_lib):
     """ Solver.fit on the common path -- device sampler, one equation term, Adam -- enqueues chunks of iterations through ONE
     library call (pinn_fit_steps; reference loop model_torch.py:426-464). Same Philox batches, same Adam steps, same loss

@@ -735,6 +735,12 @@ def test_known_answers_of_the_tutorial(pa):
     assert abs(v - 2.0) < 0.05 and err < 0.1, (v, err)              # (reference: V = 1.997 .. 2.004, error 0.006 .. 0.02)
 
 
+@pytest.mark.parametrize('which', ['reaction_2d', 'allen_cahn', 'not_combinable'])
+def test_residual_programs_on_one_combined_stream_on_the_gpu(pa, which):
+    import test_emu_engine as te
+    te._combined_program_case(pa, which, {})
+
+
 @pytest.mark.parametrize('which', ['two_third_order_columns', 'third_beside_second'])
 def test_third_order_direction_groups_on_the_gpu(pa, which):
     """ equations with more third-order content than one kernel call carries: generic path, one call per third-order column """
