@@ -100,7 +100,7 @@ class StreamSpec:
             self.single_call = (self.nd <= 3 and not (self.nd == 3 and self.n2 == 3 and hp == 256)) or \
                                (self.nd == 4 and self.n2 == 0)
         # ... or as [u, firsts, one combined second-order stream] (affine residuals only)
-        self.combinable = self.nd <= MAX_DIRS and self.n2 >= 2 and self.n3 == 0
+        self.combinable = 2 <= self.nd <= MAX_DIRS and self.n2 >= 1 and self.n3 == 0
         # groups for the generic path: (direction codes, packed n2 of the group, stream index of each of the group's streams)
         self.groups = []
         if self.single_call:
@@ -650,17 +650,24 @@ class ResidualPlan:
                               ic_row=self.ic_row, ic_const=self.ic_const)
 
 
+def _worth_combining(weights, spec):
+    nonzero = sum(1 for w in weights if w != 0.0)
+    return nonzero >= 2 or (nonzero == 1 and spec.n2 < spec.nd)
+
+
 def combine_second_order(plan, spec):
     """ Affine residual whose second derivatives enter only as  sum_k c_k u_kk  with CONSTANT c_k (Laplacian, wave,
     heat operators): propagate that one combination instead of n2 separate streams. Rewrites the plan in place to the
     stream layout [u, firsts (nd), combined] and returns True; otherwise leaves it alone. """
-    if plan.kind != RES_AFFINE or spec.n2 < 2 or spec.n3 > 0 or spec.nd > MAX_DIRS or plan.comb_w is not None:
+    if plan.kind != RES_AFFINE or spec.n2 < 1 or spec.nd < 2 or spec.n3 > 0 or spec.nd > MAX_DIRS or plan.comb_w is not None:
         return False
     first2 = 1 + spec.nd
     if any(plan.coef_row[first2 + k] >= 0 for k in range(spec.n2)):
         return False                                   # x-dependent coefficient on a second derivative
     weights = [plan.coef[first2 + k] if k < spec.n2 else 0.0 for k in range(spec.nd)]
-    if sum(1 for w in weights if w != 0.0) < 2:
+    # (ONE second derivative beside first-order directions -- u_t = nu u_xx, advection-diffusion in (x, t) -- combines as well: the
+    #  kernels are built for n2 = 0 / nd second-order streams per call, so (nd, 1) would otherwise run padded to the next size)
+    if not _worth_combining(weights, spec):
         return False
     plan.coef = plan.coef[:first2] + [1.0]
     plan.coef_row = plan.coef_row[:first2] + [-1]
@@ -803,11 +810,11 @@ def lower_residual(root, spec, n_inputs, ic_root=None):
     # the kernels propagate that ONE combined stream -- layout [u, firsts (nd), combined], as for affine residuals -- and the
     # program reads it as a register of its own
     comb_w = None
-    if spec.n2 >= 2 and spec.n3 == 0 and spec.nd <= MAX_DIRS:
+    if spec.n2 >= 1 and spec.nd >= 2 and spec.n3 == 0 and spec.nd <= MAX_DIRS:
         split = _second_order_split(root, spec, {})
         if split is not None:
             weights = [float(split[0].get(1 + spec.nd + k, 0.0)) if k < spec.n2 else 0.0 for k in range(spec.nd)]
-            if sum(1 for w in weights if w != 0.0) >= 2:
+            if _worth_combining(weights, spec):
                 comb_w = weights
                 root = _s_add(Sym('stream', alpha=('comb',)), split[1])
                 S = spec.nd + 2

@@ -184,13 +184,28 @@ def test_second_derivatives_are_combined_into_one_stream_when_possible():
     spec, plan = lower(lambda f, x, y, t: D(D(f, x), x) + D(D(f, y), y) - D(f, t), 3)      # heat: t has no second derivative
     assert trace.combine_second_order(plan, spec) and plan.comb_w == [1.0, 1.0, 0.0]
     assert plan.coef == [0.0, 0.0, 0.0, -1.0, 1.0]
-    # not combinable: x-dependent coefficient on a second derivative, a single second derivative, nonlinear residuals
+    # ONE second derivative beside a first-order direction (u_t = u_xx): the kernels carry n2 = 0 or nd second-order streams per call,
+    # so the combined form [u, u_x, u_t, 1 * u_xx] saves the padding stream
+    spec, plan = lower(lambda f, x, t: D(f, t) - D(D(f, x), x), 2)
+    assert trace.combine_second_order(plan, spec) and plan.comb_w == [-1.0, 0.0] and plan.n_streams == 4
+    # not combinable: x-dependent coefficient on a second derivative, the only direction's second derivative, products of them
     spec, plan = lower(lambda f, x, y: (1 + x) * D(D(f, x), x) + D(D(f, y), y), 2)
     assert not trace.combine_second_order(plan, spec)
-    spec, plan = lower(lambda f, x, t: D(f, t) - D(D(f, x), x), 2)
+    spec, plan = lower(lambda f, x: D(D(f, x), x) - f, 1)
     assert not trace.combine_second_order(plan, spec)
     spec, plan = lower(lambda f, x, y: D(D(f, x), x) * D(D(f, y), y) - 1, 2)
-    assert not trace.combine_second_order(plan, spec)
+    assert not trace.combine_second_order(plan, spec) and plan.comb_w is None
+    # residual PROGRAMS whose second derivatives enter as a constant-weighted sum are lowered onto the combined stream directly
+    spec, plan = lower(lambda f, x, y: 2 * D(D(f, x), x) + D(D(f, y), y) / 4 + f * f * D(f, x) - torch.cos(x), 2)
+    assert plan.kind == trace.RES_PROGRAM and plan.comb_w == [2.0, 0.25] and plan.n_streams == 4
+    rng = np.random.RandomState(5)
+    streams, xs = rng.rand(spec.n_streams, 7), rng.rand(7, 2)
+    want = (2 * streams[spec.index[(0, 0)]] + streams[spec.index[(1, 1)]] / 4 + streams[0] ** 2 * streams[spec.index[(0,)]] - np.cos(xs[:, 0]))
+    np.testing.assert_allclose(trace.run_residual_numpy(plan, streams, xs), want, rtol=1e-6)
+    spec, plan = lower(lambda f, x, t: D(f, t) + f * D(f, x) - 0.01 * D(D(f, x), x), 2)         # viscous Burgers
+    assert plan.kind == trace.RES_PROGRAM and plan.comb_w == [-0.01, 0.0] and plan.n_streams == 4
+    spec, plan = lower(lambda f, x, y: f * D(D(f, x), x) + D(D(f, y), y), 2)                      # u u_xx: separate streams stay
+    assert plan.kind == trace.RES_PROGRAM and plan.comb_w is None and plan.n_streams == 5
     # the combined plan still reproduces the callable from the caller's (uncombined) streams
     eq = lambda f, x, t: D(D(f, t), t) - 4 * D(D(f, x), x) + 3 * D(f, x) - torch.cos(x * t)
     spec, plan = lower(eq, 2)
