@@ -52,7 +52,7 @@ extern "C" {
 #define PINN_MAX_VARS     8    /* trainable V(...) scalars a residual program may read (user slots 0..n_vars-1) */
 
 #define PINN_MAX_SKIPS    4    /* skip connections ('R ... +') per net */
-#define PINN_SKIP_PRE     0x100 /* ORed into skip_dst[k]: the skip ends IN FRONT of that activation ('faR fa f+ a') */
+#define PINN_SKIP_PRE     0x100 /* ORed into skip_dst[k] / skip_src[k]: the skip ends / starts IN FRONT of that activation */
 
 #define PINN_ACT_TANH     0
 #define PINN_ACT_SIGMOID  1
@@ -152,7 +152,8 @@ int pinn_create(const int* layer_dims, int n_layers, int act, int ndims, int npa
  * (PINN_ACT_*).  Skip k adds the output of activation skip_src[k] to the output of activation skip_dst[k]
  * (0 <= src < dst <= n_layers-2, equal widths, intervals not overlapping: dst[k] <= src[k+1]) -- or, with
  * PINN_SKIP_PRE ORed into skip_dst[k], to the pre-activation of hidden layer dst ('+' between 'f' and 'a': the
- * usual residual block act(W h + skip)). */
+ * usual residual block act(W h + skip)); with PINN_SKIP_PRE ORed into skip_src[k] the PRE-activation of layer src is what
+ * the skip carries ('R' between 'f' and 'a': pre-activation residual blocks). */
 int pinn_create_ex(const int* layer_dims, int n_layers, const int* acts, int n_skips, const int* skip_src,
                    const int* skip_dst, int ndims, int nparams, int has_bc, int has_ic, const float* dom_lo,
                    const float* dom_hi, float bc_value, pinn_t** out);

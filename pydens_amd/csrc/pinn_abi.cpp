@@ -63,7 +63,7 @@ struct pinn_net {
     pinn_layout_t lay;
     int n_layers, act, ndims, nparams, has_bc, has_ic, nsp;      // act: uniform activation code or -1
     unsigned long long act_codes;                                 // 4 bits per activation index
-    int n_skips, skip_src[PINN_MAX_SKIPS], skip_dst[PINN_MAX_SKIPS], skip_pre;
+    int n_skips, skip_src[PINN_MAX_SKIPS], skip_dst[PINN_MAX_SKIPS], skip_pre, skip_src_pre;
     int dims[PINN_MAX_LAYERS + 1];
     float lo[PINN_MAX_INPUTS], hi[PINN_MAX_INPUTS], bc_value;
     int n_cu;
@@ -167,6 +167,7 @@ int make_plan(const pinn_net* net, int64_t n_points, int nd, int n2, Plan* plan,
         probe.act_codes = net->act_codes;
         probe.n_skips = net->n_skips;
         probe.skip_pre = net->skip_pre;
+        probe.skip_src_pre = net->skip_src_pre;
     }
     probe.gemm_mode = net->gemm_mode;
     probe.mode = mode;
@@ -225,6 +226,7 @@ void fill_args(const pinn_net* net, PinnKArgs* a, const float* params, const flo
     a->lh = L.lh; a->d = L.d; a->act = net->act; a->act_codes = net->act_codes;
     a->n_skips = net->n_skips;
     a->skip_pre = net->skip_pre;
+    a->skip_src_pre = net->skip_src_pre;
     for (int k = 0; k < PINN_MAX_SKIPS; ++k) { a->skip_src[k] = net->skip_src[k]; a->skip_dst[k] = net->skip_dst[k]; }
     a->off_b1 = L.off_b1; a->off_wh = L.off_wh; a->hidden_stride = L.hidden_stride; a->off_wl = L.off_wl;
     a->off_bl = L.off_bl; a->off_ls = L.off_log_scale; a->off_loss = L.off_loss;
@@ -427,15 +429,20 @@ int pinn_create_ex(const int* layer_dims, int n_layers, const int* acts, int n_s
         if (acts[a] < PINN_ACT_TANH || acts[a] > PINN_ACT_GELU) return fail("unknown activation code %d (activation %d)", acts[a], a);
     if (n_skips < 0 || n_skips > PINN_MAX_SKIPS || (n_skips > 0 && (!skip_src || !skip_dst)))
         return fail("n_skips=%d outside [0, %d]", n_skips, PINN_MAX_SKIPS);
-    int dst_of[PINN_MAX_SKIPS] = {0}, pre_mask = 0;
+    int dst_of[PINN_MAX_SKIPS] = {0}, src_of[PINN_MAX_SKIPS] = {0}, pre_mask = 0, src_pre_mask = 0;
     for (int k = 0; k < n_skips; ++k) {
         dst_of[k] = skip_dst[k] & ~PINN_SKIP_PRE;
+        src_of[k] = skip_src[k] & ~PINN_SKIP_PRE;
         if (skip_dst[k] & PINN_SKIP_PRE) pre_mask |= 1 << k;
-        if (skip_src[k] < 0 || skip_src[k] >= dst_of[k] || dst_of[k] > n_layers - 2)
-            return fail("skip %d: activations %d -> %d outside 0 <= src < dst <= %d", k, skip_src[k], dst_of[k], n_layers - 2);
-        if (layer_dims[skip_src[k] + 1] != layer_dims[dst_of[k] + 1])
-            return fail("skip %d joins widths %d and %d", k, layer_dims[skip_src[k] + 1], layer_dims[dst_of[k] + 1]);
-        if (k > 0 && dst_of[k - 1] > skip_src[k]) return fail("skip connections %d and %d overlap (nested skips are not supported)", k - 1, k);
+        if (skip_src[k] & PINN_SKIP_PRE) src_pre_mask |= 1 << k;
+        if (src_of[k] < 0 || src_of[k] >= dst_of[k] || dst_of[k] > n_layers - 2)
+            return fail("skip %d: activations %d -> %d outside 0 <= src < dst <= %d", k, src_of[k], dst_of[k], n_layers - 2);
+        if (layer_dims[src_of[k] + 1] != layer_dims[dst_of[k] + 1])
+            return fail("skip %d joins widths %d and %d", k, layer_dims[src_of[k] + 1], layer_dims[dst_of[k] + 1]);
+        if (k > 0 && dst_of[k - 1] > src_of[k]) return fail("skip connections %d and %d overlap (nested skips are not supported)", k - 1, k);
+        // (a skip may start where the previous one ends only if it does not leave IN FRONT of the activation the other one joins behind)
+        if (k > 0 && dst_of[k - 1] == src_of[k] && (src_pre_mask >> k & 1) && !(pre_mask >> (k - 1) & 1))
+            return fail("skip %d starts in front of activation %d, skip %d ends behind it: overlap", k, src_of[k], k - 1);
     }
     const int act = acts[0];
     const int d = ndims + nparams;
@@ -462,8 +469,8 @@ int pinn_create_ex(const int* layer_dims, int n_layers, const int* acts, int n_s
         if (acts[a] != act) net->act = -1;
     }
     net->n_skips = n_skips;
-    for (int k = 0; k < n_skips; ++k) { net->skip_src[k] = skip_src[k]; net->skip_dst[k] = dst_of[k]; }
-    net->skip_pre = pre_mask;
+    for (int k = 0; k < n_skips; ++k) { net->skip_src[k] = src_of[k]; net->skip_dst[k] = dst_of[k]; }
+    net->skip_pre = pre_mask; net->skip_src_pre = src_pre_mask;
     net->has_bc = has_bc ? 1 : 0; net->has_ic = has_ic ? 1 : 0; net->bc_value = bc_value;
     net->nsp = has_ic ? ndims - 1 : ndims;
     for (int l = 0; l <= n_layers; ++l) net->dims[l] = layer_dims[l];

@@ -81,6 +81,7 @@ struct PinnKArgs {
     int n_skips;                 // skip connections 'R ... +': h_out[skip_dst] += h_out[skip_src] (activation indices)
     int skip_src[PINN_MAX_SKIPS], skip_dst[PINN_MAX_SKIPS];
     int skip_pre;                // bit k: skip k ends IN FRONT of the activation ('R fa f+ a': z[skip_dst] += h_out[skip_src])
+    int skip_src_pre;            // bit k: skip k STARTS in front of the activation ('f R a ...': the pre-activation jets are carried)
     int off_b1, off_wh, hidden_stride, off_wl, off_bl, off_ls, off_loss;
     int p_core;                  // row stride of `partials` = length of the gradient buffer (user slots included)
     int off_extra, n_vars;       // first user slot; V(...) scalars a residual program reads (registers S+d+n_aux+k)
@@ -1035,6 +1036,7 @@ pinn_tile_kernel(const PinnKArgs A) {
     //  the full set runs on the VAR 8 instantiations, see the launcher)
     // (VAR 8 | 1024: skip connections over Tanh / Sigmoid layers only -- the usual residual PINN -- keep the one-bit code: with the
     //  sin / softplus / SiLU / GELU paths compiled in, the width-128 breadth kernel spills 283 registers and runs 8 % slower)
+    constexpr bool SRCPRE = SKIPS && !(VAR & 1024);        // skips that start in front of an activation: the full breadth kernels only
     auto act_at = [&](int a) -> int {
         return (ACTC >= 0) ? ACTC : (int)((A.act_codes >> (4 * a)) & ((SKIPS && !(VAR & 1024)) ? 15ull : 1ull));
     };
@@ -1421,6 +1423,7 @@ pinn_tile_kernel(const PinnKArgs A) {
         }
         f32x4 hskip[SKIPS ? NTW : 1][SKIPS ? MT : 1][S];      // activations carried by the open skip connection
         const int act0 = act_at(0);
+        const bool src_pre0 = SRCPRE && skip_from(0) >= 0 && ((A.skip_src_pre >> skip_from(0)) & 1);
         // ---- (1) first layer on the VALU: z0 = W1 x + b1, z_k = W1[:, col_k], z_kk = 0 ------------------------
 #pragma unroll
         for (int j = 0; j < NTW; ++j) {
@@ -1457,8 +1460,12 @@ pinn_tile_kernel(const PinnKArgs A) {
                     pinn_jet_fwd<ND, N2, COMB>(z, act0, h, cw);
 #pragma unroll
                     for (int s = 0; s < S; ++s) { hv[s][r] = h[s]; sv[s][r] = (s == 0) ? pinn_act_saved(h[0], z[0], act0) : z[s]; }
+                    if (SKIPS && src_pre0) {                               // 'f R a': the skip carries z, not act(z)
+#pragma unroll
+                        for (int s = 0; s < S; ++s) hskip[SKIPS ? j : 0][SKIPS ? mt : 0][s][r] = z[s];
+                    }
                 }
-                if (SKIPS && skip_from(0) >= 0) {
+                if (SKIPS && skip_from(0) >= 0 && !src_pre0) {
 #pragma unroll
                     for (int s = 0; s < S; ++s) hskip[SKIPS ? j : 0][SKIPS ? mt : 0][s] = hv[s];
                 }
@@ -1574,6 +1581,7 @@ pinn_tile_kernel(const PinnKArgs A) {
                     f32x4 hv[S], sv[S];
                     // '+' in front of the activation: the jets of the skipped activations join the pre-activation jets
                     const bool pre_in = SKIPS && sk_in >= 0 && ((A.skip_pre >> sk_in) & 1);
+                    const bool src_pre = SRCPRE && sk_out >= 0 && ((A.skip_src_pre >> sk_out) & 1);
 #pragma unroll
                     for (int r = 0; r < 4; ++r) {
                         float z[S], h[S];
@@ -1587,6 +1595,10 @@ pinn_tile_kernel(const PinnKArgs A) {
                         pinn_jet_fwd<ND, N2, COMB>(z, act, h, cw);
 #pragma unroll
                         for (int s = 0; s < S; ++s) { hv[s][r] = h[s]; sv[s][r] = (s == 0) ? pinn_act_saved(h[0], z[0], act) : z[s]; }
+                        if (SKIPS && src_pre) {                            // 'f R a': the skip carries z (read above, if a skip joined it)
+#pragma unroll
+                            for (int s = 0; s < S; ++s) hskip[SKIPS ? j : 0][SKIPS ? mt : 0][s][r] = z[s];
+                        }
                     }
                     if (SKIPS && sk_in >= 0 && !pre_in) {
                         // '+' behind the activation: add the activations saved at 'R'; the reverse half needs them again (slab slot of the skip)
@@ -1597,7 +1609,7 @@ pinn_tile_kernel(const PinnKArgs A) {
                             if (train) *slab_at(lh + 1 + sk_in, s, j, mt) = hs;
                         }
                     }
-                    if (SKIPS && sk_out >= 0) {
+                    if (SKIPS && sk_out >= 0 && !src_pre) {
 #pragma unroll
                         for (int s = 0; s < S; ++s) hskip[SKIPS ? j : 0][SKIPS ? mt : 0][s] = hv[s];
                     }
@@ -1752,7 +1764,9 @@ pinn_tile_kernel(const PinnKArgs A) {
                 // h_out(a) feeds a later '+': its gradient arrives through the skip slot; h_out(a) = act(z_a) + skipped
                 // activations: the whole gradient is handed down the skip (slot re-used: its activations are consumed)
                 // (a '+' in front of the activation hands down gz_a instead, below)
-                const int k_out = skip_from(a), k_in = skip_into(a);
+                const int k_out_any = skip_from(a), k_in = skip_into(a);
+                const int k_out = (k_out_any >= 0 && !(SRCPRE && ((A.skip_src_pre >> k_out_any) & 1))) ? k_out_any : -1;    // (a skip that left in front of
+                                                                                                              //  the activation returns to gz, below)
                 const bool post_in = k_in >= 0 && !((A.skip_pre >> k_in) & 1);
 #pragma unroll
                 for (int j = 0; j < NTW; ++j)
@@ -1763,6 +1777,12 @@ pinn_tile_kernel(const PinnKArgs A) {
                             if (k_out >= 0) g[j][mt][s] += *slab_at(lh + 1 + k_out, s, j, mt);
                             if (post_in) *slab_at(lh + 1 + k_in, s, j, mt) = g[j][mt][s];
                         }
+            }
+            // z_a fed a later '+' itself ('f R a'): the gradient that comes back along that skip belongs to gz_a
+            int src_pre_k = -1;
+            if (SRCPRE) {
+                const int k = skip_from(a);
+                if (k >= 0 && ((A.skip_src_pre >> k) & 1)) src_pre_k = k;
             }
 #pragma unroll
             for (int j = 0; j < NTW; ++j) {
@@ -1775,6 +1795,10 @@ pinn_tile_kernel(const PinnKArgs A) {
 #pragma unroll
                         for (int s = 0; s < S; ++s) { gh1[s] = g[j][mt][s][r]; sv1[s] = sv[j][mt][s][r]; }
                         pinn_jet_bwd<ND, N2, COMB>(gh1, sv1, act, gz1, cw);
+                        if (SRCPRE && src_pre_k >= 0) {
+#pragma unroll
+                            for (int s = 0; s < S; ++s) gz1[s] += (*slab_at(lh + 1 + src_pre_k, s, j, mt))[r];
+                        }
 #pragma unroll
                         for (int s = 0; s < S; ++s) gz[j][mt][s][r] = gz1[s];
                         bsum[r] += gz1[0];

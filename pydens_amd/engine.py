@@ -187,8 +187,8 @@ class Net:
     def __init__(self, layer_dims, activation, ndims, nparams=0, has_bc=False, bc_value=0.0, has_ic=False,
                  domain=None, lib=None, skips=()):
         """ activation: one name for every hidden layer or a sequence with one name per hidden layer;
-        skips: (src, dst) or (src, dst, pre) hidden-layer indices: output of dst += output of src ('R ... +' layouts); pre: the
-        sum enters in front of the activation of dst ('faR fa f+ a'). """
+        skips: (src, dst[, pre[, src_pre]]) hidden-layer indices: output of dst += output of src ('R ... +' layouts); pre: the
+        sum enters in front of the activation of dst ('faR fa f+ a'); src_pre: the pre-activation of src is what travels ('fRa'). """
         self.lib = lib if lib is not None else load_library()
         n_hidden = len(layer_dims) - 2
         names = [activation] * n_hidden if isinstance(activation, str) else list(activation)
@@ -198,15 +198,15 @@ class Net:
         if None in codes:
             raise NotImplementedError(f'activation {names[codes.index(None)]!r}: the HIP kernels implement Tanh, Sigmoid '
                                       'Sin, Softplus, SiLU and GELU (and the identity)')
-        skips = sorted((s[0], s[1], bool(s[2]) if len(s) > 2 else False) for s in skips)
+        skips = sorted((s[0], s[1], bool(s[2]) if len(s) > 2 else False, bool(s[3]) if len(s) > 3 else False) for s in skips)
         domain = list(domain) if domain is not None else [(0.0, 1.0)] * ndims
         dims = (ctypes.c_int * len(layer_dims))(*layer_dims)
         lo = (ctypes.c_float * ndims)(*[float(d[0]) for d in domain])
         hi = (ctypes.c_float * ndims)(*[float(d[1]) for d in domain])
         handle = ctypes.c_void_p()
         acts = (ctypes.c_int * max(1, n_hidden))(*codes)
-        src = (ctypes.c_int * max(1, len(skips)))(*[s for s, _, _ in skips])
-        dst = (ctypes.c_int * max(1, len(skips)))(*[d | (SKIP_PRE if pre else 0) for _, d, pre in skips])
+        src = (ctypes.c_int * max(1, len(skips)))(*[s | (SKIP_PRE if src_pre else 0) for s, _, _, src_pre in skips])
+        dst = (ctypes.c_int * max(1, len(skips)))(*[d | (SKIP_PRE if pre else 0) for _, d, pre, _ in skips])
         rc = self.lib.pinn_create_ex(dims, len(layer_dims) - 1, acts, len(skips), src, dst, ndims, nparams, int(has_bc),
                                      int(has_ic), lo, hi, float(bc_value), ctypes.byref(handle))
         self._raise(rc)

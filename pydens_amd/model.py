@@ -117,11 +117,11 @@ def parse_fc_layout(layout, features, activation):
 
     Letters (reference model_torch.py:142-156): 'f' dense layer, 'a' activation (a shared one or a sequence with one
     entry per 'a'), 'R' start / '+' end of a skip connection; spaces are ignored. The net must end in a 1-unit dense
-    layer. A hidden 'f' without an 'a' gets the identity. 'R' must sit right behind an activation (or a '+'); '+' either
-    right behind an activation ('faR fa fa+': sum of activation outputs) or between a dense layer and its activation
-    ('faR fa f+a': the usual residual block act(W h + skip)). Skips join layers of equal width and do not nest; conv
-    letters are out of scope. Skips are returned as (src, dst, pre) hidden-layer indices: the output of layer dst
-    -- its pre-activation if `pre` -- gets the output of layer src added. """
+    layer. A hidden 'f' without an 'a' gets the identity. 'R' and '+' sit behind a dense layer, either behind its activation
+    ('faR fa fa+': sum of activation outputs) or between the layer and its activation ('faR fa f+a': the usual residual block
+    act(W h + skip); 'fRa fa f+a': the pre-activation block, z carried to z). Skips join layers of equal width and do not nest;
+    conv letters are out of scope. Skips are returned as (src, dst, pre, src_pre) hidden-layer indices: the output of
+    layer dst -- its pre-activation if `pre` -- gets the output (pre-activation if `src_pre`) of layer src added. """
     letters = layout.replace(' ', '')
     features = list(features)
     if set(letters) - set('faR+'):
@@ -137,7 +137,7 @@ def parse_fc_layout(layout, features, activation):
     act_list = list(activation) if isinstance(activation, (list, tuple)) else None
     if act_list is not None and len(act_list) < letters.count('a'):
         raise ValueError(f'layout {layout!r} needs {letters.count("a")} activations, got {len(act_list)}')
-    acts, skips, open_skip, layer = [], [], None, -1
+    acts, skips, open_skip, open_pre, layer = [], [], None, False, -1
     for letter in letters:
         if letter == 'f':
             if layer >= 0 and len(acts) == layer:
@@ -148,20 +148,19 @@ def parse_fc_layout(layout, features, activation):
                 raise NotImplementedError(f"layout {layout!r}: every 'a' must follow its own dense layer")
             acts.append(_activation_name(act_list.pop(0) if act_list is not None else activation))
         else:
-            pre = letter == '+' and layer >= 0 and len(acts) == layer          # '+' between 'f' and its 'a'
+            pre = layer >= 0 and len(acts) == layer            # between a dense layer and its activation: the pre-activation
             if layer < 0 or (len(acts) != layer + 1 and not pre):
-                raise NotImplementedError(f"layout {layout!r}: 'R' must come right after an activation; '+' after an "
-                                          "activation or between a dense layer and its activation")
+                raise NotImplementedError(f"layout {layout!r}: 'R' / '+' must come after a dense layer (in front of or behind its activation)")
             if letter == 'R':
                 if open_skip is not None:
                     raise NotImplementedError(f'layout {layout!r}: nested skip connections are not supported')
-                open_skip = layer
+                open_skip, open_pre = layer, pre
             else:
                 if open_skip is None or open_skip == layer:
                     raise NotImplementedError(f"layout {layout!r}: '+' needs an open 'R' with a layer in between")
                 if features[open_skip] != features[layer]:
                     raise ValueError(f"layout {layout!r}: skip connection joins widths {features[open_skip]} and {features[layer]}")
-                skips.append((open_skip, layer, pre))
+                skips.append((open_skip, layer, pre, open_pre))
                 open_skip = None
     if open_skip is not None:
         raise ValueError(f"layout {layout!r}: 'R' without a closing '+'")

@@ -468,6 +468,10 @@ LAYOUTS = {
     'pre_activation_blocks': dict(layout='fa R fa f+a R fa f+a f', features=[16, 16, 16, 16, 16, 1],
                                   activation=['Tanh', 'Sin', 'Tanh', 'SiLU', 'Sigmoid']),
     'pre_activation_mixed': dict(layout='faR f+a R fa fa+ f', features=[24, 24, 24, 24, 1], activation='Tanh'),
+    # skips that START in front of an activation: z to z (the pre-activation ResNet block), from the first layer, and z to act(z)
+    'skip_from_pre_activation': dict(layout='fRa fa f+a fRa fa+ f', features=[20, 20, 20, 20, 20, 1],
+                                     activation=['Tanh', 'Sigmoid', 'Tanh', 'Sin', 'Tanh']),
+    'pre_blocks_back_to_back': dict(layout='fa fRa f+Ra fa f+a f', features=[16, 16, 16, 16, 16, 1], activation='Tanh'),
 }
 
 
@@ -513,7 +517,7 @@ def test_layout_errors_are_loud(pa, emu_lib):
                                   ('fa R fa + f', [8, 12, 1], ValueError),                # widths differ
                                   ('fa R fa R fa + + f', [8, 8, 8, 1], NotImplementedError),   # nested
                                   ('R fa fa + f', [8, 8, 1], NotImplementedError),        # skip from the inputs
-                                  ('fa f R a fa + f', [8, 8, 8, 1], NotImplementedError),  # skip from a pre-activation
+                                  ('fa fRa +fa f', [8, 8, 8, 1], NotImplementedError),     # '+' without a layer in between
                                   ('ca f', [8, 1], NotImplementedError)]:
         with pytest.raises(exc):
             pa.Solver(lambda f, x: pa.D(f, x), ndims=1, layout=layout, features=features, **emu_kwargs(emu_lib))

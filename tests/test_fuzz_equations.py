@@ -177,7 +177,7 @@ def _random_net(rng, wmax=41):
         b = rng.randint(a + 1, depth - 1) if a + 1 < depth - 1 else a + 1
         for i in range(a, b + 1):
             widths[i] = widths[a]
-        letters[a] = 'faR'
+        letters[a] = 'faR' if rng.rand() < 0.6 else 'fRa'          # the skip carries act(z) or z itself
         letters[b] = 'fa+' if rng.rand() < 0.5 else 'f+a'      # sum behind the activation, or the residual block act(W h + skip)
     activation = acts[0] if rng.rand() < 0.4 and not no_act else acts
     if isinstance(activation, str):

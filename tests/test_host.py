@@ -47,11 +47,12 @@ def test_layout_parsing():
     assert parse_fc_layout('fa fa fa f', [10, 12, 15, 1], 'Tanh') == ([10, 12, 15, 1], ['Tanh'] * 3, [])
     assert parse_fc_layout('fafaf', (20, 30, 1), torch.nn.Sigmoid) == ([20, 30, 1], ['Sigmoid'] * 2, [])
     # the reference's docstring example with a skip (model_torch.py:155): output of layer 2 += output of layer 0
-    assert parse_fc_layout('faR fa fa+ f', [5, 10, 5, 1], 'Sigmoid') == ([5, 10, 5, 1], ['Sigmoid'] * 3, [(0, 2, False)])
+    assert parse_fc_layout('faR fa fa+ f', [5, 10, 5, 1], 'Sigmoid') == ([5, 10, 5, 1], ['Sigmoid'] * 3, [(0, 2, False, False)])
     assert parse_fc_layout('fa R fa + R fa + f', [8, 8, 8, 1], ['Tanh', torch.sin, torch.nn.Sigmoid()])[1:] == \
-        (['Tanh', 'Sin', 'Sigmoid'], [(0, 1, False), (1, 2, False)])
+        (['Tanh', 'Sin', 'Sigmoid'], [(0, 1, False, False), (1, 2, False, False)])
     # the usual residual block act(W h + skip): '+' between the dense layer and its activation
-    assert parse_fc_layout('faR fa f+a f', [8, 8, 8, 1], 'Tanh')[1:] == (['Tanh'] * 3, [(0, 2, True)])
+    assert parse_fc_layout('faR fa f+a f', [8, 8, 8, 1], 'Tanh')[1:] == (['Tanh'] * 3, [(0, 2, True, False)])
+    assert parse_fc_layout('fRa fa f+a f', [8, 8, 8, 1], 'Tanh')[2] == [(0, 2, True, True)]       # pre-activation block: z to z
     assert parse_fc_layout('ff', [5, 1], 'Sigmoid') == ([5, 1], ['Identity'], [])
     assert parse_fc_layout('fa f fa f', [5, 4, 3, 1], 'Tanh')[1] == ['Tanh', 'Identity', 'Tanh']
     with pytest.raises(NotImplementedError):
