@@ -40,7 +40,7 @@
 extern "C" {
 #endif
 
-#define PINN_MAX_LAYERS   16   /* linear layers */
+#define PINN_MAX_LAYERS   32   /* linear layers */
 #define PINN_MAX_INPUTS   8    /* ndims + nparams */
 #define PINN_MAX_DIRS     4    /* differentiation directions of one call (3-D space + time) */
 #define PINN_EXTRA_SLOTS  16

@@ -62,7 +62,7 @@ int g_pinn_debug_flags = 0;         // -DPINN_DEBUG_ABI builds: pinn_debug_set_f
 struct pinn_net {
     pinn_layout_t lay;
     int n_layers, act, ndims, nparams, has_bc, has_ic, nsp;      // act: uniform activation code or -1
-    unsigned long long act_codes;                                 // 4 bits per activation index
+    unsigned long long act_codes[2];                              // 4 bits per activation index (pinn_act_code)
     int n_skips, skip_src[PINN_MAX_SKIPS], skip_dst[PINN_MAX_SKIPS], skip_pre, skip_src_pre;
     int dims[PINN_MAX_LAYERS + 1];
     float lo[PINN_MAX_INPUTS], hi[PINN_MAX_INPUTS], bc_value;
@@ -164,7 +164,7 @@ int make_plan(const pinn_net* net, int64_t n_points, int nd, int n2, Plan* plan,
         memset(&probe, 0, sizeof(probe));
         probe.lh = net->lay.lh;
         probe.act = net->act;
-        probe.act_codes = net->act_codes;
+        probe.act_codes[0] = net->act_codes[0]; probe.act_codes[1] = net->act_codes[1];
         probe.n_skips = net->n_skips;
         probe.skip_pre = net->skip_pre;
         probe.skip_src_pre = net->skip_src_pre;
@@ -223,7 +223,7 @@ void fill_args(const pinn_net* net, PinnKArgs* a, const float* params, const flo
     memset(a, 0, sizeof(*a));
     const pinn_layout_t& L = net->lay;
     a->params = params; a->xs = xs; a->ic_streams = ic_streams; a->n_points = n;
-    a->lh = L.lh; a->d = L.d; a->act = net->act; a->act_codes = net->act_codes;
+    a->lh = L.lh; a->d = L.d; a->act = net->act; a->act_codes[0] = net->act_codes[0]; a->act_codes[1] = net->act_codes[1];
     a->n_skips = net->n_skips;
     a->skip_pre = net->skip_pre;
     a->skip_src_pre = net->skip_src_pre;
@@ -465,7 +465,7 @@ int pinn_create_ex(const int* layer_dims, int n_layers, const int* acts, int n_s
     memset(net, 0, sizeof(*net));
     net->n_layers = n_layers; net->act = act; net->ndims = ndims; net->nparams = nparams;
     for (int a = 0; a + 1 < n_layers; ++a) {
-        net->act_codes |= (unsigned long long)acts[a] << (4 * a);
+        net->act_codes[a >> 4] |= (unsigned long long)acts[a] << (4 * (a & 15));
         if (acts[a] != act) net->act = -1;
     }
     net->n_skips = n_skips;

@@ -41,6 +41,11 @@
 
 enum { PINN_MODE_FORWARD = 0, PINN_MODE_STEP = 1, PINN_MODE_BACKWARD = 2 };
 
+// activation code of activation index a (4 bits each, 16 per word)
+PINN_HOST_DEVICE inline int pinn_act_code(const unsigned long long (&codes)[2], int a) {
+    return (int)((codes[a >> 4] >> (4 * (a & 15))) & 15ull);
+}
+
 // timing-experiment bits (kernels skip loads / stores / barriers; include/pinn.h): compiled into -DPINN_DEBUG_ABI builds only
 // (tools/variant.sh), the product kernels carry none of these paths
 #ifdef PINN_DEBUG_ABI
@@ -77,7 +82,7 @@ struct PinnKArgs {
     int debug_flags;             // timing-experiment bits (PINN_DBG; -DPINN_DEBUG_ABI builds only)
     long long n_points;
     int lh, d, act, mode;        // act: the activation code shared by every layer, or -1 when they differ (act_codes)
-    unsigned long long act_codes;   // 4 bits per activation index a = 0..lh (a = 0: first layer)
+    unsigned long long act_codes[2];   // 4 bits per activation index a = 0..lh (a = 0: first layer): pinn_act_code
     int n_skips;                 // skip connections 'R ... +': h_out[skip_dst] += h_out[skip_src] (activation indices)
     int skip_src[PINN_MAX_SKIPS], skip_dst[PINN_MAX_SKIPS];
     int skip_pre;                // bit k: skip k ends IN FRONT of the activation ('R fa f+ a': z[skip_dst] += h_out[skip_src])
@@ -1038,7 +1043,7 @@ pinn_tile_kernel(const PinnKArgs A) {
     //  sin / softplus / SiLU / GELU paths compiled in, the width-128 breadth kernel spills 283 registers and runs 8 % slower)
     constexpr bool SRCPRE = SKIPS && !(VAR & 1024);        // skips that start in front of an activation: the full breadth kernels only
     auto act_at = [&](int a) -> int {
-        return (ACTC >= 0) ? ACTC : (int)((A.act_codes >> (4 * a)) & ((SKIPS && !(VAR & 1024)) ? 15ull : 1ull));
+        return (ACTC >= 0) ? ACTC : (pinn_act_code(A.act_codes, a) & ((SKIPS && !(VAR & 1024)) ? 15 : 1));
     };
     // skip connection ending / starting at activation a (or -1); slab slot of skip k
     auto skip_into = [&](int a) -> int {

@@ -80,7 +80,7 @@ pinn_wgrad_kernel(const PinnKArgs A) {
 
     for (int li = 0; li < lh; ++li) {
         // layer a = li + 1: A operand gz_a, B operand h_{a-1} = h of activation index li
-        const int act = (int)((A.act_codes >> (4 * li)) & 1ull);
+        const int act = pinn_act_code(A.act_codes, li) & 1;
         f32x4 acc[AM][BN];
 #pragma unroll
         for (int i = 0; i < AM; ++i)

@@ -13,7 +13,7 @@ import torch
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_NAME = 'libpinn_hip.so'
 
-MAX_LAYERS, MAX_INPUTS, MAX_DIRS, EXTRA_SLOTS = 16, 8, 4, 16
+MAX_LAYERS, MAX_INPUTS, MAX_DIRS, EXTRA_SLOTS = 32, 8, 4, 16
 MAX_OPS, MAX_CONSTS, MAX_REGS = 64, 32, 40
 MAX_STREAMS, MAX_AUX, MAX_VARS = 7, 8, 8
 SAMPLE_UNIFORM, SAMPLE_NORMAL, SAMPLE_CONST = 0, 1, 2

@@ -36,7 +36,7 @@ def _ptr(t):
 def test_create_rejects_what_the_kernels_do_not_instantiate(lib):
     from pydens_amd import engine
     for dims, kw, needle in (((2, 300, 1), {}, 'width'),                      # wider than 256
-                             ((2,) + (8,) * 17 + (1,), {}, 'layer'),           # more than PINN_MAX_LAYERS linear layers
+                             ((2,) + (8,) * 33 + (1,), {}, 'layer'),           # more than PINN_MAX_LAYERS (32) linear layers
                              ((9, 8, 1), dict(ndims=9), 'ndims+nparams'),     # more than PINN_MAX_INPUTS columns
                              ((2, 8, 2), {}, 'one unit')):                     # not a scalar field
         with pytest.raises(RuntimeError) as err:

@@ -523,17 +523,28 @@ def test_layout_errors_are_loud(pa, emu_lib):
             pa.Solver(lambda f, x: pa.D(f, x), ndims=1, layout=layout, features=features, **emu_kwargs(emu_lib))
 
 
-def test_deep_network_any_number_of_hidden_layers(pa, emu_lib):
+@pytest.mark.parametrize('depth', [8, 20])
+def test_deep_network_any_number_of_hidden_layers(pa, emu_lib, depth):
+    _deep_network_case(pa, depth, emu_kwargs(emu_lib))
+
+
+def _deep_network_case(pa, depth, solver_kwargs):
     """ more hidden->hidden layers than the register-resident weight-gradient accumulators hold: generic kernel with
-    read-modify-write accumulation in the workgroup's partial buffer """
+    read-modify-write accumulation in the workgroup's partial buffer. 20 hidden layers: beyond the 16 activation codes of one
+    64-bit word (PINN_MAX_LAYERS 32 since round 3; the reference takes any `features`, model_torch.py:158-168), with a
+    per-layer activation list and a residual block so that every second word's codes are looked at """
     from oracle import pinn_oracle as po
-    kw = dict(ndims=2, boundary_condition=0.5, layout='fa' * 8 + 'f', features=[20] * 8 + [1], activation='Tanh')
+    if depth == 8:
+        kw = dict(ndims=2, boundary_condition=0.5, layout='fa' * 8 + 'f', features=[20] * 8 + [1], activation='Tanh')
+    else:
+        acts = ['Tanh', 'Sigmoid'] * 9 + ['Sin', 'Tanh']
+        kw = dict(ndims=2, boundary_condition=0.5, layout='fa' * 17 + 'faR fa fa+ f', features=[20] * depth + [1], activation=acts)
 
     def eq(D):
         return lambda f, x, y: D(D(f, x), x) + D(D(f, y), y) - 5 * torch.sin(np.pi * (x + y))
     oracle = po.OracleSolver(eq(po.D), **kw)
-    solver = pa.Solver(eq(pa.D), **kw, **emu_kwargs(emu_lib))
-    assert solver.model.net.layout.lh == 7
+    solver = pa.Solver(eq(pa.D), **kw, **solver_kwargs)
+    assert solver.model.net.layout.lh == depth - 1
     load_params(solver, oracle.export_params())
     pts = np.random.RandomState(12).rand(3, 40, 2).astype(np.float32)
     oracle.fit(niters=3, batch_size=40, points=pts, lr=0.01)

@@ -735,6 +735,12 @@ def test_known_answers_of_the_tutorial(pa):
     assert abs(v - 2.0) < 0.05 and err < 0.1, (v, err)              # (reference: V = 1.997 .. 2.004, error 0.006 .. 0.02)
 
 
+def test_twenty_hidden_layers_on_the_gpu(pa):
+    """ deeper than one 64-bit word of activation codes (PINN_MAX_LAYERS 32): per-layer activations and a residual block at the top """
+    import test_emu_engine as te
+    te._deep_network_case(pa, 20, {})
+
+
 @pytest.mark.parametrize('which', ['reaction_2d', 'allen_cahn', 'not_combinable'])
 def test_residual_programs_on_one_combined_stream_on_the_gpu(pa, which):
     import test_emu_engine as te
