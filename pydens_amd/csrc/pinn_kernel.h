@@ -166,7 +166,7 @@ struct PinnCfg {
     static constexpr int O_WT = SMEM_FLOATS;
     static constexpr int WT_LD = HP + 8;
     PINN_HOST_DEVICE static constexpr bool wt_fits(int lh) {
-        return lh > 0 && HP <= 64 && !WTG && (SMEM_FLOATS + lh * HP * WT_LD) * 4 <= 150 * 1024;
+        return lh > 0 && HP <= 64 && !WTG && (SMEM_FLOATS + lh * HP * WT_LD) * 4 <= 160 * 1024;
     }
     PINN_HOST_DEVICE static constexpr int smem_floats(int lh_static) {
         return SMEM_FLOATS + (wt_fits(lh_static) ? lh_static * HP * WT_LD : 0);
@@ -1041,7 +1041,9 @@ pinn_tile_kernel(const PinnKArgs A) {
     //  the full set runs on the VAR 8 instantiations, see the launcher)
     // (VAR 8 | 1024: skip connections over Tanh / Sigmoid layers only -- the usual residual PINN -- keep the one-bit code: with the
     //  sin / softplus / SiLU / GELU paths compiled in, the width-128 breadth kernel spills 283 registers and runs 8 % slower)
-    constexpr bool SRCPRE = SKIPS && !(VAR & 1024);        // skips that start in front of an activation: the full breadth kernels only
+    // skips that START in front of an activation ('fRa'): the generic-depth full breadth kernels only (the selects and the guarded slab
+    // reads cost the static-depth Sin kernel 3.5 % -- 9 % with the guard inside the jet loop -- and it never sees a skip)
+    constexpr bool SRCPRE = SKIPS && !(VAR & 1024) && LHC < 0;
     auto act_at = [&](int a) -> int {
         return (ACTC >= 0) ? ACTC : (pinn_act_code(A.act_codes, a) & ((SKIPS && !(VAR & 1024)) ? 15 : 1));
     };
@@ -1436,7 +1438,7 @@ pinn_tile_kernel(const PinnKArgs A) {
 #pragma unroll
             for (int mt = 0; mt < MT; ++mt) {
                 const int pt = mt * 16 + lr;
-                f32x4 hv[S], sv[S];
+                f32x4 hv[S], sv[S], z0v;
                 // point row and the four weight rows as b128 reads (all issued together: one LDS latency)
                 const f32x4 xlo = pinn_ld4(xs_t + pt * PINN_XS_LD), xhi = pinn_ld4(xs_t + pt * PINN_XS_LD + 4);
                 const f32x4 b1v = pinn_ld4(b1s + n0);
@@ -1465,14 +1467,12 @@ pinn_tile_kernel(const PinnKArgs A) {
                     pinn_jet_fwd<ND, N2, COMB>(z, act0, h, cw);
 #pragma unroll
                     for (int s = 0; s < S; ++s) { hv[s][r] = h[s]; sv[s][r] = (s == 0) ? pinn_act_saved(h[0], z[0], act0) : z[s]; }
-                    if (SKIPS && src_pre0) {                               // 'f R a': the skip carries z, not act(z)
-#pragma unroll
-                        for (int s = 0; s < S; ++s) hskip[SKIPS ? j : 0][SKIPS ? mt : 0][s][r] = z[s];
-                    }
+                    if (SRCPRE) z0v[r] = z[0];
                 }
-                if (SKIPS && skip_from(0) >= 0 && !src_pre0) {
+                if (SKIPS && skip_from(0) >= 0) {
+                    // ('f R a': the skip carries the z-jets, not act(z): z_0 kept aside, the derivative jets are what sv holds)
 #pragma unroll
-                    for (int s = 0; s < S; ++s) hskip[SKIPS ? j : 0][SKIPS ? mt : 0][s] = hv[s];
+                    for (int s = 0; s < S; ++s) hskip[SKIPS ? j : 0][SKIPS ? mt : 0][s] = (SRCPRE && src_pre0) ? (s == 0 ? z0v : sv[s]) : hv[s];
                 }
 #pragma unroll
                 for (int s = 0; s < S; ++s) {
@@ -1583,7 +1583,7 @@ pinn_tile_kernel(const PinnKArgs A) {
 #pragma unroll
                 for (int mt = 0; mt < MT; ++mt) {
                     const int pt = mt * 16 + lr;
-                    f32x4 hv[S], sv[S];
+                    f32x4 hv[S], sv[S], z0v;
                     // '+' in front of the activation: the jets of the skipped activations join the pre-activation jets
                     const bool pre_in = SKIPS && sk_in >= 0 && ((A.skip_pre >> sk_in) & 1);
                     const bool src_pre = SRCPRE && sk_out >= 0 && ((A.skip_src_pre >> sk_out) & 1);
@@ -1600,10 +1600,7 @@ pinn_tile_kernel(const PinnKArgs A) {
                         pinn_jet_fwd<ND, N2, COMB>(z, act, h, cw);
 #pragma unroll
                         for (int s = 0; s < S; ++s) { hv[s][r] = h[s]; sv[s][r] = (s == 0) ? pinn_act_saved(h[0], z[0], act) : z[s]; }
-                        if (SKIPS && src_pre) {                            // 'f R a': the skip carries z (read above, if a skip joined it)
-#pragma unroll
-                            for (int s = 0; s < S; ++s) hskip[SKIPS ? j : 0][SKIPS ? mt : 0][s][r] = z[s];
-                        }
+                        if (SRCPRE) z0v[r] = z[0];
                     }
                     if (SKIPS && sk_in >= 0 && !pre_in) {
                         // '+' behind the activation: add the activations saved at 'R'; the reverse half needs them again (slab slot of the skip)
@@ -1614,9 +1611,10 @@ pinn_tile_kernel(const PinnKArgs A) {
                             if (train) *slab_at(lh + 1 + sk_in, s, j, mt) = hs;
                         }
                     }
-                    if (SKIPS && sk_out >= 0 && !src_pre) {
+                    if (SKIPS && sk_out >= 0) {
+                        // ('f R a': the skip carries the z-jets, not act(z): z_0 kept aside, the derivative jets are what sv holds)
 #pragma unroll
-                        for (int s = 0; s < S; ++s) hskip[SKIPS ? j : 0][SKIPS ? mt : 0][s] = hv[s];
+                        for (int s = 0; s < S; ++s) hskip[SKIPS ? j : 0][SKIPS ? mt : 0][s] = (SRCPRE && src_pre) ? (s == 0 ? z0v : sv[s]) : hv[s];
                     }
                     if (li + 1 == lh) {
 #pragma unroll
@@ -1800,14 +1798,20 @@ pinn_tile_kernel(const PinnKArgs A) {
 #pragma unroll
                         for (int s = 0; s < S; ++s) { gh1[s] = g[j][mt][s][r]; sv1[s] = sv[j][mt][s][r]; }
                         pinn_jet_bwd<ND, N2, COMB>(gh1, sv1, act, gz1, cw);
-                        if (SRCPRE && src_pre_k >= 0) {
-#pragma unroll
-                            for (int s = 0; s < S; ++s) gz1[s] += (*slab_at(lh + 1 + src_pre_k, s, j, mt))[r];
-                        }
 #pragma unroll
                         for (int s = 0; s < S; ++s) gz[j][mt][s][r] = gz1[s];
                         bsum[r] += gz1[0];
                     }
+                if (SRCPRE && src_pre_k >= 0) {             // (outside the loop over r: a branch in there splits the jet arithmetic)
+#pragma unroll
+                    for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+                        for (int s = 0; s < S; ++s) {
+                            const f32x4 back = *slab_at(lh + 1 + src_pre_k, s, j, mt);
+                            gz[j][mt][s] += back;
+                            if (s == 0) bsum += back;
+                        }
+                }
                 if (REGB) {
                     bacc[j] += bsum;
                 } else {
