@@ -118,7 +118,7 @@ class OracleModel(nn.Module):
 class OracleSolver:
     """ reference Solver (model_torch.py:191-487) restated; `dtype` selects fp32 (reference) or fp64 (arbiter). """
     def __init__(self, equation, ndims, initial_condition=None, boundary_condition=None, domain=(0, 1),
-                 nparams=0, constraints=None, dtype=torch.float32, **kwargs):
+                 nparams=0, constraints=None, dtype=torch.float32, model=None, **kwargs):
         self.equation = equation
         self.dtype = dtype
         if constraints is None:
@@ -129,7 +129,8 @@ class OracleSolver:
             self.constraints = (constraints, )
         self.losses = []
         self.optimizer = None
-        self.model = OracleModel(**kwargs, ndims=ndims, initial_condition=initial_condition,
+        # (`model`: the reference's plug-in seam, model_torch.py:299-313 -- a subclass of the model with its own forward())
+        self.model = (model or OracleModel)(**kwargs, ndims=ndims, initial_condition=initial_condition,
                                  boundary_condition=boundary_condition, domain=domain, nparams=nparams, dtype=dtype)
         current_model.set(self.model)
         self.ctx = copy_context()

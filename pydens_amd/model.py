@@ -56,6 +56,30 @@ class TorchModel(ABC, nn.Module):
     def forward(self, xs):
         """ Forward of the model-network. """
 
+    def anzatc(self, u, xs):
+        """ hard binding of the boundary / initial condition in plain torch (reference model_torch.py:107-128: boundary transform
+        first, :118-121, initial-condition gate second, :124-127; time is column ndims-1, :111). ConvBlockModel's own forward
+        has this inside the HIP kernels; a subclass with its OWN forward() -- `self.anzatc(self.conv_block(xs), xs) * ...` --
+        calls it here on the network value the kernels hand over, and `D` differentiates through it by the chain rule over the
+        kernels' derivative streams. """
+        nsp = self.ndims_spatial
+        sp = xs[:, :nsp]
+        t = xs[:, self.ndims - 1:self.ndims]
+        lo = torch.tensor([d[0] for d in self.domain][:nsp], dtype=torch.float32, device=xs.device).reshape(1, -1)
+        hi = torch.tensor([d[1] for d in self.domain][:nsp], dtype=torch.float32, device=xs.device).reshape(1, -1)
+        t0 = self.domain[-1][0]
+        if self.boundary_condition is not None:
+            rise = torch.prod((sp - lo) / (hi - lo), dim=1, keepdim=True)
+            fall = torch.prod((hi - sp) / (hi - lo), dim=1, keepdim=True)
+            u = u * (rise * fall) + self.boundary_condition
+        if self.initial_condition is not None:
+            gate = torch.sigmoid((t - t0) / torch.exp(self.log_scale)) - .5
+            cols = [sp[:, i] for i in range(nsp)]                           # the IC sees 1-D [N] columns (:125)
+            ic = self.initial_condition(*cols)
+            ic = ic if isinstance(ic, torch.Tensor) else torch.tensor(float(ic), dtype=torch.float32)
+            u = gate * u + ic.to(device=xs.device, dtype=torch.float32).view(-1, 1)
+        return u
+
     def freeze_trainable(self, layers=None, variables=None):
         """ reference model_torch.py:56-80: flips requires_grad; `Solver.fit` turns it into the Adam mask. """
         for layer in (layers or []):
@@ -188,6 +212,30 @@ class _ModelForward(torch.autograd.Function):
         return None, None, None
 
 
+class KernelBlock(nn.Sequential):
+    """ `model.conv_block` (reference model_torch.py:164-172): holds the layers' parameters as views of the flat kernel buffer; CALLED
+    -- which only a subclass with its own forward() does -- it returns the network value computed by the HIP kernels: inside an
+    equation evaluation the value stream the solver already has (tagged, so that `D` finds the derivative streams), elsewhere
+    (predict, constraints) a value-only kernel forward that is differentiable with respect to the parameters. The argument must
+    be the batch of points itself: inputs transformed before the net are outside what the kernels compute. """
+    def __init__(self, model):
+        super().__init__()
+        object.__setattr__(self, '_model', model)
+
+    def forward(self, xs):
+        model = self._model
+        model.conv_block_calls += 1
+        field = model.raw_field
+        if field is not None:
+            pts, value = field
+            if xs is not pts and (xs.shape != pts.shape or not torch.equal(xs.detach(), pts.detach())):
+                raise NotImplementedError('a custom forward() may call self.conv_block only on the batch of points it was given '
+                                          '(inputs transformed in front of the net are not what the HIP kernels compute)')
+            return value
+        xs = xs.to(device=model.flat.device, dtype=torch.float32).contiguous()
+        return _ModelForward.apply(model._anchor, xs, model)
+
+
 class ConvBlockModel(TorchModel):
     """ reference model_torch.py:130-172 for fully connected layouts. """
     def __init__(self, ndims, initial_condition=None, boundary_condition=None, domain=(0, 1), nparams=0,
@@ -199,9 +247,15 @@ class ConvBlockModel(TorchModel):
         self.activation_names, self.skips = act_names, skips
         self.device = torch.device(device) if device is not None else default_device()
         self.layer_dims = [self.total] + widths
+        # a subclass with its own forward() (the reference's plug-in seam, model_torch.py:52-54, :312-313): the kernels compute the
+        # bare network, the ansatz -- if the subclass calls self.anzatc -- is torch code of its forward()
+        self.custom_forward = type(self).forward is not ConvBlockModel.forward
+        self.raw_field = None               # (points, tagged network value) while the solver evaluates the equation
+        self.conv_block_calls = 0
+        bare = self.custom_forward
         self.net = engine.Net(self.layer_dims, act_names, ndims, nparams,
-                              has_bc=boundary_condition is not None, bc_value=boundary_condition or 0.0,
-                              has_ic=initial_condition is not None, domain=self.domain, lib=lib, skips=skips)
+                              has_bc=boundary_condition is not None and not bare, bc_value=(boundary_condition or 0.0) if not bare else 0.0,
+                              has_ic=initial_condition is not None and not bare, domain=self.domain, lib=lib, skips=skips)
         lay = self.net.layout
         # flat kernel buffer; PyTorch-default nn.Linear init drawn in the reference's order
         # (fake inputs first, model_torch.py:167, then the layers of Block, :168)
@@ -212,7 +266,7 @@ class ConvBlockModel(TorchModel):
             w.copy_(lin.weight.detach()); b.copy_(lin.bias.detach())
         self.register_buffer('flat', host.to(self.device), persistent=False)
         self.log_scale = nn.Parameter(self.flat.as_strided((), (), lay.off_log_scale))   # :50, value 0.0
-        self.conv_block = nn.Sequential()
+        self.conv_block = KernelBlock(self)
         for i, (w, b) in enumerate(self.net.param_views(self.flat)):
             self.conv_block.add_module(f'fc{i + 1}', FlatLinear(w, b))
         self._next_extra = lay.off_extra
@@ -238,7 +292,7 @@ class ConvBlockModel(TorchModel):
     # ---- helpers for the solver --------------------------------------------------------------------------------
     def kernel_ic_const(self):
         """ constant initial condition handled inside the kernels (0 when the IC is a callable added by the host) """
-        return self.ic_constant if self.ic_constant is not None else 0.0
+        return self.ic_constant if (self.ic_constant is not None and not self.custom_forward) else 0.0
 
     def workspace(self, n_points, nd, n2):
         key = (nd, n2)

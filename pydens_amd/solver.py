@@ -88,10 +88,14 @@ class Solver:
         # the reference's plug-in seam (`Solver(model=...)`, model_torch.py:299-313): subclasses of ConvBlockModel that
         # change how the fully connected net / the ansatz parameters are set up run on the HIP kernels; a subclass that
         # replaces `forward` runs arbitrary torch code, which the kernels cannot see -- refused loudly
-        if not isinstance(self.model, ConvBlockModel) or type(self.model).forward is not ConvBlockModel.forward:
-            raise NotImplementedError('Solver(model=...): only ConvBlockModel and subclasses that keep its forward() (fully '
-                                      'connected layouts + the hard-binding ansatz) are backed by the HIP kernels; a custom '
-                                      'forward() is arbitrary torch code')
+        # replaces `forward` may put its own torch code AROUND the network -- `self.anzatc(self.conv_block(xs), xs) * g(xs)`, another
+        # output transform, no ansatz at all: `self.conv_block(xs)` is then the bare network on the kernels and the rest runs as torch
+        # ops on its value and derivative streams (generic step path; `D` applies the chain rule). Anything else -- a model that is
+        # not a ConvBlockModel, inputs transformed in front of the net -- is arbitrary torch code the kernels cannot see: refused
+        if not isinstance(self.model, ConvBlockModel):
+            raise NotImplementedError('Solver(model=...): only ConvBlockModel and its subclasses (fully connected layouts; a custom '
+                                      'forward() may wrap torch code around self.conv_block(xs)) are backed by the HIP kernels')
+        self.custom_forward = self.model.custom_forward
         current_model.set(self.model)                                     # :316-317
         self.ctx = copy_context()
         self.device = self.model.flat.device
@@ -103,7 +107,7 @@ class Solver:
         self._comm = None                                    # data-parallel communicator (comm.Communicator)
 
         # "fake run" (:319-325): materialises V-variables and, here, tells which derivative streams D(...) needs
-        if self.model.initial_condition is not None and self.model.ic_constant is None:
+        if self.model.initial_condition is not None and self.model.ic_constant is None and not self.custom_forward:
             fake = torch.rand((3, self.model.total), device=self.device)
             self.ctx.run(self.model.ic_values, fake)
         self._trace_equation()
@@ -127,11 +131,35 @@ class Solver:
         kernels elsewhere; include/pinn.h pinn_set_gemm_mode). Also settable for a whole process with PYDENS_AMD_GEMM. """
         self.model.net.set_gemm_mode(mode)
 
+    def _equation_of_the_network(self, net_value, *cols):
+        """ custom forward(): the equation as a function of the BARE network's value (tagged: `D` finds its derivative streams)
+        and the input columns -- u_hat = model.forward(points) is torch code around it (reference model_torch.py:437-447) """
+        model = self.model
+        pts = torch.cat(cols, dim=1)                        # = reshape_and_concat of [N,1] columns (:345-362)
+        model.raw_field = (pts, net_value)
+        calls = model.conv_block_calls
+        try:
+            u_hat = model.forward(pts)
+        finally:
+            model.raw_field = None
+        if model.conv_block_calls == calls:
+            raise NotImplementedError('Solver(model=...): this forward() never calls self.conv_block(xs) -- a model that is not the '
+                                      'fully connected net of its layout is arbitrary torch code the HIP kernels cannot see')
+        return self.equation(u_hat, *cols)
+
     def _trace_equation(self):
         """ which streams does the equation need, and can it be lowered to a residual program? (construction, and again at
         the start of a fit call whenever the cached lowering no longer reproduces the live callable) """
-        self.spec, self.needs_x_grad = trace.discover(self.equation, self.ctx.run, self.model.total, self.device,
+        self._eq = self._equation_of_the_network if self.custom_forward else self.equation
+        self.spec, self.needs_x_grad = trace.discover(self._eq, self.ctx.run, self.model.total, self.device,
                                                       hp=self.model.net.layout.hp)
+        if self.custom_forward:
+            # torch code between the network and the equation: generic step path only
+            self.needs_x_grad = True
+            self.ic_var_slot, self.ic_trainable, self.residual_plan = None, False, None
+            self.program, self.program_error = None, 'the model has its own forward(): torch code around the network (generic path)'
+            self._traced_equation = self.equation
+            return
         # a callable initial condition that IS one scalar trainable variable (`lambda *a: V('init', ...)`, reference
         # examples notebook cells 80-88) stays on the fused path: the kernels read it from its user slot and return its
         # gradient there (pinn_residual_t::ic_var1); any other dependence on variables needs torch autograd (generic path)
@@ -270,6 +298,8 @@ class Solver:
     def _try_compile_constraint(self, constraint):
         """ -> ({'program', 'plan', 'points', 'ic'}, None) or (None, reason). """
         model, total = self.model, self.model.total
+        if self.custom_forward:
+            return None, 'the model has its own forward()'
         if self.ic_trainable:
             return None, 'initial condition holds trainable variables'
         try:
@@ -344,7 +374,7 @@ class Solver:
                 col = col.clone().requires_grad_()
             col._pinn_col = c
             cols.append(col)
-        return self.ctx.run(trace.call_with_streams, sc, self.equation, sc.tensors[()], *cols)
+        return self.ctx.run(trace.call_with_streams, sc, self._eq, sc.tensors[()], *cols)
 
     def _ic_streams(self, xs, create_graph):
         """ IC(x_spatial) and its derivative streams as a list over stream indices ([N,1] tensors or None). """
@@ -689,6 +719,7 @@ class Solver:
         model.grad_sink = self.grads
         for name in model.variables:
             getattr(model, name).grad = None
+        model.log_scale.grad = None
         try:
             loss = 0
             leaf = None
@@ -708,8 +739,8 @@ class Solver:
                         leaf[idx] = part
                     leaf.requires_grad_()
                 ic_streams = None
-                if model.initial_condition is not None and model.ic_constant is None:
-                    ic_streams = self._ic_streams(xs, create_graph=True)
+                if model.initial_condition is not None and model.ic_constant is None and not self.custom_forward:
+                    ic_streams = self._ic_streams(xs, create_graph=True)       # (custom forward(): the IC is torch code of the model)
                 r = self._eval_equation(leaf, xs, ic_streams)
                 term = criterion(r, torch.zeros_like(xs[:, :1]))                        # :448
                 loss = loss + (term if world == 1 else term * w_eq)
@@ -742,6 +773,10 @@ class Solver:
                 if p.grad is not None:
                     self.grads[off:off + n] += p.grad.reshape(-1)
                     p.grad = None
+            if self.custom_forward and model.log_scale.grad is not None:
+                # (the ansatz of a custom forward() is torch code: its log_scale gradient comes from autograd, not from the kernels)
+                self.grads[lay.off_log_scale] += model.log_scale.grad.reshape(())
+                model.log_scale.grad = None
             self.grads[lay.off_loss] = loss.detach()
         finally:
             model.grad_sink = None
@@ -756,7 +791,10 @@ class Solver:
         pts = self.reshape_and_concat(xs, device=self.device).contiguous()
         model.eval()
         with torch.no_grad():
-            u = model.net.jet_forward(model.flat, pts, ic_const=model.kernel_ic_const()).view(-1, 1)
-            if model.initial_condition is not None and model.ic_constant is None:
-                u = u + self.ctx.run(model.ic_values, pts).expand_as(u)
+            if self.custom_forward:
+                u = self.ctx.run(model.forward, pts).view(-1, 1)          # bare network on the kernels, the rest is the model's torch code
+            else:
+                u = model.net.jet_forward(model.flat, pts, ic_const=model.kernel_ic_const()).view(-1, 1)
+                if model.initial_condition is not None and model.ic_constant is None:
+                    u = u + self.ctx.run(model.ic_values, pts).expand_as(u)
         return u.detach().cpu().numpy()

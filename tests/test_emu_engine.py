@@ -748,7 +748,8 @@ def test_adam_options_the_kernel_does_not_implement_go_to_torch(pa, emu_lib):
 
 
 def test_model_plugin_seam(pa, emu_lib):
-    """ `Solver(model=...)` (model_torch.py:299-313): ConvBlockModel subclasses that keep forward() are accepted """
+    """ `Solver(model=...)` (model_torch.py:299-313): ConvBlockModel subclasses that keep forward() are accepted, a forward() that
+    is not built on self.conv_block is refused (torch code AROUND the network: test_model_subclass_with_its_own_forward) """
     class MyNet(pa.ConvBlockModel):
         def __init__(self, **kwargs):
             kwargs.setdefault('layout', 'fa fa f')
@@ -943,6 +944,63 @@ def _combined_program_case(pa, which, solver_kwargs):
         assert params_close(got, want, 2e-5)
     if which == 'reaction_2d':
         assert abs(float(solver.model.k.detach()) - float(oracle.model.k.detach())) < 1e-5
+
+
+@pytest.mark.parametrize('which', ['scaled_ansatz', 'no_ansatz_head', 'with_constraint'])
+def test_model_subclass_with_its_own_forward(pa, emu_lib, which):
+    _custom_forward_case(pa, which, emu_kwargs(emu_lib))
+
+
+def _custom_forward_case(pa, which, solver_kwargs):
+    """ the reference's plug-in seam (`Solver(model=Subclass)`, model_torch.py:52-54, :299-313): a subclass whose forward() puts its
+    own torch code around the network -- the ansatz times a factor of x, a head without any ansatz -- runs with the BARE network
+    on the kernels (`self.conv_block(xs)`), the rest as torch ops over its value and derivative streams (generic path; `D` applies
+    the chain rule, second order included). Same subclass body on the oracle's model; trajectories, predict, a constraint term. """
+    from oracle import pinn_oracle as po
+
+    def subclass(base):
+        class Scaled(base):
+            def forward(self, xs):
+                return self.anzatc(self.conv_block(xs), xs) * (1.0 + 0.5 * xs[:, :1])
+
+        class Head(base):
+            def forward(self, xs):
+                return torch.tanh(self.conv_block(xs)) * xs[:, :1] * (1 - xs[:, :1]) + 0.3
+        return Head if which == 'no_ansatz_head' else Scaled
+
+    def problem(D):
+        if which == 'no_ansatz_head':
+            return (lambda f, x: D(D(f, x), x) + f * D(f, x) - torch.sin(3 * x)), dict(ndims=1)
+        eq = lambda f, x, t: D(f, t) - 0.1 * D(D(f, x), x) + f * f
+        return eq, dict(ndims=2, boundary_condition=0.2, initial_condition=lambda x: torch.sin(np.pi * x))
+    net = dict(layout='fa fa f', features=[20, 20, 1], activation='Tanh')
+    eq_o, kw = problem(po.D)
+    con_o = con_p = None
+    if which == 'with_constraint':
+        con_o = con_p = lambda f, x, t: f(torch.tensor([0.5]), torch.tensor([0.5])) - 0.7
+    oracle = po.OracleSolver(eq_o, **kw, **net, model=subclass(po.OracleModel), constraints=con_o)
+    eq_p, kw = problem(pa.D)
+    solver = pa.Solver(eq_p, **kw, **net, model=subclass(pa.ConvBlockModel), constraints=con_p, **solver_kwargs)
+    assert solver.custom_forward and solver.program is None
+    load_params(solver, oracle.export_params())
+    d = kw['ndims']
+    pts = np.random.RandomState(4).rand(3, 40, d).astype(np.float32)
+    terms = ['equation', 'constraint_0'] if which == 'with_constraint' else 'equation'
+    xs = [pts[0][:, i] for i in range(d)]
+    assert np.abs(solver.predict(*xs) - oracle.predict(*xs)).max() < 2e-6
+    oracle.fit(niters=3, batch_size=40, points=pts, lr=0.01, loss_terms=terms)
+    solver.fit(niters=3, batch_size=40, sampler=FixedBatches(pts), lr=0.01, loss_terms=terms)
+    assert solver.last_fit_path == 'generic'
+    np.testing.assert_allclose([float(v) for v in solver.losses], [float(v) for v in oracle.losses], rtol=3e-5)
+    for got, want in zip(export_params(solver), oracle.export_params()):
+        assert params_close(got, want, 3e-5)
+    assert np.abs(solver.predict(*xs) - oracle.predict(*xs)).max() < 2e-5
+    # inputs transformed in front of the net are not what the kernels compute: refused where it happens
+    class Fourier(pa.ConvBlockModel):
+        def forward(self, xs):
+            return self.conv_block(torch.sin(xs))
+    with pytest.raises(NotImplementedError):
+        pa.Solver(eq_p, **kw, **net, model=Fourier, **solver_kwargs)
 
 
 def test_chunked_fit_equals_the_per_iteration_loop(pa, emu_lib):

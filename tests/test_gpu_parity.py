@@ -650,7 +650,8 @@ def test_closure_constants_and_reassigned_equations_take_effect_in_the_next_fit(
 
 def test_convblockmodel_subclass_as_model_plugin(pa):
     """ the reference's plug-in seam `Solver(model=...)` (model_torch.py:299-313): a subclass that sets up the fully
-    connected net its own way runs on the kernels; a subclass that replaces forward() is refused loudly. """
+    connected net its own way runs on the kernels; a subclass whose forward() is not built on self.conv_block is refused loudly
+    (forward() with torch code AROUND the network: test_model_subclass_with_its_own_forward_on_the_gpu). """
     class MyNet(pa.ConvBlockModel):
         def __init__(self, **kwargs):
             kwargs.setdefault('layout', 'fa fa f')
@@ -733,6 +734,12 @@ def test_known_answers_of_the_tutorial(pa):
     v = float(solver.model.new_var)
     err = np.abs(solver.predict(xs)[:, 0] - (np.sin(2 * np.pi * xs) + 1 - 2 * xs)).max()
     assert abs(v - 2.0) < 0.05 and err < 0.1, (v, err)              # (reference: V = 1.997 .. 2.004, error 0.006 .. 0.02)
+
+
+@pytest.mark.parametrize('which', ['scaled_ansatz', 'no_ansatz_head', 'with_constraint'])
+def test_model_subclass_with_its_own_forward_on_the_gpu(pa, which):
+    import test_emu_engine as te
+    te._custom_forward_case(pa, which, {})
 
 
 def test_twenty_hidden_layers_on_the_gpu(pa):
