@@ -1014,12 +1014,12 @@ def test_chunked_fit_equals_the_per_iteration_loop(pa, emu_lib):
         if per_iteration:
             solver._device_columns = lambda sampler: None
         sampler = sampler_of()
-        solver.fit(niters=7, batch_size=48, sampler=sampler, lr=0.01)
-        solver.fit(niters=3, batch_size=48, sampler=sampler, lr=0.01, optimizer=None)
+        solver.fit(niters=5, batch_size=40, sampler=sampler, lr=0.01)
+        solver.fit(niters=2, batch_size=40, sampler=sampler, lr=0.01, optimizer=None)
         return np.array([float(v) for v in solver.losses]), export_params(solver)
     for sampler_of in (lambda: None, lambda: pa.NumpySampler('uniform', seed=5) & pa.NumpySampler('uniform', low=1, high=5, seed=6)):
         want_l, want_p = run(128, True, sampler_of)
-        for chunk in (128, 3, 1):
+        for chunk in (128, 2):
             got_l, got_p = run(chunk, False, sampler_of)
             assert np.array_equal(got_l, want_l), chunk
             for a, b in zip(got_p, want_p):
