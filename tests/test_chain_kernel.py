@@ -51,10 +51,9 @@ def test_experiment_build_knobs_keep_parity():
     import pydens_amd as pa
     from pydens_amd import engine
     from oracle import pinn_oracle as po
-    knobs = build_emu.build(extra_flags=['-DPINN_TEAM_FLAGS=3', '-DPINN_SVPF_MAX=0'], tag='knobs',
-                            widths=(64, 128))
+    knobs = build_emu.build(extra_flags=['-DPINN_TEAM_FLAGS=3', '-DPINN_SVPF_MAX=0'], tag='knobs', widths=(64,))
     libs = [engine.bind(ctypes.CDLL(build_emu.build())), engine.bind(ctypes.CDLL(knobs))]
-    for name, n in (('cfg2', 70), ('cfg3', 40)):
+    for name, n in (('cfg2', 70), ('cfg4', 70)):              # the two-team kernels (team-local barriers), 64-wide
         torch.manual_seed(0)
         co, cp = pc.make_config(name, po.D, torch), pc.make_config(name, pa.D, torch)
         oracle = po.OracleSolver(co['equation'], **co['solver_kwargs'])
