@@ -60,6 +60,19 @@ def _problem(path, pa, lib):
         # `_uneven`: 99 points per iteration on two ranks -- shares of 50 and 49 points, weighted by the GLOBAL count
         points = g.points[:3, :99] if path.endswith('_uneven') else g.points[:3]
         return solver, np.ascontiguousarray(points), dict(lr=g.lr), g.params
+    if path == 'custom_forward_generic':
+        # the model plug-in seam with a forward() of its own (model_torch.py:52-54): bare network on the kernels, the ansatz (with
+        # its log_scale gradient from autograd) and an output factor as torch code, generic step path -- under data parallelism
+        class Scaled(pa.ConvBlockModel):
+            def forward(self, xs):
+                return self.anzatc(self.conv_block(xs), xs) * (1.0 + 0.5 * xs[:, :1])
+        torch.manual_seed(5)
+        eq = lambda f, x, t: pa.D(f, t) - 0.1 * pa.D(pa.D(f, x), x) + f * f
+        solver = pa.Solver(eq, ndims=2, boundary_condition=0.2, initial_condition=lambda x: torch.sin(np.pi * x), model=Scaled,
+                           layout='fa fa f', features=[12, 10, 1], activation='Tanh', lib=lib, device='cpu')
+        rng = np.random.RandomState(6)
+        start = [np.asarray(rng.randn(*p.shape) * 0.5, dtype=np.float32) for p in export_params_of(solver)]
+        return solver, rng.rand(3, 32, 2).astype(np.float32), dict(lr=0.02), start
     # tutorial cells 50-60: trainable variable in the equation + a constraint term; every rank evaluates the constraint,
     # the all-reduce sums the copies, hence its 1 / world scale
     from test_emu_engine import _variable_problem
@@ -121,3 +134,7 @@ def test_two_ranks_constraint_term_and_variable_fused():
 
 def test_two_ranks_constraint_term_and_variable_generic():
     _run('constraint_generic')
+
+
+def test_two_ranks_model_with_its_own_forward():
+    _run('custom_forward_generic')
