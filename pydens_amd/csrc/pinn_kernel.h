@@ -977,6 +977,10 @@ PINN_DEVICE f32x4 pinn_row_sum16_v4(f32x4 v) {
 // 128 = WGX: the weight gradients of the hidden->hidden layers are NOT accumulated here -- the kernel streams gz_a and the
 // saved jets of every tile to HBM (lane-private, coalesced) and pinn_wgrad_kernel (pinn_wgrad_kernel.h) turns them into dW
 // with the whole HP x HP accumulator in registers (widths >= 128, where a workgroup's dW does not fit on chip).
+// 64 = SLABL: the saved jets of a shape-specialised static-depth kernel in LDS instead of the global slab (measured slower, off).
+// 512 = SPLIT: the hidden-layer GEMMs on v_mfma_f32_16x16x32_bf16 with every fp32 operand split exactly into three bf16 (round 3;
+// pinn_set_gemm_mode). 1024 (with 8) = the breadth kernel for skip connections over Tanh / Sigmoid layers only:
+// one-bit activation codes, no skips that start in front of an activation.
 template <int HP, int ND, int N2, int MT, int LHC, int ACTC, bool COMB = false, int VAR = 0>
 // occupancy hint: the fused kernel of a 64/128-wide net wants the whole register file of a SIMD (one wave per SIMD,
 // no spills); narrower nets (1-2 waves per workgroup) run several workgroups per CU
