@@ -31,18 +31,77 @@ def act_derivs(z, act, fourth=False):
         d2 = d1 * q
         d3 = d1 * (q * q - 2.0 * d1)
         d4 = d1 * q * (q * q - 8.0 * d1)
+    elif act == 'sin':
+        t, d1 = np.sin(z), np.cos(z)
+        d2, d3, d4 = -t, -d1, t
+    elif act == 'identity':
+        t, d1 = z, np.ones_like(z)
+        d2 = d3 = d4 = np.zeros_like(z)
+    elif act in ('softplus', 'silu', 'swish'):
+        # s = sigmoid(z), a = s(1 - s), q = 1 - 2s:  ds = a, da = a q, dq = -2a
+        sg = 1.0 / (1.0 + np.exp(-z))
+        a = sg * (1.0 - sg)
+        q = 1.0 - 2.0 * sg
+        a3 = a * (q * q - 2.0 * a)                 # second derivative of a
+        a4 = a * q * (q * q - 8.0 * a)             # third derivative of a
+        if act == 'softplus':                      # log(1 + e^z): derivatives s, a, a q, a3
+            t = np.logaddexp(0.0, z)
+            d1, d2, d3, d4 = sg, a, a * q, a3
+        else:                                      # z s
+            t = z * sg
+            d1 = sg + z * a
+            d2 = 2.0 * a + z * a * q
+            d3 = 3.0 * a * q + z * a3
+            d4 = 4.0 * a3 + z * a4
+    elif act == 'gelu':                            # z Phi(z) (erf form, torch.nn.GELU default)
+        from math import erf, pi, sqrt
+        Phi = 0.5 * (1.0 + np.vectorize(erf)(z / sqrt(2.0)))
+        phi = np.exp(-0.5 * z * z) / sqrt(2.0 * pi)
+        z2 = z * z
+        t = z * Phi
+        d1 = Phi + z * phi
+        d2 = phi * (2.0 - z2)
+        d3 = phi * z * (z2 - 4.0)
+        d4 = phi * ((7.0 - z2) * z2 - 4.0)
     else:
         raise ValueError(act)
     return (t, d1, d2, d3, d4) if fourth else (t, d1, d2, d3)
 
 
+def parse_layout(layout, activation):
+    """ the letters of the reference's Block layouts (model_torch.py:142-156) that matter to a fully connected net:
+    -> (activation name per hidden layer, skips [(src, dst, dst_pre, src_pre)]); 'R' / '+' sit behind a dense layer, in front of its
+    activation (pre) or behind it. """
+    letters = layout.replace(' ', '')
+    names = None if isinstance(activation, str) else [str(a) for a in activation]
+    acts, skips, layer, open_skip = [], [], -1, None
+    for ch in letters:
+        if ch == 'f':
+            if layer >= 0 and len(acts) == layer:
+                acts.append('identity')
+            layer += 1
+        elif ch == 'a':
+            acts.append((names.pop(0) if names is not None else activation).lower())
+        elif ch == 'R':
+            open_skip = (layer, len(acts) == layer)
+        elif ch == '+':
+            skips.append((open_skip[0], layer, len(acts) == layer, open_skip[1]))
+            open_skip = None
+        else:
+            raise ValueError(ch)
+    return acts, skips
+
+
 class Spec:
     """ Problem descriptor: network, ansatz and requested derivative streams. """
     def __init__(self, weights, biases, act, ndims, nparams=0, has_bc=False, bc_value=0.0, has_ic=False,
-                 domain=None, log_scale=0.0, dir_cols=(), n2=0, n3=0):
+                 domain=None, log_scale=0.0, dir_cols=(), n2=0, n3=0, skips=()):
         self.W = [np.asarray(w, dtype=np.float64) for w in weights]     # [out, in] per layer (nn.Linear layout)
         self.b = [np.asarray(b, dtype=np.float64) for b in biases]
-        self.act = act.lower()
+        n_hidden = len(self.W) - 1
+        self.acts = [act.lower()] * n_hidden if isinstance(act, str) else [str(a).lower() for a in act]
+        assert len(self.acts) == n_hidden
+        self.skips = list(skips)                    # (src, dst, dst_pre, src_pre) hidden-layer indices (parse_layout)
         self.ndims, self.nparams = ndims, nparams
         self.has_bc, self.bc_value, self.has_ic = has_bc, float(bc_value), has_ic
         self.nsp = ndims - 1 if has_ic else ndims
@@ -74,12 +133,19 @@ def mlp_jet_forward(sp, xs):
     for k, c in enumerate(sp.dir_cols):
         z[1 + k] = sum(W[:, j] for j in _cols(c))[None, :]
     h_prev = None
+    carried = {}
     for l in range(L - 1):
         if l > 0:
             W, b = sp.W[l], sp.b[l]
             z = np.einsum('snk,ok->sno', h_prev, W)
             z[0] += b
-        t, d1, d2, d3, d4 = act_derivs(z[0], sp.act, fourth=True)
+        for k_, (src, dst, dst_pre, src_pre) in enumerate(sp.skips):      # '+' in front of the activation: z joins the carried jets
+            if dst == l and dst_pre:
+                z = z + carried[k_]
+        for k_, (src, dst, dst_pre, src_pre) in enumerate(sp.skips):      # 'R' in front of the activation: z itself is carried
+            if src == l and src_pre:
+                carried[k_] = z
+        t, d1, d2, d3, d4 = act_derivs(z[0], sp.acts[l], fourth=True)
         h = np.zeros_like(z)
         h[0] = t
         for k in range(sp.nd):
@@ -89,6 +155,12 @@ def mlp_jet_forward(sp, xs):
         for k in range(sp.n3):                                         # h''' = s' z''' + 3 s'' z' z'' + s''' z'^3
             z1, z2 = z[1 + k], z[1 + sp.nd + k]
             h[sp.i3(k)] = d1 * z[sp.i3(k)] + 3.0 * d2 * z1 * z2 + d3 * z1 ** 3
+        for k_, (src, dst, dst_pre, src_pre) in enumerate(sp.skips):      # '+' behind the activation
+            if dst == l and not dst_pre:
+                h = h + carried[k_]
+        for k_, (src, dst, dst_pre, src_pre) in enumerate(sp.skips):      # 'R' behind the activation (after a '+' that ends here)
+            if src == l and not src_pre:
+                carried[k_] = h
         cache.append((h_prev, z, d1, d2, d3, d4))
         h_prev = h
     W, b = sp.W[L - 1], sp.b[L - 1]
@@ -106,8 +178,15 @@ def mlp_jet_backward(sp, gnet, fwd_cache):
     dW[L - 1] = np.einsum('sn,snk->k', gnet, h_last)[None, :]
     db[L - 1] = np.array([gnet[0].sum()])
     gh = gnet[:, :, None] * sp.W[L - 1][0][None, None, :]
+    gskip = {}
     for l in range(L - 2, -1, -1):
         h_prev, z, d1, d2, d3, d4 = cache[l]
+        for k_, (src, dst, dst_pre, src_pre) in enumerate(sp.skips):      # reverse of the forward order at this layer
+            if src == l and not src_pre:
+                gh = gh + gskip[k_]
+        for k_, (src, dst, dst_pre, src_pre) in enumerate(sp.skips):
+            if dst == l and not dst_pre:
+                gskip[k_] = gh
         gz = np.zeros_like(gh)
         acc = d1 * gh[0]
         for k in range(sp.nd):
@@ -126,6 +205,12 @@ def mlp_jet_backward(sp, gnet, fwd_cache):
             gz[1 + k] += (3.0 * d3 * z1 * z1 + 3.0 * d2 * z2) * g3
             acc = acc + (d4 * z1 ** 3 + 3.0 * d3 * z1 * z2 + d2 * z3) * g3
         gz[0] = acc
+        for k_, (src, dst, dst_pre, src_pre) in enumerate(sp.skips):
+            if src == l and src_pre:
+                gz = gz + gskip[k_]
+        for k_, (src, dst, dst_pre, src_pre) in enumerate(sp.skips):
+            if dst == l and dst_pre:
+                gskip[k_] = gz
         db[l] = gz[0].sum(axis=0)
         if l > 0:
             dW[l] = np.einsum('sno,snk->ok', gz, h_prev)

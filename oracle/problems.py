@@ -53,6 +53,12 @@ def stream_form(name):
             d = np.zeros_like(u); d[2] = 1.0; d[0] = 6.0 * u[1]; d[1] = 6.0 * u[0]; d[4] = 1.0
             return r, d
         return dict(dir_cols=[0, 1], n2=1, n3=1, residual=residual)
+    if name == 'resnet3':                            # u_t + u u_x + 0.05 u_xxx - 0.1 u_xx; dirs x (3rd order), t (1st):
+        def residual(u, xs):                         # streams u, ux, ut, uxx, uxxx
+            r = u[2] + u[0] * u[1] + 0.05 * u[4] - 0.1 * u[3]
+            d = np.zeros_like(u); d[2] = 1.0; d[0] = u[1]; d[1] = u[0]; d[4] = 0.05; d[3] = -0.1
+            return r, d
+        return dict(dir_cols=[0, 1], n2=1, n3=1, residual=residual)
     raise KeyError(name)
 
 
@@ -62,7 +68,7 @@ def ic_streams_f64(name, xs, dir_cols, n2, n3=0):
     nd = len(dir_cols)
     S = 1 + nd + n2 + n3
     out = np.zeros((S, xs.shape[0]))
-    if name == 'kdv':                                # x sin(pi x): streams u, ux, ut, uxx, uxxx
+    if name in ('kdv', 'resnet3'):                   # x sin(pi x): streams u, ux, ut, uxx, uxxx
         x = xs[:, 0]
         sn, cs = np.sin(PI * x), np.cos(PI * x)
         out[0] = x * sn
