@@ -1003,6 +1003,34 @@ def _custom_forward_case(pa, which, solver_kwargs):
         pa.Solver(eq_p, **kw, **net, model=Fourier, **solver_kwargs)
 
 
+def test_breadth_streams_and_gradients_match_the_fp64_jets(pa, emu_lib):
+    """ the breadth fixture `resnet3` (third derivative; Sin / Tanh / SiLU / Sigmoid; a residual block joining in front of its
+    activation and one behind) against oracle/jet_f64.py, the independent fp64 statement of the kernel mathematics that is itself
+    pinned to the reference-generated golden (tests/test_oracle_vs_golden.py): every derivative stream, the loss, every gradient """
+    from oracle import jet_f64 as jf, problems
+    from test_oracle_vs_golden import make_spec
+    g = Golden('resnet3')
+    _, solver = make_solver('resnet3', pa, **emu_kwargs(emu_lib))
+    load_params(solver, g.params)
+    sf, spec = make_spec(g)
+    pts = g.points[0]
+    ic64 = problems.ic_streams_f64('resnet3', pts, sf['dir_cols'], sf['n2'], sf.get('n3', 0))
+    out = jf.step(spec, pts, sf['residual'], ic64)
+    xs = torch.from_numpy(pts.copy())
+    n2p = sf['n2'] | (sf.get('n3', 0) << 3)
+    streams = solver.model.net.jet_forward(solver.model.flat, xs, sf['dir_cols'], n2p,
+                                           ic_streams=torch.from_numpy(ic64.astype(np.float32)).contiguous())
+    for s_idx in range(spec.S):
+        assert rel_l2(streams[s_idx].numpy(), out['u_streams'][s_idx]) < 2e-5, s_idx
+    solver._fused_step(xs, 1)
+    lay = solver.model.net.layout
+    assert abs(float(solver.grads[lay.off_loss]) - out['loss']) <= 1e-5 * out['loss']
+    flat = [t for pair in zip(out['dW'], out['db']) for t in pair]
+    for got, want in zip(export_grads(solver), flat):
+        assert rel_l2(got, want) < 2e-5
+    assert abs(float(export_grads(solver)[-1]) - out['dlog_scale']) <= 2e-5 * max(1.0, abs(out['dlog_scale']))
+
+
 def test_chunked_fit_equals_the_per_iteration_loop(pa, emu_lib):
     """ Solver.fit on the common path -- device sampler, one equation term, Adam -- enqueues chunks of iterations through ONE
     library call (pinn_fit_steps; reference loop model_torch.py:426-464). Same Philox batches, same Adam steps, same loss
