@@ -266,6 +266,11 @@ const char* pinn_last_kernel_name(void);
 /* ... and of the streamed weight-gradient kernel of widths >= 128 ("" before the first such launch); the last template argument
  * says whether it was the split-bf16 form (pinn_set_gemm_mode) */
 const char* pinn_last_wgrad_kernel_name(void);
+/* Geometry of the last tile-kernel launch: out[0] = workgroups of the grid, out[1] = workgroups per CU the grid was planned with
+ * (what hipOccupancyMaxActiveBlocksPerMultiprocessor answered for the instantiation, capped -- see pinn_debug_max_wgs_per_cu),
+ * out[2] = threads per workgroup, out[3] = bytes of dynamic LDS. The large-batch parity tests assert with it that they really
+ * ran several workgroups per CU. Returns non-zero before the first launch. */
+int pinn_last_launch_info(int32_t out[4]);
 
 /* Diagnostics (tests, tools/): never used on the training path; they leave results untouched.
  *   pinn_debug_last_kernel        0 = general tile kernel, 2 = shape-specialised tile kernel took the last launch
@@ -275,6 +280,10 @@ const char* pinn_last_wgrad_kernel_name(void);
 int pinn_debug_last_kernel(void);
 int pinn_debug_prepass_in_kernel(int enable);
 int pinn_debug_wgx_chunk_bytes(long long bytes);
+/*   pinn_debug_max_wgs_per_cu     upper bound of the workgroups per CU a tile-kernel grid is planned with (1 .. 4; <= 0 restores
+ *                                 the default, 4): tests run the same step at 1 and at several workgroups per CU; affects
+ *                                 pinn_workspace_bytes (partial rows, slabs), so set it first. Returns the previous bound. */
+int pinn_debug_max_wgs_per_cu(int cap);
 #ifdef PINN_DEBUG_ABI
 /* EXPERIMENT BUILDS ONLY (-DPINN_DEBUG_ABI, tools/variant.sh): the product library neither exports these nor compiles the
  * kernel paths behind them. The flag bits are TIMING experiments -- kernels skip loads / stores / barriers, the results of

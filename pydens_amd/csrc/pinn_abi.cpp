@@ -54,7 +54,9 @@ float prof_elapsed(hipEvent_t a, hipEvent_t b) {
 PINN_HIDDEN int g_pinn_last_kernel = -1;
 PINN_HIDDEN char g_pinn_last_kernel_name[96] = "";
 PINN_HIDDEN char g_pinn_last_wgrad_name[96] = "";
+PINN_HIDDEN int g_pinn_last_launch[4] = {0, 0, 0, 0};   // grid, workgroups per CU of the plan, threads, dynamic LDS bytes
 namespace {
+int g_pinn_max_per_cu = 4;          // pinn_debug_max_wgs_per_cu
 int g_pinn_prepass_in_kernel = 1;   // debug switch: 0 = x-only pre-pass as its own launch (pinn_aux_kernel)
 int g_pinn_debug_flags = 0;         // -DPINN_DEBUG_ABI builds: pinn_debug_set_flags
 }
@@ -128,7 +130,7 @@ int device_cus(const pinn_net* net) {
 
 struct Plan {
     launch_fn fn;
-    int n2k, grid, threads;
+    int n2k, grid, threads, per_cu;
     size_t smem, slab_vec4_per_wg;  // saved-jet slab per workgroup (per TILE for WGX kernels)
     size_t wt_floats_per_wg;        // slab-in-LDS kernels: W^T scratch of every workgroup (PinnKArgs::wt)
     int64_t ntiles;                 // tiles of T = 16 * mt points in the batch
@@ -182,6 +184,8 @@ int make_plan(const pinn_net* net, int64_t n_points, int nd, int n2, Plan* plan,
     plan->wt_floats_per_wg = (size_t)info[5];
     const int64_t ntiles = (n_points + 15) / 16;
     const int64_t wg_tiles = (ntiles + info[4] - 1) / info[4];       // a two-team workgroup streams two tiles at a time
+    if (info[3] > g_pinn_max_per_cu) info[3] = g_pinn_max_per_cu;
+    plan->per_cu = (int)info[3];
     int64_t grid = (int64_t)device_cus(net) * info[3];
     const int64_t teams = info[10] > 0 ? info[10] : 1;              // a two-team workgroup streams two tiles at a time
     if (grid > (wg_tiles + teams - 1) / teams) grid = (wg_tiles + teams - 1) / teams;
@@ -216,6 +220,11 @@ int make_plan(const pinn_net* net, int64_t n_points, int nd, int n2, Plan* plan,
         plan->chunk_tiles = chunk < wg_tiles ? chunk : wg_tiles;
     }
     return 0;
+}
+
+void note_launch(const Plan& plan) {
+    g_pinn_last_launch[0] = plan.grid; g_pinn_last_launch[1] = plan.per_cu;
+    g_pinn_last_launch[2] = plan.threads; g_pinn_last_launch[3] = (int)plan.smem;
 }
 
 void fill_args(const pinn_net* net, PinnKArgs* a, const float* params, const float* xs, int64_t n, const int* dir_cols,
@@ -368,6 +377,18 @@ int pinn_debug_prepass_in_kernel(int enable) {
 int pinn_debug_wgx_chunk_bytes(long long bytes) {
     g_wgx_chunk_bytes = bytes > 0 ? (size_t)bytes : ((size_t)6656 << 20);
     return 0;
+}
+
+int pinn_debug_max_wgs_per_cu(int cap) {
+    const int before = g_pinn_max_per_cu;
+    g_pinn_max_per_cu = (cap <= 0 || cap > 4) ? 4 : cap;
+    return before;
+}
+
+int pinn_last_launch_info(int32_t out[4]) {
+    if (!out) return fail("null argument");
+    for (int i = 0; i < 4; ++i) out[i] = g_pinn_last_launch[i];
+    return g_pinn_last_launch[0] > 0 ? 0 : 1;
 }
 
 #ifdef PINN_DEBUG_ABI
@@ -559,6 +580,7 @@ int pinn_jet_forward(pinn_t* net, const float* params, const float* xs, int64_t 
     a.out_streams = streams_out;
     set_tile_range(&a, plan, 0, plan.ntiles);
     const int rc = plan.fn(nd, plan.n2k, &a, plan.grid, stream, 0, nullptr);
+    note_launch(plan);
     return rc ? fail("tile kernel launch failed (%d)", rc) : 0;
 }
 
@@ -654,6 +676,7 @@ static int run_train(pinn_t* net, PinnKArgs* a, const Plan& plan, int nd, float*
         if (pe) hipEventRecord(pe->tile0, (hipStream_t)stream);
 #endif
         const int rc = plan.fn(nd, plan.n2k, a, plan.grid, stream, 0, nullptr);
+        note_launch(plan);
         if (rc) return fail("tile kernel launch failed (%d)", rc);
 #ifndef PINN_EMU
         if (pe) { hipEventRecord(pe->tile1, (hipStream_t)stream); pe->have_tile = true; }

@@ -1014,7 +1014,10 @@ pinn_tile_kernel(const PinnKArgs A) {
     //  form at every size) -- DESIGN.md section 6b; tests/test_gpu_parity.py holds the shipped kernels to bitwise repeatability)
     // Widths >= 128 (round 3, later): the WGX form -- forward and data-gradient GEMMs here, weight fragments streamed K block by
     // K block (they do not fit the registers), weight gradients in pinn_wgrad_kernel's own split form.
-    static_assert(!SPLIT || (HP == 64 && NTW == 1 && LHC >= 1 && !(VAR & (1 | 2 | 8 | 64 | 128)) && ((S * T) % 32) == 0 &&
+#ifndef PINN_VAR2_REFUSED
+#define PINN_VAR2_REFUSED 2     // (0 in the experiment builds that look for the cause of the finding above)
+#endif
+    static_assert(!SPLIT || (HP == 64 && NTW == 1 && LHC >= 1 && !(VAR & (1 | PINN_VAR2_REFUSED | 8 | 64 | 128)) && ((S * T) % 32) == 0 &&
                              ((T == 16 && S % 2 == 0) || T == 32)) ||
                             (HP >= 128 && (VAR & 128) && !(VAR & (1 | 2 | 8 | 64 | 256))),
                   "split-bf16 kernels: width 64 with static depth and register-resident dW (K = S * T a multiple of 32), or the WGX kernels of widths >= 128");
@@ -1040,6 +1043,13 @@ pinn_tile_kernel(const PinnKArgs A) {
     const int vbid = PINN_BID * TEAMS + team, vnblk = PINN_NBLK * TEAMS;
     const int lr = lane & 15, lq = lane >> 4;
     const int lh = (LHC >= 0) ? LHC : A.lh;
+#if defined(PINN_SCRATCH_CANARY) && !defined(PINN_EMU)
+    // experiment builds (tools/var2.sh): does a wave read back from its private segment what it stored there? A tag per lane at
+    // scratch offset 0 (inside the 160 bytes hipcc reserves and never touches), checked at the top of every tile; mismatches are
+    // counted in A.prof[0], the first one kept in A.prof[1..2] (pinn_debug_phase_buffer)
+    const unsigned canary_tag = ((unsigned)PINN_BID << 12) | (unsigned)gtid;
+    asm volatile("scratch_store_dword off, %0, off offset:0" :: "v"(canary_tag) : "memory");
+#endif
     // activation of index a (0: first layer ... lh: last hidden layer)
     // (plain instantiations only know tanh / sigmoid -- one bit, which lets the compiler drop the sin / identity paths;
     //  the full set runs on the VAR 8 instantiations, see the launcher)
@@ -1392,6 +1402,15 @@ pinn_tile_kernel(const PinnKArgs A) {
     for (long long tile0 = A.tile_begin + (long long)PINN_BID * TEAMS; tile0 < ntiles; tile0 += vnblk, tile_parity ^= 1) {
         const long long tile = tile0 + team;
         const long long base = tile * T;
+#if defined(PINN_SCRATCH_CANARY) && !defined(PINN_EMU)
+        {
+            unsigned got;
+            asm volatile("scratch_load_dword %0, off, off offset:0\n\ts_waitcnt vmcnt(0)" : "=v"(got) :: "memory");
+            if (got != canary_tag && A.prof) {
+                if (atomicAdd(reinterpret_cast<unsigned long long*>(A.prof), 1ull) == 0) { A.prof[1] = canary_tag; A.prof[2] = got; }
+            }
+        }
+#endif
         if (WGX && train) {
             // (debug flag 4, timing experiments only: every tile writes the first tile's slab -- stores stay in L2)
             const size_t tl = PINN_DBG(A, 4) ? 0 : (size_t)(tile - A.tile_begin);

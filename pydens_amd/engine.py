@@ -118,6 +118,8 @@ def bind(lib):
     if hasattr(lib, 'pinn_debug_phase_buffer'):                  # -DPINN_DEBUG_ABI experiment builds only
         lib.pinn_debug_phase_buffer.argtypes = [vp]
     lib.pinn_debug_wgx_chunk_bytes.argtypes = [ctypes.c_longlong]
+    lib.pinn_debug_max_wgs_per_cu.argtypes = [ctypes.c_int]
+    lib.pinn_last_launch_info.argtypes = [ctypes.POINTER(ctypes.c_int32)]
     for name in ('pinn_create', 'pinn_create_ex', 'pinn_destroy', 'pinn_layout', 'pinn_jet_forward', 'pinn_jet_backward',
                  'pinn_residual_step', 'pinn_residual_adam_step', 'pinn_adam_step', 'pinn_adam_step_at'):
         getattr(lib, name).restype = i32
@@ -127,7 +129,7 @@ def bind(lib):
 ABI_SYMBOLS = ('pinn_create', 'pinn_create_ex', 'pinn_destroy', 'pinn_layout', 'pinn_workspace_bytes', 'pinn_jet_forward',
                'pinn_jet_backward', 'pinn_residual_step', 'pinn_residual_step_add', 'pinn_residual_adam_step', 'pinn_adam_step', 'pinn_adam_step_at', 'pinn_sample_points', 'pinn_fit_steps', 'pinn_set_gemm_mode', 'pinn_profile_tile',
                'pinn_last_tile_ms', 'pinn_last_wgrad_ms', 'pinn_last_kernel_name', 'pinn_last_wgrad_kernel_name', 'pinn_debug_last_kernel',
-               'pinn_debug_prepass_in_kernel', 'pinn_debug_wgx_chunk_bytes',
+               'pinn_debug_prepass_in_kernel', 'pinn_debug_wgx_chunk_bytes', 'pinn_debug_max_wgs_per_cu', 'pinn_last_launch_info',
                'pinn_last_error', 'pinn_backend')
 
 _LIB = None

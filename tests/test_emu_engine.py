@@ -1081,3 +1081,12 @@ def test_sin_net_of_depth_four_takes_the_static_kernel(pa, emu_lib, bc):
     np.testing.assert_allclose([float(v) for v in solver.losses], [float(v) for v in oracle.losses], rtol=2e-5)
     for got, want in zip(export_params(solver), oracle.export_params()):
         assert params_close(got, want, 2e-5)
+
+
+@pytest.mark.parametrize('name', ['w16_program', 'w32_affine', 'w32_generic', 'w32_third_order', 'w100_heat', 'program', 'generic'])
+def test_the_large_batch_gpu_cases_on_a_few_points(pa, emu_lib, name):
+    """ tests/test_gpu_occupancy.py runs these problems at 131 072 points on full grids of the device; here the same body (oracle
+    parity, four bit-identical repeats, the workgroups-per-CU cap, pinn_last_launch_info) on the emulator with a handful of points """
+    import test_gpu_occupancy as tg
+    info = tg.run_case(pa, name, 80 if name != 'w100_heat' else 40, solver_kwargs=emu_kwargs(emu_lib), on_device=False)
+    assert info['grid'] >= 1 and info['threads'] in (64, 128, 256, 512) and info['per_cu'] >= 1
