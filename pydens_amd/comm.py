@@ -14,6 +14,8 @@ On CPU tensors (the emulator-backed tests, gloo) the same interface falls throug
 """
 import ctypes
 import os
+import threading
+import time
 
 import torch
 import torch.distributed as dist
@@ -68,7 +70,13 @@ class Communicator:
                        and os.environ.get('PYDENS_AMD_COMM', 'rccl') != 'torch')
         self.direct = False
         if not want_direct:
-            self.fallback_reason = 'CPU tensors / gloo' if self.device.type != 'cuda' else 'PYDENS_AMD_COMM=torch'
+            # (the reason names the condition that actually held -- ADVICE r3: a gloo group on a CUDA device used to read 'PYDENS_AMD_COMM=torch')
+            if self.device.type != 'cuda':
+                self.fallback_reason = f'CPU tensors ({dist.get_backend()} group)'
+            elif dist.get_backend() != 'nccl':
+                self.fallback_reason = f'the process group is {dist.get_backend()}, not nccl'
+            else:
+                self.fallback_reason = 'PYDENS_AMD_COMM=torch'
             return
         # Every rank must take the same path, and no rank may enter ncclCommInitRank alone (its peers would wait in it for
         # ever): the ranks agree (MIN all-reduce over the torch group) after each step that can fail locally -- loading the
@@ -90,19 +98,37 @@ class Communicator:
         dist.broadcast(box, src=0)                # all 128 bytes, zeros included, + rank 0's verdict
         raw = bytes(box.cpu().tolist())
         if raw[NCCL_UNIQUE_ID_BYTES]:
-            return self._fall_back(f'ncclGetUniqueId failed on rank 0 ({err})')
+            return self._fall_back(f'ncclGetUniqueId failed on rank 0 ({err if self.rank == 0 else "see the warning of rank 0"})')
         ctypes.memmove(ctypes.byref(uid), raw[:NCCL_UNIQUE_ID_BYTES], NCCL_UNIQUE_ID_BYTES)
         torch.cuda.synchronize(self.device)       # nothing of ProcessGroupNCCL's in flight while the second communicator boots
         comm = ctypes.c_void_p()
-        try:
-            with torch.cuda.device(self.device):
-                _check(lib, lib.ncclCommInitRank(ctypes.byref(comm), self.world, uid, self.rank), 'ncclCommInitRank')
-        except RuntimeError as exc:
-            err = exc
+        # ncclCommInitRank is a rendezvous: if some rank never arrives (or the bootstrap network is misconfigured) the others would
+        # wait in it for ever, and the MIN agreement below only helps ranks that RETURN. So the call runs on a helper thread (ctypes
+        # releases the GIL) and this thread waits a bounded time (PYDENS_AMD_COMM_TIMEOUT seconds, default 120): a rank whose call
+        # has not returned votes "failed", every rank falls back to torch.distributed together, the stuck helper thread is left
+        # behind (daemon) and its half-made communicator is never used.
+        outcome = {}
+
+        def init():
+            try:
+                with torch.cuda.device(self.device):
+                    _check(lib, lib.ncclCommInitRank(ctypes.byref(comm), self.world, uid, self.rank), 'ncclCommInitRank')
+                outcome['ok'] = True
+            except RuntimeError as exc:
+                outcome['err'] = exc
+
+        timeout = float(os.environ.get('PYDENS_AMD_COMM_TIMEOUT', '120'))
+        worker = threading.Thread(target=init, name='pydens_amd-rccl-init', daemon=True)
+        worker.start()
+        worker.join(timeout)
+        if worker.is_alive():
+            err = TimeoutError(f'ncclCommInitRank did not return within {timeout:g} s on rank {self.rank}')
+        elif 'err' in outcome:
+            err = outcome['err']
         if not self._agree(err is None):
             if err is None:
                 lib.ncclCommDestroy(comm)
-            return self._fall_back(f'ncclCommInitRank failed on some rank ({err})')
+            return self._fall_back(f'ncclCommInitRank failed or timed out on some rank ({err if err is not None else "not this one"})')
         self.comm, self.direct = comm, True
         count = ctypes.c_int(0)
         if hasattr(lib, 'ncclCommCount') and lib.ncclCommCount(comm, ctypes.byref(count)) == 0:
@@ -111,7 +137,16 @@ class Communicator:
         probe = torch.full((64,), float(self.rank + 1), dtype=torch.float32, device=self.device)
         try:
             self.all_reduce_(probe)
-            torch.cuda.synchronize(self.device)
+            # (bounded as well: a collective that never completes must end the job with a message, not hang it -- there is no
+            #  falling back from here, the compute stream is behind the stuck kernel)
+            landed = torch.cuda.Event()
+            landed.record(torch.cuda.current_stream(self.device))
+            deadline = time.monotonic() + timeout
+            while not landed.query():
+                if time.monotonic() > deadline:
+                    raise TimeoutError(f'the known-answer ncclAllReduce did not complete within {timeout:g} s on rank {self.rank} '
+                                       '(set PYDENS_AMD_COMM=torch to keep the gradient all-reduce on torch.distributed)')
+                time.sleep(0.001)
             good = bool((probe == self.world * (self.world + 1) / 2).all().item()) and self.n_ranks == self.world
         except RuntimeError as exc:
             good, err = False, exc

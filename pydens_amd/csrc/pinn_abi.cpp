@@ -540,22 +540,24 @@ size_t pinn_workspace_bytes(const pinn_t* net, int64_t n_points, int nd, int n2)
     if (!net) return 0;
     size_t need = 0;
     bool any = false;
-    const int modes[3][2] = {{PINN_MODE_STEP, PINN_RES_AFFINE}, {PINN_MODE_STEP, PINN_RES_PROGRAM}, {PINN_MODE_BACKWARD, 0}};
-    for (int i = 0; i < 8; ++i) {
+    // every form a step of this derivative spec may take: separate second-order streams (affine residual, residual program, the
+    // generic path's backward call) and ONE combined second-order stream (affine or program: trace.py lowers to it from a single
+    // second derivative on -- `u_t + u_y + u_z = nu u_xx` in four variables exists in that form only), each planned
+    // with the general probe and with the arguments of a typical training step (shape-specialised kernels); the largest answer
+    const int forms[5][3] = {{PINN_MODE_STEP, PINN_RES_AFFINE, 0}, {PINN_MODE_STEP, PINN_RES_PROGRAM, 0}, {PINN_MODE_BACKWARD, 0, 0},
+                             {PINN_MODE_STEP, PINN_RES_AFFINE, 1}, {PINN_MODE_STEP, PINN_RES_PROGRAM, 1}};
+    for (int i = 0; i < 10; ++i) {
         Plan plan;
-        // i & 3 == 3: the combined-second-order form of an affine step (n2 folded to 1), only where it exists;
-        // i >= 4: the same modes planned with the arguments of a typical training step (shape-specialised kernels)
-        const int m = i & 3;
-        const bool comb = (m == 3);
-        if (comb && (n2 < 2 || nd < 2 || nd > 4 || pinn_n3(n2) > 0)) continue;
+        const int* f = forms[i % 5];
+        const bool comb = f[2] != 0;
+        if (comb && (pinn_n2(n2) < 1 || nd < 2 || nd > 4 || pinn_n3(n2) > 0)) continue;
         const int n2q = comb ? 1 : n2;
         PinnKArgs typical;
-        const bool with_hint = i >= 4 && nd <= net->lay.d;
-        if (i >= 4 && !with_hint) continue;
+        const bool with_hint = i >= 5 && nd <= net->lay.d;
+        if (i >= 5 && !with_hint) continue;
         if (with_hint) typical_step_args(net, &typical, n_points, nd, n2q);
         // (a shape may exist in one form only: nd = 4 with second derivatives runs as the combined stream alone)
-        if (make_plan(net, n_points, nd, n2q, &plan, comb ? PINN_MODE_STEP : modes[m][0],
-                      comb ? PINN_RES_AFFINE : modes[m][1], comb ? 1 : 0, with_hint ? &typical : nullptr)) continue;
+        if (make_plan(net, n_points, nd, n2q, &plan, f[0], f[1], comb ? 1 : 0, with_hint ? &typical : nullptr)) continue;
         any = true;
         const size_t v = align256((size_t)plan.rows() * net->lay.p_total * sizeof(float)) +
                          align256(plan.slab_bytes()) + align256(plan.gz_bytes()) +

@@ -1008,10 +1008,15 @@ pinn_tile_kernel(const PinnKArgs A) {
     // pinn_wsplit_kernel, L2-resident); the weight-gradient operands are read point-contiguous out of the same planes with
     // ds_read_b64_tr_b16. Accumulator layouts, jets, point stage, slab and reductions are those of the exact kernel.
     constexpr bool SPLIT = C::SPLIT;
-    // (VAR 2, two independent workgroups per CU, is NOT allowed: measured 2 - 5 % faster than two teams, but with a second
-    //  workgroup resident on the CU every build that spills even two registers returned slightly wrong, run-to-run different
-    //  gradients on MI355X (1e-5 .. 1e-3; exact with one workgroup per CU, with -amdgpu-waitcnt-forcezero, and for the two-team
-    //  form at every size) -- DESIGN.md section 6b; tests/test_gpu_parity.py holds the shipped kernels to bitwise repeatability)
+    // (VAR 2, two INDEPENDENT workgroups per CU, stays refused for the split kernels -- not for the reason round 3 gave (scratch: the
+    //  failing kernel has no spill at all), but for the one round 4 found ("run-to-run different gradients"):
+    //  with the SLP vectoriser's packed fp32 code (v_pk_fma_f32 on register pairs gathered by v_mov_b32) a wave whose SIMD partner is
+    //  in a bf16-MFMA phase AT THE SAME TIME now and then computes a wrong low half in lanes 48-63 of a packed instruction (first layer:
+    //  the term W1[n][1] * y of one unit pair, inputs verified bit-identical, tools/diff_runs.py --net) -- run-to-run different, 1e-5 in
+    //  the gradients. Two teams in one workgroup share every barrier, so their vector phases never meet the other team's GEMM phases;
+    //  two independent workgroups (or flag-synchronised teams, PINN_TEAM_FLAGS) drift. Builds WITHOUT packed fp32 code
+    //  (-fno-slp-vectorize) are bit-repeatable in this form too (30 of 30 runs) but 8 % slower than the two-team kernel with it;
+    //  experiment builds lift the refusal with -DPINN_VAR2_REFUSED=0, tools/var2.sh)
     // Widths >= 128 (round 3, later): the WGX form -- forward and data-gradient GEMMs here, weight fragments streamed K block by
     // K block (they do not fit the registers), weight gradients in pinn_wgrad_kernel's own split form.
 #ifndef PINN_VAR2_REFUSED
@@ -1043,13 +1048,6 @@ pinn_tile_kernel(const PinnKArgs A) {
     const int vbid = PINN_BID * TEAMS + team, vnblk = PINN_NBLK * TEAMS;
     const int lr = lane & 15, lq = lane >> 4;
     const int lh = (LHC >= 0) ? LHC : A.lh;
-#if defined(PINN_SCRATCH_CANARY) && !defined(PINN_EMU)
-    // experiment builds (tools/var2.sh): does a wave read back from its private segment what it stored there? A tag per lane at
-    // scratch offset 0 (inside the 160 bytes hipcc reserves and never touches), checked at the top of every tile; mismatches are
-    // counted in A.prof[0], the first one kept in A.prof[1..2] (pinn_debug_phase_buffer)
-    const unsigned canary_tag = ((unsigned)PINN_BID << 12) | (unsigned)gtid;
-    asm volatile("scratch_store_dword off, %0, off offset:0" :: "v"(canary_tag) : "memory");
-#endif
     // activation of index a (0: first layer ... lh: last hidden layer)
     // (plain instantiations only know tanh / sigmoid -- one bit, which lets the compiler drop the sin / identity paths;
     //  the full set runs on the VAR 8 instantiations, see the launcher)
@@ -1209,6 +1207,16 @@ pinn_tile_kernel(const PinnKArgs A) {
         return slab + ((slot * NTW + j) * MT + mt) * NTHREADS + tid;
     };
     auto unit0 = [&](int j) { return (wave * NTW + j) * 16 + 4 * lq; };     // first of this lane's 4 units
+#if defined(PINN_DUMP_NET) && !defined(PINN_EMU)
+    // experiment builds: a checksum per (tile, layer, wave) of the value stream a wave has just produced, behind the point dump
+    // (rows 8.. of A.prof as floats): which layer and which wave of a tile differs first between two runs?
+    auto dump_layer = [&](long long tile_, int layer, const f32x4& v) {
+        if (!A.prof) return;
+        float t = fabsf(v[0]) + fabsf(v[1]) + fabsf(v[2]) + fabsf(v[3]);
+        t = pinn_rows_sum(pinn_row_sum16(t));
+        if (lane == 0) reinterpret_cast<float*>(A.prof)[8LL * A.n_points + ((tile_ * 16 + layer) * 4 + wave)] = t;
+    };
+#endif
     // split-bf16 kernels: four consecutive units [n0, n0 + 4) of row `row` (= s * T + point) into the three planes of `buf`
     auto sp_store = [&](float* buf, int row, int n0, f32x4 v) {
         char* b = reinterpret_cast<char*>(buf) + pinn_sp_off<C::SP_ROW_BYTES>(row, n0 >> 3) + ((n0 >> 2) & 1) * 8;
@@ -1402,15 +1410,6 @@ pinn_tile_kernel(const PinnKArgs A) {
     for (long long tile0 = A.tile_begin + (long long)PINN_BID * TEAMS; tile0 < ntiles; tile0 += vnblk, tile_parity ^= 1) {
         const long long tile = tile0 + team;
         const long long base = tile * T;
-#if defined(PINN_SCRATCH_CANARY) && !defined(PINN_EMU)
-        {
-            unsigned got;
-            asm volatile("scratch_load_dword %0, off, off offset:0\n\ts_waitcnt vmcnt(0)" : "=v"(got) :: "memory");
-            if (got != canary_tag && A.prof) {
-                if (atomicAdd(reinterpret_cast<unsigned long long*>(A.prof), 1ull) == 0) { A.prof[1] = canary_tag; A.prof[2] = got; }
-            }
-        }
-#endif
         if (WGX && train) {
             // (debug flag 4, timing experiments only: every tile writes the first tile's slab -- stores stay in L2)
             const size_t tl = PINN_DBG(A, 4) ? 0 : (size_t)(tile - A.tile_begin);
@@ -1471,6 +1470,20 @@ pinn_tile_kernel(const PinnKArgs A) {
                     wlo[r] = pinn_ld4(W1s + (n0 + r) * PINN_XS_LD);
                     whi[r] = pinn_ld4(W1s + (n0 + r) * PINN_XS_LD + 4);      // columns >= d are zero in both operands
                 }
+#if defined(PINN_DUMP_NET) && !defined(PINN_EMU)
+                // what do the weight registers hold when the arithmetic starts? column 0 of the four rows, copied by VALU moves
+                // right behind an explicit lgkmcnt(0)
+                f32x4 snap;
+                {
+                    PINN_SCHED_BARRIER();
+                    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                    float s0_, s1_, s2_, s3_;
+                    asm volatile("v_mov_b32 %0, %4\n\tv_mov_b32 %1, %5\n\tv_mov_b32 %2, %6\n\tv_mov_b32 %3, %7"
+                                 : "=&v"(s0_), "=&v"(s1_), "=&v"(s2_), "=&v"(s3_) : "v"(wlo[0][0]), "v"(wlo[1][0]), "v"(wlo[2][0]), "v"(wlo[3][0]));
+                    snap = f32x4{s0_, s1_, s2_, s3_};
+                    PINN_SCHED_BARRIER();
+                }
+#endif
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
                     const int n = n0 + r;
@@ -1491,7 +1504,25 @@ pinn_tile_kernel(const PinnKArgs A) {
 #pragma unroll
                     for (int s = 0; s < S; ++s) { hv[s][r] = h[s]; sv[s][r] = (s == 0) ? pinn_act_saved(h[0], z[0], act0) : z[s]; }
                     if (SRCPRE) z0v[r] = z[0];
+#if defined(PINN_DUMP_NET) && !defined(PINN_EMU)
+                    snap[r] = z[0];             // (the dump's second per-lane row: the pre-activation the activation was evaluated on)
+#endif
                 }
+#if defined(PINN_DUMP_NET) && !defined(PINN_EMU)
+                if (j == 0 && mt == 0) {
+                    // the inputs of the first layer as this wave saw them: point row, bias, weight rows; then the derivative streams
+                    dump_layer(tile, 4, xlo); dump_layer(tile, 5, b1v);
+                    dump_layer(tile, 6, wlo[0] + wlo[1] * 3.0f + wlo[2] * 5.0f + wlo[3] * 7.0f);
+                    dump_layer(tile, 7, sv[0]);
+                    for (int s = 1; s < S && s < 5; ++s) dump_layer(tile, 7 + s, hv[s]);
+                    // per lane: the value stream and the first derivative stream of the first layer (behind the checksums: [tile][wave][2][64] x 4)
+                    if (A.prof) {
+                        f32x4* per_lane = reinterpret_cast<f32x4*>(reinterpret_cast<float*>(A.prof) + 8LL * A.n_points + 64LL * (A.n_points / T + 1));
+                        per_lane[((tile * 4 + wave) * 2 + 0) * 64 + lane] = hv[0];
+                        per_lane[((tile * 4 + wave) * 2 + 1) * 64 + lane] = snap;
+                    }
+                }
+#endif
                 if (SKIPS && skip_from(0) >= 0) {
                     // ('f R a': the skip carries the z-jets, not act(z): z_0 kept aside, the derivative jets are what sv holds)
 #pragma unroll
@@ -1502,6 +1533,9 @@ pinn_tile_kernel(const PinnKArgs A) {
                     if constexpr (SPLIT) sp_store(cur, s * T + pt, n0, hv[s]);
                     else pinn_st4(cur + (s * T + pt) * LDA + n0, hv[s]);
                 }
+#if defined(PINN_DUMP_NET) && !defined(PINN_EMU)
+                if (j == 0 && mt == 0) dump_layer(tile, 0, hv[0]);
+#endif
                 if (lh == 0) {
 #pragma unroll
                     for (int s = 0; s < S; ++s) htop[j][mt][s] = hv[s];
@@ -1639,6 +1673,9 @@ pinn_tile_kernel(const PinnKArgs A) {
 #pragma unroll
                         for (int s = 0; s < S; ++s) hskip[SKIPS ? j : 0][SKIPS ? mt : 0][s] = (SRCPRE && src_pre) ? (s == 0 ? z0v : sv[s]) : hv[s];
                     }
+#if defined(PINN_DUMP_NET) && !defined(PINN_EMU)
+                    if (j == 0 && mt == 0) dump_layer(tile, li + 1, hv[0]);
+#endif
                     if (li + 1 == lh) {
 #pragma unroll
                         for (int s = 0; s < S; ++s) htop[j][mt][s] = hv[s];
@@ -1719,6 +1756,17 @@ pinn_tile_kernel(const PinnKArgs A) {
                 for (int w = 0; w < NW; ++w) v += netp[(w * S + s) * T + pt];
                 net[s] = v;
             }
+#if defined(PINN_DUMP_NET) && !defined(PINN_EMU)
+            // experiment builds (tools/var2.sh): the network's output streams of every point, [S][N] floats behind A.prof, so that two
+            // runs can be compared point by point (tools/diff_runs.py --net)
+            if (A.prof && base + pt < A.n_points) {
+#pragma unroll
+                for (int s = 0; s < S; ++s) reinterpret_cast<float*>(A.prof)[(long long)s * A.n_points + base + pt] = net[s];
+                // ... and the coordinates the tile worked on (rows S, S + 1 of the dump)
+                for (int c = 0; c < 2 && S + c < 8; ++c)
+                    reinterpret_cast<float*>(A.prof)[(long long)(S + c) * A.n_points + base + pt] = xs_t[pt * PINN_XS_LD + c];
+            }
+#endif
             PinnPointOut<ND, N2> po;
             pinn_point_stage<ND, N2, SPEC == 0, COMB, SPEC>(A, net, xs_t + pt * PINN_XS_LD, base + pt, base + pt < A.n_points,
                                      pregs + pt, padj + pt, T, ppre, po);

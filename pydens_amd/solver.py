@@ -677,15 +677,27 @@ class Solver:
                 k = min(self.FIT_CHUNK, niters - it)
                 if own is not None:         # `NumpySampler(..., seed=k)`: the sampler's own key and batch counter (see _sample)
                     seed = (own + 7919 * rank) & (2 ** 64 - 1)
-                    call0 = sampler.next_device_call(k)
+                    call0 = sampler.next_device_call(0)
                 else:
                     seed, call0 = self._sample_seed, self._sample_calls
-                model.net.fit_steps(self.program, model.flat, xs, columns, seed, call0, self.grads, ws, adam.exp_avg,
-                                    adam.exp_avg_sq, adam.mask, adam.step_count, adam.t + 1, adam.lr, adam.betas, adam.eps,
-                                    history[it:it + k], k, dir_cols=spec.dir_cols, n2=n2, ic_const=model.kernel_ic_const(),
-                                    stream=stream)
-                adam.t += k
-                self._sample_calls += k
+                t0, applied = adam.t, k
+                try:
+                    model.net.fit_steps(self.program, model.flat, xs, columns, seed, call0, self.grads, ws, adam.exp_avg,
+                                        adam.exp_avg_sq, adam.mask, adam.step_count, adam.t + 1, adam.lr, adam.betas, adam.eps,
+                                        history[it:it + k], k, dir_cols=spec.dir_cols, n2=n2, ic_const=model.kernel_ic_const(),
+                                        stream=stream)
+                except BaseException:
+                    # the library stopped inside the chunk (or an interrupt landed around the call): the device knows how many
+                    # Adam steps it applied -- the host's step number and the batch counters follow IT, so that a later
+                    # fit(optimizer=None) continues the bias correction and the point stream where the device left off
+                    applied = max(0, min(k, int(adam.step_count.item()) - t0))
+                    raise
+                finally:
+                    adam.t = t0 + applied
+                    if own is not None:
+                        sampler.next_device_call(applied)
+                    else:
+                        self._sample_calls += applied
                 it += k
                 done[0] = it
                 bar.update(k)

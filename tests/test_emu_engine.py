@@ -1090,3 +1090,30 @@ def test_the_large_batch_gpu_cases_on_a_few_points(pa, emu_lib, name):
     import test_gpu_occupancy as tg
     info = tg.run_case(pa, name, 80 if name != 'w100_heat' else 40, solver_kwargs=emu_kwargs(emu_lib), on_device=False)
     assert info['grid'] >= 1 and info['threads'] in (64, 128, 256, 512) and info['per_cu'] >= 1
+
+
+@pytest.mark.parametrize('which', ['affine', 'program'])
+def test_one_second_derivative_beside_three_first_order_directions(pa, emu_lib, which):
+    """ four differentiation directions with exactly ONE second derivative (`u_t + u_y + u_z = nu u_xx` in four variables)
+    exist as the combined second-order stream only; pinn_workspace_bytes used to plan the combined form from two second derivatives
+    on and answered 0 bytes for this shape ('workspace too small'). Affine and program residuals against the oracle. """
+    from oracle import pinn_oracle as po
+
+    def problem(D):
+        if which == 'affine':
+            return lambda f, x, y, z, t: D(f, t) + D(f, y) + D(f, z) - 0.1 * D(D(f, x), x)
+        return lambda f, x, y, z, t: D(f, t) + D(f, y) + f * D(f, z) - 0.1 * D(D(f, x), x)
+    kw = dict(ndims=4, boundary_condition=0.5, initial_condition=lambda x, y, z: torch.sin(np.pi * x) * y * z,
+              layout='fa fa f', features=[20, 20, 1], activation='Tanh')
+    oracle = po.OracleSolver(problem(po.D), **kw)
+    solver = pa.Solver(problem(pa.D), **kw, **emu_kwargs(emu_lib))
+    assert solver.program is not None, solver.program_error
+    assert solver.residual_plan.comb_w is not None and solver.residual_plan.n_streams == 6
+    load_params(solver, oracle.export_params())
+    pts = np.random.RandomState(5).rand(3, 40, 4).astype(np.float32)
+    solver.fit(niters=3, batch_size=40, sampler=FixedBatches(pts), lr=0.01)
+    oracle.fit(niters=3, batch_size=40, points=pts, lr=0.01)
+    assert solver.last_fit_path == 'fused'
+    np.testing.assert_allclose([float(v) for v in solver.losses], [float(v) for v in oracle.losses], rtol=2e-5)
+    for got, want in zip(export_params(solver), oracle.export_params()):
+        assert params_close(got, want, 2e-5)

@@ -11,7 +11,7 @@ import pytest
 import torch
 
 import pinn_configs as pc
-from helpers import export_grads, grad_close, load_params
+from helpers import export_grads, load_params
 
 pytestmark = pytest.mark.gpu
 
@@ -73,13 +73,11 @@ def run_case(pa, name, n_points, solver_kwargs=None, on_device=True):
     """ the body of the test; tests/test_emu_engine.py runs it on the emulator with a few points (same code path, one workgroup) """
     from oracle import pinn_oracle as po
     torch.manual_seed(CASES.index(name) + 40)
-    eq_o, kw, odtype, path, several = _problem(name, po.D, po.V)
+    eq_o, kw, _, path, several = _problem(name, po.D, po.V)
     oracle32 = po.OracleSolver(eq_o, **kw)
     start = oracle32.export_params()
-    oracle = oracle32
-    if odtype == torch.float64:
-        oracle = po.OracleSolver(eq_o, dtype=torch.float64, **kw)
-        oracle.import_params(start)
+    oracle = po.OracleSolver(eq_o, dtype=torch.float64, **kw)      # the arbiter (SURVEY 8c item 5)
+    oracle.import_params(start)
     eq_p, kw, _, _, _ = _problem(name, pa.D, pa.V)
     solver = pa.Solver(eq_p, **kw, **(solver_kwargs or {}))
     load_params(solver, start)
@@ -87,6 +85,7 @@ def run_case(pa, name, n_points, solver_kwargs=None, on_device=True):
     pts = np.random.RandomState(77).rand(n_points, d).astype(np.float32)
     ev = oracle.evaluate(pts, chunk=16384)
     g_want = oracle.export_grads()
+    ev32, g32 = oracle32.evaluate(pts, chunk=16384), oracle32.export_grads()
     if path == 'generic':
         solver.program = None
     else:
@@ -112,12 +111,22 @@ def run_case(pa, name, n_points, solver_kwargs=None, on_device=True):
         if several:
             assert info['per_cu'] > 1, info            # the case this file exists for: several workgroups share every CU
         assert info['grid'] >= info['per_cu'] * 64, info
-    # parity with the oracle at the full batch
+    # parity with the oracle at the full batch. A sum over 131 072 points in fp32 is itself good to ~1e-5 (the reference's own chunked
+    # fp32 gradients sit up to 3e-5 off their fp64 values on these problems), so the fp64 oracle arbitrates as SURVEY 8c item 5 says:
+    # |ours - f64| <= max(2 |ref32 - f64|, 1e-5 |f64|) -- in practice the kernels (per-lane, per-workgroup, then tree sums) are the
+    # closer of the two
     loss = float(first[lay.off_loss])
-    assert abs(loss - ev['loss']) <= 1e-5 * abs(ev['loss']), (loss, ev['loss'])
-    for got, want in zip(export_grads(solver), g_want):
+    assert abs(loss - ev['loss']) <= max(2 * abs(ev32['loss'] - ev['loss']), 1e-5 * abs(ev['loss'])), (loss, ev['loss'], ev32['loss'])
+    margins = []
+    for got, want, w32 in zip(export_grads(solver), g_want, g32):
         if want is not None:
-            assert grad_close(got, np.asarray(want, dtype=np.float64))
+            want = np.asarray(want, dtype=np.float64)
+            err = float(np.linalg.norm(np.asarray(got, dtype=np.float64) - want))
+            ref_err = float(np.linalg.norm(np.asarray(w32, dtype=np.float64) - want))
+            scale = float(np.linalg.norm(want))
+            margins.append((err / max(scale, 1e-30), ref_err / max(scale, 1e-30)))
+            assert err <= max(2 * ref_err, 1e-5 * scale + 1e-9 * np.sqrt(want.size)), (name, err / scale, ref_err / scale)
+    print(f'{name}: worst gradient error vs fp64 {max(m[0] for m in margins):.2e} (the fp32 reference: {max(m[1] for m in margins):.2e})')
     # bitwise repeatability: same inputs, same grid -> the same bits, four times
     for _ in range(3):
         again = step()

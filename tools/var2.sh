@@ -10,3 +10,11 @@ tools/variant.sh v2 $V2
 tools/variant.sh v2_fz $V2 -mllvm -amdgpu-waitcnt-forcezero
 tools/variant.sh v2_canary $V2 -DPINN_SCRATCH_CANARY
 tools/variant.sh base_canary -DPINN_SCRATCH_CANARY
+# second round: what in the split kernel of config 2 depends on the drift? (operand prefetch forms; every fragment load behind the
+# COMPLETION of the MFMAs issued before it = PINN_SP_DRAIN)
+P00='{"1": ["-DPINN_SP_PIPE=0", "-DPINN_SP_PIPE_W=0"], "2": ["-fno-slp-vectorize"]}'
+P11='{"1": ["-DPINN_SP_PIPE=1", "-DPINN_SP_PIPE_W=1"], "2": ["-fno-slp-vectorize"]}'
+PINN_SPLIT_FLAGS=$P11 tools/variant.sh v2_pipe11 $V2
+PINN_SPLIT_FLAGS=$P00 tools/variant.sh v2_pipe00 $V2
+PINN_SPLIT_FLAGS=$P00 tools/variant.sh v2_il0 $V2 -DPINN_SCHED_IL=0
+PINN_SPLIT_FLAGS=$P00 tools/variant.sh v2_drain $V2 -DPINN_SCHED_IL=0 -DPINN_SP_DRAIN=1
