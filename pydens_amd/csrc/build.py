@@ -49,6 +49,17 @@ def _sources():
     return deps
 
 
+def kernel_sources_sha1():
+    """ content hash of everything the device code is compiled from (kernel headers, launcher, this file's flags): profiles/*_pmc.json
+    carry it, and bench.py only quotes the PMC bytes of a profile taken from the SAME sources """
+    import hashlib
+    h = hashlib.sha1()
+    for name in sorted(f for f in os.listdir(HERE) if f.endswith(('.h', '.inc', '.cpp')) or f == 'build.py'):
+        with open(os.path.join(HERE, name), 'rb') as f:
+            h.update(name.encode() + b'\0' + f.read())
+    return h.hexdigest()
+
+
 def _stale(target, deps):
     if not os.path.exists(target):
         return True

@@ -54,3 +54,27 @@ def params_close(got, want, rtol, atol=3e-7):
 def rel_l2(a, b):
     a, b = np.asarray(a, dtype=np.float64).ravel(), np.asarray(b, dtype=np.float64).ravel()
     return float(np.linalg.norm(a - b) / max(np.linalg.norm(b), 1e-30))
+
+
+def pytest_sessionfinish(session, exitstatus):
+    """ achieved margins of the sweep tests (tests/helpers.py::record_margin), for profiles/rNN_grad_margins.txt """
+    try:
+        import helpers
+    except ImportError:
+        return
+    if not helpers.MARGINS:
+        return
+    out = os.path.join(ROOT, 'gpurun_out')
+    os.makedirs(out, exist_ok=True)
+    worst = {}
+    for test, case, quantity, achieved, bound, arb in helpers.MARGINS:
+        key = (test, quantity)
+        w = worst.get(key)
+        if w is None or achieved / max(bound, 1e-30) > w[1] / max(w[2], 1e-30):
+            worst[key] = (case, achieved, bound, arb, (w[4] if w else 0) + 1, (w[5] if w else 0) + int(arb))
+        else:
+            worst[key] = (w[0], w[1], w[2], w[3], w[4] + 1, w[5] + int(arb))
+    with open(os.path.join(out, 'grad_margins.txt'), 'w') as f:
+        f.write('# worst achieved margin per (test, quantity): case, achieved relative error, bound, cases, of them arbitrated in fp64\n')
+        for (test, quantity), (case, achieved, bound, arb, n, n_arb) in sorted(worst.items()):
+            f.write(f'{test:60s} {quantity:10s} worst {achieved:.2e} (bound {bound:.0e}{", fp64 arbiter" if arb else ""}) in {case[:70]}; {n} cases, {n_arb} arbitrated\n')

@@ -11,7 +11,7 @@ import pytest
 import torch
 
 from conftest import params_close, rel_l2
-from helpers import FixedBatches, export_params, load_params
+from helpers import FixedBatches, close_or_arbitrated, export_params, load_params, record_margin
 
 SCALE = int(os.environ.get('PINN_FUZZ_SCALE', '1'))       # soak runs: PINN_FUZZ_SCALE=8 pytest tests/test_fuzz_equations.py -m gpu
 LEAVES = ['u', 'ux', 'ut', 'uxx', 'x', 't', 'c']
@@ -59,6 +59,31 @@ def _ev(tree, env):
     return {'add': a + b, 'sub': a - b, 'mul': a * b}[kind]
 
 
+LOSS_RTOL, PARAM_RTOL = 2e-5, 2e-5          # SURVEY 8c items 2 - 4 (were 5e-5 / 2e-4)
+
+
+def _fit_close(test, case, solver, oracle32, oracle64_fn, param_atol=2e-6):
+    """ losses and final parameters of a short Adam trajectory against the fp32 oracle at the survey's bar; a case the reference's own
+    fp32 arithmetic cannot hold is arbitrated by the fp64 oracle stepped from the same start:
+    |ours - f64| <= max(2 |ref32 - f64|, bar). Adam turns the fp32 noise of a SMALL gradient entry into a move of size lr, hence the
+    absolute floor per parameter entry. """
+    arb = {}
+
+    def o64():
+        if 'o' not in arb:
+            arb['o'] = oracle64_fn()
+        return arb['o']
+    got_l, want_l = [float(v) for v in solver.losses], [float(v) for v in oracle32.losses]
+    ok, err, a = close_or_arbitrated(got_l, want_l, lambda: [float(v) for v in o64().losses], LOSS_RTOL, atol=0.0)
+    record_margin(test, case, 'losses', err, LOSS_RTOL, a)
+    assert ok, (case, got_l, want_l, err)
+    p64 = None
+    for i, (got, ref) in enumerate(zip(export_params(solver), oracle32.export_params())):
+        ok, err, a = close_or_arbitrated(got, ref, lambda i=i: o64().export_params()[i], PARAM_RTOL, atol=param_atol)
+        record_margin(test, case, 'parameters', err, PARAM_RTOL, a)
+        assert ok, (case, i, err)
+
+
 def _uses(tree, name):
     return tree[0] == name or any(isinstance(c, tuple) and _uses(c, name) for c in tree[1:])
 
@@ -97,14 +122,20 @@ def _run(pa, extra, n_trees, batch, fused=True, third=False):
             continue
         torch.manual_seed(trial)
         oracle = po.OracleSolver(_equation(tree, po.D, 0.05 if third else 0.0), **kw)
+        start = oracle.export_params()
+        pts = np.random.RandomState(trial).rand(2, batch, 2).astype(np.float32)
+
+        def oracle64(tree=tree, start=start, pts=pts):
+            o = po.OracleSolver(_equation(tree, po.D, 0.05 if third else 0.0), dtype=torch.float64, **kw)
+            o.import_params(start)
+            o.fit(niters=2, batch_size=batch, points=pts, lr=0.01)
+            return o
         if third:
-            start = oracle.export_params()
             oracle = po.OracleSolver(_equation(tree, po.D, 0.05 if third else 0.0), dtype=torch.float64, **kw)
             oracle.import_params(start)
         solver = pa.Solver(_equation(tree, pa.D, 0.05 if third else 0.0), **kw, **extra)
         solver.use_fused = fused
         load_params(solver, oracle.export_params())
-        pts = np.random.RandomState(trial).rand(2, batch, 2).astype(np.float32)
         oracle.fit(niters=2, batch_size=batch, points=pts, lr=0.01)
         solver.fit(niters=2, batch_size=batch, sampler=FixedBatches(pts), lr=0.01)
         want = np.array([float(v) for v in oracle.losses])
@@ -113,9 +144,12 @@ def _run(pa, extra, n_trees, batch, fused=True, third=False):
         assert solver.last_fit_path == ('fused' if fused else 'generic'), (tree, solver.program_error)
         if third:
             assert solver.spec.n3 == 1, tree
-        np.testing.assert_allclose([float(v) for v in solver.losses], want, rtol=1e-4 if third else 5e-5, err_msg=str(tree))
-        for got, ref in zip(export_params(solver), oracle.export_params()):
-            assert params_close(got, ref, 2e-4, atol=1e-5) if third else rel_l2(got, ref) < 2e-4, tree
+        if third:       # (against the fp64 trajectory itself: three nested fp32 sweeps of the reference are 1e-4 noisy)
+            np.testing.assert_allclose([float(v) for v in solver.losses], want, rtol=1e-4, err_msg=str(tree))
+            for got, ref in zip(export_params(solver), oracle.export_params()):
+                assert params_close(got, ref, 2e-4, atol=1e-5), tree
+        else:
+            _fit_close('random_equations_' + ('fused' if fused else 'generic'), tree, solver, oracle, oracle64)
         kinds['program' if solver.residual_plan.kind == 0 else 'affine'] += 1
     assert (kinds['program'] >= 5 and kinds['affine'] >= 5) or (third and sum(kinds.values()) >= 10), kinds
 
@@ -206,14 +240,19 @@ def _run_layouts(pa, extra, n_nets, batch, wide=False):
         torch.manual_seed(trial)
         oracle = po.OracleSolver(eq_o, **kw, **net)
         solver = pa.Solver(eq_p, **kw, **net, **extra)
-        load_params(solver, oracle.export_params())
+        start = oracle.export_params()
+        load_params(solver, start)
         pts = np.random.RandomState(trial).rand(2, batch, 2).astype(np.float32)
+
+        def oracle64(eq_o=eq_o, kw=kw, net=net, start=start, pts=pts):
+            o = po.OracleSolver(eq_o, dtype=torch.float64, **kw, **net)
+            o.import_params(start)
+            o.fit(niters=2, batch_size=batch, points=pts, lr=0.01)
+            return o
         oracle.fit(niters=2, batch_size=batch, points=pts, lr=0.01)
         solver.fit(niters=2, batch_size=batch, sampler=FixedBatches(pts), lr=0.01)
         assert solver.last_fit_path == 'fused', (net, solver.program_error)
-        np.testing.assert_allclose([float(v) for v in solver.losses], [float(v) for v in oracle.losses], rtol=5e-5, err_msg=str(net))
-        for got, ref in zip(export_params(solver), oracle.export_params()):
-            assert params_close(got, ref, 2e-4, atol=2e-6), net
+        _fit_close('random_layouts' + ('_wide' if wide else ''), net, solver, oracle, oracle64)
         grid = [np.linspace(0.1, 0.9, 5).astype(np.float32)] * 2
         assert np.abs(solver.predict(*grid) - oracle.predict(*grid)).max() < 2e-5, net
         seen.add(('R' in net['layout'], isinstance(net['activation'], list)))
@@ -288,17 +327,23 @@ def _run_problems(pa, extra, n_problems, max_batch):
         torch.manual_seed(trial)
         oracle = po.OracleSolver(eq_o, **kw)
         solver = pa.Solver(eq_p, **kw, **extra)
-        load_params(solver, oracle.export_params())
+        start = oracle.export_params()
+        load_params(solver, start)
         u = np.random.RandomState(trial).rand(2, batch, d)
         pts = (np.asarray(lo) + (np.asarray(hi) - np.asarray(lo)) * u).astype(np.float32)
+
+        def oracle64(trial=trial, start=start, pts=pts, batch=batch):
+            eq64, kw64 = _random_problem(np.random.RandomState(100 + trial), po.D)[:2]
+            o = po.OracleSolver(eq64, dtype=torch.float64, **kw64)
+            o.import_params(start)
+            o.fit(niters=2, batch_size=batch, points=pts, lr=0.01)
+            return o
         oracle.fit(niters=2, batch_size=batch, points=pts, lr=0.01)
         solver.fit(niters=2, batch_size=batch, sampler=FixedBatches(pts), lr=0.01)
         want = [float(v) for v in oracle.losses]
         if not np.all(np.isfinite(want)):
             continue
-        np.testing.assert_allclose([float(v) for v in solver.losses], want, rtol=5e-5, err_msg=str((trial, kw, batch)))
-        for got, ref in zip(export_params(solver), oracle.export_params()):
-            assert params_close(got, ref, 2e-4, atol=2e-6), (trial, kw, batch)
+        _fit_close('random_problem_shapes', (trial, batch), solver, oracle, oracle64)
         paths.add(solver.last_fit_path)
     assert 'fused' in paths
 

@@ -59,4 +59,7 @@ if tile:
             print(f"   {name}: MFMA pipe busy {100 * v['mfma_busy_frac']:.1f} % of SIMD cycles, effective clock "
                   f"{v['effective_clock_GHz']:.2f} GHz" if v['effective_clock_GHz'] else '')
     print('hbm bytes per step (2*FETCH+WRITE): %.1f MB' % (res['hbm_bytes_per_launch'] / 1e6))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from pydens_amd.csrc import build as hip_build      # noqa: E402
+res['kernel_sources_sha1'] = hip_build.kernel_sources_sha1()        # bench.py quotes these bytes only for the same kernel sources
 json.dump(res, open(os.path.join(out, 'pmc.json'), 'w'), indent=1)
