@@ -17,7 +17,7 @@
  *     W1 [HP][d]  b1 [HP]  { Wh_l [HP][HP]  bh_l [HP] } l=0..LH-1   WL [HP]  bL  log_scale  loss_slot  pad
  *     followed by PINN_EXTRA_SLOTS user slots (trainable V(...) scalars, model_torch.py:180-188).
  *   HP = largest hidden width rounded up to 16, 32, 64, 128 or 256 (MFMA tiles; wider nets are rejected by pinn_create),
- *   LH = number of hidden->hidden layers (<= 14).
+ *   LH = number of hidden->hidden layers (<= PINN_MAX_LAYERS - 2 = 30).
  *   nn.Linear's [out,in] row-major weight of every layer is the top-left block of its padded matrix, so the
  *   host exposes per-layer nn.Parameter views into this one buffer; padded entries stay zero (Adam mask).
  *   Gradient buffers use the same layout; `loss_slot` receives sum(r^2)/N of the step.

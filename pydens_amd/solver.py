@@ -87,7 +87,6 @@ class Solver:
                            boundary_condition=boundary_condition, domain=domain, nparams=nparams)
         # the reference's plug-in seam (`Solver(model=...)`, model_torch.py:299-313): subclasses of ConvBlockModel that
         # change how the fully connected net / the ansatz parameters are set up run on the HIP kernels; a subclass that
-        # replaces `forward` runs arbitrary torch code, which the kernels cannot see -- refused loudly
         # replaces `forward` may put its own torch code AROUND the network -- `self.anzatc(self.conv_block(xs), xs) * g(xs)`, another
         # output transform, no ansatz at all: `self.conv_block(xs)` is then the bare network on the kernels and the rest runs as torch
         # ops on its value and derivative streams (generic step path; `D` applies the chain rule). Anything else -- a model that is
