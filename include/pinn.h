@@ -238,6 +238,20 @@ int pinn_fit_steps(pinn_t* net, const pinn_residual_t* residual, float* params, 
                    const int* dir_cols, int nd, int n2, float ic_const, float* grads, float* exp_avg, float* exp_avg_sq,
                    const uint8_t* mask, int32_t* step_ptr, int32_t step0, float lr, float beta1, float beta2, float eps,
                    float* loss_history, int32_t k_steps, void* workspace, size_t workspace_bytes, void* stream);
+/* The same chunk as ONE replayable launch graph (hipGraph): for batches of a few thousand points the gaps between the three dependent
+ * launches of an iteration are a visible share of it. What changes from iteration to iteration (Philox batch counter, Adam step and its
+ * bias corrections, slot of the loss history) is read by the kernels from `ctrl` -- a caller-owned device buffer of at least
+ * pinn_fit_ctrl_bytes() bytes, rewritten by an ordinary launch in front of every replay -- indexed by the iteration number baked into the
+ * graph's nodes. The first chunk of a configuration runs eagerly and captures; later chunks with the same arguments replay; anything that
+ * does not qualify (k_steps != 128 = one whole chunk of Solver.fit, profiling on, capture refused) runs pinn_fit_steps. Same batches, updates and loss history as
+ * the eager loop, bit for bit. */
+size_t pinn_fit_ctrl_bytes(void);
+int pinn_fit_steps_graph(pinn_t* net, const pinn_residual_t* residual, float* params, float* xs, int64_t n_points,
+                         const int* kind, const float* a, const float* b, uint64_t seed, uint64_t call_index0,
+                         const int* dir_cols, int nd, int n2, float ic_const, float* grads, float* exp_avg, float* exp_avg_sq,
+                         const uint8_t* mask, int32_t* step_ptr, int32_t step0, float lr, float beta1, float beta2, float eps,
+                         float* loss_history, int32_t k_steps, void* workspace, size_t workspace_bytes, void* ctrl,
+                         size_t ctrl_bytes, void* stream);
 
 /* Arithmetic of the hidden-layer GEMMs (forward, data gradient, weight gradient) of the fused step -- what ATen's `addmm` /
  * `mm` calls do in the reference (pydens/model_torch.py:170-178, :460), per net:
@@ -284,6 +298,9 @@ int pinn_debug_wgx_chunk_bytes(long long bytes);
  *                                 the default, 4): tests run the same step at 1 and at several workgroups per CU; affects
  *                                 pinn_workspace_bytes (partial rows, slabs), so set it first. Returns the previous bound. */
 int pinn_debug_max_wgs_per_cu(int cap);
+/*   pinn_debug_fit_graph_stats    out[0] chunks replayed as launch graphs so far, out[1] graphs captured, out[2] captures the runtime
+ *                                 refused (those chunks ran eagerly), out[3] the HIP error code of the last refusal */
+int pinn_debug_fit_graph_stats(int32_t out[4]);
 #ifdef PINN_DEBUG_ABI
 /* EXPERIMENT BUILDS ONLY (-DPINN_DEBUG_ABI, tools/variant.sh): the product library neither exports these nor compiles the
  * kernel paths behind them. The flag bits are TIMING experiments -- kernels skip loads / stores / barriers, the results of

@@ -56,6 +56,10 @@ PINN_HIDDEN char g_pinn_last_kernel_name[96] = "";
 PINN_HIDDEN char g_pinn_last_wgrad_name[96] = "";
 PINN_HIDDEN int g_pinn_last_launch[4] = {0, 0, 0, 0};   // grid, workgroups per CU of the plan, threads, dynamic LDS bytes
 namespace {
+// set while pinn_fit_steps_graph captures a chunk: the sample and reduce launches then read their per-iteration values from the device
+// control block (PinnFitCtrl) at index `k` instead of taking them by value
+struct FitCapture { const PinnFitCtrl* ctrl; int k; };
+thread_local FitCapture g_fit_capture = {nullptr, 0};
 int g_pinn_max_per_cu = 4;          // pinn_debug_max_wgs_per_cu
 int g_pinn_prepass_in_kernel = 1;   // debug switch: 0 = x-only pre-pass as its own launch (pinn_aux_kernel)
 int g_pinn_debug_flags = 0;         // -DPINN_DEBUG_ABI builds: pinn_debug_set_flags
@@ -70,6 +74,11 @@ struct pinn_net {
     float lo[PINN_MAX_INPUTS], hi[PINN_MAX_INPUTS], bc_value;
     int n_cu;
     int gemm_mode;                  // PINN_GEMM_FP32 / PINN_GEMM_BF16X3 (pinn_set_gemm_mode)
+    // pinn_fit_steps_graph: the instantiated launch graph of one chunk and the arguments it was captured with (host state of the
+    // descriptor; no device memory: the control block is the caller's)
+    void* fit_graph_exec;
+    unsigned long long fit_graph_key[4];
+    int fit_graph_k;
 };
 
 namespace {
@@ -299,12 +308,13 @@ int launch_reduce(const float* partials, int n_wg, int p_core, float* grads, int
 #ifdef PINN_EMU
     emu::launch(blocks, 1024, smem, [&] {
         pinn_reduce_kernel(partials, n_wg, p_core, grads, accumulate, do_adam, a.params, a.m, a.v, a.mask, a.step_value,
-                           step_size, bc2_sqrt, a.b1, a.b2, a.eps, a.step_ptr, a.loss_out, a.off_loss);
+                           step_size, bc2_sqrt, a.b1, a.b2, a.eps, a.step_ptr, a.loss_out, a.off_loss, nullptr, 0);
     });
 #else
+    const PinnFitCtrl* ctrl = do_adam ? g_fit_capture.ctrl : nullptr;
     hipLaunchKernelGGL(pinn_reduce_kernel, dim3(blocks), dim3(1024), smem, (hipStream_t)stream, partials, n_wg, p_core,
                        grads, accumulate, do_adam, a.params, a.m, a.v, a.mask, a.step_value, step_size, bc2_sqrt, a.b1, a.b2,
-                       a.eps, a.step_ptr, a.loss_out, a.off_loss);
+                       a.eps, a.step_ptr, a.loss_out, a.off_loss, ctrl, g_fit_capture.k);
     if (hipGetLastError() != hipSuccess) return fail("reduce kernel launch failed");
 #endif
     return 0;
@@ -343,10 +353,10 @@ int pinn_sample_points(float* xs, int64_t n_points, int d, const int* kind, cons
     const unsigned c_lo = (unsigned)(call_index & 0xffffffffull), c_hi = (unsigned)(call_index >> 32);
     const int blocks = (int)((n_points + 255) / 256);
 #ifdef PINN_EMU
-    emu::launch(blocks, 256, 0, [&] { pinn_sample_kernel(xs, (long long)n_points, spec, k0, k1, c_lo, c_hi); });
+    emu::launch(blocks, 256, 0, [&] { pinn_sample_kernel(xs, (long long)n_points, spec, k0, k1, c_lo, c_hi, nullptr, 0); });
 #else
     hipLaunchKernelGGL(pinn_sample_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, xs, (long long)n_points, spec,
-                       k0, k1, c_lo, c_hi);
+                       k0, k1, c_lo, c_hi, g_fit_capture.ctrl, g_fit_capture.k);
     if (hipGetLastError() != hipSuccess) return fail("sampler kernel launch failed");
 #endif
     return 0;
@@ -526,6 +536,9 @@ int pinn_create_ex(const int* layer_dims, int n_layers, const int* acts, int n_s
 }
 
 int pinn_destroy(pinn_t* net) {
+#ifndef PINN_EMU
+    if (net && net->fit_graph_exec) (void)hipGraphExecDestroy((hipGraphExec_t)net->fit_graph_exec);
+#endif
     delete net;
     return 0;
 }
@@ -856,6 +869,116 @@ int pinn_fit_steps(pinn_t* net, const pinn_residual_t* residual, float* params, 
                                     workspace_bytes, stream)) return 1;
     }
     return 0;
+}
+
+size_t pinn_fit_ctrl_bytes(void) { return sizeof(PinnFitCtrl); }
+
+static int g_fit_graph_stats[4] = {0, 0, 0, 0};      // chunks replayed, graphs captured, captures refused, last HIP error of a refusal
+int pinn_debug_fit_graph_stats(int32_t out[4]) {
+    if (!out) return fail("null argument");
+    for (int i = 0; i < 4; ++i) out[i] = g_fit_graph_stats[i];
+    return 0;
+}
+
+// FNV-1a over the bytes of everything a captured chunk depends on
+static void key_mix(unsigned long long (&key)[4], const void* p, size_t n) {
+    const unsigned char* b = reinterpret_cast<const unsigned char*>(p);
+    for (size_t i = 0; i < n; ++i) {
+        unsigned long long& h = key[i & 3];
+        h = (h ^ b[i]) * 1099511628211ull;
+    }
+}
+
+int pinn_fit_steps_graph(pinn_t* net, const pinn_residual_t* residual, float* params, float* xs, int64_t n_points,
+                         const int* kind, const float* a, const float* b, uint64_t seed, uint64_t call_index0,
+                         const int* dir_cols, int nd, int n2, float ic_const, float* grads, float* exp_avg, float* exp_avg_sq,
+                         const uint8_t* mask, int32_t* step_ptr, int32_t step0, float lr, float beta1, float beta2, float eps,
+                         float* loss_history, int32_t k_steps, void* workspace, size_t workspace_bytes, void* ctrl,
+                         size_t ctrl_bytes, void* stream) {
+    if (!net || !residual || !xs || !loss_history || !kind || !a || !b || !dir_cols) return fail("null argument");
+    if (k_steps < 0 || step0 < 1) return fail("k_steps must be >= 0 and step0 >= 1");
+#ifdef PINN_EMU
+    (void)ctrl; (void)ctrl_bytes;
+    return pinn_fit_steps(net, residual, params, xs, n_points, kind, a, b, seed, call_index0, dir_cols, nd, n2, ic_const, grads, exp_avg,
+                          exp_avg_sq, mask, step_ptr, step0, lr, beta1, beta2, eps, loss_history, k_steps, workspace, workspace_bytes, stream);
+#else
+    // the graph pays where launch gaps are a visible share of an iteration; chunks that do not qualify run the eager loop
+    // (only whole chunks: the tail of a fit would capture a graph of its own that nothing replays)
+    if (k_steps != PINN_FIT_CHUNK_MAX || !ctrl || ctrl_bytes < sizeof(PinnFitCtrl) || g_profile || g_phase_prof)
+        return pinn_fit_steps(net, residual, params, xs, n_points, kind, a, b, seed, call_index0, dir_cols, nd, n2, ic_const, grads, exp_avg,
+                              exp_avg_sq, mask, step_ptr, step0, lr, beta1, beta2, eps, loss_history, k_steps, workspace, workspace_bytes, stream);
+    // everything the captured launches carry BY VALUE or by address (the per-iteration values travel through the control block)
+    unsigned long long key[4] = {14695981039346656037ull, 14695981039346656037ull ^ 1, 14695981039346656037ull ^ 2, 14695981039346656037ull ^ 3};
+    key_mix(key, residual, sizeof(*residual));
+    const void* ptrs[] = {params, xs, grads, exp_avg, exp_avg_sq, mask, step_ptr, workspace, ctrl, stream};
+    key_mix(key, ptrs, sizeof(ptrs));
+    const long long ints[] = {(long long)n_points, (long long)seed, nd, n2, (long long)workspace_bytes, net->gemm_mode, g_pinn_max_per_cu,
+                              g_pinn_prepass_in_kernel, (long long)g_wgx_chunk_bytes};
+    key_mix(key, ints, sizeof(ints));
+    const float flts[] = {ic_const, lr, beta1, beta2, eps};
+    key_mix(key, flts, sizeof(flts));
+    key_mix(key, kind, sizeof(int) * net->lay.d); key_mix(key, a, sizeof(float) * net->lay.d); key_mix(key, b, sizeof(float) * net->lay.d);
+    key_mix(key, dir_cols, sizeof(int) * (nd > 0 ? nd : 0));
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    key_mix(key, &dev, sizeof(dev));
+    PinnFitCtrl* dctrl = reinterpret_cast<PinnFitCtrl*>(ctrl);
+    hipStream_t hs = (hipStream_t)stream;
+    const bool hit = net->fit_graph_exec && net->fit_graph_k == k_steps && memcmp(key, net->fit_graph_key, sizeof(key)) == 0;
+    if (!hit) {
+        if (net->fit_graph_exec) { (void)hipGraphExecDestroy((hipGraphExec_t)net->fit_graph_exec); net->fit_graph_exec = nullptr; }
+        // one eager iteration's worth of planning has to have happened (function attributes, occupancy queries are not capturable):
+        // the first chunk of a configuration runs eagerly AND is followed by the capture of the graph the next chunks replay
+        const int rc = pinn_fit_steps(net, residual, params, xs, n_points, kind, a, b, seed, call_index0, dir_cols, nd, n2, ic_const, grads,
+                                      exp_avg, exp_avg_sq, mask, step_ptr, step0, lr, beta1, beta2, eps, loss_history, k_steps, workspace,
+                                      workspace_bytes, stream);
+        if (rc) return rc;
+        hipGraph_t graph = nullptr;
+        // capture happens on a stream of the library's own (torch's current stream is usually the legacy default stream, which cannot
+        // capture); nothing EXECUTES on it -- the nodes are kernel launches without a stream of their own, the graph is launched on `hs`
+        static thread_local hipStream_t cap_streams[64] = {nullptr};
+        hipStream_t& cs = cap_streams[dev & 63];
+        if (!cs && hipStreamCreateWithFlags(&cs, hipStreamNonBlocking) != hipSuccess) { (void)hipGetLastError(); ++g_fit_graph_stats[2]; return 0; }
+        const hipError_t be = hipStreamBeginCapture(cs, hipStreamCaptureModeThreadLocal);
+        if (be != hipSuccess) { (void)hipGetLastError(); ++g_fit_graph_stats[2]; g_fit_graph_stats[3] = (int)be; return 0; }
+        int crc = 0;
+        for (int32_t k = 0; k < k_steps && !crc; ++k) {
+            g_fit_capture = {dctrl, k};
+            // (the by-value step numbers and loss slots of the captured launches are placeholders: the kernels read the control block)
+            crc = pinn_sample_points(xs, n_points, net->lay.d, kind, a, b, seed, 0, cs);
+            if (!crc) crc = pinn_residual_adam_step(net, residual, params, xs, n_points, dir_cols, nd, n2, nullptr, ic_const, grads, exp_avg,
+                                                    exp_avg_sq, mask, step_ptr, 1, lr, beta1, beta2, eps, loss_history, workspace,
+                                                    workspace_bytes, cs);
+        }
+        g_fit_capture = {nullptr, 0};
+        const hipError_t ce = hipStreamEndCapture(cs, &graph);
+        if (crc || ce != hipSuccess || !graph) {
+            (void)hipGetLastError(); ++g_fit_graph_stats[2]; g_fit_graph_stats[3] = crc ? -crc : (int)ce;
+            if (graph) (void)hipGraphDestroy(graph);
+            return crc ? crc : 0;
+        }
+        hipGraphExec_t exec = nullptr;
+        const hipError_t ie = hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0);
+        if (ie != hipSuccess) { (void)hipGetLastError(); ++g_fit_graph_stats[2]; g_fit_graph_stats[3] = (int)ie; (void)hipGraphDestroy(graph); return 0; }
+        (void)hipGraphDestroy(graph);
+        net->fit_graph_exec = exec;
+        ++g_fit_graph_stats[1];
+        net->fit_graph_k = k_steps;
+        memcpy(net->fit_graph_key, key, sizeof(key));
+        return 0;                   // (this chunk ran eagerly above)
+    }
+    PinnFitCtrlArgs ca;
+    ca.c.call_index0 = call_index0; ca.c.loss_base = loss_history; ca.c.step0 = step0; ca.c.pad = 0;
+    for (int k = 0; k < PINN_FIT_CHUNK_MAX; ++k) {
+        ca.c.step_size[k] = 0.0f; ca.c.bc2_sqrt[k] = 1.0f;
+        if (k < k_steps) pinn_adam_scalars((double)(step0 + k), lr, beta1, beta2, &ca.c.step_size[k], &ca.c.bc2_sqrt[k]);
+    }
+    hipLaunchKernelGGL(pinn_fit_ctrl_kernel, dim3(1), dim3(128), 0, hs, dctrl, ca);
+    if (hipGetLastError() != hipSuccess) return fail("control-block launch failed");
+    if (hipGraphLaunch((hipGraphExec_t)net->fit_graph_exec, hs) != hipSuccess) return fail("hipGraphLaunch failed");
+    ++g_fit_graph_stats[0];
+    return 0;
+#endif
 }
 
 static int adam_launch(float* params, const float* grads, float* exp_avg, float* exp_avg_sq, const uint8_t* mask, int64_t n,

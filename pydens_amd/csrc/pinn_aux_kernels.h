@@ -68,12 +68,37 @@ PINN_DEVICE void pinn_adam_update(float* params, float gi, float* m, float* v, l
 #ifndef PINN_REDUCE_PB
 #define PINN_REDUCE_PB 32
 #endif
+// Replayable launch graph of a chunk of fit iterations (pinn_fit_steps, batches of a few thousand points: the latency regime): what
+// changes from one iteration to the next -- the Philox batch counter, the Adam step with its bias corrections, the slot of the loss
+// history -- is read from this block in device memory, indexed by the iteration number k that is baked into the graph's kernel nodes;
+// the block itself is rewritten (pinn_fit_ctrl_kernel, an ordinary launch in front of the graph) for every chunk.
+#define PINN_FIT_CHUNK_MAX 128
+struct PinnFitCtrl {
+    unsigned long long call_index0;     // Philox batch counter of iteration 0 of the chunk
+    float* loss_base;                   // entry 0 of the chunk in the loss history
+    int step0, pad;                     // Adam step number of iteration 0
+    float step_size[PINN_FIT_CHUNK_MAX], bc2_sqrt[PINN_FIT_CHUNK_MAX];      // pinn_adam_scalars per iteration (computed on the host in
+                                                                             // double, as for the eager loop: bit-identical updates)
+};
+struct PinnFitCtrlArgs { PinnFitCtrl c; };
+PINN_GLOBAL void PINN_LAUNCH_BOUNDS(128) pinn_fit_ctrl_kernel(PinnFitCtrl* dst, PinnFitCtrlArgs a) {
+    const int t = PINN_TID;
+    if (t == 0) { dst->call_index0 = a.c.call_index0; dst->loss_base = a.c.loss_base; dst->step0 = a.c.step0; dst->pad = 0; }
+    if (t < PINN_FIT_CHUNK_MAX) { dst->step_size[t] = a.c.step_size[t]; dst->bc2_sqrt[t] = a.c.bc2_sqrt[t]; }
+}
+
 PINN_GLOBAL void PINN_LAUNCH_BOUNDS(1024)
 pinn_reduce_kernel(const float* partials, int n_wg, int p_core, float* grads, int accumulate, int do_adam, float* params,
                    float* m, float* v, const unsigned char* mask, int step_value, float step_size, float bc2_sqrt, float b1,
-                   float b2, float eps, int* step_ptr, float* loss_out, int off_loss) {
+                   float b2, float eps, int* step_ptr, float* loss_out, int off_loss, const PinnFitCtrl* ctrl, int ctrl_k) {
     PINN_SMEM(red);
     const int tid = PINN_TID;
+    if (ctrl) {             // (graph replay: this iteration's Adam step and loss slot come from the control block)
+        step_value = ctrl->step0 + ctrl_k;
+        step_size = ctrl->step_size[ctrl_k];
+        bc2_sqrt = ctrl->bc2_sqrt[ctrl_k];
+        loss_out = ctrl->loss_base + ctrl_k;
+    }
     constexpr int PB = PINN_REDUCE_PB, CH = 1024 / PB;        // PB parameters x CH chunks of workgroups per block
     const int pl = tid % PB, ch = tid / PB;
     const int p = PINN_BID * PB + pl;
@@ -200,9 +225,14 @@ PINN_DEVICE float pinn_mul_then_add(float a, float w, float u) {
 // one thread per point. Counter = (point low, point high, call low, call high | block << 28): block b < 8 supplies the
 // uniform words of columns 4b .. 4b+3, block 8 + c the two extra words of a normal column c (Box-Muller).
 PINN_GLOBAL void PINN_LAUNCH_BOUNDS(256)
-pinn_sample_kernel(float* xs, long long n, PinnSampleSpec spec, unsigned k0, unsigned k1, unsigned call_lo, unsigned call_hi) {
+pinn_sample_kernel(float* xs, long long n, PinnSampleSpec spec, unsigned k0, unsigned k1, unsigned call_lo, unsigned call_hi,
+                   const PinnFitCtrl* ctrl, int ctrl_k) {
     const long long i = (long long)PINN_BID * 256 + PINN_TID;
     if (i >= n) return;
+    if (ctrl) {             // (graph replay: the batch counter of this iteration)
+        const unsigned long long call = ctrl->call_index0 + (unsigned long long)ctrl_k;
+        call_lo = (unsigned)(call & 0xffffffffull); call_hi = (unsigned)(call >> 32);
+    }
     const unsigned i_lo = (unsigned)((unsigned long long)i & 0xffffffffull), i_hi = (unsigned)((unsigned long long)i >> 32);
     unsigned r[4] = {0u, 0u, 0u, 0u};
     for (int c = 0; c < spec.d; ++c) {

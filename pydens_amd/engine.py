@@ -107,6 +107,11 @@ def bind(lib):
                                    ctypes.c_uint64, ctypes.c_uint64, ip, i32, i32, f32, vp, vp, vp, vp, vp, i32, f32, f32, f32, f32,
                                    vp, i32, vp, ctypes.c_size_t, vp]
     lib.pinn_fit_steps.restype = i32
+    lib.pinn_fit_steps_graph.argtypes = [vp, ctypes.POINTER(Residual), vp, vp, i64, ip, ctypes.POINTER(f32), ctypes.POINTER(f32),
+                                         ctypes.c_uint64, ctypes.c_uint64, ip, i32, i32, f32, vp, vp, vp, vp, vp, i32, f32, f32, f32, f32,
+                                         vp, i32, vp, ctypes.c_size_t, vp, ctypes.c_size_t, vp]
+    lib.pinn_fit_steps_graph.restype = i32
+    lib.pinn_fit_ctrl_bytes.restype = ctypes.c_size_t
     lib.pinn_set_gemm_mode.argtypes = [vp, i32]
     lib.pinn_set_gemm_mode.restype = i32
     lib.pinn_profile_tile.argtypes = [i32]
@@ -120,6 +125,7 @@ def bind(lib):
     lib.pinn_debug_wgx_chunk_bytes.argtypes = [ctypes.c_longlong]
     lib.pinn_debug_max_wgs_per_cu.argtypes = [ctypes.c_int]
     lib.pinn_last_launch_info.argtypes = [ctypes.POINTER(ctypes.c_int32)]
+    lib.pinn_debug_fit_graph_stats.argtypes = [ctypes.POINTER(ctypes.c_int32)]
     for name in ('pinn_create', 'pinn_create_ex', 'pinn_destroy', 'pinn_layout', 'pinn_jet_forward', 'pinn_jet_backward',
                  'pinn_residual_step', 'pinn_residual_adam_step', 'pinn_adam_step', 'pinn_adam_step_at'):
         getattr(lib, name).restype = i32
@@ -127,9 +133,9 @@ def bind(lib):
 
 
 ABI_SYMBOLS = ('pinn_create', 'pinn_create_ex', 'pinn_destroy', 'pinn_layout', 'pinn_workspace_bytes', 'pinn_jet_forward',
-               'pinn_jet_backward', 'pinn_residual_step', 'pinn_residual_step_add', 'pinn_residual_adam_step', 'pinn_adam_step', 'pinn_adam_step_at', 'pinn_sample_points', 'pinn_fit_steps', 'pinn_set_gemm_mode', 'pinn_profile_tile',
+               'pinn_jet_backward', 'pinn_residual_step', 'pinn_residual_step_add', 'pinn_residual_adam_step', 'pinn_adam_step', 'pinn_adam_step_at', 'pinn_sample_points', 'pinn_fit_steps', 'pinn_fit_steps_graph', 'pinn_fit_ctrl_bytes', 'pinn_set_gemm_mode', 'pinn_profile_tile',
                'pinn_last_tile_ms', 'pinn_last_wgrad_ms', 'pinn_last_kernel_name', 'pinn_last_wgrad_kernel_name', 'pinn_debug_last_kernel',
-               'pinn_debug_prepass_in_kernel', 'pinn_debug_wgx_chunk_bytes', 'pinn_debug_max_wgs_per_cu', 'pinn_last_launch_info',
+               'pinn_debug_prepass_in_kernel', 'pinn_debug_wgx_chunk_bytes', 'pinn_debug_max_wgs_per_cu', 'pinn_debug_fit_graph_stats', 'pinn_last_launch_info',
                'pinn_last_error', 'pinn_backend')
 
 _LIB = None
@@ -328,7 +334,7 @@ class Net:
                 workspace.numel() * workspace.element_size(), _stream(xs) if stream is None else stream))
 
     def fit_steps(self, residual, params, xs, columns, seed, call_index0, grads, workspace, exp_avg, exp_avg_sq, mask,
-                  step_tensor, step0, lr, betas, eps, loss_history, k_steps, dir_cols=(), n2=0, ic_const=0.0, stream=None):
+                  step_tensor, step0, lr, betas, eps, loss_history, k_steps, dir_cols=(), n2=0, ic_const=0.0, stream=None, ctrl=None):
         """ `k_steps` iterations of the fit loop (sample -> fused step -> Adam) enqueued by one call (include/pinn.h
         pinn_fit_steps); `xs` is the [N, d] batch buffer every iteration overwrites, `loss_history` a float32 device tensor
         with at least k_steps entries. """
@@ -344,13 +350,18 @@ class Net:
         a = (ctypes.c_float * d)(*[float(c[1]) for c in columns])
         b = (ctypes.c_float * d)(*[float(c[2]) for c in columns])
         dirs, nd = self._dirs(dir_cols)
+        common = (self.handle, ctypes.byref(residual), _ptr(params), _ptr(xs), xs.shape[0], kind, a, b,
+                  int(seed) & (2 ** 64 - 1), int(call_index0), dirs, nd, n2, float(ic_const), _ptr(grads), _ptr(exp_avg),
+                  _ptr(exp_avg_sq), _ptr(mask), _ptr(step_tensor), int(step0), float(lr), float(betas[0]), float(betas[1]),
+                  float(eps), _ptr(loss_history), int(k_steps), _ptr(workspace), workspace.numel() * workspace.element_size())
         with _on_device(params):
-            self._raise(self.lib.pinn_fit_steps(
-                self.handle, ctypes.byref(residual), _ptr(params), _ptr(xs), xs.shape[0], kind, a, b,
-                int(seed) & (2 ** 64 - 1), int(call_index0), dirs, nd, n2, float(ic_const), _ptr(grads), _ptr(exp_avg),
-                _ptr(exp_avg_sq), _ptr(mask), _ptr(step_tensor), int(step0), float(lr), float(betas[0]), float(betas[1]),
-                float(eps), _ptr(loss_history), int(k_steps), _ptr(workspace), workspace.numel() * workspace.element_size(),
-                _stream(xs) if stream is None else stream))
+            if ctrl is not None:
+                # `ctrl`: a uint8 device tensor of pinn_fit_ctrl_bytes() bytes -- the chunk as one replayable launch graph
+                # (pinn_fit_steps_graph; the library falls back to the eager loop by itself where a graph does not apply)
+                self._raise(self.lib.pinn_fit_steps_graph(*common, _ptr(ctrl), ctrl.numel() * ctrl.element_size(),
+                                                          _stream(xs) if stream is None else stream))
+            else:
+                self._raise(self.lib.pinn_fit_steps(*common, _stream(xs) if stream is None else stream))
 
     def sample_points(self, xs, columns, seed, call_index, stream=None):
         """ fill xs [N, d] on the device: columns = [(kind, a, b), ...] with kind SAMPLE_UNIFORM (a + (b - a) u),

@@ -13,6 +13,7 @@ Data parallelism: if torch.distributed is initialised, every rank steps on its o
 gradient buffer (loss slot included) is summed with one all-reduce (RCCL) per iteration.
 """
 import contextlib
+import os
 from contextvars import copy_context
 
 import numpy as np
@@ -646,6 +647,7 @@ class Solver:
             done[0] = it + 1
 
     FIT_CHUNK = 128             # iterations per pinn_fit_steps call (progress bar / KeyboardInterrupt granularity)
+    GRAPH_MAX_BATCH = 4096      # batches up to this size replay their chunks as one launch graph (+16 % at batch 100, +1 % at 4 096)
 
     def _device_columns(self, sampler):
         """ (kind, a, b) per input column if the Philox kernel can draw this sampler's batches, else None """
@@ -670,6 +672,13 @@ class Solver:
         xs = torch.empty((batch, model.total), dtype=torch.float32, device=self.device)
         own = sampler.device_key() if (sampler is not None and hasattr(sampler, 'device_key')) else None
         rank, _ = self._world()
+        # small batches (the latency regime): each chunk as ONE replayable launch graph; the control block the kernels read their
+        # per-iteration values from belongs to the solver (include/pinn.h pinn_fit_steps_graph)
+        ctrl = None
+        if batch <= self.GRAPH_MAX_BATCH and xs.is_cuda and os.environ.get('PYDENS_AMD_FIT_GRAPH', '1') != '0':
+            if getattr(self, '_fit_ctrl', None) is None or self._fit_ctrl.device != xs.device:
+                self._fit_ctrl = torch.zeros(int(model.net.lib.pinn_fit_ctrl_bytes()) + 64, dtype=torch.uint8, device=xs.device)
+            ctrl = self._fit_ctrl
         with tqdm(total=niters, disable=None) as bar:
             it = 0
             while it < niters:
@@ -684,7 +693,7 @@ class Solver:
                     model.net.fit_steps(self.program, model.flat, xs, columns, seed, call0, self.grads, ws, adam.exp_avg,
                                         adam.exp_avg_sq, adam.mask, adam.step_count, adam.t + 1, adam.lr, adam.betas, adam.eps,
                                         history[it:it + k], k, dir_cols=spec.dir_cols, n2=n2, ic_const=model.kernel_ic_const(),
-                                        stream=stream)
+                                        stream=stream, ctrl=ctrl)
                 except BaseException:
                     # the library stopped inside the chunk (or an interrupt landed around the call): the device knows how many
                     # Adam steps it applied -- the host's step number and the batch counters follow IT, so that a later

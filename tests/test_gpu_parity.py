@@ -936,3 +936,25 @@ def test_sin_net_of_depth_four_on_the_static_kernel(pa):
     np.testing.assert_allclose([float(v) for v in solver.losses], [float(v) for v in oracle.losses], rtol=2e-5)
     for got, want in zip(export_params(solver), oracle.export_params()):
         assert params_close(got, want, 2e-5)
+
+
+@pytest.mark.parametrize('name,batch', [('cfg1', 100), ('cfg4', 2048)])
+def test_fit_chunks_as_launch_graphs_follow_the_eager_loop_bit_for_bit(pa, name, batch, monkeypatch):
+    """ Solver.fit at small batches replays every 128-iteration chunk as ONE launch graph (pinn_fit_steps_graph: the Philox batch
+    counter, the Adam step with its bias corrections and the loss slot come from a device control block); the trajectory -- every loss,
+    every parameter, the Adam state -- must be the eager loop's, bit for bit, across several chunks and a second fit that continues """
+    def run(graph):
+        monkeypatch.setenv('PYDENS_AMD_FIT_GRAPH', '1' if graph else '0')
+        torch.manual_seed(21)
+        cfg, solver = make_solver(name, pa)
+        sampler = (pa.NumpySampler('uniform') & pa.NumpySampler('uniform', low=1, high=5)) if name == 'cfg4' else None
+        solver.fit(niters=300, batch_size=batch, sampler=sampler, lr=0.005)             # eager chunk + capture, replay, short tail (eager)
+        solver.fit(niters=260, batch_size=batch, sampler=sampler, lr=0.005, optimizer=None)      # continues: the graph is replayed at once
+        assert solver.last_fit_path == 'fused'
+        return (np.array([float(v) for v in solver.losses]), solver.model.flat.detach().cpu().numpy().copy(),
+                solver.optimizer.exp_avg.cpu().numpy().copy(), int(solver.optimizer.step_count.item()))
+    l0, p0, m0, t0 = run(False)
+    l1, p1, m1, t1 = run(True)
+    assert t0 == t1 == 560
+    assert np.array_equal(l0, l1)
+    assert np.array_equal(p0, p1) and np.array_equal(m0, m1)

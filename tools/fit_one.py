@@ -22,3 +22,7 @@ dt = time.perf_counter() - t0
 losses = solver.losses
 print(f'{name}: Solver.fit {iters / dt:9.1f} it/s  {n * iters / dt:12.4g} points/s  ({dt / iters * 1e3:.3f} ms/it, batch {n}, path {solver.last_fit_path}, '
       f'loss {float(losses[20]):.4g} -> {float(losses[-1]):.4g})')
+import ctypes
+st = (ctypes.c_int32 * 4)()
+solver.model.net.lib.pinn_debug_fit_graph_stats(st)
+print(f'{name}: launch graphs: {st[0]} chunks replayed, {st[1]} captured, {st[2]} refused (HIP error {st[3]})')
