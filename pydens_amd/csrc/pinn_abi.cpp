@@ -60,6 +60,8 @@ namespace {
 // control block (PinnFitCtrl) at index `k` instead of taking them by value
 struct FitCapture { const PinnFitCtrl* ctrl; int k; };
 thread_local FitCapture g_fit_capture = {nullptr, 0};
+// set by pinn_fit_steps around the step of iteration k < K - 1: its reduction launch also draws the batch of iteration k + 1
+thread_local PinnNextBatch g_fit_next = {nullptr, 0, {}, 0u, 0u, 0ull};
 int g_pinn_max_per_cu = 4;          // pinn_debug_max_wgs_per_cu
 int g_pinn_prepass_in_kernel = 1;   // debug switch: 0 = x-only pre-pass as its own launch (pinn_aux_kernel)
 int g_pinn_debug_flags = 0;         // -DPINN_DEBUG_ABI builds: pinn_debug_set_flags
@@ -308,13 +310,15 @@ int launch_reduce(const float* partials, int n_wg, int p_core, float* grads, int
 #ifdef PINN_EMU
     emu::launch(blocks, 1024, smem, [&] {
         pinn_reduce_kernel(partials, n_wg, p_core, grads, accumulate, do_adam, a.params, a.m, a.v, a.mask, a.step_value,
-                           step_size, bc2_sqrt, a.b1, a.b2, a.eps, a.step_ptr, a.loss_out, a.off_loss, nullptr, 0);
+                           step_size, bc2_sqrt, a.b1, a.b2, a.eps, a.step_ptr, a.loss_out, a.off_loss, nullptr, 0,
+                           do_adam ? g_fit_next : PinnNextBatch{nullptr, 0, {}, 0u, 0u, 0ull});
     });
 #else
     const PinnFitCtrl* ctrl = do_adam ? g_fit_capture.ctrl : nullptr;
     hipLaunchKernelGGL(pinn_reduce_kernel, dim3(blocks), dim3(1024), smem, (hipStream_t)stream, partials, n_wg, p_core,
                        grads, accumulate, do_adam, a.params, a.m, a.v, a.mask, a.step_value, step_size, bc2_sqrt, a.b1, a.b2,
-                       a.eps, a.step_ptr, a.loss_out, a.off_loss, ctrl, g_fit_capture.k);
+                       a.eps, a.step_ptr, a.loss_out, a.off_loss, ctrl, g_fit_capture.k,
+                       do_adam ? g_fit_next : PinnNextBatch{nullptr, 0, {}, 0u, 0u, 0ull});
     if (hipGetLastError() != hipSuccess) return fail("reduce kernel launch failed");
 #endif
     return 0;
@@ -852,6 +856,29 @@ int pinn_residual_adam_step(pinn_t* net, const pinn_residual_t* residual, float*
                               1.0f / (float)n_points, grads, workspace, workspace_bytes, stream, &adam);
 }
 
+// the sampler description of a fit chunk in the form the reduction's tail takes (non-zero: columns it cannot draw)
+static int fit_next_spec(const pinn_net* net, float* xs, int64_t n_points, const int* kind, const float* a, const float* b, uint64_t seed,
+                         PinnNextBatch* out) {
+    if (!net || !xs || !kind || !a || !b || n_points <= 0 || net->lay.d < 1 || net->lay.d > PINN_MAX_INPUTS) return 1;
+    memset(out, 0, sizeof(*out));
+    out->xs = xs; out->n = (long long)n_points; out->spec.d = net->lay.d;
+    for (int c = 0; c < net->lay.d; ++c) {
+        if (kind[c] < PINN_SAMPLE_UNIFORM || kind[c] > PINN_SAMPLE_CONST) return 1;
+        out->spec.kind[c] = kind[c]; out->spec.a[c] = a[c]; out->spec.b[c] = b[c];
+    }
+    out->k0 = (unsigned)(seed & 0xffffffffull); out->k1 = (unsigned)(seed >> 32);
+    return 0;
+}
+
+// does a fused step of this batch run as ONE tile pass + ONE reduction (not chunk by chunk)?
+static bool single_pass_step(pinn_net* net, const pinn_residual_t* residual, int64_t n_points, int nd, int n2) {
+    if (!residual) return false;
+    Plan plan;
+    const int comb = residual->combined ? 1 : 0;
+    if (make_plan(net, n_points, nd, n2, &plan, PINN_MODE_STEP, residual->kind, comb, nullptr)) return false;
+    return plan.chunk_tiles >= plan.ntiles;
+}
+
 int pinn_fit_steps(pinn_t* net, const pinn_residual_t* residual, float* params, float* xs, int64_t n_points,
                    const int* kind, const float* a, const float* b, uint64_t seed, uint64_t call_index0,
                    const int* dir_cols, int nd, int n2, float ic_const, float* grads, float* exp_avg, float* exp_avg_sq,
@@ -862,13 +889,22 @@ int pinn_fit_steps(pinn_t* net, const pinn_residual_t* residual, float* params, 
     // K iterations of the reference's fit loop (model_torch.py:426-464) enqueued by ONE call: sample, fused step, Adam. Nothing
     // here waits for the device; the arguments that change from one iteration to the next (Philox batch counter, Adam step,
     // slot of the loss history) travel by value, so a launch graph would have to be re-instantiated per iteration anyway
-    for (int32_t k = 0; k < k_steps; ++k) {
-        if (pinn_sample_points(xs, n_points, net->lay.d, kind, a, b, seed, call_index0 + (uint64_t)k, stream)) return 1;
-        if (pinn_residual_adam_step(net, residual, params, xs, n_points, dir_cols, nd, n2, nullptr, ic_const, grads, exp_avg,
-                                    exp_avg_sq, mask, step_ptr, step0 + k, lr, beta1, beta2, eps, loss_history + k, workspace,
-                                    workspace_bytes, stream)) return 1;
+    // from the second iteration on the batch is drawn by the reduction launch of the iteration before (pinn_reduce_kernel's tail: the
+    // tile kernel of that iteration is through with the buffer), which saves every iteration one dependent launch -- where the step
+    // is one pass (a chunked WGX step reduces several times per iteration: those keep the sampler launch)
+    PinnNextBatch next = {nullptr, 0, {}, 0u, 0u, 0ull};
+    const bool hand_over = fit_next_spec(net, xs, n_points, kind, a, b, seed, &next) == 0 && single_pass_step(net, residual, n_points, nd, n2);
+    int rc = 0;
+    for (int32_t k = 0; k < k_steps && !rc; ++k) {
+        if (k == 0 || !hand_over) rc = pinn_sample_points(xs, n_points, net->lay.d, kind, a, b, seed, call_index0 + (uint64_t)k, stream);
+        if (rc) break;
+        if (hand_over && k + 1 < k_steps) { next.call = call_index0 + (uint64_t)k + 1; g_fit_next = next; }
+        rc = pinn_residual_adam_step(net, residual, params, xs, n_points, dir_cols, nd, n2, nullptr, ic_const, grads, exp_avg,
+                                     exp_avg_sq, mask, step_ptr, step0 + k, lr, beta1, beta2, eps, loss_history + k, workspace,
+                                     workspace_bytes, stream);
+        g_fit_next.n = 0;
     }
-    return 0;
+    return rc;
 }
 
 size_t pinn_fit_ctrl_bytes(void) { return sizeof(PinnFitCtrl); }
@@ -942,15 +978,19 @@ int pinn_fit_steps_graph(pinn_t* net, const pinn_residual_t* residual, float* pa
         const hipError_t be = hipStreamBeginCapture(cs, hipStreamCaptureModeThreadLocal);
         if (be != hipSuccess) { (void)hipGetLastError(); ++g_fit_graph_stats[2]; g_fit_graph_stats[3] = (int)be; return 0; }
         int crc = 0;
+        PinnNextBatch cap_next = {nullptr, 0, {}, 0u, 0u, 0ull};
+        const bool cap_hand_over = fit_next_spec(net, xs, n_points, kind, a, b, seed, &cap_next) == 0 && single_pass_step(net, residual, n_points, nd, n2);
         for (int32_t k = 0; k < k_steps && !crc; ++k) {
             g_fit_capture = {dctrl, k};
             // (the by-value step numbers and loss slots of the captured launches are placeholders: the kernels read the control block)
-            crc = pinn_sample_points(xs, n_points, net->lay.d, kind, a, b, seed, 0, cs);
+            if (k == 0 || !cap_hand_over) crc = pinn_sample_points(xs, n_points, net->lay.d, kind, a, b, seed, 0, cs);
+            if (cap_hand_over && k + 1 < k_steps) g_fit_next = cap_next;
             if (!crc) crc = pinn_residual_adam_step(net, residual, params, xs, n_points, dir_cols, nd, n2, nullptr, ic_const, grads, exp_avg,
                                                     exp_avg_sq, mask, step_ptr, 1, lr, beta1, beta2, eps, loss_history, workspace,
                                                     workspace_bytes, cs);
         }
         g_fit_capture = {nullptr, 0};
+        g_fit_next.n = 0;
         const hipError_t ce = hipStreamEndCapture(cs, &graph);
         if (crc || ce != hipSuccess || !graph) {
             (void)hipGetLastError(); ++g_fit_graph_stats[2]; g_fit_graph_stats[3] = crc ? -crc : (int)ce;

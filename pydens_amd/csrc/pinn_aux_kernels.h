@@ -68,6 +68,71 @@ PINN_DEVICE void pinn_adam_update(float* params, float gi, float* m, float* v, l
 #ifndef PINN_REDUCE_PB
 #define PINN_REDUCE_PB 32
 #endif
+// ------------------------------------------------------------------------------------------------------------
+// Collocation sampler on the device: replaces the host-side draws of reference model_torch.py:430-434 (`torch.rand`
+// per input column, or `sampler.sample(batch_size)` of a batchflow NumpySampler product `a & b & ...`).
+// Counter-based generator Philox4x32-10 (Salmon, Moraes, Dror, Shaw: "Parallel random numbers: as easy as 1, 2, 3",
+// SC'11; constants of the Random123 library): no state in memory, one launch per batch whatever the number of columns,
+// every (seed, call, point, column) addresses its own random word, so a batch does not depend on the launch geometry.
+// oracle/philox.py restates it in numpy (pinned to the Random123 known-answer vectors); tests compare bit for bit.
+// ------------------------------------------------------------------------------------------------------------
+struct PinnSampleSpec {
+    int d;
+    int kind[PINN_MAX_INPUTS];      // PINN_SAMPLE_UNIFORM / _NORMAL / _CONST
+    float a[PINN_MAX_INPUTS], b[PINN_MAX_INPUTS];
+};
+
+PINN_DEVICE void pinn_philox4x32_10(unsigned c0, unsigned c1, unsigned c2, unsigned c3, unsigned k0, unsigned k1,
+                                    unsigned (&out)[4]) {
+#pragma unroll
+    for (int round = 0; round < 10; ++round) {
+        const unsigned long long p0 = (unsigned long long)0xD2511F53u * c0;
+        const unsigned long long p1 = (unsigned long long)0xCD9E8D57u * c2;
+        const unsigned n0 = (unsigned)(p1 >> 32) ^ c1 ^ k0, n1 = (unsigned)p1;
+        const unsigned n2 = (unsigned)(p0 >> 32) ^ c3 ^ k1, n3 = (unsigned)p0;
+        c0 = n0; c1 = n1; c2 = n2; c3 = n3;
+        k0 += 0x9E3779B9u; k1 += 0xBB67AE85u;
+    }
+    out[0] = c0; out[1] = c1; out[2] = c2; out[3] = c3;
+}
+
+// products / sums that must round like the numpy oracle: separately, never contracted into a fused multiply-add
+// (hipcc's __fmul_rn / __fadd_rn are plain operators and do get contracted, hence the pragma in the function bodies)
+PINN_DEVICE float pinn_mul_then_add(float a, float w, float u) {
+#pragma clang fp contract(off)
+    const float t = w * u;
+    return a + t;
+}
+
+// the d columns of point i of batch `call` (what one thread of pinn_sample_kernel does; also the tail of pinn_reduce_kernel when a fit
+// chunk lets the reduction of iteration k draw the batch of iteration k + 1: one launch less per iteration)
+PINN_DEVICE void pinn_sample_point(float* xs, long long i, const PinnSampleSpec& spec, unsigned k0, unsigned k1, unsigned call_lo,
+                                   unsigned call_hi) {
+    const unsigned i_lo = (unsigned)((unsigned long long)i & 0xffffffffull), i_hi = (unsigned)((unsigned long long)i >> 32);
+    unsigned r[4] = {0u, 0u, 0u, 0u};
+    for (int c = 0; c < spec.d; ++c) {
+        if ((c & 3) == 0) pinn_philox4x32_10(i_lo, i_hi, call_lo, (call_hi & 0x0fffffffu) | ((unsigned)(c >> 2) << 28), k0, k1, r);
+        const float a = spec.a[c], b = spec.b[c];
+        float v = a;
+        if (spec.kind[c] == PINN_SAMPLE_UNIFORM) {
+            const float u = (float)(r[c & 3] >> 8) * 5.9604644775390625e-8f;              // 24 bits -> [0, 1)
+            v = pinn_mul_then_add(a, b - a, u);
+        } else if (spec.kind[c] == PINN_SAMPLE_NORMAL) {
+            unsigned q[4];
+            pinn_philox4x32_10(i_lo, i_hi, call_lo, (call_hi & 0x0fffffffu) | ((unsigned)(8 + c) << 28), k0, k1, q);
+            const float u1 = (float)((q[0] >> 8) + 1u) * 5.9604644775390625e-8f;          // (0, 1]
+            const float u2 = (float)(q[1] >> 8) * 5.9604644775390625e-8f;
+            const float z = sqrtf(-2.0f * logf(u1)) * cosf(6.283185307179586f * u2);
+            v = pinn_mul_then_add(a, b, z);
+        }
+        xs[i * spec.d + c] = v;
+    }
+}
+// what the reduction of a fit iteration needs to draw the NEXT iteration's batch (n == 0: nothing to draw)
+struct PinnNextBatch {
+    float* xs; long long n; PinnSampleSpec spec; unsigned k0, k1; unsigned long long call;
+};
+
 // Replayable launch graph of a chunk of fit iterations (pinn_fit_steps, batches of a few thousand points: the latency regime): what
 // changes from one iteration to the next -- the Philox batch counter, the Adam step with its bias corrections, the slot of the loss
 // history -- is read from this block in device memory, indexed by the iteration number k that is baked into the graph's kernel nodes;
@@ -90,7 +155,8 @@ PINN_GLOBAL void PINN_LAUNCH_BOUNDS(128) pinn_fit_ctrl_kernel(PinnFitCtrl* dst, 
 PINN_GLOBAL void PINN_LAUNCH_BOUNDS(1024)
 pinn_reduce_kernel(const float* partials, int n_wg, int p_core, float* grads, int accumulate, int do_adam, float* params,
                    float* m, float* v, const unsigned char* mask, int step_value, float step_size, float bc2_sqrt, float b1,
-                   float b2, float eps, int* step_ptr, float* loss_out, int off_loss, const PinnFitCtrl* ctrl, int ctrl_k) {
+                   float b2, float eps, int* step_ptr, float* loss_out, int off_loss, const PinnFitCtrl* ctrl, int ctrl_k,
+                   PinnNextBatch next) {
     PINN_SMEM(red);
     const int tid = PINN_TID;
     if (ctrl) {             // (graph replay: this iteration's Adam step and loss slot come from the control block)
@@ -116,6 +182,14 @@ pinn_reduce_kernel(const float* partials, int n_wg, int p_core, float* grads, in
         if (do_adam && (!mask || mask[p])) pinn_adam_update(params, t, m, v, p, step_size, bc2_sqrt, b1, b2, eps);
     }
     if (do_adam && PINN_BID == 0 && tid == 0) step_ptr[0] = step_value;
+    // fit chunks: this iteration's tile kernel is through with the batch buffer -- the batch of the next iteration is drawn here
+    // (same generator, same counters as pinn_sample_kernel: bit-identical batches), which saves the iteration a dependent launch
+    if (next.n > 0) {
+        unsigned long long call = next.call;
+        if (ctrl) call = ctrl->call_index0 + (unsigned long long)(ctrl_k + 1);
+        for (long long i = (long long)PINN_BID * 1024 + tid; i < next.n; i += (long long)PINN_NBLK * 1024)
+            pinn_sample_point(next.xs, i, next.spec, next.k0, next.k1, (unsigned)(call & 0xffffffffull), (unsigned)(call >> 32));
+    }
 }
 
 // ------------------------------------------------------------------------------------------------------------
@@ -186,42 +260,6 @@ pinn_adam_kernel(float* params, const float* grads, float* m, float* v, const un
     pinn_adam_update(params, grads[i], m, v, i, step_size, bc2_sqrt, b1, b2, eps);
 }
 
-// ------------------------------------------------------------------------------------------------------------
-// Collocation sampler on the device: replaces the host-side draws of reference model_torch.py:430-434 (`torch.rand`
-// per input column, or `sampler.sample(batch_size)` of a batchflow NumpySampler product `a & b & ...`).
-// Counter-based generator Philox4x32-10 (Salmon, Moraes, Dror, Shaw: "Parallel random numbers: as easy as 1, 2, 3",
-// SC'11; constants of the Random123 library): no state in memory, one launch per batch whatever the number of columns,
-// every (seed, call, point, column) addresses its own random word, so a batch does not depend on the launch geometry.
-// oracle/philox.py restates it in numpy (pinned to the Random123 known-answer vectors); tests compare bit for bit.
-// ------------------------------------------------------------------------------------------------------------
-struct PinnSampleSpec {
-    int d;
-    int kind[PINN_MAX_INPUTS];      // PINN_SAMPLE_UNIFORM / _NORMAL / _CONST
-    float a[PINN_MAX_INPUTS], b[PINN_MAX_INPUTS];
-};
-
-PINN_DEVICE void pinn_philox4x32_10(unsigned c0, unsigned c1, unsigned c2, unsigned c3, unsigned k0, unsigned k1,
-                                    unsigned (&out)[4]) {
-#pragma unroll
-    for (int round = 0; round < 10; ++round) {
-        const unsigned long long p0 = (unsigned long long)0xD2511F53u * c0;
-        const unsigned long long p1 = (unsigned long long)0xCD9E8D57u * c2;
-        const unsigned n0 = (unsigned)(p1 >> 32) ^ c1 ^ k0, n1 = (unsigned)p1;
-        const unsigned n2 = (unsigned)(p0 >> 32) ^ c3 ^ k1, n3 = (unsigned)p0;
-        c0 = n0; c1 = n1; c2 = n2; c3 = n3;
-        k0 += 0x9E3779B9u; k1 += 0xBB67AE85u;
-    }
-    out[0] = c0; out[1] = c1; out[2] = c2; out[3] = c3;
-}
-
-// products / sums that must round like the numpy oracle: separately, never contracted into a fused multiply-add
-// (hipcc's __fmul_rn / __fadd_rn are plain operators and do get contracted, hence the pragma in the function bodies)
-PINN_DEVICE float pinn_mul_then_add(float a, float w, float u) {
-#pragma clang fp contract(off)
-    const float t = w * u;
-    return a + t;
-}
-
 // one thread per point. Counter = (point low, point high, call low, call high | block << 28): block b < 8 supplies the
 // uniform words of columns 4b .. 4b+3, block 8 + c the two extra words of a normal column c (Box-Muller).
 PINN_GLOBAL void PINN_LAUNCH_BOUNDS(256)
@@ -233,23 +271,5 @@ pinn_sample_kernel(float* xs, long long n, PinnSampleSpec spec, unsigned k0, uns
         const unsigned long long call = ctrl->call_index0 + (unsigned long long)ctrl_k;
         call_lo = (unsigned)(call & 0xffffffffull); call_hi = (unsigned)(call >> 32);
     }
-    const unsigned i_lo = (unsigned)((unsigned long long)i & 0xffffffffull), i_hi = (unsigned)((unsigned long long)i >> 32);
-    unsigned r[4] = {0u, 0u, 0u, 0u};
-    for (int c = 0; c < spec.d; ++c) {
-        if ((c & 3) == 0) pinn_philox4x32_10(i_lo, i_hi, call_lo, (call_hi & 0x0fffffffu) | ((unsigned)(c >> 2) << 28), k0, k1, r);
-        const float a = spec.a[c], b = spec.b[c];
-        float v = a;
-        if (spec.kind[c] == PINN_SAMPLE_UNIFORM) {
-            const float u = (float)(r[c & 3] >> 8) * 5.9604644775390625e-8f;              // 24 bits -> [0, 1)
-            v = pinn_mul_then_add(a, b - a, u);
-        } else if (spec.kind[c] == PINN_SAMPLE_NORMAL) {
-            unsigned q[4];
-            pinn_philox4x32_10(i_lo, i_hi, call_lo, (call_hi & 0x0fffffffu) | ((unsigned)(8 + c) << 28), k0, k1, q);
-            const float u1 = (float)((q[0] >> 8) + 1u) * 5.9604644775390625e-8f;          // (0, 1]
-            const float u2 = (float)(q[1] >> 8) * 5.9604644775390625e-8f;
-            const float z = sqrtf(-2.0f * logf(u1)) * cosf(6.283185307179586f * u2);
-            v = pinn_mul_then_add(a, b, z);
-        }
-        xs[i * spec.d + c] = v;
-    }
+    pinn_sample_point(xs, i, spec, k0, k1, call_lo, call_hi);
 }
