@@ -81,11 +81,15 @@ def make_config(name, D, torch, V=None):
                                        activation=['Sin', 'Tanh', 'SiLU', 'Tanh', 'Sigmoid']),
                     n_points=4096, low=[0, 0], high=[1, 1])
     # ---- breadth workloads: timed by `bench.py --workload ...`, not BASELINE configs -----------------------
-    if name in ('skip128', 'sin64', 'program', 'generic'):
+    if name in ('skip128', 'skip256', 'sin64', 'program', 'generic'):
         def poisson(f, x, y):
             return D(D(f, x), x) + D(D(f, y), y) - 5 * torch.sin(PI * (x + y))
         if name == 'skip128':                                    # skip connection 'R ... +' (reference model_torch.py:142-156), width 128
             net = dict(layout='faR fa fa+ fa f', features=[128, 128, 128, 128, 1], activation='Tanh')
+            return dict(equation=poisson, solver_kwargs=dict(ndims=2, boundary_condition=1, **net), n_points=65536,
+                        low=[0, 0], high=[1, 1])
+        if name == 'skip256':                                    # two residual blocks of width 256 (the usual post-activation ResNet form)
+            net = dict(layout='faR fa fa+ R fa fa+ f', features=[256, 256, 256, 256, 256, 1], activation='Tanh')
             return dict(equation=poisson, solver_kwargs=dict(ndims=2, boundary_condition=1, **net), n_points=65536,
                         low=[0, 0], high=[1, 1])
         if name == 'sin64':                                      # 4 x 64 with activation 'Sin'

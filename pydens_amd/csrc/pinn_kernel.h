@@ -1031,7 +1031,8 @@ pinn_tile_kernel(const PinnKArgs A) {
     static_assert(!TEAMS2 || (((VAR >> 4) & 3) != 0 && LHC >= 1 && !(VAR & (1 | 2 | 8 | 64 | 128)) && NW == 4 && C::wt_fits_teams(LHC)),
                   "two-team kernels: shape-specialised, static depth, 4 waves per team, W^T of all layers in LDS");
     constexpr bool SNT = HP >= PINN_SLAB_NT_MIN_HP;        // streaming (non-temporal) slab stores
-    static_assert(!WGX || (DWG && !SKIPS && !SLABL), "WGX kernels: generic depth, no skips, global slab");
+    static_assert(!WGX || (DWG && (!SKIPS || (VAR & 1024)) && !SLABL),
+                  "WGX kernels: generic depth, global slab; skips only in the light form (activation outputs carried, VAR 1024)");
     static_assert(!SLABL || (((VAR >> 4) & 3) != 0 && LHC >= 1 && !(VAR & 8) && !(VAR & 1) && C::slabl_fits(LHC)),
                   "slab-in-LDS kernels: shape-specialised, static depth, no skips, and the jets must fit");
     constexpr bool WTL = !SPLIT && ((C::wt_fits(LHC) && !SLABL && !(VAR & 2)) || TEAMS2);        // transposed hidden weights staged in LDS
@@ -1206,6 +1207,10 @@ pinn_tile_kernel(const PinnKArgs A) {
         const size_t slot = SLABL ? (size_t)(a == 0 ? 0 : 1 + (a - 1) * S + s) : (size_t)a * S + s;
         return slab + ((slot * NTW + j) * MT + mt) * NTHREADS + tid;
     };
+    // slab slot group of skip k: the carried activations (forward) / the gradient on its way back to the source (reverse). One
+    // slot serves both in the kernels that accumulate dW themselves (the activations are consumed first); the WGX kernels keep
+    // the activations for pinn_wgrad_kernel (h_{a-1} of the layer behind a '+') and send the gradient through a slot of its own
+    auto skip_grad_slot = [&](int k) -> int { return lh + 1 + ((WGX && SKIPS) ? A.n_skips : 0) + k; };
     auto unit0 = [&](int j) { return (wave * NTW + j) * 16 + 4 * lq; };     // first of this lane's 4 units
 #if defined(PINN_DUMP_NET) && !defined(PINN_EMU)
     // experiment builds: a checksum per (tile, layer, wave) of the value stream a wave has just produced, behind the point dump
@@ -1413,7 +1418,7 @@ pinn_tile_kernel(const PinnKArgs A) {
         if (WGX && train) {
             // (debug flag 4, timing experiments only: every tile writes the first tile's slab -- stores stay in L2)
             const size_t tl = PINN_DBG(A, 4) ? 0 : (size_t)(tile - A.tile_begin);
-            slab = A.slab + tl * C::slab_vec4_per_wg(lh);
+            slab = A.slab + tl * C::slab_vec4_per_wg(lh, SKIPS ? 2 * A.n_skips : 0);
             gzs = A.gzslab + tl * C::gz_vec4_per_tile(lh);
         }
         float* xs_t = xs_base + tile_parity * T * PINN_XS_LD;
@@ -1665,7 +1670,10 @@ pinn_tile_kernel(const PinnKArgs A) {
                         for (int s = 0; s < S; ++s) {
                             const f32x4 hs = hskip[SKIPS ? j : 0][SKIPS ? mt : 0][s];
                             hv[s] += hs;
-                            if (train) *slab_at(lh + 1 + sk_in, s, j, mt) = hs;
+                            if (train) {
+                                if (WGX) pinn_st4_stream<SNT>(slab_at(lh + 1 + sk_in, s, j, mt), hs);
+                                else *slab_at(lh + 1 + sk_in, s, j, mt) = hs;
+                            }
                         }
                     }
                     if (SKIPS && sk_out >= 0) {
@@ -1810,7 +1818,10 @@ pinn_tile_kernel(const PinnKArgs A) {
 #ifndef PINN_SVPF_MAX
 #define PINN_SVPF_MAX 8
 #endif
-        constexpr bool SVPF = (S * MT * NTW <= PINN_SVPF_MAX) && !ONEBUF && NW <= 4;    // (8-wave kernels: registers first)
+#ifndef PINN_SVPF_WIDE_MAX
+#define PINN_SVPF_WIDE_MAX 4       // 8-wave kernels: registers first -- only the shape-specialised ones with S <= 4 streams at width 128 have
+#endif                             // room (same-box A/B, round 4: skip128 tile kernel -1.2 %; the S = 5 kernel of config 3 spills and loses 4 %)
+        constexpr bool SVPF = (S * MT * NTW <= ((NW <= 4) ? PINN_SVPF_MAX : ((VAR & 48) ? PINN_SVPF_WIDE_MAX : 0))) && !ONEBUF;
         if (SVPF && lh > 0) load_saved(lh - 1, svn);
 #pragma unroll
         for (int j = 0; j < NTW; ++j) {
@@ -1848,8 +1859,8 @@ pinn_tile_kernel(const PinnKArgs A) {
                     for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
                         for (int s = 0; s < S; ++s) {
-                            if (k_out >= 0) g[j][mt][s] += *slab_at(lh + 1 + k_out, s, j, mt);
-                            if (post_in) *slab_at(lh + 1 + k_in, s, j, mt) = g[j][mt][s];
+                            if (k_out >= 0) g[j][mt][s] += *slab_at(skip_grad_slot(k_out), s, j, mt);
+                            if (post_in) *slab_at(skip_grad_slot(k_in), s, j, mt) = g[j][mt][s];
                         }
             }
             // z_a fed a later '+' itself ('f R a'): the gradient that comes back along that skip belongs to gz_a
@@ -1878,7 +1889,7 @@ pinn_tile_kernel(const PinnKArgs A) {
                     for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
                         for (int s = 0; s < S; ++s) {
-                            const f32x4 back = *slab_at(lh + 1 + src_pre_k, s, j, mt);
+                            const f32x4 back = *slab_at(skip_grad_slot(src_pre_k), s, j, mt);
                             gz[j][mt][s] += back;
                             if (s == 0) bsum += back;
                         }
@@ -1901,7 +1912,7 @@ pinn_tile_kernel(const PinnKArgs A) {
 #pragma unroll
                         for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
-                            for (int s = 0; s < S; ++s) *slab_at(lh + 1 + k_in, s, j, mt) = gz[j][mt][s];
+                            for (int s = 0; s < S; ++s) *slab_at(skip_grad_slot(k_in), s, j, mt) = gz[j][mt][s];
                 }
             }
         };

@@ -45,7 +45,10 @@ struct PinnWgCfg {
     static constexpr int WGS_PER_CU = (!SPLIT && SMEM_FLOATS * 4 <= 75 * 1024 && AM * BN * 4 <= 64) ? 2 : 1;
 };
 
-template <int HP, int ND, int N2, bool COMB, int MT, bool SPLIT = false>
+// SKIPS: the partner of the VAR 8 | 1024 | 128 tile kernels (skip connections 'R ... +' over Tanh / Sigmoid layers): where a skip
+// joins BEHIND activation a - 1, h_{a-1} = act(z) + the carried activations, which the tile kernel left in the skip's slab slot
+// (one more streamed operand for that layer; a '+' in front of the activation is already part of the saved jets)
+template <int HP, int ND, int N2, bool COMB, int MT, bool SPLIT = false, bool SKIPS = false>
 PINN_GLOBAL void PINN_LAUNCH_BOUNDS2((PinnWgCfg<HP, ND, N2, MT, SPLIT>::NTHREADS), (2 * PinnWgCfg<HP, ND, N2, MT, SPLIT>::WGS_PER_CU))
 pinn_wgrad_kernel(const PinnKArgs A) {
     using W = PinnWgCfg<HP, ND, N2, MT, SPLIT>;
@@ -74,13 +77,15 @@ pinn_wgrad_kernel(const PinnKArgs A) {
     }
     PINN_SYNC();
     const int m0 = (wave / W::WN) * AM * 16, n0 = (wave % W::WN) * BN * 16;
-    const size_t sv_tile = C::slab_vec4_per_wg(lh), gz_tile = C::gz_vec4_per_tile(lh);
+    const size_t sv_tile = C::slab_vec4_per_wg(lh, SKIPS ? 2 * A.n_skips : 0), gz_tile = C::gz_vec4_per_tile(lh);
     const long long t_first = A.tile_begin + PINN_BID, t_step = PINN_NBLK;
     auto unit0 = [&](int j) { return (wave * NTW + j) * 16 + 4 * lq; };
 
     for (int li = 0; li < lh; ++li) {
         // layer a = li + 1: A operand gz_a, B operand h_{a-1} = h of activation index li
         const int act = pinn_act_code(A.act_codes, li) & 1;
+        int sk_in = -1;                   // skip that joins behind activation li
+        if (SKIPS) for (int i = 0; i < A.n_skips; ++i) if (A.skip_dst[i] == li && !((A.skip_pre >> i) & 1)) sk_in = i;
         f32x4 acc[AM][BN];
 #pragma unroll
         for (int i = 0; i < AM; ++i)
@@ -89,13 +94,18 @@ pinn_wgrad_kernel(const PinnKArgs A) {
 
         // raw operands of a stage, straight from HBM (the tile kernel's lane-private layout: this thread reads what the
         // thread with the same id stored)
-        auto load_raw = [&](long long tile, int mt, int s, f32x4 (&gzr)[NTW], f32x4 (&svr)[NTW]) {
+        auto load_raw = [&](long long tile, int mt, int s, f32x4 (&gzr)[NTW], f32x4 (&svr)[NTW], f32x4 (&skr)[SKIPS ? NTW : 1]) {
             // (uniform 64-bit base per slot + this thread's 32-bit index: scalar address arithmetic, one VGPR of offset)
             // (debug flag 2, timing experiments only: every stage re-reads the first tile -- operands from L2 instead of HBM)
             const size_t tl = PINN_DBG(A, 2) ? 0 : (size_t)(tile - A.tile_begin);
             const f32x4* gzp = A.gzslab + tl * gz_tile + (((size_t)(li * S + s) * NTW) * MT + mt) * NTHREADS;
             const f32x4* svp = A.slab + tl * sv_tile + (((size_t)(li * S + s) * NTW) * MT + mt) * NTHREADS;
             const unsigned t = (unsigned)tid;
+            if (SKIPS && sk_in >= 0) {
+                const f32x4* skp = A.slab + tl * sv_tile + (((size_t)((lh + 1 + sk_in) * S + s) * NTW) * MT + mt) * NTHREADS;
+#pragma unroll
+                for (int j = 0; j < NTW; ++j) skr[SKIPS ? j : 0] = pinn_ld4_stream<(HP >= PINN_SLAB_NT_MIN_HP)>(skp + (size_t)j * MT * NTHREADS + t);
+            }
 #pragma unroll
             for (int j = 0; j < NTW; ++j) {
                 gzr[j] = pinn_ld4_stream<(HP >= PINN_SLAB_NT_MIN_HP)>(gzp + (size_t)j * MT * NTHREADS + t);
@@ -113,7 +123,7 @@ pinn_wgrad_kernel(const PinnKArgs A) {
         // running sum_k c_k z_k^2 for the combined second-order stream, else z_k^2 of the N2 directions that have one)
         f32x4 d1v[NTW], d2v[NTW], zz[(COMB || N2n == 0) ? 1 : N2n][NTW];
         f32x4 z1v[N3n > 0 ? N3n : 1][NTW], z2v[N3n > 0 ? N3n : 1][NTW];      // first / second streams of the third-order directions
-        auto transform = [&](int s, const f32x4 (&svr)[NTW], f32x4 (&hv)[NTW]) {
+        auto transform = [&](int s, const f32x4 (&svr)[NTW], f32x4 (&hv)[NTW], const f32x4 (&skr)[SKIPS ? NTW : 1]) {
 #pragma unroll
             for (int j = 0; j < NTW; ++j) {
 #pragma unroll
@@ -142,6 +152,7 @@ pinn_wgrad_kernel(const PinnKArgs A) {
                         hv[j][r] = d1 * svr[j][r] + 3.0f * d2 * z1 * z2 + d3 * z1 * z1 * z1;
                     }
                 }
+                if (SKIPS && sk_in >= 0) hv[j] += skr[SKIPS ? j : 0];
             }
         };
         auto write_stage = [&](float* buf, const f32x4 (&gzr)[NTW], const f32x4 (&hv)[NTW]) {
@@ -250,23 +261,23 @@ pinn_wgrad_kernel(const PinnKArgs A) {
                 mt = (int)(g % MT);
             };
             // raw operands of the NEXT pair are requested from HBM before the MFMAs of the current one
-            f32x4 gzr[2][NTW], svr[2][NTW];
+            f32x4 gzr[2][NTW], svr[2][NTW], skr[2][SKIPS ? NTW : 1];
             auto load_pair = [&](long long i0, int s_a, int s_b) {
                 long long tile; int mt;
-                if (i0 < n_stages) { stage_pos(i0, tile, mt); load_raw(tile, mt, s_a, gzr[0], svr[0]); }
-                if (i0 + 1 < n_stages) { stage_pos(i0 + 1, tile, mt); load_raw(tile, mt, s_b, gzr[1], svr[1]); }
+                if (i0 < n_stages) { stage_pos(i0, tile, mt); load_raw(tile, mt, s_a, gzr[0], svr[0], skr[0]); }
+                if (i0 + 1 < n_stages) { stage_pos(i0 + 1, tile, mt); load_raw(tile, mt, s_b, gzr[1], svr[1], skr[1]); }
             };
             auto build_pair = [&](char* buf, long long i0, int s_a, int s_b) {
                 f32x4 ha[NTW], hb[NTW], ga[NTW], gb[NTW];
 #pragma unroll
                 for (int j = 0; j < NTW; ++j) { ga[j] = gzr[0][j]; gb[j] = f32x4{0.f, 0.f, 0.f, 0.f}; hb[j] = f32x4{0.f, 0.f, 0.f, 0.f}; ha[j] = f32x4{0.f, 0.f, 0.f, 0.f}; }
-                if (i0 < n_stages) transform(s_a, svr[0], ha);
+                if (i0 < n_stages) transform(s_a, svr[0], ha, skr[0]);
                 else {
 #pragma unroll
                     for (int j = 0; j < NTW; ++j) ga[j] = f32x4{0.f, 0.f, 0.f, 0.f};
                 }
                 if (i0 + 1 < n_stages) {
-                    transform(s_b, svr[1], hb);
+                    transform(s_b, svr[1], hb, skr[1]);
 #pragma unroll
                     for (int j = 0; j < NTW; ++j) gb[j] = gzr[1][j];
                 }
@@ -297,11 +308,11 @@ pinn_wgrad_kernel(const PinnKArgs A) {
         } else {
         // (the HBM loads of stage i + 1 run during the MFMAs of stage i, one register set. Two sets with the loads two stages ahead
         //  measured 1-5 % SLOWER on MI355X: the loads are not what the waves wait for -- DESIGN.md section 6a)
-        f32x4 gzr[NTW], svr[NTW], hv[NTW];
+        f32x4 gzr[NTW], svr[NTW], hv[NTW], skr[SKIPS ? NTW : 1];
         int p = 0;
         if (t_first < A.tile_end) {
-            load_raw(t_first, 0, 0, gzr, svr);
-            transform(0, svr, hv);
+            load_raw(t_first, 0, 0, gzr, svr, skr);
+            transform(0, svr, hv, skr);
             write_stage(smem, gzr, hv);
         }
         PINN_SYNC();
@@ -315,10 +326,10 @@ pinn_wgrad_kernel(const PinnKArgs A) {
                     const int nmt = (k + 1 == S) ? (mt + 1) % MT : mt;
                     const long long ntile = (k + 1 == S && mt + 1 == MT) ? tile + t_step : tile;
                     // (debug flags 8 / 16 / 32, timing experiments only: no barrier / no LDS staging / no HBM loads)
-                    if (has_next && !PINN_DBG(A, 32)) load_raw(ntile, nmt, ns, gzr, svr);
+                    if (has_next && !PINN_DBG(A, 32)) load_raw(ntile, nmt, ns, gzr, svr, skr);
                     mfma_stage(smem + p * 2 * OPER);
                     if (has_next && !PINN_DBG(A, 16)) {
-                        transform(ns, svr, hv);
+                        transform(ns, svr, hv, skr);
                         write_stage(smem + (p ^ 1) * 2 * OPER, gzr, hv);
                     }
                     if (!PINN_DBG(A, 8)) PINN_SYNC();

@@ -227,6 +227,8 @@ class Net:
         self.gemm_mode = 'fp32'
         if os.environ.get('PYDENS_AMD_GEMM'):
             self.set_gemm_mode(os.environ['PYDENS_AMD_GEMM'])
+        if os.environ.get('PYDENS_AMD_WGX_CHUNK_MB'):           # experiments: slab budget of the widths >= 128 (pinn_debug_wgx_chunk_bytes)
+            self.lib.pinn_debug_wgx_chunk_bytes(int(float(os.environ['PYDENS_AMD_WGX_CHUNK_MB']) * (1 << 20)))
 
     def set_gemm_mode(self, mode):
         """ 'fp32' (default: exact-fp32 MFMA) or 'bf16x3' (fp32 operands as three bf16, six products, fp32 accumulate: the

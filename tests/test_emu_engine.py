@@ -615,6 +615,43 @@ def test_streamed_weight_gradient_kernel_chunks_and_paths(pa, emu_lib):
         emu_lib.pinn_debug_wgx_chunk_bytes(0)
 
 
+@pytest.mark.parametrize('which', ['poisson', 'burgers'])
+def test_streamed_weight_gradients_through_skip_connections(pa, emu_lib, which):
+    """ residual nets of widths >= 128 (round 4): the skip kernels (VAR 8 | 1024) hand their hidden->hidden weight gradients to
+    pinn_wgrad_kernel<..., SKIPS> as well -- the activations a skip carries stay in the per-tile slab for that kernel (h behind
+    a '+' = act(z) + carried), the gradient on its way back to 'R' travels in a slot of its own. One '+' behind an activation,
+    one in front of one, back to back; one pass and chunk by chunk; fused and generic path; against the oracle. """
+    from oracle import pinn_oracle as po
+    net = dict(layout='fa R fa fa + R fa f+a f', features=[96, 96, 96, 96, 96, 1], activation=['Tanh', 'Sigmoid', 'Tanh', 'Tanh', 'Sigmoid'])
+    eq_o, kw = _layout_problems(po.D, torch, which, net)
+    oracle = po.OracleSolver(eq_o, **kw)
+    pts = np.random.RandomState(5).rand(70, 2).astype(np.float32)
+    ev = oracle.evaluate(pts)
+    want = oracle.export_grads()
+    try:
+        for budget in (0, 1):
+            emu_lib.pinn_debug_wgx_chunk_bytes(budget)
+            for path in ('fused', 'generic'):
+                eq_p, kw = _layout_problems(pa.D, torch, which, net)
+                solver = pa.Solver(eq_p, **kw, **emu_kwargs(emu_lib))
+                assert solver.model.net.layout.hp == 128
+                load_params(solver, oracle.export_params())
+                if path == 'fused':
+                    assert solver.program is not None, solver.program_error
+                    solver._fused_step(torch.from_numpy(pts.copy()), 1)
+                else:
+                    solver._generic_step(torch.from_numpy(pts.copy()), ('equation',), [], torch.nn.MSELoss(), 1)
+                assert emu_lib.pinn_last_kernel_name().decode().rsplit(',', 1)[1] in ('%d>' % (8 | 1024 | 128), '%d>' % (8 | 16 | 1024 | 128))
+                assert emu_lib.pinn_last_wgrad_kernel_name().decode().endswith(',true>')
+                lay = solver.model.net.layout
+                assert abs(float(solver.grads[lay.off_loss]) - ev['loss']) <= 1e-5 * ev['loss'], (budget, path)
+                for got, w in zip(export_grads(solver), want):
+                    if w is not None:
+                        assert rel_l2(got, w) < 1e-4, (budget, path)
+    finally:
+        emu_lib.pinn_debug_wgx_chunk_bytes(0)
+
+
 def test_parametric_heat_equation_with_domain(pa, emu_lib):
     """ tutorial cells 37-40: heat equation in (x, y, t) with an uncertain diffusivity parameter `a` (4 input columns,
     3 differentiated), callable IC, BC, Sigmoid net -- on a non-default domain with t0 != 0 (model_torch.py:37-46, :115) """

@@ -342,6 +342,56 @@ def test_every_width_and_depth_uses_all_its_units(pa, width, depth):
                 assert ok, (path, i, err)
 
 
+@pytest.mark.parametrize('width', [128, 200])
+@pytest.mark.parametrize('which', ['poisson', 'burgers'])
+def test_wide_residual_nets_stream_their_weight_gradients(pa, width, which):
+    """ skip connections at widths >= 128 (round 4): tile kernel VAR 8 | 1024 | 128 + pinn_wgrad_kernel<..., SKIPS>. A '+' behind an
+    activation, one in front of one, a skip from the first layer; 1100 points (69 tiles, the last one ragged); loss and every
+    gradient of the fused and the generic step against the oracle at the sweep tolerance, fp64-arbitrated. """
+    from oracle import pinn_oracle as po
+    import test_emu_engine as te
+    net = dict(layout='faR fa fa+ R fa f+a f', features=[width] * 5 + [1], activation=['Tanh', 'Sigmoid', 'Tanh', 'Tanh', 'Sigmoid'])
+    torch.manual_seed(width + len(which))
+    eq_o, kw_o = te._layout_problems(po.D, torch, which, net)
+    oracle = po.OracleSolver(eq_o, **kw_o)
+    eq_p, kw = te._layout_problems(pa.D, torch, which, net)
+    solver = pa.Solver(eq_p, **kw)
+    assert solver.program is not None, solver.program_error
+    load_params(solver, oracle.export_params())
+    pts = np.random.RandomState(6).rand(1100, 2).astype(np.float32)
+    loss_o = oracle.evaluate(pts)['loss']
+    grads_o = oracle.export_grads()
+    arbiter = {}
+
+    def f64():
+        if not arbiter:
+            o64 = po.OracleSolver(eq_o, dtype=torch.float64, **kw_o)
+            o64.import_params(oracle.export_params())
+            arbiter['loss'] = o64.evaluate(pts)['loss']
+            arbiter['grads'] = o64.export_grads()
+        return arbiter
+    lib = solver.model.net.lib
+    for path in ('fused', 'generic'):
+        solver.grads.zero_()
+        xs_dev = torch.from_numpy(pts.copy()).cuda()
+        if path == 'fused':
+            solver._fused_step(xs_dev, 1)
+        else:
+            solver._generic_step(xs_dev, ('equation',), (), torch.nn.MSELoss(), 1)
+        torch.cuda.synchronize()
+        assert lib.pinn_last_kernel_name().decode().rsplit(',', 1)[1] in ('%d>' % (8 | 1024 | 128), '%d>' % (8 | 16 | 1024 | 128)), lib.pinn_last_kernel_name()
+        assert lib.pinn_last_wgrad_kernel_name().decode().endswith(',true>'), lib.pinn_last_wgrad_kernel_name()
+        lay = solver.model.net.layout
+        ok, err, arb = close_or_arbitrated([float(solver.grads[lay.off_loss])], [loss_o], lambda: [f64()['loss']], 1e-5, atol=0.0)
+        record_margin('wide_residual_nets', (width, which, path), 'loss', err, 1e-5, arb)
+        assert ok, (path, err)
+        for i, (got, want) in enumerate(zip(export_grads(solver), grads_o)):
+            if want is not None:
+                ok, err, arb = close_or_arbitrated(got, want, lambda i=i: f64()['grads'][i], GRAD_RTOL)
+                record_margin('wide_residual_nets', (width, which, path), 'gradient', err, GRAD_RTOL, arb)
+                assert ok, (path, i, err)
+
+
 @pytest.mark.parametrize('net', ['skip', 'two_skips', 'sin', 'identity', 'skip_to_top_wide', 'full64', 'softplus_silu_gelu'])
 @pytest.mark.parametrize('which', ['poisson', 'burgers'])
 def test_layout_breadth_matches_the_oracle(pa, net, which):

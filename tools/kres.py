@@ -1,40 +1,24 @@
-""" register / scratch / LDS usage of the kernels in one translation unit (compile only, no GPU).
-usage: python tools/kres.py <file.hip|HP> [symbol regex] [-- extra hipcc flags...]   (HP: pinn_inst.inc at that width) """
-import os, re, subprocess, sys
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-CSRC = os.path.join(ROOT, 'pydens_amd', 'csrc')
-args = sys.argv[1:]
-extra = []
-if '--' in args:
-    i = args.index('--'); args, extra = args[:i], args[i + 1:]
-src, pat = args[0], (args[1] if len(args) > 1 else '.')
-cmd = ['/opt/rocm/bin/hipcc', '--offload-arch=gfx950', '-O3', '-std=c++17', '-fPIC', '-x', 'hip', '-Wno-unused-result',
-       '--cuda-device-only', '-Rpass-analysis=kernel-resource-usage', '-I', CSRC, *extra]
-if src.isdigit():
-    cmd += [f'-DPINN_INST_HP={src}', '-c', os.path.join(CSRC, 'pinn_inst.inc')]
-else:
-    cmd += ['-c', src]
-cmd += ['-o', '/tmp/kres_%d.o' % os.getpid()]
-out = subprocess.run(cmd, capture_output=True, text=True).stderr
-cur = None
-rows = {}
-for line in out.splitlines():
-    m = re.search(r'remark: .*?(Function Name|VGPRs|AGPRs|ScratchSize \[bytes/lane\]|Occupancy \[waves/SIMD\]|SGPRs|LDS Size \[bytes/block\]): (\S+)', line)
-    if not m:
-        if 'error' in line:
-            print(line)
+#!/usr/bin/env python
+""" register / scratch usage of every kernel instantiation of one width's translation unit (compile only, no GPU)
+usage: python tools/kres.py <HP> [name filter regex] [-- extra hipcc flags...] """
+import re
+import subprocess
+import sys
+
+hp = sys.argv[1]
+pat = sys.argv[2] if len(sys.argv) > 2 and sys.argv[2] != '--' else ''
+extra = sys.argv[sys.argv.index('--') + 1:] if '--' in sys.argv else []
+cmd = ['/opt/rocm/bin/hipcc', '--offload-arch=gfx950', '-O3', '-std=c++17', '-fPIC', '-x', 'hip', '-Wno-unused-result', '--cuda-device-only',
+       '-Rpass-analysis=kernel-resource-usage', '-DPINN_INST_HP=' + hp, *extra, '-c', 'pinn_inst.inc', '-o', '/tmp/kres_py.o']
+out = subprocess.run(cmd, cwd='/root/repo/pydens_amd/csrc', capture_output=True, text=True).stderr
+rows = []
+for block in out.split('Function Name: ')[1:]:
+    sym = block.split()[0]
+    name = subprocess.run(['c++filt', sym], capture_output=True, text=True).stdout.strip()
+    name = name.replace('void ', '').replace('(PinnKArgs)', '')
+    get = lambda key: int(re.search(key + r': (\d+)', block).group(1))
+    if pat and not re.search(pat, name):
         continue
-    k, v = m.group(1), m.group(2)
-    if k == 'Function Name':
-        cur = v; rows[cur] = {}
-    elif cur:
-        rows[cur][k.split(' ')[0]] = v
-for name, r in rows.items():
-    dem = subprocess.run(['c++filt', name], capture_output=True, text=True).stdout.strip()
-    dem = dem.replace('void ', '').split('(')[0]
-    if re.search(pat, dem):
-        print(f"{dem:70s} VGPR {r.get('VGPRs','?'):>4} AGPR {r.get('AGPRs','?'):>4} scratch {r.get('ScratchSize','?'):>5} occ {r.get('Occupancy','?')} SGPR {r.get('SGPRs','?')}")
-try:
-    os.remove('/tmp/kres_%d.o' % os.getpid())
-except OSError:
-    pass
+    rows.append((name, get('VGPRs'), get('AGPRs'), get(r'VGPRs Spill'), get(r'ScratchSize \[bytes/lane\]'), get(r'Occupancy \[waves/SIMD\]')))
+for r in sorted(rows):
+    print('%-70s vgpr %3d agpr %3d spill %4d scratch %5d B occ %d' % r)
