@@ -81,7 +81,7 @@ def make_config(name, D, torch, V=None):
                                        activation=['Sin', 'Tanh', 'SiLU', 'Tanh', 'Sigmoid']),
                     n_points=4096, low=[0, 0], high=[1, 1])
     # ---- breadth workloads: timed by `bench.py --workload ...`, not BASELINE configs -----------------------
-    if name in ('skip128', 'skip256', 'sin64', 'program', 'generic'):
+    if name in ('skip128', 'skip256', 'sin64', 'sin128', 'gelu256', 'program', 'generic'):
         def poisson(f, x, y):
             return D(D(f, x), x) + D(D(f, y), y) - 5 * torch.sin(PI * (x + y))
         if name == 'skip128':                                    # skip connection 'R ... +' (reference model_torch.py:142-156), width 128
@@ -92,6 +92,16 @@ def make_config(name, D, torch, V=None):
             net = dict(layout='faR fa fa+ R fa fa+ f', features=[256, 256, 256, 256, 256, 1], activation='Tanh')
             return dict(equation=poisson, solver_kwargs=dict(ndims=2, boundary_condition=1, **net), n_points=65536,
                         low=[0, 0], high=[1, 1])
+        if name == 'sin128':                                     # 4 x 128 'Sin': full breadth kernel + streamed weight gradients
+            net = dict(layout='fa fa fa fa f', features=[128, 128, 128, 128, 1], activation='Sin')
+            return dict(equation=poisson, solver_kwargs=dict(ndims=2, boundary_condition=1, **net), n_points=65536,
+                        low=[0, 0], high=[1, 1])
+        if name == 'gelu256':                                    # Burgers (residual program, IC + BC) on a pre-activation residual net, 4 x 256 GELU
+            def burgers(f, x, t):
+                return D(f, t) + f * D(f, x) - 0.05 * D(D(f, x), x)
+            net = dict(layout='fa fRa fa f+a f', features=[256, 256, 256, 256, 1], activation='GELU')
+            return dict(equation=burgers, solver_kwargs=dict(ndims=2, boundary_condition=0, initial_condition=lambda x: torch.sin(PI * x), **net),
+                        n_points=65536, low=[0, 0], high=[1, 1])
         if name == 'sin64':                                      # 4 x 64 with activation 'Sin'
             net = dict(layout='fa fa fa fa f', features=[64, 64, 64, 64, 1], activation='Sin')
             return dict(equation=poisson, solver_kwargs=dict(ndims=2, boundary_condition=1, **net), n_points=65536,

@@ -1031,8 +1031,7 @@ pinn_tile_kernel(const PinnKArgs A) {
     static_assert(!TEAMS2 || (((VAR >> 4) & 3) != 0 && LHC >= 1 && !(VAR & (1 | 2 | 8 | 64 | 128)) && NW == 4 && C::wt_fits_teams(LHC)),
                   "two-team kernels: shape-specialised, static depth, 4 waves per team, W^T of all layers in LDS");
     constexpr bool SNT = HP >= PINN_SLAB_NT_MIN_HP;        // streaming (non-temporal) slab stores
-    static_assert(!WGX || (DWG && (!SKIPS || (VAR & 1024)) && !SLABL),
-                  "WGX kernels: generic depth, global slab; skips only in the light form (activation outputs carried, VAR 1024)");
+    static_assert(!WGX || (DWG && !SLABL), "WGX kernels: generic depth, global slab");
     static_assert(!SLABL || (((VAR >> 4) & 3) != 0 && LHC >= 1 && !(VAR & 8) && !(VAR & 1) && C::slabl_fits(LHC)),
                   "slab-in-LDS kernels: shape-specialised, static depth, no skips, and the jets must fit");
     constexpr bool WTL = !SPLIT && ((C::wt_fits(LHC) && !SLABL && !(VAR & 2)) || TEAMS2);        // transposed hidden weights staged in LDS

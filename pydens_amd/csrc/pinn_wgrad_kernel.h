@@ -48,7 +48,10 @@ struct PinnWgCfg {
 // SKIPS: the partner of the VAR 8 | 1024 | 128 tile kernels (skip connections 'R ... +' over Tanh / Sigmoid layers): where a skip
 // joins BEHIND activation a - 1, h_{a-1} = act(z) + the carried activations, which the tile kernel left in the skip's slab slot
 // (one more streamed operand for that layer; a '+' in front of the activation is already part of the saved jets)
-template <int HP, int ND, int N2, bool COMB, int MT, bool SPLIT = false, bool SKIPS = false>
+// HEAVY: the partner of the full breadth kernels (VAR 8 | 128): any activation of the library per layer (h rebuilt from the value or
+// from the pre-activation, whichever the tile kernel saved: pinn_act_saved), skips that carry pre-activation jets included (the slot
+// holds whatever was carried)
+template <int HP, int ND, int N2, bool COMB, int MT, bool SPLIT = false, bool SKIPS = false, bool HEAVY = false>
 PINN_GLOBAL void PINN_LAUNCH_BOUNDS2((PinnWgCfg<HP, ND, N2, MT, SPLIT>::NTHREADS), (2 * PinnWgCfg<HP, ND, N2, MT, SPLIT>::WGS_PER_CU))
 pinn_wgrad_kernel(const PinnKArgs A) {
     using W = PinnWgCfg<HP, ND, N2, MT, SPLIT>;
@@ -83,7 +86,7 @@ pinn_wgrad_kernel(const PinnKArgs A) {
 
     for (int li = 0; li < lh; ++li) {
         // layer a = li + 1: A operand gz_a, B operand h_{a-1} = h of activation index li
-        const int act = pinn_act_code(A.act_codes, li) & 1;
+        const int act = pinn_act_code(A.act_codes, li) & (HEAVY ? 15 : 1);
         int sk_in = -1;                   // skip that joins behind activation li
         if (SKIPS) for (int i = 0; i < A.n_skips; ++i) if (A.skip_dst[i] == li && !((A.skip_pre >> i) & 1)) sk_in = i;
         f32x4 acc[AM][BN];
@@ -123,6 +126,7 @@ pinn_wgrad_kernel(const PinnKArgs A) {
         // running sum_k c_k z_k^2 for the combined second-order stream, else z_k^2 of the N2 directions that have one)
         f32x4 d1v[NTW], d2v[NTW], zz[(COMB || N2n == 0) ? 1 : N2n][NTW];
         f32x4 z1v[N3n > 0 ? N3n : 1][NTW], z2v[N3n > 0 ? N3n : 1][NTW];      // first / second streams of the third-order directions
+        f32x4 s0v[(HEAVY && N3n > 0) ? NTW : 1];                              // HEAVY: what was saved of the value stream (third derivative of any activation)
         auto transform = [&](int s, const f32x4 (&svr)[NTW], f32x4 (&hv)[NTW], const f32x4 (&skr)[SKIPS ? NTW : 1]) {
 #pragma unroll
             for (int j = 0; j < NTW; ++j) {
@@ -133,6 +137,7 @@ pinn_wgrad_kernel(const PinnKArgs A) {
                         pinn_act_d12(svr[j][r], act, d1, d2);
                         d1v[j][r] = d1; d2v[j][r] = d2;
                         hv[j][r] = pinn_act_value(svr[j][r], act);
+                        if (HEAVY && N3n > 0) s0v[(HEAVY && N3n > 0) ? j : 0][r] = svr[j][r];
                         if (COMB) zz[0][j][r] = 0.0f;
                     } else if (s <= ND) {
                         hv[j][r] = d1v[j][r] * svr[j][r];
@@ -145,10 +150,11 @@ pinn_wgrad_kernel(const PinnKArgs A) {
                         if (s - 1 - ND < N3n) z2v[N3n > 0 ? s - 1 - ND : 0][j][r] = svr[j][r];
                     } else {
                         // third order: h3 = a1 z3 + 3 a2 z1 z2 + a3 z1^3 with the activation's derivatives a1, a2, a3; a3 from
-                        // a1 (tanh: a1 (4 - 6 a1), sigmoid: a1 (1 - 6 a1) -- the only activations that reach this kernel)
+                        // a1 (tanh: a1 (4 - 6 a1), sigmoid: a1 (1 - 6 a1); HEAVY: any activation, from what was saved of the value stream)
                         const int k = N3n > 0 ? s - 1 - ND - N2n : 0;
                         const float d1 = d1v[j][r], d2 = d2v[j][r], z1 = z1v[k][j][r], z2 = z2v[k][j][r];
-                        const float d3 = (act == PINN_ACT_TANH) ? d1 * (4.0f - 6.0f * d1) : d1 * (1.0f - 6.0f * d1);
+                        const float d3 = HEAVY ? pinn_act_d3(s0v[(HEAVY && N3n > 0) ? j : 0][r], d1, d2, act)
+                                               : (act == PINN_ACT_TANH) ? d1 * (4.0f - 6.0f * d1) : d1 * (1.0f - 6.0f * d1);
                         hv[j][r] = d1 * svr[j][r] + 3.0f * d2 * z1 * z2 + d3 * z1 * z1 * z1;
                     }
                 }

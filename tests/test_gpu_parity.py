@@ -343,7 +343,7 @@ def test_every_width_and_depth_uses_all_its_units(pa, width, depth):
 
 
 @pytest.mark.parametrize('width', [128, 200])
-@pytest.mark.parametrize('which', ['poisson', 'burgers'])
+@pytest.mark.parametrize('which', ['poisson', 'burgers', 'poisson_any_activation', 'burgers_any_activation'])
 def test_wide_residual_nets_stream_their_weight_gradients(pa, width, which):
     """ skip connections at widths >= 128 (round 4): tile kernel VAR 8 | 1024 | 128 + pinn_wgrad_kernel<..., SKIPS>. A '+' behind an
     activation, one in front of one, a skip from the first layer; 1100 points (69 tiles, the last one ragged); loss and every
@@ -351,6 +351,10 @@ def test_wide_residual_nets_stream_their_weight_gradients(pa, width, which):
     from oracle import pinn_oracle as po
     import test_emu_engine as te
     net = dict(layout='faR fa fa+ R fa f+a f', features=[width] * 5 + [1], activation=['Tanh', 'Sigmoid', 'Tanh', 'Tanh', 'Sigmoid'])
+    heavy = which.endswith('_any_activation')
+    if heavy:       # the full breadth kernels (VAR 8 | 128) + pinn_wgrad_kernel<..., SKIPS, HEAVY>
+        net = dict(layout='fRa fa f+a R f fa+ fa f', features=[width] * 6 + [1], activation=['Sin', 'SiLU', 'GELU', 'Softplus', 'Tanh'])
+        which = which[:-len('_any_activation')]
     torch.manual_seed(width + len(which))
     eq_o, kw_o = te._layout_problems(po.D, torch, which, net)
     oracle = po.OracleSolver(eq_o, **kw_o)
@@ -379,16 +383,17 @@ def test_wide_residual_nets_stream_their_weight_gradients(pa, width, which):
         else:
             solver._generic_step(xs_dev, ('equation',), (), torch.nn.MSELoss(), 1)
         torch.cuda.synchronize()
-        assert lib.pinn_last_kernel_name().decode().rsplit(',', 1)[1] in ('%d>' % (8 | 1024 | 128), '%d>' % (8 | 16 | 1024 | 128)), lib.pinn_last_kernel_name()
-        assert lib.pinn_last_wgrad_kernel_name().decode().endswith(',true>'), lib.pinn_last_wgrad_kernel_name()
+        want_var = ('%d>' % (8 | 128),) if heavy else ('%d>' % (8 | 1024 | 128), '%d>' % (8 | 16 | 1024 | 128))
+        assert lib.pinn_last_kernel_name().decode().rsplit(',', 1)[1] in want_var, lib.pinn_last_kernel_name()
+        assert lib.pinn_last_wgrad_kernel_name().decode().endswith(',true,true>' if heavy else ',true,false>'), lib.pinn_last_wgrad_kernel_name()
         lay = solver.model.net.layout
         ok, err, arb = close_or_arbitrated([float(solver.grads[lay.off_loss])], [loss_o], lambda: [f64()['loss']], 1e-5, atol=0.0)
-        record_margin('wide_residual_nets', (width, which, path), 'loss', err, 1e-5, arb)
+        record_margin('wide_residual_nets', (width, which, heavy, path), 'loss', err, 1e-5, arb)
         assert ok, (path, err)
         for i, (got, want) in enumerate(zip(export_grads(solver), grads_o)):
             if want is not None:
                 ok, err, arb = close_or_arbitrated(got, want, lambda i=i: f64()['grads'][i], GRAD_RTOL)
-                record_margin('wide_residual_nets', (width, which, path), 'gradient', err, GRAD_RTOL, arb)
+                record_margin('wide_residual_nets', (width, which, heavy, path), 'gradient', err, GRAD_RTOL, arb)
                 assert ok, (path, i, err)
 
 

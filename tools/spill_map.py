@@ -1,0 +1,57 @@
+#!/usr/bin/env python
+""" Where do the spilled registers of the tile / weight-gradient kernels live?  For every kernel of a width's translation unit
+(hipcc -S of pinn_inst.inc): the static spill count (.vgpr_spill_count) and the scratch loads / stores split by where they sit --
+in a barrier-delimited segment that holds MFMAs (the GEMM loops: what a spill would cost there is paid per K step) or outside
+(prologue, first layer, epilogues, point stage: paid once per tile).
+usage: python tools/spill_map.py <HP> [min spills]     (compiles; ~3 min per width) """
+import os
+import re
+import subprocess
+import sys
+
+HERE = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, HERE)
+from pydens_amd.csrc import build      # noqa: E402
+
+hp = int(sys.argv[1])
+floor = int(sys.argv[2]) if len(sys.argv) > 2 else 0
+asm = f'/tmp/spill_map_{hp}.s'
+cmd = ['/opt/rocm/bin/hipcc', *build.FLAGS, *build.WIDTH_FLAGS.get(hp, []), f'-DPINN_INST_HP={hp}', '--cuda-device-only', '-S', '-o', asm,
+       os.path.join(HERE, 'pydens_amd', 'csrc', 'pinn_inst.inc')]
+if not (os.environ.get('SPILL_MAP_REUSE') and os.path.exists(asm)):
+    subprocess.run(cmd, check=True, stderr=subprocess.DEVNULL)
+text = open(asm).read()
+spills = {m.group(1): int(m.group(2)) for m in re.finditer(r'\.name:\s+(\S+)\n(?:.*\n)*?\s+\.vgpr_spill_count:\s+(\d+)', text)}
+lines = text.split('\n')
+rows = []
+i = 0
+while i < len(lines):
+    m = re.match(r'^(_Z\d+pinn_(?:tile|wgrad)_kernel\S+):', lines[i])
+    if not m:
+        i += 1
+        continue
+    sym = m.group(1)
+    segs, cur = [], dict(mfma=0, st=0, ld=0)
+    i += 1
+    while not lines[i].startswith('.Lfunc_end'):
+        t = lines[i].strip()
+        if t.startswith('s_barrier'):
+            segs.append(cur)
+            cur = dict(mfma=0, st=0, ld=0)
+        elif t.startswith('v_mfma'):
+            cur['mfma'] += 1
+        elif t.startswith('scratch_store'):
+            cur['st'] += 1
+        elif t.startswith('scratch_load'):
+            cur['ld'] += 1
+        i += 1
+    segs.append(cur)
+    name = subprocess.run(['c++filt', sym], capture_output=True, text=True).stdout.strip().replace('void ', '').replace('(PinnKArgs)', '')
+    gemm = [s for s in segs if s['mfma'] >= 16]
+    rest = [s for s in segs if s['mfma'] < 16]
+    rows.append((name, spills.get(sym, -1), sum(s['mfma'] for s in gemm), sum(s['st'] for s in gemm), sum(s['ld'] for s in gemm),
+                 sum(s['st'] for s in rest), sum(s['ld'] for s in rest)))
+print(f'width {hp}: kernel | spilled VGPRs | MFMAs | scratch stores / loads inside GEMM segments | ... outside')
+for r in sorted(rows):
+    if r[1] >= floor:
+        print('%-66s %4d   mfma %5d   gemm st %3d ld %3d   other st %3d ld %3d' % r)
