@@ -146,4 +146,5 @@ def run_case(pa, name, n_points, solver_kwargs=None, on_device=True):
 
 @pytest.mark.parametrize('name', CASES)
 def test_large_batch_on_a_full_grid(pa, name):
-    run_case(pa, name, N_BIG)
+    # (skip256: 32 768 points = 8 tiles per workgroup of a full grid -- the two CPU oracles of a 5 x 256 net take minutes beyond that)
+    run_case(pa, name, N_BIG // 4 if name == 'skip256' else N_BIG)
