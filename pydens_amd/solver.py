@@ -573,6 +573,7 @@ class Solver:
         elif self.optimizer is None:
             raise ValueError('optimizer=None reuses the optimizer of a previous fit call; there is none yet')
         self.optimizer.refresh()
+        self._generic_graph = None          # launch graphs of the generic step are recorded per fit call (closure constants may have changed)
         model.train()
         loss_terms = loss_terms if isinstance(loss_terms, (tuple, list)) else (loss_terms, )
         nums_constraints = [int(term.replace('constraint', '').replace('_', ''))
@@ -636,7 +637,7 @@ class Solver:
                     self._constraint_step(num, world, accumulate=not first)
                     first = False
             else:
-                self._generic_step(xs, loss_terms, nums_constraints, criterion, world)
+                self._generic_step_auto(xs, loss_terms, nums_constraints, criterion, world)
             if world > 1:
                 self._all_reduce(stream)                # flat [p_total]: network, log_scale, loss slot, V slots
             if flat_adam:
@@ -731,6 +732,42 @@ class Solver:
         model.net.residual_step(self.program, model.flat, xs, self.grads, ws, spec.dir_cols, n2,
                                 ic_streams=ic_streams, ic_const=model.kernel_ic_const(),
                                 inv_n_global=1.0 / n_global, stream=stream)
+
+    GENERIC_GRAPH_WARMUP = 3    # eager generic steps in front of the recording (instantiations, workspaces, autograd buffers settle)
+
+    def _generic_step_auto(self, xs, loss_terms, nums_constraints, criterion, world):
+        """ the generic step, replayed as ONE launch graph where that is safe: pinn_jet_forward -> the user's torch code and its
+        autograd sweep (a few dozen small kernels the interpreter launches one by one) -> pinn_jet_backward, recorded after a few eager
+        steps on static buffers (torch.cuda.graph) and replayed with the next batch copied in. Single process, equation term only,
+        one direction group, the model's own forward(), no callable-IC autograd; anything else -- or an equation whose torch code
+        cannot be captured (data-dependent shapes, host reads) -- stays eager. Same kernels, same order: bit-identical. """
+        model = self.model
+        st = getattr(self, '_generic_graph', None)
+        ok = (xs.is_cuda and world == 1 and not nums_constraints and tuple(loss_terms) == ('equation',) and len(self.spec.groups) == 1
+              and not self.custom_forward and not (model.initial_condition is not None and model.ic_constant is None)
+              and os.environ.get('PYDENS_AMD_GENERIC_GRAPH', '1') != '0' and not (st and st.get('failed')))
+        if not ok:
+            return self._generic_step(xs, loss_terms, nums_constraints, criterion, world)
+        key = (tuple(xs.shape), id(criterion), id(self._eq))
+        if st is None or st['key'] != key:
+            st = self._generic_graph = dict(key=key, count=0, graph=None, xs=None, failed=False, replays=0)
+        if st['graph'] is None:
+            if st['count'] < self.GENERIC_GRAPH_WARMUP:
+                st['count'] += 1
+                return self._generic_step(xs, loss_terms, nums_constraints, criterion, world)
+            try:
+                st['xs'] = xs.clone()
+                graph = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(graph):
+                    self._generic_step(st['xs'], ('equation',), [], criterion, 1)
+                st['graph'] = graph
+            except Exception as exc:         # noqa: BLE001 -- whatever the equation's torch code does that a capture refuses
+                st['failed'], st['graph'], st['error'] = True, None, repr(exc)
+                torch.cuda.synchronize()
+                return self._generic_step(xs, loss_terms, nums_constraints, criterion, world)
+        st['xs'].copy_(xs)
+        st['graph'].replay()
+        st['replays'] += 1
 
     def _generic_step(self, xs, loss_terms, nums_constraints, criterion, world):
         model, spec = self.model, self.spec

@@ -1013,3 +1013,36 @@ def test_fit_chunks_as_launch_graphs_follow_the_eager_loop_bit_for_bit(pa, name,
     assert t0 == t1 == 560
     assert np.array_equal(l0, l1)
     assert np.array_equal(p0, p1) and np.array_equal(m0, m1)
+
+
+@pytest.mark.parametrize('which', ['cfg2_forced_generic', 'tensor_variable'])
+def test_generic_fit_as_a_launch_graph_follows_the_eager_loop_bit_for_bit(pa, which, monkeypatch):
+    """ the generic step (pinn_jet_forward -> the user's torch code + autograd -> pinn_jet_backward) is recorded after three eager
+    iterations and replayed as ONE launch graph (Solver._generic_step_auto); same kernels in the same order: every loss, every
+    parameter and the Adam state equal the eager loop's bit for bit; a second fit records anew. """
+    def run(graph):
+        monkeypatch.setenv('PYDENS_AMD_GENERIC_GRAPH', '1' if graph else '0')
+        torch.manual_seed(22)
+        if which == 'cfg2_forced_generic':
+            cfg, solver = make_solver('cfg2', pa)
+            solver.program = None
+            batch = 4096
+        else:
+            def eq(f, x, t):                 # a vector-valued trainable: the tracer leaves it to torch autograd (generic path)
+                w = pa.V('w', data=torch.Tensor([0.5, 1.5]))
+                return pa.D(f, t) - 0.1 * w[0] * pa.D(pa.D(f, x), x) + w[1] * f * pa.D(f, x)
+            solver = pa.Solver(eq, ndims=2, boundary_condition=0.0, initial_condition=0.3, layout='fa fa f', features=[32, 32, 1],
+                               activation='Tanh')
+            batch = 1000
+        solver.fit(niters=20, batch_size=batch, lr=0.005)
+        replays = (getattr(solver, '_generic_graph', None) or {}).get('replays', 0)
+        solver.fit(niters=12, batch_size=batch, lr=0.005, optimizer=None)
+        assert solver.last_fit_path == 'generic'
+        replays += (getattr(solver, '_generic_graph', None) or {}).get('replays', 0)
+        return (np.array([float(v) for v in solver.losses]), solver.model.flat.detach().cpu().numpy().copy(),
+                solver.optimizer.exp_avg.cpu().numpy().copy(), replays, (getattr(solver, '_generic_graph', None) or {}).get('error'))
+    l0, p0, m0, r0, _ = run(False)
+    l1, p1, m1, r1, err = run(True)
+    assert r0 == 0 and r1 == (20 - 3) + (12 - 3), (r1, err)
+    assert np.array_equal(l0, l1)
+    assert np.array_equal(p0, p1) and np.array_equal(m0, m1)
