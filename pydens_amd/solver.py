@@ -468,6 +468,32 @@ class Solver:
             cols.append(col)
         return torch.cat(cols, dim=1)
 
+    def _points_on_device(self, pts):
+        """ reshape_and_concat(pts) on the device. Small HOST constants -- the fixed points a constraint builds in every call,
+        `f(torch.tensor([0.5]))` -- are looked up by content in a cache of device tensors: no host-to-device copy per iteration, and
+        nothing in the step that a launch-graph recording would refuse (pageable-memory copies are not capturable). """
+        key = []
+        for x in pts:
+            if isinstance(x, torch.Tensor):
+                if x.is_cuda or x.requires_grad or x.numel() > 4096:
+                    return self.reshape_and_concat(pts, device=self.device)
+                key.append(('t', str(x.dtype), tuple(x.shape), x.detach().contiguous().numpy().tobytes()))
+            elif isinstance(x, np.ndarray):
+                if x.size > 4096:
+                    return self.reshape_and_concat(pts, device=self.device)
+                key.append(('a', str(x.dtype), x.shape, np.ascontiguousarray(x).tobytes()))
+            elif isinstance(x, (list, tuple, int, float)):
+                key.append(('v', repr(x)))
+            else:
+                return self.reshape_and_concat(pts, device=self.device)
+        cache = self.__dict__.setdefault('_host_constants', {})
+        key = tuple(key)
+        if key not in cache:
+            if len(cache) >= 64:
+                cache.clear()
+            cache[key] = self.reshape_and_concat(pts, device=self.device)
+        return cache[key]
+
     def _world(self):
         dist = torch.distributed
         if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
@@ -628,14 +654,9 @@ class Solver:
                 done[0] = it + 1
                 continue
             if fused:
-                # summed loss (:441-457): the equation term stores gradient + loss, every constraint term adds its own
-                first = True
-                if 'equation' in loss_terms:
-                    self._fused_step(xs, world, stream=stream)
-                    first = False
-                for num in nums_constraints:
-                    self._constraint_step(num, world, accumulate=not first)
-                    first = False
+                # (two to four launches per iteration: replaying them as a launch graph measured 0.048 -> 0.046 ms/it at batch 500 and
+                #  0.072 -> 0.081 at 65 536 -- the eager loop stays)
+                self._fused_terms_step(xs, loss_terms, nums_constraints, world, stream=stream)
             else:
                 self._generic_step_auto(xs, loss_terms, nums_constraints, criterion, world)
             if world > 1:
@@ -733,41 +754,57 @@ class Solver:
                                 ic_streams=ic_streams, ic_const=model.kernel_ic_const(),
                                 inv_n_global=1.0 / n_global, stream=stream)
 
-    GENERIC_GRAPH_WARMUP = 3    # eager generic steps in front of the recording (instantiations, workspaces, autograd buffers settle)
+    GENERIC_GRAPH_WARMUP = 3    # eager steps in front of the recording (instantiations, workspaces, autograd buffers settle)
 
-    def _generic_step_auto(self, xs, loss_terms, nums_constraints, criterion, world):
-        """ the generic step, replayed as ONE launch graph where that is safe: pinn_jet_forward -> the user's torch code and its
-        autograd sweep (a few dozen small kernels the interpreter launches one by one) -> pinn_jet_backward, recorded after a few eager
-        steps on static buffers (torch.cuda.graph) and replayed with the next batch copied in. Single process, equation term only,
-        one direction group, the model's own forward(), no callable-IC autograd; anything else -- or an equation whose torch code
-        cannot be captured (data-dependent shapes, host reads) -- stays eager. Same kernels, same order: bit-identical. """
-        model = self.model
+    def _graph_step(self, xs, key, run, enabled=True):
+        """ `run(points)` -- the gradient part of one iteration, everything between drawing the batch and the optimizer step -- replayed
+        as ONE launch graph: recorded after a few eager iterations on a static copy of the batch (torch.cuda.graph; the library's
+        launches go to the current stream, i.e. into the recording) and replayed with the next batch copied in. Same kernels, same
+        order: bit-identical. A step whose torch code cannot be captured (data-dependent shapes, host reads) stays eager for good. """
         st = getattr(self, '_generic_graph', None)
-        ok = (xs.is_cuda and world == 1 and not nums_constraints and tuple(loss_terms) == ('equation',) and len(self.spec.groups) == 1
-              and not self.custom_forward and not (model.initial_condition is not None and model.ic_constant is None)
-              and os.environ.get('PYDENS_AMD_GENERIC_GRAPH', '1') != '0' and not (st and st.get('failed')))
-        if not ok:
-            return self._generic_step(xs, loss_terms, nums_constraints, criterion, world)
-        key = (tuple(xs.shape), id(criterion), id(self._eq))
+        if not (enabled and xs.is_cuda and os.environ.get('PYDENS_AMD_STEP_GRAPH', os.environ.get('PYDENS_AMD_GENERIC_GRAPH', '1')) != '0'
+                and not (st and st.get('failed') and st['key'] == key)):
+            return run(xs)
         if st is None or st['key'] != key:
             st = self._generic_graph = dict(key=key, count=0, graph=None, xs=None, failed=False, replays=0)
         if st['graph'] is None:
             if st['count'] < self.GENERIC_GRAPH_WARMUP:
                 st['count'] += 1
-                return self._generic_step(xs, loss_terms, nums_constraints, criterion, world)
+                return run(xs)
             try:
                 st['xs'] = xs.clone()
                 graph = torch.cuda.CUDAGraph()
                 with torch.cuda.graph(graph):
-                    self._generic_step(st['xs'], ('equation',), [], criterion, 1)
+                    run(st['xs'])
                 st['graph'] = graph
-            except Exception as exc:         # noqa: BLE001 -- whatever the equation's torch code does that a capture refuses
+            except Exception as exc:         # noqa: BLE001 -- whatever the step's torch code does that a capture refuses
                 st['failed'], st['graph'], st['error'] = True, None, repr(exc)
                 torch.cuda.synchronize()
-                return self._generic_step(xs, loss_terms, nums_constraints, criterion, world)
+                return run(xs)
         st['xs'].copy_(xs)
         st['graph'].replay()
         st['replays'] += 1
+
+    def _generic_step_auto(self, xs, loss_terms, nums_constraints, criterion, world):
+        """ the generic step -- pinn_jet_forward -> the user's torch code and its autograd sweep (a few dozen small kernels the
+        interpreter launches one by one) -> pinn_jet_backward, constraint terms (the model on fixed points) included -- as a launch
+        graph where that is safe: single process, one direction group, the model's own forward(), no callable-IC autograd; anything
+        else stays eager. """
+        model = self.model
+        ok = (world == 1 and len(self.spec.groups) == 1 and not self.custom_forward
+              and not (model.initial_condition is not None and model.ic_constant is None))
+        return self._graph_step(xs, ('generic', tuple(xs.shape), id(criterion), id(self._eq), tuple(loss_terms)),
+                                lambda pts: self._generic_step(pts, loss_terms, nums_constraints, criterion, world), enabled=ok)
+
+    def _fused_terms_step(self, xs, loss_terms, nums_constraints, world, stream=None):
+        """ summed loss (:441-457) on the fused kernels: the equation term stores gradient + loss, every constraint term adds its own """
+        first = True
+        if 'equation' in loss_terms:
+            self._fused_step(xs, world, stream=stream)
+            first = False
+        for num in nums_constraints:
+            self._constraint_step(num, world, accumulate=not first)
+            first = False
 
     def _generic_step(self, xs, loss_terms, nums_constraints, criterion, world):
         model, spec = self.model, self.spec
@@ -803,7 +840,7 @@ class Solver:
                 loss = loss + (term if world == 1 else term * w_eq)
 
             def _forward(*pts):                                                          # :451-454
-                return model(self.reshape_and_concat(pts, device=self.device))
+                return model(self._points_on_device(pts))
 
             cols = [xs[:, c:c + 1] for c in range(model.total)]
             for num in nums_constraints:                                                  # :456-457

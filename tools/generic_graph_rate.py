@@ -1,5 +1,5 @@
 """ Solver.fit rate on the GENERIC step path (pinn_jet_forward -> the user's torch code + autograd -> pinn_jet_backward -> Adam) at the
-batch sizes the reference's tutorials use, eager (PYDENS_AMD_GENERIC_GRAPH=0) against the launch-graph replay (Solver._generic_step_auto).
+batch sizes the reference's tutorials use, eager (PYDENS_AMD_STEP_GRAPH=0) against the launch-graph replay (Solver._generic_step_auto).
 One fresh process per cell.  usage: python tools/generic_graph_rate.py            (children: ... <graph> <problem> <batch>) """
 import os, subprocess, sys, time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -10,7 +10,7 @@ if len(sys.argv) == 1:
         for batch in (100, 1000, 8192):
             for graph in ('0', '1'):
                 out = subprocess.run([sys.executable, os.path.abspath(__file__), graph, problem, str(batch)], capture_output=True, text=True,
-                                     env=dict(os.environ, PYDENS_AMD_GENERIC_GRAPH=graph))
+                                     env=dict(os.environ, PYDENS_AMD_STEP_GRAPH=graph))
                 print(out.stdout.strip().splitlines()[-1] if out.stdout.strip() else f'FAILED {out.stderr[-300:]}', flush=True)
     sys.exit(0)
 

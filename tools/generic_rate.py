@@ -11,6 +11,7 @@ from pydens_amd import D, V
 def odevar(f, x):
     return D(f, x) - 2 * np.pi * torch.cos(2 * np.pi * x) + V('new_var', data=torch.Tensor([1.0]))
 
+# (PYDENS_AMD_STEP_GRAPH=0: the eager loops; default: the gradient part of an iteration replayed as one launch graph, round 4)
 for batch in (500, 65536):
     solver = pa.Solver(odevar, ndims=1, initial_condition=1, constraints=lambda f, x: f(torch.tensor([0.5])))
     for terms, fused in (('equation', True), (['equation', 'constraint_0'], True), (['equation', 'constraint_0'], False)):
@@ -21,4 +22,6 @@ for batch in (500, 65536):
         solver.fit(niters=200, batch_size=batch, lr=0.01, loss_terms=terms)
         torch.cuda.synchronize()
         dt = (time.perf_counter() - t0) / 200
-        print(f'batch {batch:6d} terms {terms!s:32s} path {solver.last_fit_path:8s} {dt * 1e3:8.3f} ms/it', flush=True)
+        st = getattr(solver, '_generic_graph', None) or {}
+        print(f'batch {batch:6d} terms {terms!s:32s} path {solver.last_fit_path:8s} {dt * 1e3:8.3f} ms/it   '
+              f'({st.get("replays", 0)} launch-graph replays{", refused: " + st["error"] if st.get("error") else ""})', flush=True)
