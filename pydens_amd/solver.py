@@ -468,6 +468,15 @@ class Solver:
             cols.append(col)
         return torch.cat(cols, dim=1)
 
+    def _group_rows(self, num, idx):
+        """ stream rows of direction group `num` as a device index tensor, built once (indexing with a Python list uploads it in every
+        step, which a launch-graph recording refuses) """
+        cache = self.__dict__.setdefault('_group_row_cache', {})
+        key = (num, tuple(idx))
+        if key not in cache:
+            cache[key] = torch.tensor(list(idx), dtype=torch.long, device=self.device)
+        return cache[key]
+
     def _points_on_device(self, pts):
         """ reshape_and_concat(pts) on the device. Small HOST constants -- the fixed points a constraint builds in every call,
         `f(torch.tensor([0.5]))` -- are looked up by content in a cache of device tensors: no host-to-device copy per iteration, and
@@ -788,10 +797,12 @@ class Solver:
     def _generic_step_auto(self, xs, loss_terms, nums_constraints, criterion, world):
         """ the generic step -- pinn_jet_forward -> the user's torch code and its autograd sweep (a few dozen small kernels the
         interpreter launches one by one) -> pinn_jet_backward, constraint terms (the model on fixed points) included -- as a launch
-        graph where that is safe: single process, one direction group, the model's own forward(), no callable-IC autograd; anything
-        else stays eager. """
+        graph in a single process (direction groups included). Kept eager: data-parallel steps (the all-reduce sits between the halves)
+        and every step that differentiates INSIDE its torch code with create_graph -- a callable initial condition's derivative
+        streams, an equation that takes torch gradients with respect to its inputs, a model subclass's own forward(): recording those
+        ends in a crash inside hipStreamEndCapture on ROCm 7.2 (not an exception: tools/graph_crash_probe.py), so they are never tried. """
         model = self.model
-        ok = (world == 1 and len(self.spec.groups) == 1 and not self.custom_forward
+        ok = (world == 1 and not self.custom_forward and not self.needs_x_grad
               and not (model.initial_condition is not None and model.ic_constant is None))
         return self._graph_step(xs, ('generic', tuple(xs.shape), id(criterion), id(self._eq), tuple(loss_terms)),
                                 lambda pts: self._generic_step(pts, loss_terms, nums_constraints, criterion, world), enabled=ok)
@@ -828,9 +839,9 @@ class Solver:
                 else:
                     # more directions than one kernel call carries: one forward per group of directions (u comes with each)
                     leaf = torch.empty((spec.n_streams, xs.shape[0]), dtype=torch.float32, device=self.device)
-                    for dirs_g, n2g, idx in spec.groups:
+                    for num, (dirs_g, n2g, idx) in enumerate(spec.groups):
                         part = model.net.jet_forward(model.flat, xs, dirs_g, n2g, ic_const=model.kernel_ic_const())
-                        leaf[idx] = part
+                        leaf.index_copy_(0, self._group_rows(num, idx), part)
                     leaf.requires_grad_()
                 ic_streams = None
                 if model.initial_condition is not None and model.ic_constant is None and not self.custom_forward:
@@ -856,7 +867,7 @@ class Solver:
                     # the parameter gradient is linear in the upstream stream gradients: one backward per group, the
                     # gradient of u itself rides with the first group only
                     for num, (dirs_g, n2g, idx) in enumerate(spec.groups):
-                        gin = leaf.grad[idx].contiguous()
+                        gin = leaf.grad.index_select(0, self._group_rows(num, idx))
                         if num > 0:
                             gin[0].zero_()
                         ws = model.workspace(xs.shape[0], len(dirs_g), n2g)

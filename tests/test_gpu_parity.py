@@ -1077,3 +1077,44 @@ def test_generic_terms_with_a_constraint_as_a_launch_graph_follow_the_eager_loop
     #  step then stays eager, which the equalities above cover as well; when it is recorded, every iteration behind the warm-up replays)
     assert r1 in (0, (15 - 3) + (9 - 3)), (r1, err)
     print('launch-graph replays:', r1, 'refused:', err)
+
+
+def test_generic_launch_graph_covers_direction_groups_and_leaves_inner_autograd_eager(pa, monkeypatch):
+    """ several kernel calls per half (direction groups: two third-order columns) are recorded and replayed like the plain case,
+    bit-identical to the eager loop; steps that differentiate inside their torch code (a callable IC holding a variable, a model
+    subclass's own forward()) are never recorded (recording them crashes inside the HIP runtime) and run eagerly. """
+    D = pa.D
+
+    def build(which):
+        if which == 'direction_groups':
+            eq = lambda f, x, y, t: D(f, t) + 0.05 * D(D(D(f, x), x), x) + 0.02 * D(D(D(f, y), y), y) + f * D(f, x)
+            return pa.Solver(eq, ndims=3, boundary_condition=0.0, initial_condition=0.2, layout='fa fa f', features=[24, 24, 1], activation='Tanh')
+        if which == 'callable_ic':
+            ic = lambda x: pa.V('amp', data=torch.Tensor([0.8])) * torch.sin(np.pi * x)
+            solver = pa.Solver(lambda f, x, t: D(f, t) - 0.1 * D(D(f, x), x), ndims=2, boundary_condition=0.0, initial_condition=ic,
+                               layout='fa fa f', features=[24, 24, 1], activation='Tanh')
+            solver.program = None
+            solver.use_fused = False
+            return solver
+
+        class Scaled(pa.ConvBlockModel):
+            def forward(self, xs):
+                return self.anzatc(self.conv_block(xs), xs) * (1.0 + 0.5 * xs[:, :1])
+        eq = lambda f, x, y: D(D(f, x), x) + D(D(f, y), y) - 5 * torch.sin(np.pi * (x + y))
+        return pa.Solver(eq, ndims=2, boundary_condition=1, model=Scaled, layout='fa fa f', features=[24, 24, 1], activation='Tanh')
+
+    def run(which, graph):
+        monkeypatch.setenv('PYDENS_AMD_STEP_GRAPH', '1' if graph else '0')
+        torch.manual_seed(24)
+        solver = build(which)
+        solver.fit(niters=12, batch_size=600, lr=0.005)
+        assert solver.last_fit_path == 'generic'
+        st = getattr(solver, '_generic_graph', None) or {}
+        return (np.array([float(v) for v in solver.losses]), solver.model.flat.detach().cpu().numpy().copy(), st.get('replays', 0), st.get('error'))
+    l0, p0, r0, _ = run('direction_groups', False)
+    l1, p1, r1, err = run('direction_groups', True)
+    assert np.array_equal(l0, l1) and np.array_equal(p0, p1)
+    assert r0 == 0 and r1 == 12 - 3, (r1, err)
+    for which in ('callable_ic', 'custom_forward'):
+        _, _, replays, err = run(which, True)
+        assert replays == 0 and err is None, (which, replays, err)
