@@ -23,6 +23,7 @@ from tqdm import tqdm
 
 from . import engine, trace
 from .model import ConvBlockModel
+from . import tokens
 from .tokens import current_model
 
 
@@ -779,7 +780,14 @@ class Solver:
         if st['graph'] is None:
             if st['count'] < self.GENERIC_GRAPH_WARMUP:
                 st['count'] += 1
-                return run(xs)
+                before = tokens.AUTOGRAD_FALLBACKS[0]
+                out = run(xs)
+                if tokens.AUTOGRAD_FALLBACKS[0] != before:
+                    # D(...) on something that is not a kernel stream (a constraint that differentiates the model at its point, a
+                    # function of the inputs): torch.autograd.grad(create_graph=True) inside the step -- never recorded (see
+                    # _generic_step_auto)
+                    st['failed'], st['error'] = True, 'the step differentiates inside its torch code (D by autograd): kept eager'
+                return out
             try:
                 st['xs'] = xs.clone()
                 graph = torch.cuda.CUDAGraph()

@@ -10,6 +10,11 @@ from . import trace
 current_model = ContextVar("current_model")          # reference model_torch.py:15
 
 
+# how often D had to differentiate by torch autograd (create_graph) instead of picking a kernel stream: the solver never records a step
+# as a launch graph in which that happens (Solver._graph_step)
+AUTOGRAD_FALLBACKS = [0]
+
+
 def D(y, x):
     """ Differentiation token: per-sample dy/dx with y, x of shape [N,1] (reference model_torch.py:174-178).
 
@@ -30,6 +35,7 @@ def D(y, x):
         return y._pinn_ctx.derivative(alpha, col)
     if sc is not None and col is not None and y.requires_grad:
         sc.used_autograd_fallback = True
+        AUTOGRAD_FALLBACKS[0] += 1
         items = [(a, t) for a, t in sc.stream_tensors() if t.requires_grad]
         wrt = [x] + [t for _, t in items]
         grads = torch.autograd.grad(y.sum(), wrt, retain_graph=True, create_graph=True, allow_unused=True)
@@ -40,6 +46,7 @@ def D(y, x):
         return total
     if sc is not None:
         sc.used_autograd_fallback = True
+    AUTOGRAD_FALLBACKS[0] += 1
     return torch.autograd.grad(y.sum(), x, retain_graph=True, create_graph=True)[0]
 
 
