@@ -17,6 +17,10 @@ from conftest import params_close
 from helpers import FixedBatches, export_params, load_params
 
 
+# an experiment outside the product (tools/experiments/): not part of the default CPU suite (a second emulator build + 35 s of emulation)
+pytestmark = pytest.mark.skipif(os.environ.get('PINN_TEST_EXPERIMENTS', '0') != '1', reason='experiment kernels: run with PINN_TEST_EXPERIMENTS=1')
+
+
 @pytest.fixture(scope='module')
 def chain_lib():
     import build_emu

@@ -615,7 +615,7 @@ def test_streamed_weight_gradient_kernel_chunks_and_paths(pa, emu_lib):
         emu_lib.pinn_debug_wgx_chunk_bytes(0)
 
 
-@pytest.mark.parametrize('which', ['poisson', 'burgers', 'poisson_any_activation', 'burgers_any_activation'])
+@pytest.mark.parametrize('which', ['poisson', 'poisson_any_activation', 'burgers_any_activation'])
 def test_streamed_weight_gradients_through_skip_connections(pa, emu_lib, which):
     """ residual nets of widths >= 128 (round 4): the skip kernels (VAR 8 | 1024) hand their hidden->hidden weight gradients to
     pinn_wgrad_kernel<..., SKIPS> as well -- the activations a skip carries stay in the per-tile slab for that kernel (h behind
@@ -632,7 +632,7 @@ def test_streamed_weight_gradients_through_skip_connections(pa, emu_lib, which):
         which = which[:-len('_any_activation')]
     eq_o, kw = _layout_problems(po.D, torch, which, net)
     oracle = po.OracleSolver(eq_o, **kw)
-    pts = np.random.RandomState(5).rand(70, 2).astype(np.float32)
+    pts = np.random.RandomState(5).rand(52, 2).astype(np.float32)        # 4 tiles, the last one ragged; the emulator has 2 CUs
     ev = oracle.evaluate(pts)
     want = oracle.export_grads()
     try:
