@@ -934,6 +934,9 @@ def test_two_ranks_over_rccl_follow_the_single_process_trajectory(pa):
                 assert rel_l2(z[f'p{i}'], want) < fit_rtol('cfg4'), (rank, i)
 
 
+_FULL_BATCH_ORACLE = {}
+
+
 @pytest.mark.parametrize('gemm', ['fp32', 'bf16x3'])
 @pytest.mark.parametrize('name,n', [('cfg3', 262144), ('cfg5', 131072)])
 def test_wide_nets_at_their_full_batch_against_the_chunked_oracle(pa, name, n, gemm):
@@ -943,15 +946,22 @@ def test_wide_nets_at_their_full_batch_against_the_chunked_oracle(pa, name, n, g
     from oracle import pinn_oracle as po
     torch.manual_seed(5)
     cfg, solver = make_solver(name, pa, gemm=gemm)
-    ocfg = pc.make_config(name, po.D, torch)
-    oracle = po.OracleSolver(ocfg['equation'], **ocfg['solver_kwargs'])
-    oracle.import_params(export_params(solver))
     pts = pc.sample_points(cfg, n, seed=2)
-    ev = oracle.evaluate(pts, chunk=16384)
+    start = export_params(solver)
+    cached = _FULL_BATCH_ORACLE.get((name, n))
+    if cached is None or any(not np.array_equal(a, b) for a, b in zip(cached[0], start)):
+        # (the oracle's pass over 131 072 - 262 144 points takes 20 - 150 s of host time: both GEMM modes start from the same
+        #  parameters and points, so it is evaluated once)
+        ocfg = pc.make_config(name, po.D, torch)
+        oracle = po.OracleSolver(ocfg['equation'], **ocfg['solver_kwargs'])
+        oracle.import_params(start)
+        ev = oracle.evaluate(pts, chunk=16384)
+        cached = _FULL_BATCH_ORACLE[(name, n)] = ([np.array(a, copy=True) for a in start], ev['loss'], oracle.export_grads())
+    _, loss_o, grads_o = cached
     solver._fused_step(torch.from_numpy(pts).cuda(), 1)
     lay = solver.model.net.layout
-    assert abs(float(solver.grads[lay.off_loss]) - ev['loss']) <= 1e-5 * ev['loss']
-    for got, want in zip(export_grads(solver), oracle.export_grads()):
+    assert abs(float(solver.grads[lay.off_loss]) - loss_o) <= 1e-5 * loss_o
+    for got, want in zip(export_grads(solver), grads_o):
         if want is not None:
             assert grad_close(got, want)
 
