@@ -39,6 +39,15 @@ CASES = {
     'ode_family_4x64_two_teams': (lambda D: (lambda u, x, e: D(u, x) - e * np.pi * torch.cos(e * np.pi * x)),
                                   dict(ndims=1, nparams=1, initial_condition=1, layout='fa' * 4 + 'f',
                                        features=[64] * 4 + [1], activation='Tanh'), 2, {}),
+    # residual nets of widths >= 128 at their smallest: ONE hidden->hidden layer whose input a skip joins (the streamed weight-gradient
+    # kernel's only layer takes first-layer jets + the carried activations), and a pre-activation skip from the first layer on the full
+    # breadth kernels
+    'wide_skip_one_hidden_matrix': (lambda D: (lambda u, x, y: D(D(u, x), x) + D(D(u, y), y) - 5 * torch.sin(np.pi * (x + y))),
+                                    dict(ndims=2, boundary_condition=1, layout='faR fa+ f', features=[96, 96, 1], activation='Tanh'), 2, {}),
+    'wide_pre_activation_skip_any_activation': (
+        lambda D: (lambda u, x, t: D(u, t) + u * D(u, x) - 0.05 * D(D(u, x), x)),
+        dict(ndims=2, boundary_condition=0, initial_condition=lambda x: torch.sin(np.pi * x), layout='fRa f+a f', features=[96, 96, 1],
+             activation=['Sin', 'GELU']), 2, {}),
     'shifted_domain': (lambda D: (lambda u, x, y: D(D(u, x), x) + D(D(u, y), y) - torch.exp(x)),
                        dict(ndims=2, boundary_condition=1, domain=(-1, 2), layout='fafaf', features=[16, 16, 1],
                             activation='Tanh'), 2, {}),
