@@ -4,7 +4,7 @@ import csv, glob, json, os, re, sys
 from collections import defaultdict
 
 cfg, out = sys.argv[1], sys.argv[2]
-BATCH = {'cfg2': 65536, 'cfg3': 262144, 'cfg4': 131072, 'cfg5': 131072}[cfg]
+BATCH = {'cfg2': 65536, 'cfg3': 262144, 'cfg4': 131072, 'cfg5': 131072}.get(cfg, 65536)      # (the breadth workloads of bench.py: 65 536 points)
 
 
 def short(name):
