@@ -1128,3 +1128,25 @@ def test_generic_launch_graph_covers_direction_groups_and_leaves_inner_autograd_
     for which in ('callable_ic', 'custom_forward'):
         _, _, replays, err = run(which, True)
         assert replays == 0 and err is None, (which, replays, err)
+
+
+@pytest.mark.parametrize('batch', [1, 17, 4097])
+def test_launch_graphs_at_tiny_and_boundary_batches(pa, batch, monkeypatch):
+    """ a batch below one 16-point tile, one just above it and one just above the fused path's graph threshold: chunk graphs (fused) and
+    step graphs (generic) against the eager loops, bit for bit (tools/tiny_batch_graph_check.py is the same check as a script) """
+    def run(graph, generic):
+        monkeypatch.setenv('PYDENS_AMD_FIT_GRAPH', '1' if graph else '0')
+        monkeypatch.setenv('PYDENS_AMD_STEP_GRAPH', '1' if graph else '0')
+        torch.manual_seed(3)
+        solver = pa.Solver(lambda f, x, y: pa.D(pa.D(f, x), x) + pa.D(pa.D(f, y), y) - 5 * torch.sin(np.pi * (x + y)), ndims=2,
+                           boundary_condition=1, layout='fa fa f', features=[20, 20, 1], activation='Tanh')
+        if generic:
+            solver.program = None
+        solver.fit(niters=260, batch_size=batch, lr=0.005)
+        assert solver.last_fit_path == ('generic' if generic else 'fused')
+        return np.array([float(v) for v in solver.losses]), solver.model.flat.detach().cpu().numpy().copy()
+    for generic in (False, True):
+        l0, p0 = run(False, generic)
+        l1, p1 = run(True, generic)
+        assert np.isfinite(l1).all()
+        assert np.array_equal(l0, l1) and np.array_equal(p0, p1), generic
