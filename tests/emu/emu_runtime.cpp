@@ -6,6 +6,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <algorithm>
 #include <vector>
 
 namespace emu {
@@ -34,6 +35,12 @@ int g_cur = 0, g_block = 0, g_bid = 0, g_grid = 0;
 int g_barrier_count = 0;
 unsigned g_barrier_gen = 0;
 float* g_smem = nullptr;
+unsigned long long g_shuffle = 0, g_rng = 0;
+
+unsigned next_random() {                 // xorshift64*
+    g_rng ^= g_rng >> 12; g_rng ^= g_rng << 25; g_rng ^= g_rng >> 27;
+    return (unsigned)((g_rng * 2685821657736338717ull) >> 33);
+}
 
 void yield() { swapcontext(&g_fibers[g_cur].ctx, &g_sched); }
 
@@ -144,6 +151,9 @@ float row_sum16(float v) {
 
 void launch(int grid, int block, size_t smem_bytes, const std::function<void()>& body) {
     if (block % 64) { fprintf(stderr, "emu: block size must be a multiple of 64\n"); abort(); }
+    const char* sh = getenv("PINN_EMU_SHUFFLE");
+    g_shuffle = sh ? strtoull(sh, nullptr, 10) : 0;
+    if (g_shuffle && !g_rng) g_rng = g_shuffle * 0x9E3779B97F4A7C15ull + 1;
     g_body = &body; g_block = block; g_grid = grid;
     g_fibers.assign(block, Fiber());
     for (auto& f : g_fibers) f.stack = (char*)malloc(kStack);
@@ -160,14 +170,31 @@ void launch(int grid, int block, size_t smem_bytes, const std::function<void()>&
             makecontext(&f.ctx, trampoline, 0);
         }
         int remaining = block;
+        const int n_waves = block / 64;
+        std::vector<int> order(n_waves);
+        for (int w = 0; w < n_waves; ++w) order[w] = w;
         while (remaining > 0) {
             remaining = 0;
-            for (int i = 0; i < block; ++i) {
-                if (g_fibers[i].done) continue;
-                g_cur = i;
-                swapcontext(&g_sched, &g_fibers[i].ctx);
-                if (!g_fibers[i].done) ++remaining;
+            if (g_shuffle) {
+                // PINN_EMU_SHUFFLE=<seed>: the waves of a workgroup advance in a random order, and a wave sits out a scheduling pass
+                // with probability 3/8 -- waves then run whole phases ahead of each other, up to the next barrier, so that a missing
+                // barrier (a fast wave overwriting LDS a slow one still reads) changes results instead of hiding behind round-robin
+                for (int w = n_waves - 1; w > 0; --w) { const int r = (int)(next_random() % (unsigned)(w + 1)); std::swap(order[w], order[r]); }
             }
+            bool ran = false;
+            for (int pass = 0; pass < 2 && !ran; ++pass)
+                for (int wi = 0; wi < n_waves; ++wi) {
+                    const int w = order[wi];
+                    if (g_shuffle && pass == 0 && (next_random() & 7) < 3) continue;        // (second pass: nobody sits out)
+                    for (int i = 64 * w; i < 64 * w + 64; ++i) {
+                        if (g_fibers[i].done) continue;
+                        g_cur = i;
+                        swapcontext(&g_sched, &g_fibers[i].ctx);
+                        ran = true;
+                    }
+                }
+            for (int i = 0; i < block; ++i)
+                if (!g_fibers[i].done) ++remaining;
         }
     }
     for (auto& f : g_fibers) free(f.stack);

@@ -1166,3 +1166,34 @@ def test_one_second_derivative_beside_three_first_order_directions(pa, emu_lib, 
     np.testing.assert_allclose([float(v) for v in solver.losses], [float(v) for v in oracle.losses], rtol=2e-5)
     for got, want in zip(export_params(solver), oracle.export_params()):
         assert params_close(got, want, 2e-5)
+
+
+@pytest.mark.parametrize('case', ['cfg2', 'cfg2_bf16x3', 'cfg4', 'cfg3_streamed', 'wide_skip_any_activation'])
+def test_results_do_not_depend_on_the_order_the_waves_run_in(pa, emu_lib, case, monkeypatch):
+    """ the emulator normally advances the waves of a workgroup round-robin, which hides a missing barrier; under PINN_EMU_SHUFFLE=<seed>
+    they advance in random order, whole phases apart up to the next barrier (tests/emu/emu_runtime.cpp). Every gradient of a fused step
+    must come out bit-identical to the round-robin run -- two-team, split-bf16, streamed weight-gradient and skip kernels.
+    (Negative control: tools/emu_shuffle_check.py -DPINN_ABL=16, the same kernels built without the tile loop's barriers, differs by
+    O(10) under every seed.) """
+    def run(shuffle):
+        if shuffle:
+            monkeypatch.setenv('PINN_EMU_SHUFFLE', str(shuffle))
+        else:
+            monkeypatch.delenv('PINN_EMU_SHUFFLE', raising=False)
+        torch.manual_seed(0)
+        if case == 'wide_skip_any_activation':
+            eq, kw = _layout_problems(pa.D, torch, 'burgers', dict(layout='fRa fa f+a R f fa+ fa f', features=[96] * 6 + [1],
+                                                                  activation=['Sin', 'SiLU', 'GELU', 'Softplus', 'Tanh']))
+            solver = pa.Solver(eq, **kw, **emu_kwargs(emu_lib))
+            pts = torch.from_numpy(np.random.RandomState(1).rand(24, 2).astype(np.float32))
+        else:
+            name = case.split('_')[0]
+            cfg, solver = make_solver(name, pa, **emu_kwargs(emu_lib))
+            if case.endswith('bf16x3'):
+                solver.set_gemm_mode('bf16x3')
+            pts = torch.from_numpy(pc.sample_points(cfg, 24 if name == 'cfg3' else 150, seed=1))
+        solver._fused_step(pts, 1)
+        return solver.grads.clone().numpy()
+    want = run(0)
+    for seed in (1, 2):
+        assert np.array_equal(run(seed), want), seed
