@@ -171,28 +171,33 @@ void launch(int grid, int block, size_t smem_bytes, const std::function<void()>&
         }
         int remaining = block;
         const int n_waves = block / 64;
-        std::vector<int> order(n_waves);
+        std::vector<int> order(n_waves), stall(n_waves, 0);
         for (int w = 0; w < n_waves; ++w) order[w] = w;
         while (remaining > 0) {
             remaining = 0;
             if (g_shuffle) {
-                // PINN_EMU_SHUFFLE=<seed>: the waves of a workgroup advance in a random order, and a wave sits out a scheduling pass
-                // with probability 3/8 -- waves then run whole phases ahead of each other, up to the next barrier, so that a missing
-                // barrier (a fast wave overwriting LDS a slow one still reads) changes results instead of hiding behind round-robin
+                // PINN_EMU_SHUFFLE=<seed>: the waves of a workgroup advance in a random order, and now and then a wave STALLS for a random
+                // stretch of up to 512 scheduling passes (a pass moves a wave from one wave-wide rendezvous -- an MFMA, a shuffle -- to
+                // the next): the others run whole phases ahead of it, up to the next barrier, so that a missing barrier (a fast wave
+                // overwriting LDS a slow one still reads) changes results instead of hiding behind round-robin
                 for (int w = n_waves - 1; w > 0; --w) { const int r = (int)(next_random() % (unsigned)(w + 1)); std::swap(order[w], order[r]); }
-            }
-            bool ran = false;
-            for (int pass = 0; pass < 2 && !ran; ++pass)
-                for (int wi = 0; wi < n_waves; ++wi) {
-                    const int w = order[wi];
-                    if (g_shuffle && pass == 0 && (next_random() & 7) < 3) continue;        // (second pass: nobody sits out)
-                    for (int i = 64 * w; i < 64 * w + 64; ++i) {
-                        if (g_fibers[i].done) continue;
-                        g_cur = i;
-                        swapcontext(&g_sched, &g_fibers[i].ctx);
-                        ran = true;
-                    }
+                bool all_stalled = true;
+                for (int w = 0; w < n_waves; ++w) {
+                    if (stall[w] > 0) --stall[w];
+                    else if ((next_random() & 127) == 0) stall[w] = 1 + (int)(next_random() & 511);
+                    if (stall[w] == 0) all_stalled = false;
                 }
+                if (all_stalled) std::fill(stall.begin(), stall.end(), 0);
+            }
+            for (int wi = 0; wi < n_waves; ++wi) {
+                const int w = order[wi];
+                if (g_shuffle && stall[w] > 0) continue;
+                for (int i = 64 * w; i < 64 * w + 64; ++i) {
+                    if (g_fibers[i].done) continue;
+                    g_cur = i;
+                    swapcontext(&g_sched, &g_fibers[i].ctx);
+                }
+            }
             for (int i = 0; i < block; ++i)
                 if (!g_fibers[i].done) ++remaining;
         }

@@ -1185,15 +1185,15 @@ def test_results_do_not_depend_on_the_order_the_waves_run_in(pa, emu_lib, case, 
             eq, kw = _layout_problems(pa.D, torch, 'burgers', dict(layout='fRa fa f+a R f fa+ fa f', features=[96] * 6 + [1],
                                                                   activation=['Sin', 'SiLU', 'GELU', 'Softplus', 'Tanh']))
             solver = pa.Solver(eq, **kw, **emu_kwargs(emu_lib))
-            pts = torch.from_numpy(np.random.RandomState(1).rand(24, 2).astype(np.float32))
+            pts = torch.from_numpy(np.random.RandomState(1).rand(40, 2).astype(np.float32))
         else:
             name = case.split('_')[0]
             cfg, solver = make_solver(name, pa, **emu_kwargs(emu_lib))
             if case.endswith('bf16x3'):
                 solver.set_gemm_mode('bf16x3')
-            pts = torch.from_numpy(pc.sample_points(cfg, 24 if name == 'cfg3' else 150, seed=1))
+            pts = torch.from_numpy(pc.sample_points(cfg, 40 if name == 'cfg3' else 150, seed=1))
         solver._fused_step(pts, 1)
         return solver.grads.clone().numpy()
     want = run(0)
-    for seed in (1, 2):
+    for seed in (1,):           # (tools/emu_shuffle_check.py runs more seeds; a stalled wave costs the emulator many idle passes)
         assert np.array_equal(run(seed), want), seed
