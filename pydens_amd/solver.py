@@ -487,7 +487,10 @@ class Solver:
             if isinstance(x, torch.Tensor):
                 if x.is_cuda or x.requires_grad or x.numel() > 4096:
                     return self.reshape_and_concat(pts, device=self.device)
-                key.append(('t', str(x.dtype), tuple(x.shape), x.detach().contiguous().numpy().tobytes()))
+                try:
+                    key.append(('t', str(x.dtype), tuple(x.shape), x.detach().contiguous().numpy().tobytes()))
+                except (TypeError, RuntimeError):       # (a dtype numpy does not have: no cache entry, the plain upload)
+                    return self.reshape_and_concat(pts, device=self.device)
             elif isinstance(x, np.ndarray):
                 if x.size > 4096:
                     return self.reshape_and_concat(pts, device=self.device)
