@@ -123,3 +123,36 @@ def test_hip_library_exports_every_declared_symbol():
     bad = (ctypes.c_int * 3)(2, 512, 1)
     assert lib.pinn_create(bad, 2, 0, 2, 0, 0, 0, None, None, 0.0, ctypes.byref(handle)) != 0
     assert b'512' in lib.pinn_last_error()
+
+
+def test_host_constants_of_a_constraint_are_cached_on_the_device_by_content():
+    """ Solver._points_on_device: the fixed points a constraint builds in every call (`f(torch.tensor([0.5]))`) are uploaded once and
+    found again by content -- what keeps the generic step recordable as a launch graph (a pageable-memory upload is not capturable);
+    anything that needs autograd or already lives on the device takes the plain path """
+    from pydens_amd import Solver
+    host = type('H', (), {'device': torch.device('cpu'), 'reshape_and_concat': Solver.reshape_and_concat,
+                          '_points_on_device': Solver._points_on_device})()
+    a = host._points_on_device((torch.tensor([0.5]),))
+    b = host._points_on_device((torch.tensor([0.5]),))
+    c = host._points_on_device((torch.tensor([0.25]),))
+    assert a is b and c is not a and torch.equal(a, torch.tensor([[0.5]])) and torch.equal(c, torch.tensor([[0.25]]))
+    assert host._points_on_device((np.array([0.5, 0.75]), 2.0)) is host._points_on_device((np.array([0.5, 0.75]), 2.0))
+    assert torch.equal(host._points_on_device((np.array([0.5, 0.75]), 2.0)), torch.tensor([[0.5, 2.0], [0.75, 2.0]]))
+    x = torch.tensor([0.5], requires_grad=True)
+    assert host._points_on_device((x,)) is not host._points_on_device((x,))        # differentiable inputs are never cached
+    big = torch.zeros(5000)
+    assert host._points_on_device((big,)) is not host._points_on_device((big,))    # nor are batches of points
+    for i in range(80):                                                               # the cache stays bounded
+        host._points_on_device((torch.tensor([float(i)]),))
+    assert len(host._host_constants) <= 64
+
+
+def test_autograd_fallbacks_of_D_are_counted():
+    """ tokens.AUTOGRAD_FALLBACKS: D on something that is not a kernel stream differentiates by torch autograd (create_graph); the solver
+    never records a step in which that happened as a launch graph """
+    from pydens_amd import tokens
+    x = torch.linspace(0, 1, 5).reshape(-1, 1).requires_grad_()
+    before = tokens.AUTOGRAD_FALLBACKS[0]
+    d = tokens.D(torch.sin(x), x)
+    assert tokens.AUTOGRAD_FALLBACKS[0] == before + 1
+    assert torch.allclose(d, torch.cos(x))
