@@ -345,12 +345,17 @@ pinn_wgrad_kernel(const PinnKArgs A) {
         }
         }
         // this workgroup's dW_li: D[(l >> 4) * 4 + r][l & 15] of tile (i, jn) -> row (out) m0 + 16 i + 4 lq + r, column (in) n0 + 16 jn + lr
-        float* dst = part + A.off_wh + (size_t)li * A.hidden_stride;
+        // (one 32-bit lane offset + a pointer per output tile row i; rows r and column tiles jn sit at immediate offsets below 4 KB: left
+        //  to itself the compiler hoists all AM * BN * 4 sixty-four-bit element offsets out of the layer loop and parks them in scratch
+        //  -- 200 spilled registers at width 256, none of them inside a stage, but 800 B of scratch per lane for nothing)
+        float* dst = part + A.off_wh + (size_t)li * A.hidden_stride + (unsigned)((m0 + 4 * lq) * HP + n0 + lr);
 #pragma unroll
-        for (int i = 0; i < AM; ++i)
+        for (int i = 0; i < AM; ++i) {
+            float* row = dst + (unsigned)(16 * i * HP);
 #pragma unroll
             for (int jn = 0; jn < BN; ++jn)
 #pragma unroll
-                for (int r = 0; r < 4; ++r) dst[(m0 + 16 * i + 4 * lq + r) * HP + n0 + 16 * jn + lr] = acc[i][jn][r];
+                for (int r = 0; r < 4; ++r) row[r * HP + 16 * jn] = acc[i][jn][r];
+        }
     }
 }
