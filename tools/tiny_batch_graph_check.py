@@ -1,3 +1,5 @@
+""" Launch graphs (fused chunks, generic steps) against the eager loops at tiny / boundary batch sizes (1, 7, 17, 4096, 4097 points): bit-identical?
+The GPU suite runs the same check (tests/test_gpu_parity.py::test_launch_graphs_at_tiny_and_boundary_batches).  usage: python tools/tiny_batch_graph_check.py """
 import os, sys
 sys.path.insert(0, '/root/repo')
 import numpy as np, torch
