@@ -286,18 +286,19 @@ const char* pinn_last_wgrad_kernel_name(void);
  * ran several workgroups per CU. Returns non-zero before the first launch. */
 int pinn_last_launch_info(int32_t out[4]);
 
-/* Diagnostics (tests, tools/): never used on the training path; they leave results untouched.
+/* Diagnostics (tests, tools/): never used on the training path; they leave results untouched. The three that change how launches
+ * are PLANNED act on ONE descriptor (round 5: they were process-wide switches -- two Solvers in a process would have shared them):
  *   pinn_debug_last_kernel        0 = general tile kernel, 2 = shape-specialised tile kernel took the last launch
- *   pinn_debug_prepass_in_kernel  0: x-only pre-pass as its own launch (pinn_aux_kernel) instead of the tile kernel's prologue
+ *   pinn_debug_prepass_in_kernel  0: x-only pre-pass of this net as its own launch (pinn_aux_kernel) instead of the tile kernel's prologue
  *   pinn_debug_wgx_chunk_bytes    slab budget per pass of the widths >= 128 (default 6.5 GB; <= 0 restores it): tests force
- *                                 multi-chunk steps with a tiny budget; affects pinn_workspace_bytes, so set it first */
+ *                                 multi-chunk steps with a tiny budget; affects pinn_workspace_bytes of this net, so set it first */
 int pinn_debug_last_kernel(void);
-int pinn_debug_prepass_in_kernel(int enable);
-int pinn_debug_wgx_chunk_bytes(long long bytes);
-/*   pinn_debug_max_wgs_per_cu     upper bound of the workgroups per CU a tile-kernel grid is planned with (1 .. 4; <= 0 restores
- *                                 the default, 4): tests run the same step at 1 and at several workgroups per CU; affects
- *                                 pinn_workspace_bytes (partial rows, slabs), so set it first. Returns the previous bound. */
-int pinn_debug_max_wgs_per_cu(int cap);
+int pinn_debug_prepass_in_kernel(pinn_t* net, int enable);
+int pinn_debug_wgx_chunk_bytes(pinn_t* net, long long bytes);
+/*   pinn_debug_max_wgs_per_cu     upper bound of the workgroups per CU this net's tile-kernel grids are planned with (1 .. 4; <= 0
+ *                                 restores the default, 4): tests run the same step at 1 and at several workgroups per CU; affects
+ *                                 pinn_workspace_bytes (partial rows, slabs), so set it first. Returns the previous bound (-1: null). */
+int pinn_debug_max_wgs_per_cu(pinn_t* net, int cap);
 /*   pinn_debug_fit_graph_stats    out[0] chunks replayed as launch graphs so far, out[1] graphs captured, out[2] captures the runtime
  *                                 refused (those chunks ran eagerly), out[3] the HIP error code of the last refusal */
 int pinn_debug_fit_graph_stats(int32_t out[4]);

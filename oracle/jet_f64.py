@@ -63,6 +63,43 @@ def act_derivs(z, act, fourth=False):
         d2 = phi * (2.0 - z2)
         d3 = phi * z * (z2 - 4.0)
         d4 = phi * ((7.0 - z2) * z2 - 4.0)
+    elif act in ('relu', 'leakyrelu'):             # torch: slope 0 / 0.01 (the defaults) on z <= 0, derivative taken as in torch (z > 0 ? 1 : slope)
+        slope = 0.0 if act == 'relu' else 0.01
+        t = np.where(z > 0, z, slope * z)
+        d1 = np.where(z > 0, 1.0, slope)
+        d2 = d3 = d4 = np.zeros_like(z)
+    elif act in ('elu', 'selu'):                   # s (z > 0 ? z : alpha (e^z - 1)); ELU: s = alpha = 1
+        s_, al = (1.0507009873554805, 1.6732632423543772) if act == 'selu' else (1.0, 1.0)
+        e = s_ * al * np.exp(z)
+        t = np.where(z > 0, s_ * z, s_ * al * np.expm1(z))
+        d1 = np.where(z > 0, s_, e)
+        d2 = d3 = d4 = np.where(z > 0, 0.0, e)
+    elif act == 'softsign':                        # z / (1 + |z|)
+        a, sg = 1.0 / (1.0 + np.abs(z)), np.sign(z)
+        t, d1, d2, d3, d4 = z * a, a ** 2, -2.0 * sg * a ** 3, 6.0 * a ** 4, -24.0 * sg * a ** 5
+    elif act == 'tanhshrink':                      # z - tanh z
+        _, a1, a2, a3, a4 = act_derivs(z, 'tanh', fourth=True)
+        t, d1, d2, d3, d4 = z - np.tanh(z), 1.0 - a1, -a2, -a3, -a4
+    elif act == 'logsigmoid':                      # log sigmoid(z) = -softplus(-z)
+        sg = 1.0 / (1.0 + np.exp(-z))
+        a, q = sg * (1.0 - sg), 1.0 - 2.0 * sg
+        t, d1, d2, d3, d4 = -np.logaddexp(0.0, -z), 1.0 - sg, -a, -a * q, -a * (q * q - 2.0 * a)
+    elif act in ('gelu_tanh', 'mish'):
+        # F(z) = tanh(u(z)) by Faa di Bruno to fourth order, then (z F)^(n) = z F^(n) + n F^(n-1)
+        if act == 'gelu_tanh':                     # 0.5 z (1 + tanh(k (z + c z^3)))   (torch.nn.GELU(approximate='tanh'))
+            k, c = 0.7978845608028654, 0.044715
+            u, u1, u2, u3, u4 = k * (z + c * z ** 3), k * (1.0 + 3.0 * c * z * z), 6.0 * k * c * z, 6.0 * k * c * np.ones_like(z), 0.0
+        else:                                      # z tanh(softplus(z))               (torch.nn.Mish)
+            sg = 1.0 / (1.0 + np.exp(-z))
+            a, q = sg * (1.0 - sg), 1.0 - 2.0 * sg
+            u, u1, u2, u3, u4 = np.logaddexp(0.0, z), sg, a, a * q, a * (q * q - 2.0 * a)
+        T, a1, a2, a3, a4 = act_derivs(u, 'tanh', fourth=True)
+        t1 = a1 * u1
+        t2 = a2 * u1 ** 2 + a1 * u2
+        t3 = a3 * u1 ** 3 + 3.0 * a2 * u1 * u2 + a1 * u3
+        t4 = a4 * u1 ** 4 + 6.0 * a3 * u1 ** 2 * u2 + a2 * (4.0 * u1 * u3 + 3.0 * u2 ** 2) + a1 * u4
+        sc, f0 = (0.5, 0.5 * (1.0 + T)) if act == 'gelu_tanh' else (1.0, T)
+        t, d1, d2, d3, d4 = z * f0, f0 + sc * z * t1, sc * (z * t2 + 2.0 * t1), sc * (z * t3 + 3.0 * t2), sc * (z * t4 + 4.0 * t3)
     else:
         raise ValueError(act)
     return (t, d1, d2, d3, d4) if fourth else (t, d1, d2, d3)

@@ -42,6 +42,9 @@ def _rccl():
         lib.ncclAllReduce.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_size_t, ctypes.c_int, ctypes.c_int,
                                       ctypes.c_void_p, ctypes.c_void_p]
         lib.ncclCommDestroy.argtypes = [ctypes.c_void_p]
+        if hasattr(lib, 'ncclCommAbort'):
+            lib.ncclCommAbort.argtypes = [ctypes.c_void_p]
+            lib.ncclCommAbort.restype = ctypes.c_int
         if hasattr(lib, 'ncclCommCount'):
             lib.ncclCommCount.argtypes = [ctypes.c_void_p, ctypes.POINTER(ctypes.c_int)]
             lib.ncclCommCount.restype = ctypes.c_int
@@ -59,15 +62,24 @@ def _check(lib, rc, what):
 
 
 class Communicator:
-    """ all_reduce_(tensor, stream): in-place sum over the ranks of the default torch.distributed group. """
+    """ all_reduce_(tensor, stream): in-place sum over the ranks of the default torch.distributed group.
+
+    Falling back after a TIMEOUT of ncclCommInitRank is best effort: the helper thread of the rank that timed out is still inside
+    the call when every rank moves on to torch.distributed's collectives on the same device; if the call returns later, the thread
+    itself aborts the communicator it got (ncclCommAbort: it is never used and must not be leaked), and a peer that is really gone
+    hangs the agreement all-reduce like any other torch.distributed collective would. `PYDENS_AMD_COMM_STRICT=1` ends the job with the
+    error instead of falling back. """
+    _FORCE_DIRECT = False       # tests: run the direct-communicator bootstrap on a gloo group / CPU tensors with a stand-in library
+
     def __init__(self, device):
         self.device = torch.device(device)
         self.rank, self.world = dist.get_rank(), dist.get_world_size()
         self.comm = None
         self.n_ranks = self.world                 # RCCL's own count once the direct communicator exists (ncclCommCount)
         self.fallback_reason = None
-        want_direct = (self.device.type == 'cuda' and dist.get_backend() == 'nccl'
-                       and os.environ.get('PYDENS_AMD_COMM', 'rccl') != 'torch')
+        want_direct = ((self.device.type == 'cuda' and dist.get_backend() == 'nccl'
+                        and os.environ.get('PYDENS_AMD_COMM', 'rccl') != 'torch') or self._FORCE_DIRECT)
+        on_gpu = self.device.type == 'cuda'
         self.direct = False
         if not want_direct:
             # (the reason names the condition that actually held -- ADVICE r3: a gloo group on a CUDA device used to read 'PYDENS_AMD_COMM=torch')
@@ -100,20 +112,29 @@ class Communicator:
         if raw[NCCL_UNIQUE_ID_BYTES]:
             return self._fall_back(f'ncclGetUniqueId failed on rank 0 ({err if self.rank == 0 else "see the warning of rank 0"})')
         ctypes.memmove(ctypes.byref(uid), raw[:NCCL_UNIQUE_ID_BYTES], NCCL_UNIQUE_ID_BYTES)
-        torch.cuda.synchronize(self.device)       # nothing of ProcessGroupNCCL's in flight while the second communicator boots
+        if on_gpu:
+            torch.cuda.synchronize(self.device)   # nothing of ProcessGroupNCCL's in flight while the second communicator boots
         comm = ctypes.c_void_p()
         # ncclCommInitRank is a rendezvous: if some rank never arrives (or the bootstrap network is misconfigured) the others would
         # wait in it for ever, and the MIN agreement below only helps ranks that RETURN. So the call runs on a helper thread (ctypes
         # releases the GIL) and this thread waits a bounded time (PYDENS_AMD_COMM_TIMEOUT seconds, default 120): a rank whose call
         # has not returned votes "failed", every rank falls back to torch.distributed together, the stuck helper thread is left
-        # behind (daemon) and its half-made communicator is never used.
+        # behind (daemon) and its half-made communicator is never used; should the call return after all, the
+        # thread aborts what it got (no leaked communicator on the timed-out rank).
         outcome = {}
+        handover = threading.Lock()
 
         def init():
+            import contextlib
             try:
-                with torch.cuda.device(self.device):
+                with (torch.cuda.device(self.device) if on_gpu else contextlib.nullcontext()):
                     _check(lib, lib.ncclCommInitRank(ctypes.byref(comm), self.world, uid, self.rank), 'ncclCommInitRank')
-                outcome['ok'] = True
+                with handover:
+                    if outcome.get('abandoned'):
+                        (lib.ncclCommAbort if hasattr(lib, 'ncclCommAbort') else lib.ncclCommDestroy)(comm)
+                        outcome['aborted_late'] = True
+                    else:
+                        outcome['ok'] = True
             except RuntimeError as exc:
                 outcome['err'] = exc
 
@@ -121,13 +142,19 @@ class Communicator:
         worker = threading.Thread(target=init, name='pydens_amd-rccl-init', daemon=True)
         worker.start()
         worker.join(timeout)
-        if worker.is_alive():
-            err = TimeoutError(f'ncclCommInitRank did not return within {timeout:g} s on rank {self.rank}')
-        elif 'err' in outcome:
-            err = outcome['err']
+        with handover:
+            if 'ok' not in outcome and 'err' not in outcome:
+                outcome['abandoned'] = True
+                err = TimeoutError(f'ncclCommInitRank did not return within {timeout:g} s on rank {self.rank}')
+            elif 'err' in outcome:
+                err = outcome['err']
+        self._late_init = (worker, outcome)       # (kept for inspection: tests, post-mortems)
         if not self._agree(err is None):
             if err is None:
                 lib.ncclCommDestroy(comm)
+            if os.environ.get('PYDENS_AMD_COMM_STRICT') == '1':
+                raise RuntimeError(f'pydens_amd.comm: ncclCommInitRank failed or timed out on some rank ({err if err is not None else "not this one"}) '
+                                   'and PYDENS_AMD_COMM_STRICT=1 forbids the torch.distributed fallback')
             return self._fall_back(f'ncclCommInitRank failed or timed out on some rank ({err if err is not None else "not this one"})')
         self.comm, self.direct = comm, True
         count = ctypes.c_int(0)
@@ -139,10 +166,11 @@ class Communicator:
             self.all_reduce_(probe)
             # (bounded as well: a collective that never completes must end the job with a message, not hang it -- there is no
             #  falling back from here, the compute stream is behind the stuck kernel)
-            landed = torch.cuda.Event()
-            landed.record(torch.cuda.current_stream(self.device))
+            landed = torch.cuda.Event() if on_gpu else None
+            if on_gpu:
+                landed.record(torch.cuda.current_stream(self.device))
             deadline = time.monotonic() + timeout
-            while not landed.query():
+            while on_gpu and not landed.query():
                 if time.monotonic() > deadline:
                     raise TimeoutError(f'the known-answer ncclAllReduce did not complete within {timeout:g} s on rank {self.rank} '
                                        '(set PYDENS_AMD_COMM=torch to keep the gradient all-reduce on torch.distributed)')
@@ -179,7 +207,7 @@ class Communicator:
         if not tensor.is_contiguous() or tensor.dtype != torch.float32:
             raise ValueError('all_reduce_ needs a contiguous float32 tensor')
         if stream is None:
-            stream = ctypes.c_void_p(torch.cuda.current_stream(tensor.device).cuda_stream)
+            stream = ctypes.c_void_p(torch.cuda.current_stream(tensor.device).cuda_stream) if tensor.is_cuda else None
         lib = _rccl()
         ptr = ctypes.c_void_p(tensor.data_ptr())
         _check(lib, lib.ncclAllReduce(ptr, ptr, tensor.numel(), NCCL_FLOAT32, NCCL_SUM, self.comm, stream), 'ncclAllReduce')
@@ -187,7 +215,8 @@ class Communicator:
 
     def close(self):
         if self.comm is not None:
-            torch.cuda.synchronize(self.device)
+            if self.device.type == 'cuda':
+                torch.cuda.synchronize(self.device)
             _rccl().ncclCommDestroy(self.comm)
             self.comm = None
             self.direct = False

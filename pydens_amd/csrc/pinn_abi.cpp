@@ -62,8 +62,6 @@ struct FitCapture { const PinnFitCtrl* ctrl; int k; };
 thread_local FitCapture g_fit_capture = {nullptr, 0};
 // set by pinn_fit_steps around the step of iteration k < K - 1: its reduction launch also draws the batch of iteration k + 1
 thread_local PinnNextBatch g_fit_next = {nullptr, 0, {}, 0u, 0u, 0ull};
-int g_pinn_max_per_cu = 4;          // pinn_debug_max_wgs_per_cu
-int g_pinn_prepass_in_kernel = 1;   // debug switch: 0 = x-only pre-pass as its own launch (pinn_aux_kernel)
 int g_pinn_debug_flags = 0;         // -DPINN_DEBUG_ABI builds: pinn_debug_set_flags
 }
 
@@ -81,6 +79,11 @@ struct pinn_net {
     void* fit_graph_exec;
     unsigned long long fit_graph_key[4];
     int fit_graph_k;
+    // diagnostics of THIS descriptor (pinn_debug_*: tests run one net at 1 workgroup per CU, with a separate pre-pass launch, with a
+    // tiny slab budget -- a second Solver in the same process keeps its own planning)
+    int max_per_cu;                 // pinn_debug_max_wgs_per_cu (default 4)
+    int prepass_in_kernel;          // pinn_debug_prepass_in_kernel (default 1)
+    size_t wgx_chunk_bytes;         // pinn_debug_wgx_chunk_bytes (default PINN_WGX_CHUNK_DEFAULT)
 };
 
 namespace {
@@ -97,7 +100,7 @@ wgrad_fn wgrad_launcher_for(int hp) {
 
 // WGX kernels keep the saved jets and gz of EVERY tile of a launch in HBM (44 B per point, layer and unit at S = 4): a
 // batch larger than this many bytes of slab goes through the kernels chunk by chunk (gradients accumulate in the reduction)
-size_t g_wgx_chunk_bytes = (size_t)6656 << 20;
+constexpr size_t PINN_WGX_CHUNK_DEFAULT = (size_t)6656 << 20;
 
 launch_fn launcher_for(int hp) {
     switch (hp) {
@@ -195,7 +198,7 @@ int make_plan(const pinn_net* net, int64_t n_points, int nd, int n2, Plan* plan,
     plan->wt_floats_per_wg = (size_t)info[5];
     const int64_t ntiles = (n_points + 15) / 16;
     const int64_t wg_tiles = (ntiles + info[4] - 1) / info[4];       // a two-team workgroup streams two tiles at a time
-    if (info[3] > g_pinn_max_per_cu) info[3] = g_pinn_max_per_cu;
+    if (info[3] > net->max_per_cu) info[3] = net->max_per_cu;
     plan->per_cu = (int)info[3];
     int64_t grid = (int64_t)device_cus(net) * info[3];
     const int64_t teams = info[10] > 0 ? info[10] : 1;              // a two-team workgroup streams two tiles at a time
@@ -226,7 +229,7 @@ int make_plan(const pinn_net* net, int64_t n_points, int nd, int n2, Plan* plan,
         // whole sweeps of the persistent workgroups per chunk
         const size_t per_tile = (plan->slab_vec4_per_wg + plan->gz_vec4_per_tile) * 16;
         const int64_t sweep = plan->grid2 > plan->grid ? plan->grid2 : plan->grid;
-        int64_t chunk = (int64_t)(g_wgx_chunk_bytes / (per_tile ? per_tile : 1)) / sweep * sweep;
+        int64_t chunk = (int64_t)(net->wgx_chunk_bytes / (per_tile ? per_tile : 1)) / sweep * sweep;
         if (chunk < sweep) chunk = sweep;
         plan->chunk_tiles = chunk < wg_tiles ? chunk : wg_tiles;
     }
@@ -383,19 +386,22 @@ const char* pinn_last_kernel_name(void) { return g_pinn_last_kernel_name; }
 
 const char* pinn_last_wgrad_kernel_name(void) { return g_pinn_last_wgrad_name; }
 
-int pinn_debug_prepass_in_kernel(int enable) {
-    g_pinn_prepass_in_kernel = enable ? 1 : 0;
+int pinn_debug_prepass_in_kernel(pinn_t* net, int enable) {
+    if (!net) return fail("null argument");
+    net->prepass_in_kernel = enable ? 1 : 0;
     return 0;
 }
 
-int pinn_debug_wgx_chunk_bytes(long long bytes) {
-    g_wgx_chunk_bytes = bytes > 0 ? (size_t)bytes : ((size_t)6656 << 20);
+int pinn_debug_wgx_chunk_bytes(pinn_t* net, long long bytes) {
+    if (!net) return fail("null argument");
+    net->wgx_chunk_bytes = bytes > 0 ? (size_t)bytes : PINN_WGX_CHUNK_DEFAULT;
     return 0;
 }
 
-int pinn_debug_max_wgs_per_cu(int cap) {
-    const int before = g_pinn_max_per_cu;
-    g_pinn_max_per_cu = (cap <= 0 || cap > 4) ? 4 : cap;
+int pinn_debug_max_wgs_per_cu(pinn_t* net, int cap) {
+    if (!net) return -1;
+    const int before = net->max_per_cu;
+    net->max_per_cu = (cap <= 0 || cap > 4) ? 4 : cap;
     return before;
 }
 
@@ -498,6 +504,7 @@ int pinn_create_ex(const int* layer_dims, int n_layers, const int* acts, int n_s
     pinn_net* net = new (std::nothrow) pinn_net();
     if (!net) return fail("out of memory");
     memset(net, 0, sizeof(*net));
+    net->max_per_cu = 4; net->prepass_in_kernel = 1; net->wgx_chunk_bytes = PINN_WGX_CHUNK_DEFAULT;
     net->n_layers = n_layers; net->act = act; net->ndims = ndims; net->nparams = nparams;
     for (int a = 0; a + 1 < n_layers; ++a) {
         net->act_codes[a >> 4] |= (unsigned long long)acts[a] << (4 * (a & 15));
@@ -629,7 +636,7 @@ static int run_train(pinn_t* net, PinnKArgs* a, const Plan& plan, int nd, float*
     if (aux_bytes) {
         float* aux = reinterpret_cast<float*>(ws + part_bytes + slab_bytes);
         a->aux = aux;
-        if (g_pinn_prepass_in_kernel) {
+        if (net->prepass_in_kernel) {
             a->pre = *pre;          // evaluated in the prologue of the tile kernel: one launch (and one dependent-launch gap) less
             int nregs = a->d;
             for (int i = 0; i < pre->n_ops; ++i) {
@@ -686,7 +693,7 @@ static int run_train(pinn_t* net, PinnKArgs* a, const Plan& plan, int nd, float*
     if (g_profile && !pe) return fail("hipEventCreate failed");
     if (pe) pe->have_wgrad = false;
 #endif
-    // one pass (any non-WGX kernel; a WGX batch whose slabs fit g_wgx_chunk_bytes) or chunk by chunk: tile kernel ->
+    // one pass (any non-WGX kernel; a WGX batch whose slabs fit the net's wgx_chunk_bytes) or chunk by chunk: tile kernel ->
     // weight-gradient kernel -> reduction of the partial rows, later chunks ADD into `grads`, Adam rides in the last reduction
     for (int64_t t0 = 0; t0 < plan.ntiles || t0 == 0; t0 += plan.chunk_tiles) {
         const bool last = t0 + plan.chunk_tiles >= plan.ntiles;
@@ -948,8 +955,9 @@ int pinn_fit_steps_graph(pinn_t* net, const pinn_residual_t* residual, float* pa
     key_mix(key, residual, sizeof(*residual));
     const void* ptrs[] = {params, xs, grads, exp_avg, exp_avg_sq, mask, step_ptr, workspace, ctrl, stream};
     key_mix(key, ptrs, sizeof(ptrs));
-    const long long ints[] = {(long long)n_points, (long long)seed, nd, n2, (long long)workspace_bytes, net->gemm_mode, g_pinn_max_per_cu,
-                              g_pinn_prepass_in_kernel, (long long)g_wgx_chunk_bytes};
+    // (not the sampler's key `seed`: it travels through the control block, so the chunk recorded by one fit call is replayed by the next)
+    const long long ints[] = {(long long)n_points, nd, n2, (long long)workspace_bytes, net->gemm_mode, net->max_per_cu,
+                              net->prepass_in_kernel, (long long)net->wgx_chunk_bytes};
     key_mix(key, ints, sizeof(ints));
     const float flts[] = {ic_const, lr, beta1, beta2, eps};
     key_mix(key, flts, sizeof(flts));
@@ -988,6 +996,7 @@ int pinn_fit_steps_graph(pinn_t* net, const pinn_residual_t* residual, float* pa
             if (!crc) crc = pinn_residual_adam_step(net, residual, params, xs, n_points, dir_cols, nd, n2, nullptr, ic_const, grads, exp_avg,
                                                     exp_avg_sq, mask, step_ptr, 1, lr, beta1, beta2, eps, loss_history, workspace,
                                                     workspace_bytes, cs);
+            g_fit_next.n = 0;       // (as in the eager loop: the LAST reduction of a chunk draws nothing -- ADVICE r4)
         }
         g_fit_capture = {nullptr, 0};
         g_fit_next.n = 0;
@@ -1009,6 +1018,7 @@ int pinn_fit_steps_graph(pinn_t* net, const pinn_residual_t* residual, float* pa
     }
     PinnFitCtrlArgs ca;
     ca.c.call_index0 = call_index0; ca.c.loss_base = loss_history; ca.c.step0 = step0; ca.c.pad = 0;
+    ca.c.k0 = (unsigned)(seed & 0xffffffffull); ca.c.k1 = (unsigned)(seed >> 32);
     for (int k = 0; k < PINN_FIT_CHUNK_MAX; ++k) {
         ca.c.step_size[k] = 0.0f; ca.c.bc2_sqrt[k] = 1.0f;
         if (k < k_steps) pinn_adam_scalars((double)(step0 + k), lr, beta1, beta2, &ca.c.step_size[k], &ca.c.bc2_sqrt[k]);

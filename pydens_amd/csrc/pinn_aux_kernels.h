@@ -142,13 +142,16 @@ struct PinnFitCtrl {
     unsigned long long call_index0;     // Philox batch counter of iteration 0 of the chunk
     float* loss_base;                   // entry 0 of the chunk in the loss history
     int step0, pad;                     // Adam step number of iteration 0
+    unsigned k0, k1;                    // Philox key of the fit call's sampler (round 5: the key changes per fit call; in the control
+                                        // block, not baked into the graph's nodes, a recorded chunk survives across fit calls)
     float step_size[PINN_FIT_CHUNK_MAX], bc2_sqrt[PINN_FIT_CHUNK_MAX];      // pinn_adam_scalars per iteration (computed on the host in
                                                                              // double, as for the eager loop: bit-identical updates)
 };
 struct PinnFitCtrlArgs { PinnFitCtrl c; };
 PINN_GLOBAL void PINN_LAUNCH_BOUNDS(128) pinn_fit_ctrl_kernel(PinnFitCtrl* dst, PinnFitCtrlArgs a) {
     const int t = PINN_TID;
-    if (t == 0) { dst->call_index0 = a.c.call_index0; dst->loss_base = a.c.loss_base; dst->step0 = a.c.step0; dst->pad = 0; }
+    if (t == 0) { dst->call_index0 = a.c.call_index0; dst->loss_base = a.c.loss_base; dst->step0 = a.c.step0; dst->pad = 0;
+                  dst->k0 = a.c.k0; dst->k1 = a.c.k1; }
     if (t < PINN_FIT_CHUNK_MAX) { dst->step_size[t] = a.c.step_size[t]; dst->bc2_sqrt[t] = a.c.bc2_sqrt[t]; }
 }
 
@@ -186,9 +189,10 @@ pinn_reduce_kernel(const float* partials, int n_wg, int p_core, float* grads, in
     // (same generator, same counters as pinn_sample_kernel: bit-identical batches), which saves the iteration a dependent launch
     if (next.n > 0) {
         unsigned long long call = next.call;
-        if (ctrl) call = ctrl->call_index0 + (unsigned long long)(ctrl_k + 1);
+        unsigned nk0 = next.k0, nk1 = next.k1;
+        if (ctrl) { call = ctrl->call_index0 + (unsigned long long)(ctrl_k + 1); nk0 = ctrl->k0; nk1 = ctrl->k1; }
         for (long long i = (long long)PINN_BID * 1024 + tid; i < next.n; i += (long long)PINN_NBLK * 1024)
-            pinn_sample_point(next.xs, i, next.spec, next.k0, next.k1, (unsigned)(call & 0xffffffffull), (unsigned)(call >> 32));
+            pinn_sample_point(next.xs, i, next.spec, nk0, nk1, (unsigned)(call & 0xffffffffull), (unsigned)(call >> 32));
     }
 }
 
@@ -270,6 +274,7 @@ pinn_sample_kernel(float* xs, long long n, PinnSampleSpec spec, unsigned k0, uns
     if (ctrl) {             // (graph replay: the batch counter of this iteration)
         const unsigned long long call = ctrl->call_index0 + (unsigned long long)ctrl_k;
         call_lo = (unsigned)(call & 0xffffffffull); call_hi = (unsigned)(call >> 32);
+        k0 = ctrl->k0; k1 = ctrl->k1;
     }
     pinn_sample_point(xs, i, spec, k0, k1, call_lo, call_hi);
 }

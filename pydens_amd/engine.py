@@ -122,8 +122,9 @@ def bind(lib):
     lib.pinn_last_wgrad_kernel_name.restype = ctypes.c_char_p
     if hasattr(lib, 'pinn_debug_phase_buffer'):                  # -DPINN_DEBUG_ABI experiment builds only
         lib.pinn_debug_phase_buffer.argtypes = [vp]
-    lib.pinn_debug_wgx_chunk_bytes.argtypes = [ctypes.c_longlong]
-    lib.pinn_debug_max_wgs_per_cu.argtypes = [ctypes.c_int]
+    lib.pinn_debug_wgx_chunk_bytes.argtypes = [vp, ctypes.c_longlong]
+    lib.pinn_debug_max_wgs_per_cu.argtypes = [vp, ctypes.c_int]
+    lib.pinn_debug_prepass_in_kernel.argtypes = [vp, ctypes.c_int]
     lib.pinn_last_launch_info.argtypes = [ctypes.POINTER(ctypes.c_int32)]
     lib.pinn_debug_fit_graph_stats.argtypes = [ctypes.POINTER(ctypes.c_int32)]
     for name in ('pinn_create', 'pinn_create_ex', 'pinn_destroy', 'pinn_layout', 'pinn_jet_forward', 'pinn_jet_backward',
@@ -228,7 +229,7 @@ class Net:
         if os.environ.get('PYDENS_AMD_GEMM'):
             self.set_gemm_mode(os.environ['PYDENS_AMD_GEMM'])
         if os.environ.get('PYDENS_AMD_WGX_CHUNK_MB'):           # experiments: slab budget of the widths >= 128 (pinn_debug_wgx_chunk_bytes)
-            self.lib.pinn_debug_wgx_chunk_bytes(int(float(os.environ['PYDENS_AMD_WGX_CHUNK_MB']) * (1 << 20)))
+            self.lib.pinn_debug_wgx_chunk_bytes(self.handle, int(float(os.environ['PYDENS_AMD_WGX_CHUNK_MB']) * (1 << 20)))
 
     def set_gemm_mode(self, mode):
         """ 'fp32' (default: exact-fp32 MFMA) or 'bf16x3' (fp32 operands as three bf16, six products, fp32 accumulate: the

@@ -229,15 +229,16 @@ class KernelBlock(nn.Sequential):
         if field is not None:
             pts, value = field
             if xs is not pts:
-                # a forward() that hands over a copy of its argument (`xs.float()`, `.contiguous()`): compared ONCE per tensor
-                # (data pointer, shape, version) -- the full compare is an N x d pass and a device sync, and the generic path
-                # evaluates the equation in every iteration
-                key = (xs.data_ptr(), tuple(xs.shape), xs._version, pts.data_ptr(), pts._version)
-                if getattr(model, '_same_points_key', None) != key:
-                    if xs.shape != pts.shape or not torch.equal(xs.detach(), pts.detach()):
-                        raise NotImplementedError('a custom forward() may call self.conv_block only on the batch of points it was given '
-                                                  '(inputs transformed in front of the net are not what the HIP kernels compute)')
-                    model._same_points_key = key
+                # a forward() that hands over a view or a copy of its argument. The SAME MEMORY seen through the same shape and strides
+                # (`xs[:, :]`, `xs.view_as(xs)`) is the batch by construction: no compare. A real copy (`xs.clone()`, `torch.cat(cols, 1)`)
+                # is another buffer whose content only a compare can vouch for -- in every call: the caching allocator hands a fresh
+                # temporary the address of the last one, so a remembered verdict would keep accepting `xs * self.scale` after `scale`
+                # moved away from 1 (the compare is an N x d pass + a device sync, paid only by forwards that copy)
+                same_memory = (xs.data_ptr() == pts.data_ptr() and xs.shape == pts.shape and xs.stride() == pts.stride()
+                               and xs.dtype == pts.dtype and xs.device == pts.device)
+                if not same_memory and (xs.shape != pts.shape or not torch.equal(xs.detach(), pts.detach())):
+                    raise NotImplementedError('a custom forward() may call self.conv_block only on the batch of points it was given '
+                                              '(inputs transformed in front of the net are not what the HIP kernels compute)')
             return value
         xs = xs.to(device=model.flat.device, dtype=torch.float32).contiguous()
         return _ModelForward.apply(model._anchor, xs, model)

@@ -34,14 +34,29 @@ class FlatAdam:
             raise NotImplementedError('the HIP Adam kernel implements plain Adam (lr, betas, eps); got '
                                       f'weight_decay={weight_decay}, amsgrad={amsgrad}, {kwargs}')
         self.model, self.lr, self.betas, self.eps = model, lr, betas, eps
-        self.exp_avg = torch.zeros_like(model.flat)
-        self.exp_avg_sq = torch.zeros_like(model.flat)
-        self.step_count = torch.zeros(1, dtype=torch.int32, device=model.flat.device)
+        # the moment buffers and the device step counter belong to the MODEL and are zeroed here: every fit call builds a fresh
+        # optimizer (reference :419-422) -- at the same device addresses, so that the launch graph a previous fit call recorded
+        # (pinn_fit_steps_graph keys on the addresses its nodes carry) is replayed instead of re-recorded. One live
+        # FlatAdam per model: the Solver never keeps an old one.
+        state = getattr(model, '_adam_state', None)
+        if state is None or state[0].shape != model.flat.shape or state[0].device != model.flat.device:
+            state = model._adam_state = (torch.zeros_like(model.flat), torch.zeros_like(model.flat),
+                                         torch.zeros(1, dtype=torch.int32, device=model.flat.device))
+        else:
+            for t in state:
+                t.zero_()
+        self.exp_avg, self.exp_avg_sq, self.step_count = state
         self.t = 0                  # host copy of the step counter (the fused single-rank step passes it by value)
         self.mask = None
 
     def refresh(self):
-        self.mask = self.model.trainable_mask()
+        new = self.model.trainable_mask()
+        buf = getattr(self.model, '_adam_mask', None)         # (same address from fit to fit, like the moment buffers)
+        if buf is None or buf.shape != new.shape or buf.device != new.device:
+            self.model._adam_mask = buf = new
+        else:
+            buf.copy_(new)
+        self.mask = buf
 
     def step(self, grads, loss_out=None, stream=None):
         """ loss_out: device address that receives grads[off_loss] in the same launch (the fit's loss history) """
@@ -671,7 +686,7 @@ class Solver:
                 #  0.072 -> 0.081 at 65 536 -- the eager loop stays)
                 self._fused_terms_step(xs, loss_terms, nums_constraints, world, stream=stream)
             else:
-                self._generic_step_auto(xs, loss_terms, nums_constraints, criterion, world)
+                self._generic_step_auto(xs, loss_terms, nums_constraints, criterion, world, remaining=niters - it)
             if world > 1:
                 self._all_reduce(stream)                # flat [p_total]: network, log_scale, loss slot, V slots
             if flat_adam:
@@ -704,7 +719,10 @@ class Solver:
         comb_w = self.residual_plan.comb_w if self.residual_plan is not None else None
         n2 = spec.n2p if comb_w is None else 1
         ws = model.workspace(batch, spec.nd, spec.n2p)
-        xs = torch.empty((batch, model.total), dtype=torch.float32, device=self.device)
+        # (the batch buffer is kept per shape: its address is part of what a recorded chunk carries)
+        xs = self.__dict__.setdefault('_fit_xs', {}).get((batch, model.total))
+        if xs is None or xs.device != model.flat.device:
+            xs = self._fit_xs[(batch, model.total)] = torch.empty((batch, model.total), dtype=torch.float32, device=self.device)
         own = sampler.device_key() if (sampler is not None and hasattr(sampler, 'device_key')) else None
         rank, _ = self._world()
         # small batches (the latency regime): each chunk as ONE replayable launch graph; the control block the kernels read their
@@ -768,12 +786,22 @@ class Solver:
                                 inv_n_global=1.0 / n_global, stream=stream)
 
     GENERIC_GRAPH_WARMUP = 3    # eager steps in front of the recording (instantiations, workspaces, autograd buffers settle)
+    GENERIC_GRAPH_MIN_REPLAYS = 48      # a recording (device synchronise, gc, allocator trim inside torch.cuda.graph) is only made when at
+                                        # least this many iterations of the fit call are left to replay it (short fits in a loop)
+    GENERIC_GRAPH_CHECK_EVERY = 64      # every this many replays the step is ALSO run eagerly on the same batch and compared bit for bit
 
-    def _graph_step(self, xs, key, run, enabled=True):
+    def _graph_step(self, xs, key, run, enabled=True, remaining=None):
         """ `run(points)` -- the gradient part of one iteration, everything between drawing the batch and the optimizer step -- replayed
         as ONE launch graph: recorded after a few eager iterations on a static copy of the batch (torch.cuda.graph; the library's
         launches go to the current stream, i.e. into the recording) and replayed with the next batch copied in. Same kernels, same
-        order: bit-identical. A step whose torch code cannot be captured (data-dependent shapes, host reads) stays eager for good. """
+        order: bit-identical. A step whose torch code cannot be captured (data-dependent shapes, host reads) stays eager for good.
+
+        What a recording FREEZES: the user's equation / constraint Python runs while the graph is recorded and not again -- host-side
+        state it reads (closure scalars, numpy RNG used for arithmetic) keeps the value it had then, until the next fit call (graphs
+        are per fit call). The reference re-evaluates that Python every iteration. Guard: every GENERIC_GRAPH_CHECK_EVERY replays the
+        same batch is also stepped eagerly and the gradient buffers are compared bit for bit (the kernels are deterministic: a
+        difference means the Python changed its mind); on a mismatch the eager result is kept and the fit goes on eagerly.
+        `PYDENS_AMD_STEP_GRAPH=0` turns recording off altogether. """
         st = getattr(self, '_generic_graph', None)
         if not (enabled and xs.is_cuda and os.environ.get('PYDENS_AMD_STEP_GRAPH', os.environ.get('PYDENS_AMD_GENERIC_GRAPH', '1')) != '0'
                 and not (st and st.get('failed') and st['key'] == key)):
@@ -791,6 +819,8 @@ class Solver:
                     # _generic_step_auto)
                     st['failed'], st['error'] = True, 'the step differentiates inside its torch code (D by autograd): kept eager'
                 return out
+            if remaining is not None and remaining < self.GENERIC_GRAPH_MIN_REPLAYS:
+                return run(xs)                  # (too few iterations left to pay for a recording)
             try:
                 st['xs'] = xs.clone()
                 graph = torch.cuda.CUDAGraph()
@@ -804,8 +834,16 @@ class Solver:
         st['xs'].copy_(xs)
         st['graph'].replay()
         st['replays'] += 1
+        if st['replays'] % self.GENERIC_GRAPH_CHECK_EVERY == 0:
+            replayed = self.grads.clone()
+            run(xs)
+            if not torch.equal(replayed, self.grads):
+                import warnings
+                warnings.warn('pydens_amd: the recorded step no longer matches the equation / constraint code (host-side state it reads '
+                              'changed during fit); continuing without the launch graph', RuntimeWarning)
+                st['failed'], st['graph'], st['error'] = True, None, 'replay differs from the eager step'
 
-    def _generic_step_auto(self, xs, loss_terms, nums_constraints, criterion, world):
+    def _generic_step_auto(self, xs, loss_terms, nums_constraints, criterion, world, remaining=None):
         """ the generic step -- pinn_jet_forward -> the user's torch code and its autograd sweep (a few dozen small kernels the
         interpreter launches one by one) -> pinn_jet_backward, constraint terms (the model on fixed points) included -- as a launch
         graph in a single process (direction groups included). Kept eager: data-parallel steps (the all-reduce sits between the halves)
@@ -816,7 +854,8 @@ class Solver:
         ok = (world == 1 and not self.custom_forward and not self.needs_x_grad
               and not (model.initial_condition is not None and model.ic_constant is None))
         return self._graph_step(xs, ('generic', tuple(xs.shape), id(criterion), id(self._eq), tuple(loss_terms)),
-                                lambda pts: self._generic_step(pts, loss_terms, nums_constraints, criterion, world), enabled=ok)
+                                lambda pts: self._generic_step(pts, loss_terms, nums_constraints, criterion, world), enabled=ok,
+                                remaining=remaining)
 
     def _fused_terms_step(self, xs, loss_terms, nums_constraints, world, stream=None):
         """ summed loss (:441-457) on the fused kernels: the equation term stores gradient + loss, every constraint term adds its own """

@@ -1,6 +1,9 @@
 """ Data-parallel path: one process per device, each rank steps on its shard, ONE all-reduce of the flat
-gradient buffer per iteration. Covered on CPU with gloo, world_size 2, through the emulated kernels: two ranks on
-half batches must follow the single-process trajectory on the full batches (same mean-square loss, same Adam). """
+gradient buffer per iteration. Covered on CPU with gloo through the emulated kernels at world sizes 1, 2, 4 and 8 (SURVEY section 4
+iv: 1 / 2 / 8): R ranks on their shares of every batch must follow the single-process trajectory on the full batches (same
+mean-square loss, same Adam), also when the shares are uneven (1 003 points over 4 / 8 ranks, 99 over 2). The communicator's
+bounded bootstrap (ncclCommInitRank that never returns on one rank -> every rank falls back together) is driven with a stand-in
+library on a gloo group. """
 import os
 import socket
 import sys
@@ -52,13 +55,16 @@ def _variables(solver):
 def _problem(path, pa, lib):
     """ -> (solver, batches [steps, N, d], fit kwargs, start parameters) """
     from helpers import make_solver
-    if path in ('fused', 'generic', 'fused_uneven', 'generic_uneven'):
+    if path in ('fused', 'generic', 'fused_uneven', 'generic_uneven', 'fused_1003', 'generic_1003'):
         g = Golden('cfg1')
         _, solver = make_solver('cfg1', pa, lib=lib, device='cpu')
         if path.startswith('generic'):
             solver.program = None
         # `_uneven`: 99 points per iteration on two ranks -- shares of 50 and 49 points, weighted by the GLOBAL count
         points = g.points[:3, :99] if path.endswith('_uneven') else g.points[:3]
+        if path.endswith('_1003'):
+            # 1 003 points per iteration: 4 ranks own 251 / 251 / 251 / 250 of them, 8 ranks 126 x 3 / 125 x 5 (ragged last tiles everywhere)
+            points = np.random.RandomState(1003).rand(2, 1003, 2).astype(np.float32)
         return solver, np.ascontiguousarray(points), dict(lr=g.lr), g.params
     if path == 'custom_forward_generic':
         # the model plug-in seam with a forward() of its own (model_torch.py:52-54): bare network on the kernels, the ansatz (with
@@ -91,7 +97,7 @@ def export_params_of(solver):
     return export_params(solver)
 
 
-def _run(path):
+def _run(path, world=2):
     import ctypes
     sys.path.insert(0, os.path.join(HERE, 'emu'))
     import build_emu
@@ -106,8 +112,8 @@ def _run(path):
     want_losses = np.array([float(v) for v in single.losses])
     want, want_vars = export_params(single), _variables(single)
     with tempfile.TemporaryDirectory() as tmp:
-        mp.spawn(_worker, args=(2, _free_port(), tmp, path), nprocs=2, join=True)
-        for rank in range(2):
+        mp.spawn(_worker, args=(world, _free_port(), tmp, path), nprocs=world, join=True)
+        for rank in range(world):
             z = np.load(os.path.join(tmp, f'rank{rank}.npz'))
             np.testing.assert_allclose(z['losses'], want_losses, rtol=1e-5)      # loss slot is all-reduced too
             np.testing.assert_allclose(z['variables'], want_vars, rtol=1e-5, atol=1e-6)
@@ -138,3 +144,100 @@ def test_two_ranks_constraint_term_and_variable_generic():
 
 def test_two_ranks_model_with_its_own_forward():
     _run('custom_forward_generic')
+
+
+def test_one_rank_group_equals_single_process():
+    _run('fused', world=1)
+    _run('generic', world=1)
+
+
+def test_four_ranks_uneven_shares_of_1003_points():
+    _run('fused_1003', world=4)
+    _run('generic_1003', world=4)
+
+
+def test_eight_ranks_uneven_shares_of_1003_points():
+    _run('fused_1003', world=8)
+    _run('generic_1003', world=8)
+
+
+def test_eight_ranks_constraint_term_and_variable():
+    _run('constraint_fused', world=8)
+
+
+# ---- the communicator's bounded bootstrap -----------------------------------------------------------------------------------------
+class _FakeRccl:
+    """ stand-in for librccl with the calling convention comm.py uses: rank `stuck` never returns from ncclCommInitRank in time """
+    def __init__(self, rank, stuck, log):
+        self.rank, self.stuck, self.log = rank, stuck, log
+
+    def ncclGetUniqueId(self, uid_ref):
+        uid = uid_ref._obj
+        for i in range(128):
+            uid.internal[i] = (i * 7 + 1) & 255
+        return 0
+
+    def ncclCommInitRank(self, comm_ref, world, uid, rank):
+        import time
+        assert bytes(uid.internal) == bytes(((i * 7 + 1) & 255) for i in range(128))          # the id arrived whole on every rank
+        if rank in self.stuck:
+            time.sleep(3.0)                    # (longer than PYDENS_AMD_COMM_TIMEOUT below, short enough for the late-abort check)
+        comm_ref._obj.value = 4242 + rank
+        return 0
+
+    def ncclCommAbort(self, comm):
+        self.log.append(('abort', comm.value))
+        return 0
+
+    def ncclCommDestroy(self, comm):
+        self.log.append(('destroy', comm.value if hasattr(comm, 'value') else comm))
+        return 0
+
+    def ncclGetErrorString(self, rc):
+        return b'fake'
+
+
+def _comm_worker(rank, world, port, out_dir, stuck):
+    import json
+    import time
+    import warnings
+    sys.path.insert(0, os.path.dirname(HERE))
+    import torch.distributed as dist
+    from pydens_amd import comm
+    os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), PYDENS_AMD_COMM_TIMEOUT='1')
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    log = []
+    fake = _FakeRccl(rank, stuck, log)
+    comm._rccl = lambda: fake
+    comm.Communicator._FORCE_DIRECT = True
+    t0 = time.time()
+    with warnings.catch_warnings(record=True) as seen:
+        warnings.simplefilter('always')
+        c = comm.Communicator(torch.device('cpu'))
+    took = time.time() - t0
+    x = torch.full((5,), float(rank + 1))
+    c.all_reduce_(x)                            # the agreed fallback path works on every rank
+    worker, outcome = c._late_init
+    worker.join(10.0)                           # the abandoned call returns later: its thread must abort what it got
+    json.dump({'direct': c.direct, 'reason': c.fallback_reason, 'took': took, 'sum': x.tolist(), 'log': log,
+               'warned': [str(w.message) for w in seen], 'late': bool(outcome.get('aborted_late')), 'describe': c.describe()},
+              open(os.path.join(out_dir, f'comm{rank}.json'), 'w'))
+    dist.destroy_process_group()
+
+
+def test_communicator_bootstrap_timeout_makes_every_rank_fall_back_together():
+    import json
+    world, stuck = 4, (2,)
+    with tempfile.TemporaryDirectory() as tmp:
+        mp.spawn(_comm_worker, args=(world, _free_port(), tmp, stuck), nprocs=world, join=True)
+        for rank in range(world):
+            r = json.load(open(os.path.join(tmp, f'comm{rank}.json')))
+            assert r['direct'] is False and 'timed out' in r['reason'], r
+            assert r['took'] < 2.5, r['took']                       # bounded by PYDENS_AMD_COMM_TIMEOUT, not by the stuck call
+            assert r['sum'] == [float(sum(range(1, world + 1)))] * 5
+            assert any('torch.distributed' in w for w in r['warned'])
+            assert 'fallback' in r['describe']['all_reduce']
+            if rank in stuck:
+                assert r['late'] and ('abort', 4242 + rank) in [tuple(e) for e in r['log']]      # no leaked communicator
+            else:
+                assert ('destroy', 4242 + rank) in [tuple(e) for e in r['log']]                  # made, agreed "failed", destroyed

@@ -595,10 +595,10 @@ def test_streamed_weight_gradient_kernel_chunks_and_paths(pa, emu_lib):
     want = oracle.export_grads()
     try:
         for budget in (0, 1):                               # 0: default budget (one pass); 1 byte: one sweep per chunk
-            emu_lib.pinn_debug_wgx_chunk_bytes(budget)
             for path in ('fused', 'generic'):
                 eq_p, kw = problem(pa.D)
                 solver = pa.Solver(eq_p, **kw, **emu_kwargs(emu_lib))
+                emu_lib.pinn_debug_wgx_chunk_bytes(solver.model.net.handle, budget)      # (per descriptor since round 5)
                 assert solver.model.net.layout.hp == 128
                 load_params(solver, oracle.export_params())
                 if path == 'fused':
@@ -612,7 +612,7 @@ def test_streamed_weight_gradient_kernel_chunks_and_paths(pa, emu_lib):
                     if w is not None:
                         assert rel_l2(got, w) < 1e-4, (budget, path)
     finally:
-        emu_lib.pinn_debug_wgx_chunk_bytes(0)
+        pass            # (the budget belongs to each solver's own descriptor: nothing process-wide to restore)
 
 
 @pytest.mark.parametrize('which', ['poisson', 'poisson_any_activation', 'burgers_any_activation'])
@@ -637,10 +637,10 @@ def test_streamed_weight_gradients_through_skip_connections(pa, emu_lib, which):
     want = oracle.export_grads()
     try:
         for budget in budgets:
-            emu_lib.pinn_debug_wgx_chunk_bytes(budget)
             for path in (('fused',) if (heavy and which == 'poisson' and budget == 1) else ('fused', 'generic')):
                 eq_p, kw = _layout_problems(pa.D, torch, which, net)
                 solver = pa.Solver(eq_p, **kw, **emu_kwargs(emu_lib))
+                emu_lib.pinn_debug_wgx_chunk_bytes(solver.model.net.handle, budget)
                 assert solver.model.net.layout.hp == 128
                 load_params(solver, oracle.export_params())
                 if path == 'fused':
@@ -657,7 +657,7 @@ def test_streamed_weight_gradients_through_skip_connections(pa, emu_lib, which):
                     if w is not None:
                         assert rel_l2(got, w) < 1e-4, (budget, path)
     finally:
-        emu_lib.pinn_debug_wgx_chunk_bytes(0)
+        pass            # (the budget belongs to each solver's own descriptor: nothing process-wide to restore)
 
 
 def test_parametric_heat_equation_with_domain(pa, emu_lib):

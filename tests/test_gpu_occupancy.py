@@ -132,13 +132,13 @@ def run_case(pa, name, n_points, solver_kwargs=None, on_device=True):
         again = step()
         assert torch.equal(first, again), f'{name}: run-to-run different gradients on {info}'
     # ... and the same step on ONE workgroup per CU: another summation order, nothing more
-    before = lib.pinn_debug_max_wgs_per_cu(1)
+    before = lib.pinn_debug_max_wgs_per_cu(solver.model.net.handle, 1)
     try:
         # (the workspace was sized for the larger grid: partial rows and slabs of a smaller one fit)
         one = step()
         assert launch_info(solver)['per_cu'] == 1
     finally:
-        lib.pinn_debug_max_wgs_per_cu(before)
+        lib.pinn_debug_max_wgs_per_cu(solver.model.net.handle, before)
     a, b = first[:lay.p_core].double().cpu().numpy(), one[:lay.p_core].double().cpu().numpy()
     assert np.linalg.norm(a - b) <= 2e-6 * np.linalg.norm(b), (np.linalg.norm(a - b), np.linalg.norm(b))
     return info

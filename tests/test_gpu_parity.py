@@ -669,11 +669,11 @@ def test_streamed_weight_gradients_chunk_by_chunk_on_the_gpu(pa, width):
     solver._fused_step(xs, 1)
     one_pass = solver.grads.clone()
     try:
-        lib.pinn_debug_wgx_chunk_bytes(1)
+        lib.pinn_debug_wgx_chunk_bytes(solver.model.net.handle, 1)
         solver.model._workspaces.clear()
         solver._fused_step(xs, 1)
     finally:
-        lib.pinn_debug_wgx_chunk_bytes(0)
+        lib.pinn_debug_wgx_chunk_bytes(solver.model.net.handle, 0)
         solver.model._workspaces.clear()
     lay = solver.model.net.layout
     assert rel_l2(solver.grads[:lay.p_core].cpu().numpy(), one_pass[:lay.p_core].cpu().numpy()) < 2e-6
@@ -1032,6 +1032,7 @@ def test_generic_fit_as_a_launch_graph_follows_the_eager_loop_bit_for_bit(pa, wh
     parameter and the Adam state equal the eager loop's bit for bit; a second fit records anew. """
     def run(graph):
         monkeypatch.setenv('PYDENS_AMD_STEP_GRAPH', '1' if graph else '0')
+        monkeypatch.setattr(pa.Solver, 'GENERIC_GRAPH_MIN_REPLAYS', 0)      # (these fits are short on purpose: record whatever is left)
         torch.manual_seed(22)
         if which == 'cfg2_forced_generic':
             cfg, solver = make_solver('cfg2', pa)
@@ -1068,6 +1069,7 @@ def test_generic_terms_with_a_constraint_as_a_launch_graph_follow_the_eager_loop
 
     def run(graph):
         monkeypatch.setenv('PYDENS_AMD_STEP_GRAPH', '1' if graph else '0')
+        monkeypatch.setattr(pa.Solver, 'GENERIC_GRAPH_MIN_REPLAYS', 0)      # (these fits are short on purpose: record whatever is left)
         torch.manual_seed(23)
         solver = pa.Solver(odevar, ndims=1, initial_condition=1, constraints=lambda f, x: f(torch.tensor([0.5])))
         solver.use_fused = False
@@ -1115,6 +1117,7 @@ def test_generic_launch_graph_covers_direction_groups_and_leaves_inner_autograd_
 
     def run(which, graph):
         monkeypatch.setenv('PYDENS_AMD_STEP_GRAPH', '1' if graph else '0')
+        monkeypatch.setattr(pa.Solver, 'GENERIC_GRAPH_MIN_REPLAYS', 0)      # (these fits are short on purpose: record whatever is left)
         torch.manual_seed(24)
         solver = build(which)
         solver.fit(niters=12, batch_size=600, lr=0.005)
@@ -1130,6 +1133,57 @@ def test_generic_launch_graph_covers_direction_groups_and_leaves_inner_autograd_
         assert replays == 0 and err is None, (which, replays, err)
 
 
+def test_generic_launch_graph_policy_short_fits_stay_eager_and_replays_are_rechecked(pa, monkeypatch):
+    """ round 5: a recording is only made when enough iterations of the fit call are left to replay it -- `for epoch:
+    solver.fit(niters=20)` must not pay a capture per call -- and every GENERIC_GRAPH_CHECK_EVERY replays the batch is also stepped
+    eagerly and compared bit for bit: an equation whose host-side state changes during the fit (a closure scalar) is caught, the
+    fit goes on eagerly and ends where the eager loop ends. """
+    monkeypatch.setenv('PYDENS_AMD_STEP_GRAPH', '1')
+    torch.manual_seed(25)
+    cfg, solver = make_solver('cfg2', pa)
+    solver.program = None
+    for _ in range(3):
+        solver.fit(niters=20, batch_size=1024, lr=0.005)
+        st = getattr(solver, '_generic_graph', None) or {}
+        assert st.get('graph') is None and st.get('replays', 0) == 0 and not st.get('failed')
+    solver.fit(niters=3 + 130, batch_size=1024, lr=0.005)
+    st = solver._generic_graph
+    assert st['replays'] == 130 and not st['failed'], st.get('error')           # (two bitwise re-checks passed on the way)
+
+    # host-side state that moves during the fit: the recorded step keeps the old value, the re-check notices
+    state = {'k': 5.0}
+
+    def eq(f, x, y):
+        return pa.D(pa.D(f, x), x) + pa.D(pa.D(f, y), y) - state['k'] * torch.sin(np.pi * (x + y))
+
+    class Drift:
+        """ sampler that changes the closure scalar half-way through (the reference re-reads it every iteration) """
+        def __init__(self):
+            self.calls, self.rng = 0, np.random.RandomState(3)
+
+        def sample(self, size):
+            self.calls += 1
+            if self.calls == 40:
+                state['k'] = 7.0
+            return self.rng.rand(size, 2)
+
+    def run(graph):
+        monkeypatch.setenv('PYDENS_AMD_STEP_GRAPH', '1' if graph else '0')
+        state['k'] = 5.0
+        torch.manual_seed(26)
+        s2 = pa.Solver(eq, ndims=2, boundary_condition=1, layout='fa fa f', features=[20, 20, 1], activation='Tanh')
+        s2.program = None
+        s2.fit(niters=140, batch_size=512, sampler=Drift(), lr=0.005)
+        return np.array([float(v) for v in s2.losses]), (getattr(s2, '_generic_graph', None) or {})
+    l_eager, _ = run(False)
+    with pytest.warns(RuntimeWarning, match='no longer matches'):
+        l_graph, st = run(True)
+    assert st['failed'] and st['replays'] == pa.Solver.GENERIC_GRAPH_CHECK_EVERY
+    # before the change and from the re-check on the two loops agree bit for bit; in between the replay used the frozen scalar
+    assert np.array_equal(l_eager[:39], l_graph[:39])
+    assert np.isfinite(l_graph).all() and abs(l_graph[-1] - l_eager[-1]) < 0.5 * abs(l_eager[-1]) + 1.0
+
+
 @pytest.mark.parametrize('batch', [1, 17, 4097])
 def test_launch_graphs_at_tiny_and_boundary_batches(pa, batch, monkeypatch):
     """ a batch below one 16-point tile, one just above it and one just above the fused path's graph threshold: chunk graphs (fused) and
@@ -1137,6 +1191,7 @@ def test_launch_graphs_at_tiny_and_boundary_batches(pa, batch, monkeypatch):
     def run(graph, generic):
         monkeypatch.setenv('PYDENS_AMD_FIT_GRAPH', '1' if graph else '0')
         monkeypatch.setenv('PYDENS_AMD_STEP_GRAPH', '1' if graph else '0')
+        monkeypatch.setattr(pa.Solver, 'GENERIC_GRAPH_MIN_REPLAYS', 0)      # (these fits are short on purpose: record whatever is left)
         torch.manual_seed(3)
         solver = pa.Solver(lambda f, x, y: pa.D(pa.D(f, x), x) + pa.D(pa.D(f, y), y) - 5 * torch.sin(np.pi * (x + y)), ndims=2,
                            boundary_condition=1, layout='fa fa f', features=[20, 20, 1], activation='Tanh')

@@ -39,10 +39,10 @@ def main():
     ap.add_argument('--save', default=None, help='prefix of .npz files with the per-lane dumps of the differing (tile, wave) pairs')
     args = ap.parse_args()
     lib = engine.bind(ctypes.CDLL(args.lib))
-    lib.pinn_debug_max_wgs_per_cu(args.cap)
     torch.manual_seed(0)
     cfg = pc.make_config(args.workload, pa.D, torch, V=pa.V)
     solver = pa.Solver(cfg['equation'], **cfg['solver_kwargs'], lib=lib)
+    lib.pinn_debug_max_wgs_per_cu(solver.model.net.handle, args.cap)
     solver.set_gemm_mode(args.gemm)
     n = min(cfg['n_points'], 131072)
     xs = torch.from_numpy(pc.sample_points(cfg, n, seed=1)).cuda()

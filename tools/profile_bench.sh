@@ -1,12 +1,14 @@
 #!/bin/bash
 # rocprofv3 evidence for ONE bench.py workload (the same command the bench line comes from): kernel trace + stats, then
 # PMC passes, each in its own run (counters never share a run with a trace domain other than --kernel-trace).
+# (--no-parity --no-cold: every launch of a matrix kernel in the profile has the workload's full grid and runs in the settled clock
+#  state, so that rocprofv3's own AverageNs is the duration the bench line prices -- VERDICT r4 item 1)
 # usage: tools/profile_bench.sh <cfg2|cfg3|cfg4|cfg5> <tag> [suffix] [extra bench.py arguments, e.g. --gemm bf16x3]
 #        -> gpurun_out/<tag>/prof_<cfg><suffix>/, summary + JSON for profiles/
 CFG=${1:-cfg2}; TAG=${2:-prof}; SUF=${3:-}; shift 3 2>/dev/null; EXTRA="$@"; OUT=/root/repo/gpurun_out/$TAG/prof_$CFG$SUF; mkdir -p $OUT
 export TMPDIR=/tmp; cd /tmp
 STEPS=30; WARM=5; case $CFG in cfg3|cfg5) STEPS=8; WARM=2;; esac
-CMD="python /root/repo/bench.py --workload $CFG --no-cpu-baseline --no-strong --no-side --steps $STEPS --warmup $WARM $EXTRA"
+CMD="python /root/repo/bench.py --workload $CFG --no-cpu-baseline --no-strong --no-side --no-parity --no-cold --steps $STEPS --warmup $WARM $EXTRA"
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -- $CMD > $OUT/trace.log 2>&1
 rocprofv3 --kernel-trace --output-format csv --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_MFMA SQ_INSTS_VALU SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY GRBM_GUI_ACTIVE -d $OUT/pmc1 -- $CMD > $OUT/pmc1.log 2>&1
 rocprofv3 --kernel-trace --output-format csv --pmc FETCH_SIZE -d $OUT/pmc2 -- $CMD > $OUT/pmc2.log 2>&1

@@ -19,10 +19,10 @@ from pydens_amd import engine   # noqa: E402
 
 def check(workload, lib_path, cap, gemm, n, reps):
     lib = engine.bind(ctypes.CDLL(lib_path))
-    lib.pinn_debug_max_wgs_per_cu(cap)
     torch.manual_seed(0)
     cfg = pc.make_config(workload, pa.D, torch, V=pa.V)
     solver = pa.Solver(cfg['equation'], **cfg['solver_kwargs'], lib=lib)
+    lib.pinn_debug_max_wgs_per_cu(solver.model.net.handle, cap)
     solver.set_gemm_mode(gemm)
     n = n or min(cfg['n_points'], 131072)
     xs = torch.from_numpy(pc.sample_points(cfg, n, seed=1)).cuda()
@@ -50,7 +50,7 @@ def check(workload, lib_path, cap, gemm, n, reps):
         print(f'    scratch canary: {c[0]} tiles read back a tag that is not their own'
               + (f' (first: wanted block {c[1] >> 12} thread {c[1] & 4095}, got block {c[2] >> 12} thread {c[2] & 4095} = {int(c[2]):#x})' if c[0] else ''))
         lib.pinn_debug_phase_buffer(None)
-    lib.pinn_debug_max_wgs_per_cu(0)
+    lib.pinn_debug_max_wgs_per_cu(solver.model.net.handle, 0)
 
 
 def main():

@@ -1,5 +1,8 @@
 """ Summary of tools/profile_bench.sh: per-kernel durations (kernel trace) and per-launch counter means of the step's matrix
-kernels; writes <dir>/pmc.json in the format bench.py's `roofline.traffic` reads (profiles/r02_<cfg>_pmc.json). """
+kernels; writes <dir>/pmc.json in the format bench.py's `roofline.traffic` reads (profiles/r02_<cfg>_pmc.json).
+Round 5: a kernel row holds launches of ONE grid size -- the workload's (the commonest grid of that kernel in the run); launches
+of another grid (bench.py's 4 096-point parity launches when the profile was taken without --no-parity) are listed apart and
+enter no mean, neither durations nor counters (they made AverageNs imply frac 0.992 for cfg5). """
 import csv, glob, json, os, re, sys
 from collections import defaultdict
 
@@ -14,21 +17,34 @@ def short(name):
 
 
 res = {'workload': cfg, 'points_per_launch': BATCH, 'kernels': {}}
+MAIN_GRID = {}          # kernel -> Grid_Size_X (threads) of the workload's launches
 for path in sorted(glob.glob(os.path.join(out, 'trace', '**', '*kernel_trace.csv'), recursive=True)):
-    dur = defaultdict(list)
+    by_grid = defaultdict(lambda: defaultdict(list))
     for row in csv.DictReader(open(path)):
-        dur[short(row['Kernel_Name'])].append(int(row['End_Timestamp']) - int(row['Start_Timestamp']))
+        by_grid[short(row['Kernel_Name'])][int(row.get('Grid_Size_X', 0) or 0)].append(int(row['End_Timestamp']) - int(row['Start_Timestamp']))
+    dur = {}
+    for k, grids in by_grid.items():
+        main = max(grids, key=lambda g: (len(grids[g]), g))       # the workload's grid: the commonest one (ties: the larger)
+        dur[k] = grids[main]
+        MAIN_GRID[k] = main
+        for g, v in grids.items():
+            if g != main and (k.startswith('pinn_tile_kernel') or k.startswith('pinn_wgrad_kernel')):
+                print(f'   (left out of the means: {len(v)} launches of {k} with grid {g} instead of {main}, mean {sum(v) / len(v) / 1e3:.2f} us)')
     print('== kernel trace (rocprofv3 --kernel-trace --stats of bench.py --workload %s)' % cfg)
     for k, v in sorted(dur.items(), key=lambda kv: -sum(kv[1]))[:8]:
         print(f'   {k:90s} calls {len(v):5d}  mean {sum(v) / len(v) / 1e3:10.2f} us  min {min(v) / 1e3:10.2f} us  total {sum(v) / 1e6:9.3f} ms')
         if k.startswith('pinn_tile_kernel') or k.startswith('pinn_wgrad_kernel'):
             res['kernels'].setdefault(k, {})['mean_us'] = sum(v) / len(v) / 1e3
             res['kernels'][k]['calls'] = len(v)
+            res['kernels'][k]['grid_threads'] = MAIN_GRID[k]
 for sub in ('pmc1', 'pmc2', 'pmc3', 'pmc4'):
     for path in sorted(glob.glob(os.path.join(out, sub, '**', '*counter_collection.csv'), recursive=True)):
         vals = defaultdict(lambda: defaultdict(list))
         for row in csv.DictReader(open(path)):
-            vals[short(row['Kernel_Name'])][row['Counter_Name']].append(float(row['Counter_Value']))
+            k = short(row['Kernel_Name'])
+            if k in MAIN_GRID and row.get('Grid_Size') and int(row['Grid_Size']) != MAIN_GRID[k]:
+                continue                    # a launch of another grid (parity check): not this workload's
+            vals[k][row['Counter_Name']].append(float(row['Counter_Value']))
         print(f'== counters ({sub}), per-launch means')
         for k, ctrs in vals.items():
             if not (k.startswith('pinn_tile_kernel') or k.startswith('pinn_wgrad_kernel')):
