@@ -61,6 +61,18 @@ extern "C" {
 #define PINN_ACT_SOFTPLUS 4    /* torch.nn.Softplus (beta 1, threshold 20) */
 #define PINN_ACT_SILU     5    /* torch.nn.SiLU (swish) */
 #define PINN_ACT_GELU     6    /* torch.nn.GELU (erf form) */
+/* round 5 -- the rest of what `getattr(nn, activation)()` commonly names (model_torch.py:159, :164-168), each in its torch DEFAULT form;
+ * derivatives to fourth order from the pre-activation like codes 4-6 (full breadth kernels only) */
+#define PINN_ACT_RELU        7   /* torch.nn.ReLU: derivative z > 0 ? 1 : 0, higher ones 0 (what autograd returns) */
+#define PINN_ACT_LEAKYRELU   8   /* torch.nn.LeakyReLU (negative_slope 0.01) */
+#define PINN_ACT_ELU         9   /* torch.nn.ELU (alpha 1) */
+#define PINN_ACT_SOFTSIGN   10   /* torch.nn.Softsign: z / (1 + |z|) */
+#define PINN_ACT_GELU_TANH  11   /* torch.nn.GELU(approximate='tanh') */
+#define PINN_ACT_MISH       12   /* torch.nn.Mish: z tanh(softplus(z)) */
+#define PINN_ACT_SELU       13   /* torch.nn.SELU */
+#define PINN_ACT_TANHSHRINK 14   /* torch.nn.Tanhshrink: z - tanh z */
+#define PINN_ACT_LOGSIGMOID 15   /* torch.nn.LogSigmoid */
+#define PINN_ACT_LAST       15
 
 typedef struct pinn_net pinn_t;
 
@@ -150,7 +162,9 @@ int pinn_create(const int* layer_dims, int n_layers, int act, int ndims, int npa
 /* General form of the descriptor: per-layer activations and skip connections of the reference's layout strings
  * ('faR fa fa+ f', model_torch.py:143-156).  acts[a], a = 0 .. n_layers-2, is the activation after hidden layer a
  * (PINN_ACT_*).  Skip k adds the output of activation skip_src[k] to the output of activation skip_dst[k]
- * (0 <= src < dst <= n_layers-2, equal widths, intervals not overlapping: dst[k] <= src[k+1]) -- or, with
+ * (0 <= src < dst <= n_layers-2, equal widths; round 5: the intervals may nest or cross -- the reference's 'R' / '+' pair like
+ * brackets -- as long as at most one skip starts and at most one ends at an activation; forward passes of such a net need scratch:
+ * pinn_jet_forward_ws) -- or, with
  * PINN_SKIP_PRE ORed into skip_dst[k], to the pre-activation of hidden layer dst ('+' between 'f' and 'a': the
  * usual residual block act(W h + skip)); with PINN_SKIP_PRE ORed into skip_src[k] the PRE-activation of layer src is what
  * the skip carries ('R' between 'f' and 'a': pre-activation residual blocks). */
@@ -158,6 +172,12 @@ int pinn_create_ex(const int* layer_dims, int n_layers, const int* acts, int n_s
                    const int* skip_dst, int ndims, int nparams, int has_bc, int has_ic, const float* dom_lo,
                    const float* dom_hi, float bc_value, pinn_t** out);
 int pinn_destroy(pinn_t* net);
+/* pinn_jet_forward (below) with caller-owned scratch: a net with NESTED skip connections parks the jets of its outer skip in global
+ * memory between 'R' and '+', in a value-only forward pass too; `workspace` of pinn_workspace_bytes(net, n_points, nd, n2) bytes
+ * (16-byte aligned) covers it. Nets without nested skips ignore the workspace; pinn_jet_forward on a nested net fails with a message. */
+int pinn_jet_forward_ws(pinn_t* net, const float* params, const float* xs, int64_t n_points, const int* dir_cols, int nd,
+                        int n2, const float* ic_streams, float ic_const, float* streams_out, void* workspace, size_t workspace_bytes,
+                        void* stream);
 int pinn_layout(const pinn_t* net, pinn_layout_t* out);
 
 /* Bytes of scratch the step/backward entry points need for n_points (per-workgroup partial gradients +

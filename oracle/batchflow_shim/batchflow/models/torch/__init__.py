@@ -16,6 +16,16 @@ class Sin(nn.Module):
         return torch.sin(x)
 
 
+class Lambda(nn.Module):
+    """ a plain callable as an activation (the docstring at :150 says "Sequence of callables, str") """
+    def __init__(self, fn):
+        super().__init__()
+        self.fn = fn
+
+    def forward(self, x):
+        return self.fn(x)
+
+
 def make_activation(act):
     if isinstance(act, str):
         act = Sin if act == 'Sin' else getattr(nn, act)
@@ -25,6 +35,8 @@ def make_activation(act):
         return act
     if act is torch.sin:
         return Sin()
+    if callable(act):
+        return Lambda(act)
     raise NotImplementedError(f'activation {act!r}')
 
 

@@ -97,6 +97,12 @@ def _build(force, verbose, extra_flags, widths):
             extra = []
         jobs.append((obj, [hipcc, *FLAGS, *WIDTH_FLAGS.get(hp, []), *extra_flags, *extra, f'-DPINN_INST_HP={hp}', '-c',
                            os.path.join(HERE, 'pinn_inst.inc'), '-o', obj]))
+    # second set of full breadth kernels (round 5: all sixteen activations, nested skips -- pinn_inst.inc PINN_INST_ALLACT): a unit of
+    # its own per width, so that the build's wall time stays that of its longest unit
+    for hp in WIDTHS:
+        obj = os.path.join(OBJ, f'inst_hp{hp}_allact.o')
+        jobs.append((obj, [hipcc, *FLAGS, *WIDTH_FLAGS.get(hp, []), *extra_flags, *([] if hp in widths else ['-DPINN_ONLY_BASELINE']),
+                           f'-DPINN_INST_HP={hp}', '-DPINN_INST_ALLACT=1', '-c', os.path.join(HERE, 'pinn_inst.inc'), '-o', obj]))
     # split-bf16 kernels of width 64 (pinn_inst.inc, PINN_INST_SPLIT): their own translation units and flags
     for which, flags in SPLIT_FLAGS.items():
         obj = os.path.join(OBJ, f'inst_hp64_split{which}.o')

@@ -69,7 +69,7 @@ struct pinn_net {
     pinn_layout_t lay;
     int n_layers, act, ndims, nparams, has_bc, has_ic, nsp;      // act: uniform activation code or -1
     unsigned long long act_codes[2];                              // 4 bits per activation index (pinn_act_code)
-    int n_skips, skip_src[PINN_MAX_SKIPS], skip_dst[PINN_MAX_SKIPS], skip_pre, skip_src_pre;
+    int n_skips, skip_src[PINN_MAX_SKIPS], skip_dst[PINN_MAX_SKIPS], skip_pre, skip_src_pre, skip_outer;
     int dims[PINN_MAX_LAYERS + 1];
     float lo[PINN_MAX_INPUTS], hi[PINN_MAX_INPUTS], bc_value;
     int n_cu;
@@ -184,6 +184,7 @@ int make_plan(const pinn_net* net, int64_t n_points, int nd, int n2, Plan* plan,
         probe.n_skips = net->n_skips;
         probe.skip_pre = net->skip_pre;
         probe.skip_src_pre = net->skip_src_pre;
+        probe.skip_outer = net->skip_outer;
     }
     probe.gemm_mode = net->gemm_mode;
     probe.mode = mode;
@@ -250,6 +251,7 @@ void fill_args(const pinn_net* net, PinnKArgs* a, const float* params, const flo
     a->n_skips = net->n_skips;
     a->skip_pre = net->skip_pre;
     a->skip_src_pre = net->skip_src_pre;
+    a->skip_outer = net->skip_outer;
     for (int k = 0; k < PINN_MAX_SKIPS; ++k) { a->skip_src[k] = net->skip_src[k]; a->skip_dst[k] = net->skip_dst[k]; }
     a->off_b1 = L.off_b1; a->off_wh = L.off_wh; a->hidden_stride = L.hidden_stride; a->off_wl = L.off_wl;
     a->off_bl = L.off_bl; a->off_ls = L.off_log_scale; a->off_loss = L.off_loss;
@@ -467,7 +469,7 @@ int pinn_create_ex(const int* layer_dims, int n_layers, const int* acts, int n_s
     if (!layer_dims || !out || !acts) return fail("null argument");
     if (n_layers < 2 || n_layers > PINN_MAX_LAYERS) return fail("n_layers=%d outside [2, %d]", n_layers, PINN_MAX_LAYERS);
     for (int a = 0; a + 1 < n_layers; ++a)
-        if (acts[a] < PINN_ACT_TANH || acts[a] > PINN_ACT_GELU) return fail("unknown activation code %d (activation %d)", acts[a], a);
+        if (acts[a] < PINN_ACT_TANH || acts[a] > PINN_ACT_LAST) return fail("unknown activation code %d (activation %d)", acts[a], a);
     if (n_skips < 0 || n_skips > PINN_MAX_SKIPS || (n_skips > 0 && (!skip_src || !skip_dst)))
         return fail("n_skips=%d outside [0, %d]", n_skips, PINN_MAX_SKIPS);
     int dst_of[PINN_MAX_SKIPS] = {0}, src_of[PINN_MAX_SKIPS] = {0}, pre_mask = 0, src_pre_mask = 0;
@@ -480,11 +482,21 @@ int pinn_create_ex(const int* layer_dims, int n_layers, const int* acts, int n_s
             return fail("skip %d: activations %d -> %d outside 0 <= src < dst <= %d", k, src_of[k], dst_of[k], n_layers - 2);
         if (layer_dims[src_of[k] + 1] != layer_dims[dst_of[k] + 1])
             return fail("skip %d joins widths %d and %d", k, layer_dims[src_of[k] + 1], layer_dims[dst_of[k] + 1]);
-        if (k > 0 && dst_of[k - 1] > src_of[k]) return fail("skip connections %d and %d overlap (nested skips are not supported)", k - 1, k);
-        // (a skip may start where the previous one ends only if it does not leave IN FRONT of the activation the other one joins behind)
-        if (k > 0 && dst_of[k - 1] == src_of[k] && (src_pre_mask >> k & 1) && !(pre_mask >> (k - 1) & 1))
-            return fail("skip %d starts in front of activation %d, skip %d ends behind it: overlap", k, src_of[k], k - 1);
     }
+    // Nesting (round 5): skips may lie inside one another ('fa R fa R fa fa + fa + f': the reference's layout letters pair like brackets)
+    // or cross; at most one may START and at most one may END at an activation. A skip during whose life another one opens is "outer":
+    // its jets wait in the skip's slab slot, the inner one rides in the registers.
+    int outer_mask = 0;
+    for (int k = 0; k < n_skips; ++k)
+        for (int j = 0; j < n_skips; ++j) {
+            if (j == k) continue;
+            if (src_of[j] == src_of[k]) return fail("skips %d and %d both start at activation %d", k, j, src_of[k]);
+            if (dst_of[j] == dst_of[k]) return fail("skips %d and %d both end at activation %d", k, j, dst_of[k]);
+            if (src_of[j] > src_of[k] && src_of[j] < dst_of[k]) outer_mask |= 1 << k;
+            // (a skip may start where another one ends only if it does not leave IN FRONT of the activation the other one joins behind)
+            if (dst_of[j] == src_of[k] && (src_pre_mask >> k & 1) && !(pre_mask >> j & 1))
+                return fail("skip %d starts in front of activation %d, skip %d ends behind it: overlap", k, src_of[k], j);
+        }
     const int act = acts[0];
     const int d = ndims + nparams;
     if (ndims < 1 || nparams < 0 || d > PINN_MAX_INPUTS) return fail("ndims+nparams=%d outside [1, %d]", d, PINN_MAX_INPUTS);
@@ -512,7 +524,7 @@ int pinn_create_ex(const int* layer_dims, int n_layers, const int* acts, int n_s
     }
     net->n_skips = n_skips;
     for (int k = 0; k < n_skips; ++k) { net->skip_src[k] = src_of[k]; net->skip_dst[k] = dst_of[k]; }
-    net->skip_pre = pre_mask; net->skip_src_pre = src_pre_mask;
+    net->skip_pre = pre_mask; net->skip_src_pre = src_pre_mask; net->skip_outer = outer_mask;
     net->has_bc = has_bc ? 1 : 0; net->has_ic = has_ic ? 1 : 0; net->bc_value = bc_value;
     net->nsp = has_ic ? ndims - 1 : ndims;
     for (int l = 0; l <= n_layers; ++l) net->dims[l] = layer_dims[l];
@@ -593,8 +605,9 @@ size_t pinn_workspace_bytes(const pinn_t* net, int64_t n_points, int nd, int n2)
            wsp_workspace_bytes(net) + 256;
 }
 
-int pinn_jet_forward(pinn_t* net, const float* params, const float* xs, int64_t n_points, const int* dir_cols, int nd,
-                     int n2, const float* ic_streams, float ic_const, float* streams_out, void* stream) {
+static int jet_forward_impl(pinn_t* net, const float* params, const float* xs, int64_t n_points, const int* dir_cols, int nd,
+                            int n2, const float* ic_streams, float ic_const, float* streams_out, void* workspace, size_t workspace_bytes,
+                            void* stream) {
     if (!net || !params || !xs || !streams_out) return fail("null argument");
     if (n_points <= 0) return 0;
     if (check_dirs(net, dir_cols, nd, n2)) return 1;
@@ -604,10 +617,30 @@ int pinn_jet_forward(pinn_t* net, const float* params, const float* xs, int64_t 
     fill_args(net, &a, params, xs, n_points, dir_cols, nd, n2, ic_streams, ic_const);
     a.mode = PINN_MODE_FORWARD;
     a.out_streams = streams_out;
+    if (net->skip_outer) {
+        // nested skips: the outer skip's jets wait in a slab slot between 'R' and '+' -- also in a value-only forward pass
+        const size_t need = align256((size_t)plan.grid * plan.slab_vec4_per_wg * sizeof(f32x4));
+        if (!workspace || workspace_bytes < need)
+            return fail("a net with nested skip connections needs scratch for its forward pass too: call pinn_jet_forward_ws with %zu bytes "
+                        "(pinn_workspace_bytes covers it), got %zu", need, workspace ? workspace_bytes : (size_t)0);
+        if (((uintptr_t)workspace & 15) != 0) return fail("workspace must be 16-byte aligned");
+        a.slab = reinterpret_cast<f32x4*>(workspace);
+    }
     set_tile_range(&a, plan, 0, plan.ntiles);
     const int rc = plan.fn(nd, plan.n2k, &a, plan.grid, stream, 0, nullptr);
     note_launch(plan);
     return rc ? fail("tile kernel launch failed (%d)", rc) : 0;
+}
+
+int pinn_jet_forward(pinn_t* net, const float* params, const float* xs, int64_t n_points, const int* dir_cols, int nd,
+                     int n2, const float* ic_streams, float ic_const, float* streams_out, void* stream) {
+    return jet_forward_impl(net, params, xs, n_points, dir_cols, nd, n2, ic_streams, ic_const, streams_out, nullptr, 0, stream);
+}
+
+int pinn_jet_forward_ws(pinn_t* net, const float* params, const float* xs, int64_t n_points, const int* dir_cols, int nd,
+                        int n2, const float* ic_streams, float ic_const, float* streams_out, void* workspace, size_t workspace_bytes,
+                        void* stream) {
+    return jet_forward_impl(net, params, xs, n_points, dir_cols, nd, n2, ic_streams, ic_const, streams_out, workspace, workspace_bytes, stream);
 }
 
 static int run_train(pinn_t* net, PinnKArgs* a, const Plan& plan, int nd, float* grads, int accumulate, void* workspace,

@@ -25,6 +25,10 @@
 //   PINN_FAST_MT_S5 / _S2 / _COMB, PINN_FAST_VAR_COMB, PINN_WIDE_MT (pinn_inst.inc)   tile heights of the fast kernels
 //   PINN_SP_ROUND (2), PINN_SP_PIPE / PINN_SP_PIPE_W (per translation unit: build.py)   split-bf16 kernels
 //   PINN_TEAM_FLAGS (0)           team-local LDS arrival counters instead of s_barrier in the two-team kernels (measured slower)
+//   PINN_PTALL (round 5)          shape-specialised kernels: the point stage (ansatz, residual, their reverse) evaluated by EVERY lane for
+//                                 its own point (16 * MT points, replicated over the unit quads and the waves) instead of by the first T
+//                                 threads: the LDS round trip of the upstream gradient and the barrier behind the point stage disappear
+//   PINN_TANH_POLY (round 5)      tanh of small arguments by an odd minimax polynomial (relative accuracy where e^{-2|z|} cancels)
 //   PINN_ONLY_BASELINE            experiment builds: only the BASELINE kernels (seconds to compile)
 //   PINN_DEBUG_ABI                experiment builds: pinn_debug_set_flags / pinn_debug_phase_buffer and the kernel paths behind them
 //   PINN_PROFILE_PHASES           per-phase cycle counters (tools/phases.py);  PINN_ABL  timing ablations
@@ -87,6 +91,8 @@ struct PinnKArgs {
     int skip_src[PINN_MAX_SKIPS], skip_dst[PINN_MAX_SKIPS];
     int skip_pre;                // bit k: skip k ends IN FRONT of the activation ('R fa f+ a': z[skip_dst] += h_out[skip_src])
     int skip_src_pre;            // bit k: skip k STARTS in front of the activation ('f R a ...': the pre-activation jets are carried)
+    int skip_outer;              // bit k: another skip opens while skip k is open (nested 'R .. R .. + .. +', round 5): the jets skip k carries
+                                 // travel through its slab slot instead of the one register set (full breadth kernels, generic depth)
     int off_b1, off_wh, hidden_stride, off_wl, off_bl, off_ls, off_loss;
     int p_core;                  // row stride of `partials` = length of the gradient buffer (user slots included)
     int off_extra, n_vars;       // first user slot; V(...) scalars a residual program reads (registers S+d+n_aux+k)
@@ -242,6 +248,17 @@ PINN_DEVICE float pinn_act(float z, int act) {
         const float t = pinn_exp2(fabsf(z) * -2.8853900817779268f);
         const float r = pinn_rcp(1.0f + t);
         const float lo = (1.0f - t) * r, hi = 1.0f - (t + t) * r;
+#ifndef PINN_TANH_POLY
+#define PINN_TANH_POLY 0
+#endif
+        if (PINN_TANH_POLY) {
+            // |z| < 0.45: z P(z^2), P of degree 4 (Chebyshev fit of tanh(sqrt(w)) / sqrt(w) on [0, 0.2025]; 1.5e-7 relative in fp32
+            // evaluation, where the exponential form loses relative accuracy to the cancellation in 1 - t)
+            const float w = z * z;
+            const float p = z * fmaf(fmaf(fmaf(fmaf(0.017927762120962143f, w, -0.05330030247569084f), w, 0.13328608870506287f), w,
+                                          -0.3333321511745453f), w, 1.0f);
+            return fabsf(z) < 0.45f ? p : copysignf(t < 0.5f ? hi : lo, z);
+        }
         return copysignf(t < 0.5f ? hi : lo, z);
     }
     if (act == PINN_ACT_SIGMOID) return pinn_rcp(1.0f + pinn_exp2(z * -1.4426950408889634f));
@@ -249,6 +266,16 @@ PINN_DEVICE float pinn_act(float z, int act) {
     if (act == PINN_ACT_SOFTPLUS) return z > 20.0f ? z : log1pf(expf(z));           // torch.nn.Softplus (beta 1, threshold 20)
     if (act == PINN_ACT_SILU) return z / (1.0f + expf(-z));
     if (act == PINN_ACT_GELU) return 0.5f * z * (1.0f + erff(z * 0.70710678118654752f));   // torch.nn.GELU (erf form)
+    // round 5: the torch-default forms of the other common `nn` activations (include/pinn.h)
+    if (act == PINN_ACT_RELU) return z > 0.0f ? z : 0.0f;
+    if (act == PINN_ACT_LEAKYRELU) return z > 0.0f ? z : 0.01f * z;
+    if (act == PINN_ACT_ELU) return z > 0.0f ? z : expm1f(z);
+    if (act == PINN_ACT_SELU) return 1.0507009873554805f * (z > 0.0f ? z : 1.6732632423543772f * expm1f(z));
+    if (act == PINN_ACT_SOFTSIGN) return z / (1.0f + fabsf(z));
+    if (act == PINN_ACT_GELU_TANH) return 0.5f * z * (1.0f + tanhf(0.7978845608028654f * (z + 0.044715f * z * z * z)));
+    if (act == PINN_ACT_MISH) return z * tanhf(z > 20.0f ? z : log1pf(expf(z)));
+    if (act == PINN_ACT_TANHSHRINK) return z - tanhf(z);
+    if (act == PINN_ACT_LOGSIGMOID) return fminf(z, 0.0f) - log1pf(expf(-fabsf(z)));
     return z;                                                     // PINN_ACT_IDENTITY ('f f': no activation in between)
 }
 // what the reverse half keeps of an activation: its VALUE (tanh, sigmoid, identity: all derivatives follow from it) or the
@@ -261,7 +288,62 @@ PINN_DEVICE float pinn_act_value(float saved, int act) { return pinn_act_keeps_z
 //   softplus: s | a | a q | a (q^2 - 2 a)
 //   SiLU z s:  s + z a | 2 a + z a q | 3 a q + z a (q^2 - 2 a) | 4 a (q^2 - 2 a) + z a q (q^2 - 8 a)
 //   GELU z Phi: Phi + z phi | phi (2 - z^2) | phi z (z^2 - 4) | phi (-z^4 + 7 z^2 - 4)
+// derivatives 1..4 of F(z) = tanh(u(z)) from T = tanh(u) and u', .., u'''' (Faa di Bruno); tanh' .. tanh'''' as polynomials in T
+PINN_DEVICE void pinn_tanh_chain(float T, float u1, float u2, float u3, float u4, float& t1, float& t2, float& t3, float& t4) {
+    const float a1 = 1.0f - T * T, a2 = -2.0f * T * a1, a3 = a1 * (6.0f * T * T - 2.0f), a4 = a1 * T * (16.0f - 24.0f * T * T);
+    t1 = a1 * u1;
+    t2 = a2 * u1 * u1 + a1 * u2;
+    t3 = a3 * u1 * u1 * u1 + 3.0f * a2 * u1 * u2 + a1 * u3;
+    t4 = a4 * u1 * u1 * u1 * u1 + 6.0f * a3 * u1 * u1 * u2 + a2 * (4.0f * u1 * u3 + 3.0f * u2 * u2) + a1 * u4;
+}
+// ... of the round-5 activations (codes >= PINN_ACT_RELU; oracle/jet_f64.py act_derivs states the same formulas in fp64 and
+// tests/test_activations.py holds both to torch's nested autograd): piecewise ones as autograd differentiates them (kinks: the
+// z > 0 branch decides, every higher derivative of a linear piece is 0), GELU-tanh and Mish as z F(z) with F built on tanh(u(z)):
+// (z F)^(n) = z F^(n) + n F^(n-1)
+PINN_DEVICE void pinn_act_zderivs_ext(float z, int act, float& d1, float& d2, float& d3, float& d4) {
+    d2 = 0.0f; d3 = 0.0f; d4 = 0.0f;
+    if (act == PINN_ACT_RELU) { d1 = z > 0.0f ? 1.0f : 0.0f; return; }
+    if (act == PINN_ACT_LEAKYRELU) { d1 = z > 0.0f ? 1.0f : 0.01f; return; }
+    if (act == PINN_ACT_ELU || act == PINN_ACT_SELU) {
+        const float sc = act == PINN_ACT_SELU ? 1.0507009873554805f : 1.0f, al = act == PINN_ACT_SELU ? 1.6732632423543772f : 1.0f;
+        if (z > 0.0f) { d1 = sc; return; }
+        const float e = sc * al * expf(z);
+        d1 = e; d2 = e; d3 = e; d4 = e;
+        return;
+    }
+    if (act == PINN_ACT_SOFTSIGN) {
+        const float a = 1.0f / (1.0f + fabsf(z)), sg = z > 0.0f ? 1.0f : (z < 0.0f ? -1.0f : 0.0f), a2 = a * a;
+        d1 = a2; d2 = -2.0f * sg * a2 * a; d3 = 6.0f * a2 * a2; d4 = -24.0f * sg * a2 * a2 * a;
+        return;
+    }
+    if (act == PINN_ACT_TANHSHRINK) {
+        float t1, t2, t3, t4;
+        pinn_tanh_chain(tanhf(z), 1.0f, 0.0f, 0.0f, 0.0f, t1, t2, t3, t4);
+        d1 = 1.0f - t1; d2 = -t2; d3 = -t3; d4 = -t4;
+        return;
+    }
+    // (every case an equality test with its own code: a kernel whose activation codes are masked to the first eight -- ACTC -1,
+    //  see act_at -- drops the cases above 7 at compile time)
+    if (!(act == PINN_ACT_LOGSIGMOID || act == PINN_ACT_GELU_TANH || act == PINN_ACT_MISH)) { d1 = 1.0f; return; }
+    const float sg = 1.0f / (1.0f + expf(-z)), a = sg * (1.0f - sg), q = 1.0f - 2.0f * sg;       // sigmoid and its derivatives a, a q, a (q^2 - 2 a)
+    if (act == PINN_ACT_LOGSIGMOID) { d1 = 1.0f - sg; d2 = -a; d3 = -a * q; d4 = -a * (q * q - 2.0f * a); return; }
+    float T, u1, u2, u3, u4;
+    const bool gelu = act == PINN_ACT_GELU_TANH;
+    if (gelu) {
+        const float k = 0.7978845608028654f, c = 0.044715f;
+        T = tanhf(k * (z + c * z * z * z));
+        u1 = k * (1.0f + 3.0f * c * z * z); u2 = 6.0f * k * c * z; u3 = 6.0f * k * c; u4 = 0.0f;
+    } else {                                                                                // Mish: u = softplus(z)
+        T = tanhf(z > 20.0f ? z : log1pf(expf(z)));
+        u1 = sg; u2 = a; u3 = a * q; u4 = a * (q * q - 2.0f * a);
+    }
+    float t1, t2, t3, t4;
+    pinn_tanh_chain(T, u1, u2, u3, u4, t1, t2, t3, t4);
+    const float sc = gelu ? 0.5f : 1.0f, f0 = gelu ? 0.5f * (1.0f + T) : T;
+    d1 = f0 + sc * z * t1; d2 = sc * (z * t2 + 2.0f * t1); d3 = sc * (z * t3 + 3.0f * t2); d4 = sc * (z * t4 + 4.0f * t3);
+}
 PINN_DEVICE void pinn_act_zderivs(float z, int act, float& d1, float& d2, float& d3, float& d4) {
+    if (act >= PINN_ACT_RELU) { pinn_act_zderivs_ext(z, act, d1, d2, d3, d4); return; }
     if (act == PINN_ACT_GELU) {
         const float phi = 0.3989422804014327f * expf(-0.5f * z * z), Phi = 0.5f * (1.0f + erff(z * 0.70710678118654752f));
         const float z2 = z * z;
@@ -1056,8 +1138,16 @@ pinn_tile_kernel(const PinnKArgs A) {
     // skips that START in front of an activation ('fRa'): the generic-depth full breadth kernels only (the selects and the guarded slab
     // reads cost the static-depth Sin kernel 3.5 % -- 9 % with the guard inside the jet loop -- and it never sees a skip)
     constexpr bool SRCPRE = SKIPS && !(VAR & 1024) && LHC < 0;
+    // nested skips (round 5): the same kernels. ONE skip rides in registers (`hskip`); a skip during whose life another one opens
+    // ("outer", A.skip_outer) parks its jets in its own slab slot at 'R' and reads them back at '+' -- lane-private, written and
+    // read by the same lane, L2-resident -- so that nesting costs no second register set (the launcher sends nested nets here)
+    constexpr bool NEST = SRCPRE && ACTC == -2;
+    // (full breadth kernels come in two sets, round 5: ACTC -1 knows the activation codes 0 .. 7 -- the seven of round 4 and ReLU -- and
+    //  no nested skips: exactly the kernels round 4 measured; ACTC -2 knows all sixteen codes and parks the outer skip of a nest. The
+    //  second set spills 50 - 150 registers more at width 256, which the nets of the first set should not pay)
+    constexpr bool ALLACT = ACTC == -2;
     auto act_at = [&](int a) -> int {
-        return (ACTC >= 0) ? ACTC : (pinn_act_code(A.act_codes, a) & ((SKIPS && !(VAR & 1024)) ? 15 : 1));
+        return (ACTC >= 0) ? ACTC : (pinn_act_code(A.act_codes, a) & ((SKIPS && !(VAR & 1024)) ? (ALLACT ? 15 : 7) : 1));
     };
     // skip connection ending / starting at activation a (or -1); slab slot of skip k
     auto skip_into = [&](int a) -> int {
@@ -1211,6 +1301,11 @@ pinn_tile_kernel(const PinnKArgs A) {
     // the activations for pinn_wgrad_kernel (h_{a-1} of the layer behind a '+') and send the gradient through a slot of its own
     auto skip_grad_slot = [&](int k) -> int { return lh + 1 + ((WGX && SKIPS) ? A.n_skips : 0) + k; };
     auto unit0 = [&](int j) { return (wave * NTW + j) * 16 + 4 * lq; };     // first of this lane's 4 units
+    // outer skip of a nest: its carried jets wait in the skip's slab slot (the slot the reverse half / pinn_wgrad_kernel reads anyway)
+    auto skip_park = [&](int k, int s, int j, int mt, f32x4 v) {
+        if (WGX) pinn_st4_stream<HP >= PINN_SLAB_NT_MIN_HP>(slab_at(lh + 1 + k, s, j, mt), v);
+        else *slab_at(lh + 1 + k, s, j, mt) = v;
+    };
 #if defined(PINN_DUMP_NET) && !defined(PINN_EMU)
     // experiment builds: a checksum per (tile, layer, wave) of the value stream a wave has just produced, behind the point dump
     // (rows 8.. of A.prof as floats): which layer and which wave of a tile differs first between two runs?
@@ -1422,8 +1517,20 @@ pinn_tile_kernel(const PinnKArgs A) {
         }
         float* xs_t = xs_base + tile_parity * T * PINN_XS_LD;
         float* xs_next = xs_base + (tile_parity ^ 1) * T * PINN_XS_LD;
-        PinnPointPre<ND, N2> ppre;
-        if (tid < T) pinn_point_prefetch<ND, N2, SPEC>(A, base + tid, base + tid < A.n_points, pregs + tid, T, ppre);
+#ifndef PINN_PTALL
+#define PINN_PTALL 0
+#endif
+        // PTALL: every lane runs the point stage of ITS point(s) -- lane (lr, any lq, any wave) owns points mt * 16 + lr -- so the
+        // upstream gradient gnet is in the registers of every lane that needs it and the tile has one barrier less
+        constexpr bool PTALL = (PINN_PTALL != 0) && SPEC != 0;
+        PinnPointPre<ND, N2> ppre, ppre_all[PTALL ? MT : 1];
+        if constexpr (PTALL) {
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt)
+                pinn_point_prefetch<ND, N2, SPEC>(A, base + mt * 16 + lr, base + mt * 16 + lr < A.n_points, pregs, T, ppre_all[mt]);
+        } else {
+            if (tid < T) pinn_point_prefetch<ND, N2, SPEC>(A, base + tid, base + tid < A.n_points, pregs + tid, T, ppre);
+        }
         PH(0)
 
         float* cur = bufA;
@@ -1529,8 +1636,13 @@ pinn_tile_kernel(const PinnKArgs A) {
 #endif
                 if (SKIPS && skip_from(0) >= 0) {
                     // ('f R a': the skip carries the z-jets, not act(z): z_0 kept aside, the derivative jets are what sv holds)
+                    const bool park = NEST && ((A.skip_outer >> skip_from(0)) & 1);
 #pragma unroll
-                    for (int s = 0; s < S; ++s) hskip[SKIPS ? j : 0][SKIPS ? mt : 0][s] = (SRCPRE && src_pre0) ? (s == 0 ? z0v : sv[s]) : hv[s];
+                    for (int s = 0; s < S; ++s) {
+                        const f32x4 carried = (SRCPRE && src_pre0) ? (s == 0 ? z0v : sv[s]) : hv[s];
+                        if (NEST && park) skip_park(skip_from(0), s, j, mt, carried);
+                        else hskip[SKIPS ? j : 0][SKIPS ? mt : 0][s] = carried;
+                    }
                 }
 #pragma unroll
                 for (int s = 0; s < S; ++s) {
@@ -1648,6 +1760,14 @@ pinn_tile_kernel(const PinnKArgs A) {
                     // '+' in front of the activation: the jets of the skipped activations join the pre-activation jets
                     const bool pre_in = SKIPS && sk_in >= 0 && ((A.skip_pre >> sk_in) & 1);
                     const bool src_pre = SRCPRE && sk_out >= 0 && ((A.skip_src_pre >> sk_out) & 1);
+                    // the jets that join here: out of the register set, or (outer skip of a nest) back from the skip's slab slot
+                    const bool in_parked = NEST && sk_in >= 0 && ((A.skip_outer >> sk_in) & 1);
+                    f32x4 hin[SKIPS ? S : 1];
+                    if (SKIPS && sk_in >= 0) {
+#pragma unroll
+                        for (int s = 0; s < S; ++s)
+                            hin[SKIPS ? s : 0] = (NEST && in_parked) ? *slab_at(lh + 1 + sk_in, s, j, mt) : hskip[SKIPS ? j : 0][SKIPS ? mt : 0][s];
+                    }
 #pragma unroll
                     for (int r = 0; r < 4; ++r) {
                         float z[S], h[S];
@@ -1656,7 +1776,7 @@ pinn_tile_kernel(const PinnKArgs A) {
                         z[0] += bias[r];
                         if (SKIPS && pre_in) {
 #pragma unroll
-                            for (int s = 0; s < S; ++s) z[s] += hskip[SKIPS ? j : 0][SKIPS ? mt : 0][s][r];
+                            for (int s = 0; s < S; ++s) z[s] += hin[SKIPS ? s : 0][r];
                         }
                         pinn_jet_fwd<ND, N2, COMB>(z, act, h, cw);
 #pragma unroll
@@ -1667,9 +1787,9 @@ pinn_tile_kernel(const PinnKArgs A) {
                         // '+' behind the activation: add the activations saved at 'R'; the reverse half needs them again (slab slot of the skip)
 #pragma unroll
                         for (int s = 0; s < S; ++s) {
-                            const f32x4 hs = hskip[SKIPS ? j : 0][SKIPS ? mt : 0][s];
+                            const f32x4 hs = hin[SKIPS ? s : 0];
                             hv[s] += hs;
-                            if (train) {
+                            if (train && !(NEST && in_parked)) {            // (a parked skip's jets are in the slot already)
                                 if (WGX) pinn_st4_stream<SNT>(slab_at(lh + 1 + sk_in, s, j, mt), hs);
                                 else *slab_at(lh + 1 + sk_in, s, j, mt) = hs;
                             }
@@ -1677,8 +1797,13 @@ pinn_tile_kernel(const PinnKArgs A) {
                     }
                     if (SKIPS && sk_out >= 0) {
                         // ('f R a': the skip carries the z-jets, not act(z): z_0 kept aside, the derivative jets are what sv holds)
+                        const bool park = NEST && ((A.skip_outer >> sk_out) & 1);
 #pragma unroll
-                        for (int s = 0; s < S; ++s) hskip[SKIPS ? j : 0][SKIPS ? mt : 0][s] = (SRCPRE && src_pre) ? (s == 0 ? z0v : sv[s]) : hv[s];
+                        for (int s = 0; s < S; ++s) {
+                            const f32x4 carried = (SRCPRE && src_pre) ? (s == 0 ? z0v : sv[s]) : hv[s];
+                            if (NEST && park) skip_park(sk_out, s, j, mt, carried);
+                            else hskip[SKIPS ? j : 0][SKIPS ? mt : 0][s] = carried;
+                        }
                     }
 #if defined(PINN_DUMP_NET) && !defined(PINN_EMU)
                     if (j == 0 && mt == 0) dump_layer(tile, li + 1, hv[0]);
@@ -1753,6 +1878,27 @@ pinn_tile_kernel(const PinnKArgs A) {
         // ---- (4) ansatz + residual + their reverse, one thread per point; all threads: stage the NEXT tile's points ------
         store_points(xs_next);
         fetch_points(tile + 2LL * vnblk);
+        float gnet_r[PTALL ? MT : 1][S];
+        if constexpr (PTALL) {
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt) {
+                const int pt = mt * 16 + lr;
+                float net[S];
+#pragma unroll
+                for (int s = 0; s < S; ++s) {
+                    float v = (s == 0) ? bL : 0.0f;
+#pragma unroll
+                    for (int w = 0; w < NW; ++w) v += netp[(w * S + s) * T + pt];
+                    net[s] = v;
+                }
+                PinnPointOut<ND, N2> po;
+                pinn_point_stage<ND, N2, false, COMB, SPEC>(A, net, xs_t + pt * PINN_XS_LD, base + pt, base + pt < A.n_points,
+                                                            pregs, padj, T, ppre_all[mt], po);
+#pragma unroll
+                for (int s = 0; s < S; ++s) gnet_r[PTALL ? mt : 0][s] = po.gnet[s];
+                if (wave == 0 && lq == 0) { sum_loss += po.loss; sum_ls += po.g_ls; sum_bl += po.gnet[0]; }     // (one lane per point counts)
+            }
+        } else
         if (tid < T) {
             const int pt = tid;
             float net[S];
@@ -1783,7 +1929,8 @@ pinn_tile_kernel(const PinnKArgs A) {
             if (SPEC == 0) sum_ic += po.g_ic;
         }
         PH(8)
-        tsync();
+        if (!PTALL || lh == 0) tsync();         // (PTALL: nothing crossed the LDS, the next write to `netp` is a whole tile of barriers away; a net without
+                                                //  hidden->hidden layers has no other barrier between the staging of the next tile's points and their first reader)
         PH(9)
         if (!train) continue;
 
@@ -1832,7 +1979,7 @@ pinn_tile_kernel(const PinnKArgs A) {
 #pragma unroll
                 for (int s = 0; s < S; ++s) {
                     sv[j][mt][s] = svtop[j][mt][s];
-                    const float gn = gnetb[s * T + pt];
+                    const float gn = PTALL ? gnet_r[PTALL ? mt : 0][s] : gnetb[s * T + pt];
                     g[j][mt][s] = wl * gn;
                     accWL[j] += htop[j][mt][s] * gn;
                 }

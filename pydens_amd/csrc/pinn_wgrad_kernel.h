@@ -51,7 +51,8 @@ struct PinnWgCfg {
 // HEAVY: the partner of the full breadth kernels (VAR 8 | 128): any activation of the library per layer (h rebuilt from the value or
 // from the pre-activation, whichever the tile kernel saved: pinn_act_saved), skips that carry pre-activation jets included (the slot
 // holds whatever was carried)
-template <int HP, int ND, int N2, bool COMB, int MT, bool SPLIT = false, bool SKIPS = false, bool HEAVY = false>
+// ALLACT (round 5): HEAVY with all sixteen activation codes (the partner of the ACTC -2 tile kernels); HEAVY alone knows codes 0 .. 7
+template <int HP, int ND, int N2, bool COMB, int MT, bool SPLIT = false, bool SKIPS = false, bool HEAVY = false, bool ALLACT = false>
 PINN_GLOBAL void PINN_LAUNCH_BOUNDS2((PinnWgCfg<HP, ND, N2, MT, SPLIT>::NTHREADS), (2 * PinnWgCfg<HP, ND, N2, MT, SPLIT>::WGS_PER_CU))
 pinn_wgrad_kernel(const PinnKArgs A) {
     using W = PinnWgCfg<HP, ND, N2, MT, SPLIT>;
@@ -86,7 +87,7 @@ pinn_wgrad_kernel(const PinnKArgs A) {
 
     for (int li = 0; li < lh; ++li) {
         // layer a = li + 1: A operand gz_a, B operand h_{a-1} = h of activation index li
-        const int act = pinn_act_code(A.act_codes, li) & (HEAVY ? 15 : 1);
+        const int act = pinn_act_code(A.act_codes, li) & (HEAVY ? (ALLACT ? 15 : 7) : 1);
         int sk_in = -1;                   // skip that joins behind activation li
         if (SKIPS) for (int i = 0; i < A.n_skips; ++i) if (A.skip_dst[i] == li && !((A.skip_pre >> i) & 1)) sk_in = i;
         f32x4 acc[AM][BN];

@@ -19,7 +19,10 @@ MAX_STREAMS, MAX_AUX, MAX_VARS = 7, 8, 8
 SAMPLE_UNIFORM, SAMPLE_NORMAL, SAMPLE_CONST = 0, 1, 2
 RES_PROGRAM, RES_AFFINE = 0, 1
 SKIP_PRE = 0x100         # include/pinn.h PINN_SKIP_PRE
-ACT_CODES = {'tanh': 0, 'sigmoid': 1, 'sin': 2, 'identity': 3, 'softplus': 4, 'silu': 5, 'swish': 5, 'gelu': 6}
+ACT_CODES = {'tanh': 0, 'sigmoid': 1, 'sin': 2, 'identity': 3, 'softplus': 4, 'silu': 5, 'swish': 5, 'gelu': 6,
+             # round 5 (include/pinn.h PINN_ACT_RELU ..): torch-default forms
+             'relu': 7, 'leakyrelu': 8, 'elu': 9, 'softsign': 10, 'gelu_tanh': 11, 'mish': 12, 'selu': 13, 'tanhshrink': 14,
+             'logsigmoid': 15}
 
 OPS = dict(CONST=0, ADD=1, SUB=2, MUL=3, DIV=4, NEG=5, SIN=6, COS=7, EXP=8, LOG=9, TANH=10, SQRT=11, POW=12,
            ABS=13, SIGMOID=14, RECIP=15, COPY=16, STORE=17)
@@ -93,6 +96,7 @@ def bind(lib):
     lib.pinn_workspace_bytes.argtypes = [vp, i64, i32, i32]
     lib.pinn_workspace_bytes.restype = ctypes.c_size_t
     lib.pinn_jet_forward.argtypes = [vp, vp, vp, i64, ip, i32, i32, vp, f32, vp, vp]
+    lib.pinn_jet_forward_ws.argtypes = [vp, vp, vp, i64, ip, i32, i32, vp, f32, vp, vp, ctypes.c_size_t, vp]
     lib.pinn_jet_backward.argtypes = [vp, vp, vp, i64, ip, i32, i32, vp, f32, vp, vp, i32, vp, ctypes.c_size_t, vp]
     lib.pinn_residual_step.argtypes = [vp, ctypes.POINTER(Residual), vp, vp, i64, ip, i32, i32, vp, f32, f32, vp, vp,
                                        ctypes.c_size_t, vp]
@@ -127,13 +131,13 @@ def bind(lib):
     lib.pinn_debug_prepass_in_kernel.argtypes = [vp, ctypes.c_int]
     lib.pinn_last_launch_info.argtypes = [ctypes.POINTER(ctypes.c_int32)]
     lib.pinn_debug_fit_graph_stats.argtypes = [ctypes.POINTER(ctypes.c_int32)]
-    for name in ('pinn_create', 'pinn_create_ex', 'pinn_destroy', 'pinn_layout', 'pinn_jet_forward', 'pinn_jet_backward',
+    for name in ('pinn_create', 'pinn_create_ex', 'pinn_destroy', 'pinn_layout', 'pinn_jet_forward', 'pinn_jet_forward_ws', 'pinn_jet_backward',
                  'pinn_residual_step', 'pinn_residual_adam_step', 'pinn_adam_step', 'pinn_adam_step_at'):
         getattr(lib, name).restype = i32
     return lib
 
 
-ABI_SYMBOLS = ('pinn_create', 'pinn_create_ex', 'pinn_destroy', 'pinn_layout', 'pinn_workspace_bytes', 'pinn_jet_forward',
+ABI_SYMBOLS = ('pinn_create', 'pinn_create_ex', 'pinn_destroy', 'pinn_layout', 'pinn_workspace_bytes', 'pinn_jet_forward', 'pinn_jet_forward_ws',
                'pinn_jet_backward', 'pinn_residual_step', 'pinn_residual_step_add', 'pinn_residual_adam_step', 'pinn_adam_step', 'pinn_adam_step_at', 'pinn_sample_points', 'pinn_fit_steps', 'pinn_fit_steps_graph', 'pinn_fit_ctrl_bytes', 'pinn_set_gemm_mode', 'pinn_profile_tile',
                'pinn_last_tile_ms', 'pinn_last_wgrad_ms', 'pinn_last_kernel_name', 'pinn_last_wgrad_kernel_name', 'pinn_debug_last_kernel',
                'pinn_debug_prepass_in_kernel', 'pinn_debug_wgx_chunk_bytes', 'pinn_debug_max_wgs_per_cu', 'pinn_debug_fit_graph_stats', 'pinn_last_launch_info',
@@ -205,9 +209,12 @@ class Net:
             raise ValueError(f'{n_hidden} hidden layers need {n_hidden} activations, got {names}')
         codes = [ACT_CODES.get(str(name).lower()) for name in names]
         if None in codes:
-            raise NotImplementedError(f'activation {names[codes.index(None)]!r}: the HIP kernels implement Tanh, Sigmoid '
-                                      'Sin, Softplus, SiLU and GELU (and the identity)')
+            raise NotImplementedError(f'activation {names[codes.index(None)]!r}: the HIP kernels implement '
+                                      + ', '.join(sorted(ACT_CODES)) + ' (torch-default forms)')
         skips = sorted((s[0], s[1], bool(s[2]) if len(s) > 2 else False, bool(s[3]) if len(s) > 3 else False) for s in skips)
+        # nested skips (another 'R' while one is open): their forward passes need scratch (include/pinn.h pinn_jet_forward_ws)
+        self.nested = any(a[0] < b[0] < a[1] for a in skips for b in skips if a is not b)
+        self._fwd_ws = None
         domain = list(domain) if domain is not None else [(0.0, 1.0)] * ndims
         dims = (ctypes.c_int * len(layer_dims))(*layer_dims)
         lo = (ctypes.c_float * ndims)(*[float(d[0]) for d in domain])
@@ -287,8 +294,16 @@ class Net:
             out = torch.empty((s, n), dtype=torch.float32, device=xs.device)
         _check(out, 'out')
         with _on_device(params):
-            self._raise(self.lib.pinn_jet_forward(self.handle, _ptr(params), _ptr(xs), n, dirs, nd, n2, _ptr(ic_streams),
-                                                  float(ic_const), _ptr(out), _stream(xs)))
+            if self.nested:
+                need = self.workspace_bytes(n, nd, n2)
+                if self._fwd_ws is None or self._fwd_ws.numel() * 4 < need or self._fwd_ws.device != xs.device:
+                    self._fwd_ws = torch.empty((need + 3) // 4, dtype=torch.float32, device=xs.device)
+                self._raise(self.lib.pinn_jet_forward_ws(self.handle, _ptr(params), _ptr(xs), n, dirs, nd, n2, _ptr(ic_streams),
+                                                         float(ic_const), _ptr(out), _ptr(self._fwd_ws), self._fwd_ws.numel() * 4,
+                                                         _stream(xs)))
+            else:
+                self._raise(self.lib.pinn_jet_forward(self.handle, _ptr(params), _ptr(xs), n, dirs, nd, n2, _ptr(ic_streams),
+                                                      float(ic_const), _ptr(out), _stream(xs)))
         return out
 
     def jet_backward(self, params, xs, grad_streams, grads, workspace, dir_cols=(), n2=0, ic_streams=None,

@@ -110,30 +110,34 @@ class FlatLinear(nn.Module):
 
 
 def _activation_name(act):
+    """ what `getattr(nn, activation)()` / a module class / a module instance / a torch function names (model_torch.py:159, :164-168) ->
+    the kernels' activation name. The kernels implement the torch-DEFAULT form of each; an instance configured otherwise is refused. """
     if isinstance(act, str):
         return act
     if isinstance(act, type):
         return act.__name__
     if isinstance(act, nn.Module):
-        # the kernels implement the DEFAULT form of each activation
-        if isinstance(act, nn.Softplus) and (act.beta != 1 or act.threshold != 20):
-            raise NotImplementedError('nn.Softplus with beta != 1 or threshold != 20 is not implemented by the HIP kernels')
+        defaults = {nn.Softplus: dict(beta=1, threshold=20), nn.LeakyReLU: dict(negative_slope=0.01), nn.ELU: dict(alpha=1.0)}
+        for cls, want in defaults.items():
+            if isinstance(act, cls):
+                got = {k: getattr(act, k) for k in want}
+                if any(float(got[k]) != float(v) for k, v in want.items()):
+                    raise NotImplementedError(f'nn.{cls.__name__} with {got}: the HIP kernels implement the default form ({want}) only')
         if isinstance(act, nn.GELU) and getattr(act, 'approximate', 'none') != 'none':
-            raise NotImplementedError("nn.GELU(approximate='tanh') is not implemented by the HIP kernels (erf form only)")
+            if act.approximate != 'tanh':
+                raise NotImplementedError(f'nn.GELU(approximate={act.approximate!r}) is not implemented by the HIP kernels')
+            return 'GELU_tanh'
         return type(act).__name__
-    if act is torch.sin:
-        return 'Sin'
-    if act is torch.tanh:
-        return 'Tanh'
-    if act is torch.sigmoid:
-        return 'Sigmoid'
-    if act is torch.nn.functional.softplus:
-        return 'Softplus'
-    if act is torch.nn.functional.silu:
-        return 'SiLU'
-    if act is torch.nn.functional.gelu:
-        return 'GELU'
-    raise NotImplementedError(f'activation {act!r}: the HIP kernels implement Tanh, Sigmoid, Sin, Softplus, SiLU and GELU')
+    functions = {torch.sin: 'Sin', torch.tanh: 'Tanh', torch.sigmoid: 'Sigmoid', torch.nn.functional.softplus: 'Softplus',
+                 torch.nn.functional.silu: 'SiLU', torch.nn.functional.gelu: 'GELU', torch.relu: 'ReLU', torch.nn.functional.relu: 'ReLU',
+                 torch.nn.functional.leaky_relu: 'LeakyReLU', torch.nn.functional.elu: 'ELU', torch.nn.functional.softsign: 'Softsign',
+                 torch.nn.functional.mish: 'Mish', torch.nn.functional.selu: 'SELU', torch.nn.functional.tanhshrink: 'Tanhshrink',
+                 torch.nn.functional.logsigmoid: 'LogSigmoid', torch.nn.functional.tanh: 'Tanh', torch.nn.functional.sigmoid: 'Sigmoid'}
+    for fn, name in functions.items():
+        if act is fn:
+            return name
+    raise NotImplementedError(f'activation {act!r}: the HIP kernels implement Tanh, Sigmoid, Sin, Softplus, SiLU, GELU (erf and tanh '
+                              'forms), ReLU, LeakyReLU, ELU, SELU, Softsign, Mish, Tanhshrink and LogSigmoid (torch defaults)')
 
 
 def parse_fc_layout(layout, features, activation):
@@ -143,8 +147,9 @@ def parse_fc_layout(layout, features, activation):
     entry per 'a'), 'R' start / '+' end of a skip connection; spaces are ignored. The net must end in a 1-unit dense
     layer. A hidden 'f' without an 'a' gets the identity. 'R' and '+' sit behind a dense layer, either behind its activation
     ('faR fa fa+': sum of activation outputs) or between the layer and its activation ('faR fa f+a': the usual residual block
-    act(W h + skip); 'fRa fa f+a': the pre-activation block, z carried to z). Skips join layers of equal width and do not nest;
-    conv letters are out of scope. Skips are returned as (src, dst, pre, src_pre) hidden-layer indices: the output of
+    act(W h + skip); 'fRa fa f+a': the pre-activation block, z carried to z). Skips join layers of equal width; they may NEST
+    ('fa R fa R fa fa + fa + f': '+' closes the most recent open 'R', the way the letters pair in the reference's Block) as long as at
+    most one skip starts and at most one ends at a layer; conv letters are out of scope. Skips are returned as (src, dst, pre, src_pre) hidden-layer indices: the output of
     layer dst -- its pre-activation if `pre` -- gets the output (pre-activation if `src_pre`) of layer src added. """
     letters = layout.replace(' ', '')
     features = list(features)
@@ -161,7 +166,7 @@ def parse_fc_layout(layout, features, activation):
     act_list = list(activation) if isinstance(activation, (list, tuple)) else None
     if act_list is not None and len(act_list) < letters.count('a'):
         raise ValueError(f'layout {layout!r} needs {letters.count("a")} activations, got {len(act_list)}')
-    acts, skips, open_skip, open_pre, layer = [], [], None, False, -1
+    acts, skips, open_stack, layer = [], [], [], -1
     for letter in letters:
         if letter == 'f':
             if layer >= 0 and len(acts) == layer:
@@ -176,17 +181,19 @@ def parse_fc_layout(layout, features, activation):
             if layer < 0 or (len(acts) != layer + 1 and not pre):
                 raise NotImplementedError(f"layout {layout!r}: 'R' / '+' must come after a dense layer (in front of or behind its activation)")
             if letter == 'R':
-                if open_skip is not None:
-                    raise NotImplementedError(f'layout {layout!r}: nested skip connections are not supported')
-                open_skip, open_pre = layer, pre
+                if any(src == layer for src, _ in open_stack) or any(s[0] == layer for s in skips):
+                    raise NotImplementedError(f"layout {layout!r}: two skip connections start at dense layer {layer + 1}")
+                open_stack.append((layer, pre))
             else:
-                if open_skip is None or open_skip == layer:
+                if not open_stack or open_stack[-1][0] == layer:
                     raise NotImplementedError(f"layout {layout!r}: '+' needs an open 'R' with a layer in between")
+                open_skip, open_pre = open_stack.pop()             # (brackets: '+' closes the most recent 'R')
+                if any(s[1] == layer for s in skips):
+                    raise NotImplementedError(f"layout {layout!r}: two skip connections end at dense layer {layer + 1}")
                 if features[open_skip] != features[layer]:
                     raise ValueError(f"layout {layout!r}: skip connection joins widths {features[open_skip]} and {features[layer]}")
                 skips.append((open_skip, layer, pre, open_pre))
-                open_skip = None
-    if open_skip is not None:
+    if open_stack:
         raise ValueError(f"layout {layout!r}: 'R' without a closing '+'")
     return features, acts, skips
 

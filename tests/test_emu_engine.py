@@ -472,6 +472,14 @@ LAYOUTS = {
     'skip_from_pre_activation': dict(layout='fRa fa f+a fRa fa+ f', features=[20, 20, 20, 20, 20, 1],
                                      activation=['Tanh', 'Sigmoid', 'Tanh', 'Sin', 'Tanh']),
     'pre_blocks_back_to_back': dict(layout='fa fRa f+Ra fa f+a f', features=[16, 16, 16, 16, 16, 1], activation='Tanh'),
+    # round 5: NESTED skips ('+' closes the most recent 'R'): the outer skip's jets wait in its slab slot, the inner one rides in
+    # registers; one nest of post-activation skips, one where the outer skip carries pre-activation jets into a pre-activation join
+    'nested_skips': dict(layout='fa R fa R fa fa + fa + f', features=[16, 16, 16, 16, 16, 1], activation=['Tanh', 'Sigmoid', 'Tanh', 'Sin', 'Tanh']),
+    'nested_pre_activation': dict(layout='fRa faR fa fa+ f+a f', features=[20, 20, 20, 20, 20, 1], activation=['Tanh', 'Tanh', 'SiLU', 'Tanh', 'Sigmoid']),
+    # round 5: the rest of the activations `getattr(nn, name)()` commonly names, torch-default forms (include/pinn.h PINN_ACT_RELU ..)
+    'relu_family': dict(layout='fa fa fa fa f', features=[16, 12, 16, 12, 1], activation=['ELU', 'LeakyReLU', 'SELU', 'ReLU']),
+    'softsign_gelutanh_mish': dict(layout='fa fa fa f', features=[12, 16, 12, 1], activation=['Softsign', torch.nn.GELU(approximate='tanh'), 'Mish']),
+    'shrink_logsigmoid': dict(layout='fa fa fa f', features=[12, 16, 12, 1], activation=[torch.nn.Tanhshrink, 'LogSigmoid', torch.nn.functional.mish]),
 }
 
 
@@ -615,7 +623,7 @@ def test_streamed_weight_gradient_kernel_chunks_and_paths(pa, emu_lib):
         pass            # (the budget belongs to each solver's own descriptor: nothing process-wide to restore)
 
 
-@pytest.mark.parametrize('which', ['poisson', 'poisson_any_activation', 'burgers_any_activation'])
+@pytest.mark.parametrize('which', ['poisson', 'poisson_any_activation', 'burgers_any_activation', 'poisson_nested'])
 def test_streamed_weight_gradients_through_skip_connections(pa, emu_lib, which):
     """ residual nets of widths >= 128 (round 4): the skip kernels (VAR 8 | 1024) hand their hidden->hidden weight gradients to
     pinn_wgrad_kernel<..., SKIPS> as well -- the activations a skip carries stay in the per-tile slab for that kernel (h behind
@@ -623,9 +631,14 @@ def test_streamed_weight_gradients_through_skip_connections(pa, emu_lib, which):
     one in front of one, back to back; one pass and chunk by chunk; fused and generic path; against the oracle. """
     from oracle import pinn_oracle as po
     net = dict(layout='fa R fa fa + R fa f+a f', features=[96, 96, 96, 96, 96, 1], activation=['Tanh', 'Sigmoid', 'Tanh', 'Tanh', 'Sigmoid'])
-    heavy = which.endswith('_any_activation')
+    heavy = which.endswith('_any_activation') or which == 'poisson_nested'
     budgets = (0, 1) if which in ('poisson', 'poisson_any_activation') else (0,)     # (the chunked pass once per kernel family: the emulator is slow)
-    if heavy:
+    if which == 'poisson_nested':
+        # round 5: NESTED skips at a streamed width -- the outer skip's jets are parked in its per-tile slab slot at 'R' (not at '+'),
+        # which is also where pinn_wgrad_kernel<..., SKIPS, HEAVY> looks for them; full breadth kernels (VAR 8 | 128)
+        net = dict(layout='fa R fa R fa fa + fa + f', features=[96] * 5 + [1], activation=['Tanh', 'Sigmoid', 'ELU', 'Tanh', 'Softsign'])
+        which = 'poisson'
+    elif heavy:
         # the full breadth kernels (VAR 8 | 128) and their partner: every activation of the library, an activation-free dense layer,
         # a skip that starts in front of an activation (carries pre-activation jets) and one from the first layer
         net = dict(layout='fRa fa f+a R f fa+ fa f', features=[96] * 6 + [1], activation=['Sin', 'SiLU', 'GELU', 'Softplus', 'Tanh'])
@@ -650,7 +663,11 @@ def test_streamed_weight_gradients_through_skip_connections(pa, emu_lib, which):
                     solver._generic_step(torch.from_numpy(pts.copy()), ('equation',), [], torch.nn.MSELoss(), 1)
                 want_var = ('%d>' % (8 | 128),) if heavy else ('%d>' % (8 | 1024 | 128), '%d>' % (8 | 16 | 1024 | 128))
                 assert emu_lib.pinn_last_kernel_name().decode().rsplit(',', 1)[1] in want_var
-                assert emu_lib.pinn_last_wgrad_kernel_name().decode().endswith(',true,true>' if heavy else ',true,false>')
+                # (nested skips / activation codes above 7: the second set of full breadth kernels -- ACTC -2, ALLACT weight-gradient partner)
+                allact = 'R fa R' in net['layout']
+                assert emu_lib.pinn_last_wgrad_kernel_name().decode().endswith(',true,true,true>' if allact else ',true,true>' if heavy else ',true,false>')
+                if heavy:
+                    assert emu_lib.pinn_last_kernel_name().decode().split(',')[5] == ('-2' if allact else '-1')
                 lay = solver.model.net.layout
                 assert abs(float(solver.grads[lay.off_loss]) - ev['loss']) <= 1e-5 * ev['loss'], (budget, path)
                 for got, w in zip(export_grads(solver), want):

@@ -397,7 +397,8 @@ def test_wide_residual_nets_stream_their_weight_gradients(pa, width, which):
                 assert ok, (path, i, err)
 
 
-@pytest.mark.parametrize('net', ['skip', 'two_skips', 'sin', 'identity', 'skip_to_top_wide', 'full64', 'softplus_silu_gelu'])
+@pytest.mark.parametrize('net', ['skip', 'two_skips', 'sin', 'identity', 'skip_to_top_wide', 'full64', 'softplus_silu_gelu',
+                                 'nested_skips', 'nested_pre_activation', 'relu_family', 'softsign_gelutanh_mish', 'shrink_logsigmoid'])
 @pytest.mark.parametrize('which', ['poisson', 'burgers'])
 def test_layout_breadth_matches_the_oracle(pa, net, which):
     """ skip connections 'R ... +', per-layer activation lists, Sin, activation-free dense layers (reference
