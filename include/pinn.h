@@ -24,10 +24,12 @@
  *
  * Derivative streams (what D(...) needs, model_torch.py:174-178): stream 0 = u; 1..nd = first derivative along
  * direction k; 1+nd..nd+n2 = second derivative along the first n2 directions. A direction dir_cols[k] is an input
- * column c (value c) or the diagonal e_a + e_b of two columns (value a | (b + 1) << 4): the host obtains mixed partials
- * by polarisation, u_ab = (u_vv - u_aa - u_bb) / 2.  Stream arrays are stream-major: [S][N], S = 1 + nd + n2.
+ * column c (value c) or a diagonal e_a + e_b / e_a - e_b of two columns (value a | (b + 1) << 4, | PINN_DIR_MINUS for the minus
+ * diagonal): the host obtains mixed partials by polarisation, u_ab = (u_vv - u_aa - u_bb) / 2, and (round 5) mixed THIRD-order
+ * partials from third derivatives along both diagonals, u_aab = (D3_{a+b} - D3_{a-b} - 2 u_bbb) / 6.
+ * Stream arrays are stream-major: [S][N], S = 1 + nd + n2.
  * Third order: wherever an entry point takes `n2`, the value may be PACKED as n2 | n3 << 3 -- n3 of the n2 second-order
- * directions (the first ones, single columns) also carry a third derivative, streams 1+nd+n2 .. nd+n2+n3, S = 1 + nd + n2 + n3
+ * directions (the first ones; columns or diagonals) also carry a third derivative, streams 1+nd+n2 .. nd+n2+n3, S = 1 + nd + n2 + n3
  * (built: one third-order direction with nd <= 2, i.e. u_xxx-type equations such as KdV; plain n2 < 8 means n3 = 0).
  */
 #ifndef PINN_H
@@ -51,6 +53,7 @@ extern "C" {
 #define PINN_MAX_AUX      8    /* per-point rows produced by the x-only pre-pass */
 #define PINN_MAX_VARS     8    /* trainable V(...) scalars a residual program may read (user slots 0..n_vars-1) */
 
+#define PINN_DIR_MINUS    0x100  /* ORed into a diagonal's direction code: e_a - e_b instead of e_a + e_b */
 #define PINN_MAX_SKIPS    4    /* skip connections ('R ... +') per net */
 #define PINN_SKIP_PRE     0x100 /* ORed into skip_dst[k] / skip_src[k]: the skip ends / starts IN FRONT of that activation */
 
@@ -273,6 +276,13 @@ int pinn_fit_steps_graph(pinn_t* net, const pinn_residual_t* residual, float* pa
                          float* loss_history, int32_t k_steps, void* workspace, size_t workspace_bytes, void* ctrl,
                          size_t ctrl_bytes, void* stream);
 
+/* tanh of the hidden layers (round 5). PINN_TANH_FAST (default): sign(z)(1 - t)/(1 + t), t = e^{-2|z|} -- absolute error 1.5e-7, relative
+ * accuracy lost to cancellation below |z| ~ 0.3. PINN_TANH_ACCURATE: z P(z^2) below |z| = 0.45 (degree-4 minimax fit, 1.5e-7 RELATIVE); on
+ * trained models the gradient error against fp64 drops from 1.7 - 1.9x to 0.6 - 1.2x the fp32 reference's own for +2.5 % kernel time. Built
+ * for the Poisson-box shape of BASELINE configs 1 / 2 at width 64 (the other kernels keep the fast form whatever the mode says). */
+#define PINN_TANH_FAST     0
+#define PINN_TANH_ACCURATE 1
+int pinn_set_tanh_mode(pinn_t* net, int mode);
 /* Arithmetic of the hidden-layer GEMMs (forward, data gradient, weight gradient) of the fused step -- what ATen's `addmm` /
  * `mm` calls do in the reference (pydens/model_torch.py:170-178, :460), per net:
  *   PINN_GEMM_FP32    (default) v_mfma_f32_16x16x4_f32: exact fp32, bitwise an fmaf chain
@@ -319,6 +329,12 @@ int pinn_debug_wgx_chunk_bytes(pinn_t* net, long long bytes);
  *                                 restores the default, 4): tests run the same step at 1 and at several workgroups per CU; affects
  *                                 pinn_workspace_bytes (partial rows, slabs), so set it first. Returns the previous bound (-1: null). */
 int pinn_debug_max_wgs_per_cu(pinn_t* net, int cap);
+/*   pinn_debug_fit_persistent     0: pinn_fit_steps_graph never runs a chunk as ONE launch (pinn_fit_kernel: narrow nets, grids of at most
+ *                                 64 resident workgroups); 1 switches it on. Off by default: on MI355X the device-scope arrive / wait between
+ *                                 workgroups on different XCDs (L2 write-back + invalidate per iteration) costs more than the two launch gaps of
+ *                                 a replayed launch graph -- 22 - 37 us against 16 - 17 us per iteration (profiles/r05_small_fit_rate.txt).
+ *                                 Returns the previous setting (-1: null). */
+int pinn_debug_fit_persistent(pinn_t* net, int enable);
 /*   pinn_debug_fit_graph_stats    out[0] chunks replayed as launch graphs so far, out[1] graphs captured, out[2] captures the runtime
  *                                 refused (those chunks ran eagerly), out[3] the HIP error code of the last refusal */
 int pinn_debug_fit_graph_stats(int32_t out[4]);

@@ -100,9 +100,10 @@ def _build(force, verbose, extra_flags, widths):
     # second set of full breadth kernels (round 5: all sixteen activations, nested skips -- pinn_inst.inc PINN_INST_ALLACT): a unit of
     # its own per width, so that the build's wall time stays that of its longest unit
     for hp in WIDTHS:
-        obj = os.path.join(OBJ, f'inst_hp{hp}_allact.o')
-        jobs.append((obj, [hipcc, *FLAGS, *WIDTH_FLAGS.get(hp, []), *extra_flags, *([] if hp in widths else ['-DPINN_ONLY_BASELINE']),
-                           f'-DPINN_INST_HP={hp}', '-DPINN_INST_ALLACT=1', '-c', os.path.join(HERE, 'pinn_inst.inc'), '-o', obj]))
+        for part in ((1, 2) if hp >= 128 else (1,)):         # 1: tile kernels (+ the stub of the partner launcher below width 128), 2: weight-gradient partners
+            obj = os.path.join(OBJ, f'inst_hp{hp}_allact{part}.o')
+            jobs.append((obj, [hipcc, *FLAGS, *WIDTH_FLAGS.get(hp, []), *extra_flags, *([] if hp in widths else ['-DPINN_ONLY_BASELINE']),
+                               f'-DPINN_INST_HP={hp}', f'-DPINN_INST_ALLACT={part}', '-c', os.path.join(HERE, 'pinn_inst.inc'), '-o', obj]))
     # split-bf16 kernels of width 64 (pinn_inst.inc, PINN_INST_SPLIT): their own translation units and flags
     for which, flags in SPLIT_FLAGS.items():
         obj = os.path.join(OBJ, f'inst_hp64_split{which}.o')
@@ -115,9 +116,19 @@ def _build(force, verbose, extra_flags, widths):
     obj = os.path.join(OBJ, 'abi.o')
     jobs.append((obj, [hipcc, *FLAGS, *extra_flags, '-c', os.path.join(HERE, 'pinn_abi.cpp'), '-o', obj]))
 
+    guard_report = {}
+
     def run(job):
         obj, cmd = job
         if not force and not _stale(obj, deps):
+            return obj
+        if '-DPINN_INST_SPLIT' in ' '.join(cmd) and os.environ.get('PINN_ASM_GUARD', '1') != '0':
+            # split-bf16 units: the device code goes through its assembly listing, where no packed fp32 instruction keeps a source
+            # that is overwritten within three issue slots (asm_guard.py)
+            from pydens_amd.csrc import asm_guard
+            src = cmd[cmd.index('-c') + 1]
+            flags = [c for c in cmd[1:] if c not in ('-c', src, '-o', obj)]
+            guard_report[os.path.basename(obj)] = asm_guard.compile_guarded(hipcc, flags, src, obj, verbose=verbose)
             return obj
         if verbose:
             print(' '.join(cmd), flush=True)
@@ -128,13 +139,31 @@ def _build(force, verbose, extra_flags, widths):
             print(res.stderr)
         return obj
 
+    # (the widest units take longest: start them first so that the pool's tail is short)
+    order = sorted(range(len(jobs)), key=lambda i: (0 if 'hp256' in jobs[i][0] else 1 if 'hp128' in jobs[i][0] else 2, i))
     with ThreadPoolExecutor(max_workers=min(len(jobs), os.cpu_count() or 4)) as pool:
-        objs = list(pool.map(run, jobs))
+        done = dict(zip(order, pool.map(run, [jobs[i] for i in order])))
+    objs = [done[i] for i in range(len(jobs))]
     cmd = [hipcc, '--offload-arch=gfx950', '-shared', '-fPIC', '-o', OUT + '.tmp', *objs]
     res = subprocess.run(cmd, capture_output=True, text=True)
     if res.returncode != 0:
         raise RuntimeError(f'link failed:\n{res.stdout}\n{res.stderr}')
     os.replace(OUT + '.tmp', OUT)
+    # what the guard did, beside the library (tests read it; units that were not recompiled keep their earlier entry)
+    import json
+    rec_path = OUT[:-3] + '.guard.json'
+    record = {}
+    if os.path.exists(rec_path):
+        try:
+            with open(rec_path) as f:
+                record = json.load(f)
+        except (OSError, ValueError):
+            record = {}
+    record.update(guard_report)
+    if os.environ.get('PINN_ASM_GUARD', '1') == '0':
+        record = {'disabled': True}
+    with open(rec_path, 'w') as f:
+        json.dump(record, f, indent=1, sort_keys=True)
     return OUT
 
 

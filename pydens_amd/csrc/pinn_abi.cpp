@@ -1,6 +1,7 @@
 // pinn_abi.cpp -- C-ABI of libpinn_hip.so (declared in include/pinn.h): descriptor, layout, launch dispatch.
 // Built with hipcc for gfx950 (product) or, with -DPINN_EMU, as tests/emu/_build/libpinn_emu.so (test only).
 #include "pinn_inst.h"
+#include "pinn_fit_kernel.h"
 #include "pinn_aux_kernels.h"
 
 #include <cstdarg>
@@ -62,6 +63,10 @@ struct FitCapture { const PinnFitCtrl* ctrl; int k; };
 thread_local FitCapture g_fit_capture = {nullptr, 0};
 // set by pinn_fit_steps around the step of iteration k < K - 1: its reduction launch also draws the batch of iteration k + 1
 thread_local PinnNextBatch g_fit_next = {nullptr, 0, {}, 0u, 0u, 0ull};
+// set by pinn_fit_steps_graph around ONE residual step call: run_train then launches the one-launch fit chunk (pinn_fit_kernel) over the
+// tiles of that step instead of tile kernel + reduction; `done` says whether it did (0: the plan does not qualify -- nothing was launched)
+struct FitPersist { PinnFitP p; int active, done; };
+thread_local FitPersist g_fit_persist = {{}, 0, 0};
 int g_pinn_debug_flags = 0;         // -DPINN_DEBUG_ABI builds: pinn_debug_set_flags
 }
 
@@ -74,6 +79,7 @@ struct pinn_net {
     float lo[PINN_MAX_INPUTS], hi[PINN_MAX_INPUTS], bc_value;
     int n_cu;
     int gemm_mode;                  // PINN_GEMM_FP32 / PINN_GEMM_BF16X3 (pinn_set_gemm_mode)
+    int tanh_mode;                  // PINN_TANH_FAST / PINN_TANH_ACCURATE (pinn_set_tanh_mode)
     // pinn_fit_steps_graph: the instantiated launch graph of one chunk and the arguments it was captured with (host state of the
     // descriptor; no device memory: the control block is the caller's)
     void* fit_graph_exec;
@@ -81,6 +87,7 @@ struct pinn_net {
     int fit_graph_k;
     // diagnostics of THIS descriptor (pinn_debug_*: tests run one net at 1 workgroup per CU, with a separate pre-pass launch, with a
     // tiny slab budget -- a second Solver in the same process keeps its own planning)
+    int fit_persistent;             // pinn_debug_fit_persistent (default 0: measured slower than launch-graph replay on MI355X): small fit chunks as ONE launch
     int max_per_cu;                 // pinn_debug_max_wgs_per_cu (default 4)
     int prepass_in_kernel;          // pinn_debug_prepass_in_kernel (default 1)
     size_t wgx_chunk_bytes;         // pinn_debug_wgx_chunk_bytes (default PINN_WGX_CHUNK_DEFAULT)
@@ -187,6 +194,7 @@ int make_plan(const pinn_net* net, int64_t n_points, int nd, int n2, Plan* plan,
         probe.skip_outer = net->skip_outer;
     }
     probe.gemm_mode = net->gemm_mode;
+    probe.tanh_mode = net->tanh_mode;
     probe.mode = mode;
     probe.res_kind = res_kind;
     probe.comb = comb;
@@ -266,6 +274,7 @@ void fill_args(const pinn_net* net, PinnKArgs* a, const float* params, const flo
     for (int k = 0; k < PINN_MAX_DIRS; ++k) a->dir_cols[k] = (k < nd) ? dir_cols[k] : 0;
     a->s_user = pinn_ns(nd, n2);
     a->gemm_mode = net->gemm_mode;
+    a->tanh_mode = net->tanh_mode;
     a->tile_begin = 0;
     a->tile_end = 0;                // set from the plan (set_tile_range) before every launch
 }
@@ -288,11 +297,12 @@ int check_dirs(const pinn_net* net, const int* dir_cols, int nd, int n2p) {
     const int n2 = pinn_n2(n2p), n3 = pinn_n3(n2p);       // packed count: seconds | thirds << 3 (include/pinn.h)
     if (nd < 0 || nd > PINN_MAX_DIRS || n2 > nd || n3 > n2 || n2p < 0) return fail("bad derivative spec nd=%d n2=%d n3=%d", nd, n2, n3);
     for (int k = 0; k < nd; ++k) {
-        // direction code: column a, or the diagonal e_a + e_b as a | (b + 1) << 4 (include/pinn.h)
-        if (!dir_cols || dir_cols[k] < 0 || dir_cols[k] > 255) return fail("dir_cols[%d] out of range", k);
+        // direction code: column a, or the diagonal e_a +- e_b as a | (b + 1) << 4 | PINN_DIR_MINUS (include/pinn.h)
+        if (!dir_cols || dir_cols[k] < 0 || dir_cols[k] > 511) return fail("dir_cols[%d] out of range", k);
         const int a = dir_cols[k] & 15, b = ((dir_cols[k] >> 4) & 15) - 1;
         if (a >= net->lay.d || b >= net->lay.d || a == b) return fail("dir_cols[%d] names a column outside the %d inputs", k, net->lay.d);
-        if (k < n3 && b >= 0) return fail("dir_cols[%d]: third derivatives are taken along single columns, not diagonals", k);
+        if ((dir_cols[k] & PINN_DIR_MINUS) && b < 0) return fail("dir_cols[%d]: PINN_DIR_MINUS needs a second column", k);
+        // (round 5: third derivatives along diagonals too -- what mixed third-order partials are assembled from)
     }
     return 0;
 }
@@ -377,6 +387,13 @@ int pinn_debug_set_flags(int flags) { g_pinn_debug_flags = flags; return 0; }
 
 int pinn_debug_last_kernel(void) { return g_pinn_last_kernel; }
 
+int pinn_set_tanh_mode(pinn_t* net, int mode) {
+    if (!net) return fail("null argument");
+    if (mode != PINN_TANH_FAST && mode != PINN_TANH_ACCURATE) return fail("unknown tanh mode %d", mode);
+    net->tanh_mode = mode;
+    return 0;
+}
+
 int pinn_set_gemm_mode(pinn_t* net, int mode) {
     if (!net) return fail("null argument");
     if (mode != PINN_GEMM_FP32 && mode != PINN_GEMM_BF16X3) return fail("unknown GEMM mode %d", mode);
@@ -398,6 +415,13 @@ int pinn_debug_wgx_chunk_bytes(pinn_t* net, long long bytes) {
     if (!net) return fail("null argument");
     net->wgx_chunk_bytes = bytes > 0 ? (size_t)bytes : PINN_WGX_CHUNK_DEFAULT;
     return 0;
+}
+
+int pinn_debug_fit_persistent(pinn_t* net, int enable) {
+    if (!net) return -1;
+    const int before = net->fit_persistent;
+    net->fit_persistent = enable ? 1 : 0;
+    return before;
 }
 
 int pinn_debug_max_wgs_per_cu(pinn_t* net, int cap) {
@@ -516,7 +540,7 @@ int pinn_create_ex(const int* layer_dims, int n_layers, const int* acts, int n_s
     pinn_net* net = new (std::nothrow) pinn_net();
     if (!net) return fail("out of memory");
     memset(net, 0, sizeof(*net));
-    net->max_per_cu = 4; net->prepass_in_kernel = 1; net->wgx_chunk_bytes = PINN_WGX_CHUNK_DEFAULT;
+    net->fit_persistent = 0; net->max_per_cu = 4; net->prepass_in_kernel = 1; net->wgx_chunk_bytes = PINN_WGX_CHUNK_DEFAULT;
     net->n_layers = n_layers; net->act = act; net->ndims = ndims; net->nparams = nparams;
     for (int a = 0; a + 1 < n_layers; ++a) {
         net->act_codes[a >> 4] |= (unsigned long long)acts[a] << (4 * (a & 15));
@@ -601,8 +625,12 @@ size_t pinn_workspace_bytes(const pinn_t* net, int64_t n_points, int nd, int n2)
         if (v > need) need = v;
     }
     if (!any) return 0;
+    // (narrow nets: partial rows of both parities and the private (parameters, exp_avg, exp_avg_sq) of every workgroup of a one-launch fit
+    //  chunk, pinn_fit_kernel.h -- 5 x 16 x p_total floats at most)
+    const size_t persist = net->lay.hp <= 32 ? align256(2 * (size_t)PINN_FIT_MAX_WGS * net->lay.p_total * sizeof(float)) +
+                                               align256(3 * (size_t)PINN_FIT_MAX_WGS * net->lay.p_total * sizeof(float)) + 512 : 0;
     return need + align256((size_t)PINN_MAX_AUX * (size_t)n_points * sizeof(float)) + wt_workspace_bytes(net) +
-           wsp_workspace_bytes(net) + 256;
+           wsp_workspace_bytes(net) + 256 + persist;
 }
 
 static int jet_forward_impl(pinn_t* net, const float* params, const float* xs, int64_t n_points, const int* dir_cols, int nd,
@@ -725,6 +753,33 @@ static int run_train(pinn_t* net, PinnKArgs* a, const Plan& plan, int nd, float*
     ProfEvents* pe = g_profile ? prof_events() : nullptr;
     if (g_profile && !pe) return fail("hipEventCreate failed");
     if (pe) pe->have_wgrad = false;
+#endif
+#ifndef PINN_EMU
+    if (g_fit_persist.active) {
+        // a whole chunk of fit iterations in ONE launch (pinn_fit_kernel.h): the step must be one pass of a non-streamed kernel on a grid
+        // of resident workgroups, the instantiation must carry the kernel, the scratch for rows / private states must fit behind `need`
+        g_fit_persist.done = 0;
+        long long has = 0;
+        const size_t pc = (size_t)net->lay.p_total;
+        const size_t rows_b = align256(2 * (size_t)plan.grid * pc * sizeof(float)), state_b = align256(3 * (size_t)plan.grid * pc * sizeof(float));
+        if (!plan.wgx && !plan.wt_global && !plan.split && plan.chunk_tiles >= plan.ntiles && plan.grid <= PINN_FIT_MAX_WGS && !g_profile &&
+            plan.fn(nd, plan.n2k, a, plan.grid, stream, 3, &has) == 0 && has && workspace_bytes >= need + rows_b + state_b + 256 && adam &&
+            (!aux_bytes || net->prepass_in_kernel)) {
+            PinnFitP& P = g_fit_persist.p;
+            P.rows = reinterpret_cast<float*>(ws + need);
+            P.state = reinterpret_cast<float*>(ws + need + rows_b);
+            P.sync = reinterpret_cast<unsigned*>(ws + need + rows_b + state_b);
+            P.params = adam->params; P.m = adam->m; P.v = adam->v; P.mask = adam->mask; P.step_ptr = adam->step_ptr; P.grads = grads;
+            P.b1 = adam->b1; P.b2 = adam->b2; P.eps = adam->eps; P.off_loss = net->lay.off_loss;
+            if (hipMemsetAsync(P.sync, 0, 256, (hipStream_t)stream) != hipSuccess) return fail("hipMemsetAsync failed");
+            set_tile_range(a, plan, 0, plan.ntiles);
+            const int rc = plan.fn(nd, plan.n2k, a, plan.grid, stream, 2, reinterpret_cast<long long*>(&P));
+            note_launch(plan);
+            if (rc) return fail("fit kernel launch failed (%d)", rc);
+            g_fit_persist.done = 1;
+        }
+        return 0;
+    }
 #endif
     // one pass (any non-WGX kernel; a WGX batch whose slabs fit the net's wgx_chunk_bytes) or chunk by chunk: tile kernel ->
     // weight-gradient kernel -> reduction of the partial rows, later chunks ADD into `grads`, Adam rides in the last reduction
@@ -978,6 +1033,36 @@ int pinn_fit_steps_graph(pinn_t* net, const pinn_residual_t* residual, float* pa
     return pinn_fit_steps(net, residual, params, xs, n_points, kind, a, b, seed, call_index0, dir_cols, nd, n2, ic_const, grads, exp_avg,
                           exp_avg_sq, mask, step_ptr, step0, lr, beta1, beta2, eps, loss_history, k_steps, workspace, workspace_bytes, stream);
 #else
+    // narrow nets, grids of a few resident workgroups: the whole chunk -- any length up to PINN_FIT_CHUNK_MAX -- as ONE launch
+    // (pinn_fit_kernel.h); bit-identical to the eager loop below
+    if (net->fit_persistent && net->lay.hp <= 32 && ctrl && ctrl_bytes >= sizeof(PinnFitCtrl) && k_steps >= 1 && k_steps <= PINN_FIT_CHUNK_MAX &&
+        !g_profile && !g_phase_prof && residual && params && grads && exp_avg && exp_avg_sq && step_ptr) {
+        PinnNextBatch spec_probe = {nullptr, 0, {}, 0u, 0u, 0ull};
+        if (fit_next_spec(net, xs, n_points, kind, a, b, seed, &spec_probe) == 0) {
+            PinnFitCtrl* dctrl = reinterpret_cast<PinnFitCtrl*>(ctrl);
+            hipStream_t hs = (hipStream_t)stream;
+            PinnFitCtrlArgs ca;
+            ca.c.call_index0 = call_index0; ca.c.loss_base = loss_history; ca.c.step0 = step0; ca.c.pad = 0;
+            ca.c.k0 = (unsigned)(seed & 0xffffffffull); ca.c.k1 = (unsigned)(seed >> 32);
+            for (int k = 0; k < PINN_FIT_CHUNK_MAX; ++k) {
+                ca.c.step_size[k] = 0.0f; ca.c.bc2_sqrt[k] = 1.0f;
+                if (k < k_steps) pinn_adam_scalars((double)(step0 + k), lr, beta1, beta2, &ca.c.step_size[k], &ca.c.bc2_sqrt[k]);
+            }
+            memset(&g_fit_persist, 0, sizeof(g_fit_persist));
+            PinnFitP& P = g_fit_persist.p;
+            P.ctrl = dctrl; P.k_steps = k_steps; P.xs = xs; P.n = (long long)n_points; P.spec = spec_probe.spec;
+            g_fit_persist.active = 1;
+            hipLaunchKernelGGL(pinn_fit_ctrl_kernel, dim3(1), dim3(128), 0, hs, dctrl, ca);
+            const int rc = (hipGetLastError() != hipSuccess) ? fail("control-block launch failed")
+                           : pinn_residual_adam_step(net, residual, params, xs, n_points, dir_cols, nd, n2, nullptr, ic_const, grads, exp_avg,
+                                                     exp_avg_sq, mask, step_ptr, step0, lr, beta1, beta2, eps, loss_history, workspace,
+                                                     workspace_bytes, stream);
+            const int did = g_fit_persist.done;
+            g_fit_persist.active = 0;
+            if (rc) return rc;
+            if (did) { ++g_fit_graph_stats[0]; return 0; }          // (counted with the replayed chunks: one launch for the chunk)
+        }
+    }
     // the graph pays where launch gaps are a visible share of an iteration; chunks that do not qualify run the eager loop
     // (only whole chunks: the tail of a fit would capture a graph of its own that nothing replays)
     if (k_steps != PINN_FIT_CHUNK_MAX || !ctrl || ctrl_bytes < sizeof(PinnFitCtrl) || g_profile || g_phase_prof)
@@ -989,7 +1074,7 @@ int pinn_fit_steps_graph(pinn_t* net, const pinn_residual_t* residual, float* pa
     const void* ptrs[] = {params, xs, grads, exp_avg, exp_avg_sq, mask, step_ptr, workspace, ctrl, stream};
     key_mix(key, ptrs, sizeof(ptrs));
     // (not the sampler's key `seed`: it travels through the control block, so the chunk recorded by one fit call is replayed by the next)
-    const long long ints[] = {(long long)n_points, nd, n2, (long long)workspace_bytes, net->gemm_mode, net->max_per_cu,
+    const long long ints[] = {(long long)n_points, nd, n2, (long long)workspace_bytes, net->gemm_mode, net->tanh_mode, net->max_per_cu,
                               net->prepass_in_kernel, (long long)net->wgx_chunk_bytes};
     key_mix(key, ints, sizeof(ints));
     const float flts[] = {ic_const, lr, beta1, beta2, eps};

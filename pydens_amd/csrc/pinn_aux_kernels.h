@@ -1,5 +1,13 @@
 // pinn_aux_kernels.h -- small non-template kernels (gradient reduction, Adam); included by pinn_abi.cpp only.
 #pragma once
+// (the small kernels of this header are launched from pinn_abi.cpp only; the per-width units of widths <= 32 include the header for the
+//  structs and device functions pinn_fit_kernel.h shares with them -- there the kernels get internal linkage and are dropped unused)
+#ifdef PINN_AUX_KERNELS_STATIC
+#define PINN_AUX_GLOBAL static PINN_GLOBAL
+#else
+#define PINN_AUX_GLOBAL PINN_GLOBAL
+#endif
+
 #include "pinn_port.h"
 #include "pinn_kernel.h"
 
@@ -7,7 +15,7 @@
 // x-only pre-pass: evaluates the source terms / variable coefficients of the residual for every point once,
 // outside the tile kernel (one thread per point, registers in private memory; N * a-few-ops, microseconds).
 // ------------------------------------------------------------------------------------------------------------
-PINN_GLOBAL void PINN_LAUNCH_BOUNDS(256)
+PINN_AUX_GLOBAL void PINN_LAUNCH_BOUNDS(256)
 pinn_aux_kernel(const float* xs, long long n, int d, pinn_program_t pg, float* aux) {
     const long long i = (long long)PINN_BID * 256 + PINN_TID;
     if (i >= n) return;
@@ -148,14 +156,14 @@ struct PinnFitCtrl {
                                                                              // double, as for the eager loop: bit-identical updates)
 };
 struct PinnFitCtrlArgs { PinnFitCtrl c; };
-PINN_GLOBAL void PINN_LAUNCH_BOUNDS(128) pinn_fit_ctrl_kernel(PinnFitCtrl* dst, PinnFitCtrlArgs a) {
+PINN_AUX_GLOBAL void PINN_LAUNCH_BOUNDS(128) pinn_fit_ctrl_kernel(PinnFitCtrl* dst, PinnFitCtrlArgs a) {
     const int t = PINN_TID;
     if (t == 0) { dst->call_index0 = a.c.call_index0; dst->loss_base = a.c.loss_base; dst->step0 = a.c.step0; dst->pad = 0;
                   dst->k0 = a.c.k0; dst->k1 = a.c.k1; }
     if (t < PINN_FIT_CHUNK_MAX) { dst->step_size[t] = a.c.step_size[t]; dst->bc2_sqrt[t] = a.c.bc2_sqrt[t]; }
 }
 
-PINN_GLOBAL void PINN_LAUNCH_BOUNDS(1024)
+PINN_AUX_GLOBAL void PINN_LAUNCH_BOUNDS(1024)
 pinn_reduce_kernel(const float* partials, int n_wg, int p_core, float* grads, int accumulate, int do_adam, float* params,
                    float* m, float* v, const unsigned char* mask, int step_value, float step_size, float bc2_sqrt, float b1,
                    float b2, float eps, int* step_ptr, float* loss_out, int off_loss, const PinnFitCtrl* ctrl, int ctrl_k,
@@ -201,7 +209,7 @@ pinn_reduce_kernel(const float* partials, int n_wg, int p_core, float* grads, in
 // ------------------------------------------------------------------------------------------------------------
 // wt[l][in][out] = W_l[out][in] for the lh hidden->hidden matrices (hp x hp, row stride hp, layer stride hidden_stride):
 // 32 x 32 tiles through LDS, both sides coalesced. Grid: (hp/32)^2 * lh workgroups of 256 threads.
-PINN_GLOBAL void PINN_LAUNCH_BOUNDS(256) pinn_transpose_kernel(const float* wh, int hidden_stride, int hp, float* wt) {
+PINN_AUX_GLOBAL void PINN_LAUNCH_BOUNDS(256) pinn_transpose_kernel(const float* wh, int hidden_stride, int hp, float* wt) {
     PINN_SMEM(tile);                                     // [32][33]
     const int tiles = hp / 32;
     const int l = PINN_BID / (tiles * tiles), t = PINN_BID % (tiles * tiles), tr = t / tiles, tc = t % tiles;
@@ -220,7 +228,7 @@ PINN_GLOBAL void PINN_LAUNCH_BOUNDS(256) pinn_transpose_kernel(const float* wh, 
 // W[16 j + lr][32 kb + 8 lq + e], e = 0..7; direction 1 (data gradient): W[32 kb + 8 lq + e][16 j + lr]. One thread per
 // (layer, direction, K block, tile, lane); rewritten before every step (the weights change every step), 147 KB at 3 x 64 x 64.
 // ------------------------------------------------------------------------------------------------------------
-PINN_GLOBAL void PINN_LAUNCH_BOUNDS(256) pinn_wsplit_kernel(const float* wh, int hidden_stride, int hp, int lh, pinn_s16x8* out) {
+PINN_AUX_GLOBAL void PINN_LAUNCH_BOUNDS(256) pinn_wsplit_kernel(const float* wh, int hidden_stride, int hp, int lh, pinn_s16x8* out) {
     const int kbs = hp / 32, nt = hp / 16;
     const int idx = PINN_BID * 256 + PINN_TID;
     if (idx >= lh * 2 * kbs * nt * 64) return;
@@ -243,11 +251,11 @@ PINN_GLOBAL void PINN_LAUNCH_BOUNDS(256) pinn_wsplit_kernel(const float* wh, int
     }
 }
 
-PINN_GLOBAL void PINN_LAUNCH_BOUNDS(64) pinn_tick_kernel(int* step_ptr) {
+PINN_AUX_GLOBAL void PINN_LAUNCH_BOUNDS(64) pinn_tick_kernel(int* step_ptr) {
     if (PINN_TID == 0 && PINN_BID == 0) step_ptr[0] += 1;
 }
 
-PINN_GLOBAL void PINN_LAUNCH_BOUNDS(256)
+PINN_AUX_GLOBAL void PINN_LAUNCH_BOUNDS(256)
 pinn_adam_kernel(float* params, const float* grads, float* m, float* v, const unsigned char* mask, long long n,
                  int* step_ptr, int step_value, float lr, float step_size, float bc2_sqrt, float b1, float b2, float eps,
                  float* loss_out, int off_loss) {
@@ -266,7 +274,7 @@ pinn_adam_kernel(float* params, const float* grads, float* m, float* v, const un
 
 // one thread per point. Counter = (point low, point high, call low, call high | block << 28): block b < 8 supplies the
 // uniform words of columns 4b .. 4b+3, block 8 + c the two extra words of a normal column c (Box-Muller).
-PINN_GLOBAL void PINN_LAUNCH_BOUNDS(256)
+PINN_AUX_GLOBAL void PINN_LAUNCH_BOUNDS(256)
 pinn_sample_kernel(float* xs, long long n, PinnSampleSpec spec, unsigned k0, unsigned k1, unsigned call_lo, unsigned call_hi,
                    const PinnFitCtrl* ctrl, int ctrl_k) {
     const long long i = (long long)PINN_BID * 256 + PINN_TID;

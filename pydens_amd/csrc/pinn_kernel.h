@@ -44,6 +44,10 @@
 #endif
 
 enum { PINN_MODE_FORWARD = 0, PINN_MODE_STEP = 1, PINN_MODE_BACKWARD = 2 };
+#ifndef PINN_PTALL
+#define PINN_PTALL 1            // (documented at its use in the tile kernel)
+#endif
+#define PINN_PTALL_DEFAULT PINN_PTALL
 
 // activation code of activation index a (4 bits each, 16 per word)
 PINN_HOST_DEVICE inline int pinn_act_code(const unsigned long long (&codes)[2], int a) {
@@ -82,6 +86,7 @@ struct PinnKArgs {
     const float* wt;             // widths >= 128: transposed copy of the hidden weights, [lh][in][out] (pinn_transpose_kernel)
     const void* wsp;             // split-bf16 kernels (VAR 512): hidden weights as hi / mid / lo bf16 MFMA fragments (pinn_wsplit_kernel)
     int gemm_mode;               // PINN_GEMM_FP32 / PINN_GEMM_BF16X3 (pinn_set_gemm_mode): which instantiation the launcher picks
+    int tanh_mode;               // PINN_TANH_FAST / PINN_TANH_ACCURATE (pinn_set_tanh_mode): likewise
     long long* prof;             // optional per-phase cycle counters (PINN_PROFILE_PHASES builds only)
     int debug_flags;             // timing-experiment bits (PINN_DBG; -DPINN_DEBUG_ABI builds only)
     long long n_points;
@@ -236,7 +241,12 @@ PINN_DEVICE void pinn_sincos(float x, float& sn, float& cs) {
 #ifndef PINN_ABL
 #define PINN_ABL 0
 #endif
-PINN_DEVICE float pinn_act(float z, int act) {
+// (bit 8 of the code handed to pinn_act / pinn_jet_fwd: tanh of small arguments by its minimax polynomial -- the kernels that can pay
+//  for it, see PTALL in the tile kernel; every other function sees the plain code)
+#define PINN_ACT_TANH_POLYBIT 0x100
+PINN_DEVICE float pinn_act(float z, int act_) {
+    const bool poly = (act_ & PINN_ACT_TANH_POLYBIT) != 0;
+    const int act = act_ & 0xff;
     if (PINN_ABL & 32) return 0.5f * z;
     if (act == PINN_ACT_TANH) {
         // sign(z) (1 - t)/(1 + t) with t = e^{-2|z|} (symmetric, no overflow) for small |z|; 1 - 2t/(1 + t) where the unit saturates
@@ -249,9 +259,9 @@ PINN_DEVICE float pinn_act(float z, int act) {
         const float r = pinn_rcp(1.0f + t);
         const float lo = (1.0f - t) * r, hi = 1.0f - (t + t) * r;
 #ifndef PINN_TANH_POLY
-#define PINN_TANH_POLY 0
+#define PINN_TANH_POLY 0        // 1: in every kernel (experiment builds); the product asks for it per kernel with PINN_ACT_TANH_POLYBIT
 #endif
-        if (PINN_TANH_POLY) {
+        if (PINN_TANH_POLY || poly) {
             // |z| < 0.45: z P(z^2), P of degree 4 (Chebyshev fit of tanh(sqrt(w)) / sqrt(w) on [0, 0.2025]; 1.5e-7 relative in fp32
             // evaluation, where the exponential form loses relative accuracy to the cancellation in 1 - t)
             const float w = z * z;
@@ -385,15 +395,20 @@ PINN_DEVICE float pinn_act_d4(float sv, float d1, float d2, int act) {
     return 0.0f;
 }
 
-// A differentiation direction is an input column c or the diagonal e_a + e_b of two columns (mixed partials by
-// polarisation: u_ab = (u_vv - u_aa - u_bb) / 2 with v = e_a + e_b). Code: a | (b + 1) << 4, b + 1 == 0 for a single column.
+// A differentiation direction is an input column c or a diagonal e_a + e_b / e_a - e_b of two columns (mixed partials by
+// polarisation: u_ab = (u_vv - u_aa - u_bb) / 2 with v = e_a + e_b; round 5, mixed THIRD-order partials from third derivatives along
+// both diagonals: u_aab = (D3_{a+b} - D3_{a-b} - 2 u_bbb) / 6, u_abb = (D3_{a+b} + D3_{a-b} - 2 u_aaa) / 6).
+// Code: a | (b + 1) << 4 | minus << 8, b + 1 == 0 for a single column (include/pinn.h PINN_DIR_MINUS).
 PINN_DEVICE int pinn_dir_a(int code) { return code & 15; }
 PINN_DEVICE int pinn_dir_b(int code) { return ((code >> 4) & 15) - 1; }
+PINN_DEVICE float pinn_dir_sb(int code) { return (code & 0x100) ? -1.0f : 1.0f; }        // weight of column b in the direction
 PINN_DEVICE bool pinn_dir_has(int code, int c) { return pinn_dir_a(code) == c || pinn_dir_b(code) == c; }
-// first-layer pre-activation derivative along a direction: sum of the weight columns it contains
+// weight of input column c in the direction: 1 for a, +-1 for b, 0 otherwise
+PINN_DEVICE float pinn_dir_coef(int code, int c) { return pinn_dir_a(code) == c ? 1.0f : (pinn_dir_b(code) == c ? pinn_dir_sb(code) : 0.0f); }
+// first-layer pre-activation derivative along a direction: signed sum of the weight columns it contains
 PINN_DEVICE float pinn_dir_weight(const float* w1row, int code) {
     const int b = pinn_dir_b(code);
-    return w1row[pinn_dir_a(code)] + (b >= 0 ? w1row[b] : 0.0f);
+    return w1row[pinn_dir_a(code)] + (b >= 0 ? pinn_dir_sb(code) * w1row[b] : 0.0f);
 }
 
 // Second-order streams. Standard form: stream 1+ND+k is d2/dx_k2 for k < N2. COMB form (N2 == 1): ONE stream
@@ -414,10 +429,11 @@ struct PinnJet {
 
 // forward jet of one (point, unit): z[S] pre-activations -> h[S] activations
 template <int ND, int N2P, bool COMB = false>
-PINN_DEVICE void pinn_jet_fwd(const float (&z)[pinn_ns(ND, N2P)], int act, float (&h)[pinn_ns(ND, N2P)], const float* cw = nullptr) {
+PINN_DEVICE void pinn_jet_fwd(const float (&z)[pinn_ns(ND, N2P)], int act_, float (&h)[pinn_ns(ND, N2P)], const float* cw = nullptr) {
     using J = PinnJet<ND, N2P, COMB>;
     constexpr int N2 = J::N2, N3 = J::N3;
-    const float v = pinn_act(z[0], act);
+    const float v = pinn_act(z[0], act_);
+    const int act = act_ & 0xff;                // (PINN_ACT_TANH_POLYBIT concerns the value only)
     float d1, d2;
     pinn_act_d12(pinn_act_saved(v, z[0], act), act, d1, d2);
     h[0] = v;
@@ -550,9 +566,11 @@ PINN_DEVICE float pinn_prog_forward(const pinn_program_t& pg, float* regs, int T
 // `regs` / T: the register file -- LDS of the workgroup (register r of this thread at regs[r * T], T = threads) when the
 // program's registers fit the free activation buffers, else null: private memory (scratch; 10x the latency per access).
 PINN_DEVICE void pinn_prepass_point(const pinn_program_t& pg, const float* x, int d, float* aux, long long n, long long gi,
-                                    float* regs, int T) {
+                                    float* regs, int T, bool in_lds = true) {
     float priv[PINN_MAX_REGS];                 // private (scratch): the program indexes it at run time
-    if (!regs) { regs = priv; T = 1; }
+    // (`in_lds` instead of a null test of `regs`: comparing an LDS-derived generic pointer with null makes hipcc 7.2 emit
+    //  `v_cmp_ne_u32 0, src_shared_base` -- "Illegal instruction detected" -- once this body sits inside pinn_fit_kernel's loop)
+    if (!in_lds) { regs = priv; T = 1; }
     for (int c = 0; c < d; ++c) regs[c * T] = x[c];
     for (int i = 0; i < pg.n_ops; ++i) {
         const unsigned w = pg.code[i];
@@ -662,7 +680,7 @@ struct PinnPointPre {
 };
 
 template <int ND, int N2P, int SPEC = 0>
-PINN_DEVICE void pinn_point_prefetch(const PinnKArgs& A, long long gidx, bool valid, float* pregs, int T,
+PINN_DEVICE void pinn_point_prefetch(const PinnKArgs& A, const float* params_, long long gidx, bool valid, float* pregs, int T,
                                      PinnPointPre<ND, N2P>& pre) {
     constexpr int S = pinn_ns(ND, N2P);
     using SH = PinnShape<SPEC, ND>;
@@ -692,13 +710,13 @@ PINN_DEVICE void pinn_point_prefetch(const PinnKArgs& A, long long gidx, bool va
             for (int s = 0; s < S; ++s)
                 if (s < SH::s_user(A)) pre.ic[s] = (A.ic_row[s] >= 0) ? A.aux[(long long)A.ic_row[s] * A.n_points + gi] : A.ic_cst[s];
         } else {
-            pre.ic[0] = (SPEC == 0 && A.ic_var1 > 0) ? A.params[A.off_extra + A.ic_var1 - 1] : A.ic_const;
+            pre.ic[0] = (SPEC == 0 && A.ic_var1 > 0) ? params_[A.off_extra + A.ic_var1 - 1] : A.ic_const;
         }
     }
 }
 
 template <int ND, int N2P, bool WITH_PROGRAMS = true, bool COMB = false, int SPEC = 0>
-PINN_DEVICE void pinn_point_stage(const PinnKArgs& A, const float (&net)[pinn_ns(ND, N2P)], const float* x /*[d]*/,
+PINN_DEVICE void pinn_point_stage(const PinnKArgs& A, const float* params_, const float (&net)[pinn_ns(ND, N2P)], const float* x /*[d]*/,
                                   long long gidx, bool valid, float* pregs, float* padj, int T,
                                   const PinnPointPre<ND, N2P>& pre, PinnPointOut<ND, N2P>& out) {
     constexpr int S = pinn_ns(ND, N2P), N2 = pinn_n2(N2P), N3 = pinn_n3(N2P);
@@ -707,9 +725,11 @@ PINN_DEVICE void pinn_point_stage(const PinnKArgs& A, const float (&net)[pinn_ns
     constexpr int NIN = SH::FIXED ? (ND > 0 ? ND : 1) : PINN_MAX_INPUTS;   // input columns the box factors may range over
     const float* cw = A.comb_w;
     // ---- BC factor P and its direction derivatives --------------------------------------------------------
-    float P = 1.0f, Pk[ND > 0 ? ND : 1], Pkk[ND > 0 ? ND : 1];
+    float P = 1.0f, Pk[ND > 0 ? ND : 1], Pkk[ND > 0 ? ND : 1], Pkkk[N3 > 0 ? N3 : 1];
 #pragma unroll
     for (int k = 0; k < ND; ++k) { Pk[k] = 0.0f; Pkk[k] = 0.0f; }
+#pragma unroll
+    for (int k = 0; k < (N3 > 0 ? N3 : 1); ++k) Pkkk[k] = 0.0f;
     if (SH::has_bc(A)) {
         float p[NIN], p1[NIN], p2[NIN];
 #pragma unroll
@@ -725,10 +745,13 @@ PINN_DEVICE void pinn_point_stage(const PinnKArgs& A, const float (&net)[pinn_ns
         }
 #pragma unroll
         for (int k = 0; k < ND; ++k) {
-            // directional derivatives of P = prod_j p_j along e_a (+ e_b): first = sum_c p'_c prod_{j != c} p_j,
-            // second = sum_c p''_c prod_{j != c} p_j + 2 p'_a p'_b prod_{j != a,b} p_j (columns outside the spatial block: 0)
+            // directional derivatives of P = prod_j p_j along v = e_a + w e_b (w = +-1): with A(t) = p_a(x_a + t), B(t) = p_b(x_b + w t)
+            // and R = prod_{j != a, b} p_j:   first = (A1 B + A B1) R,   second = (A2 B + 2 A1 B1 + A B2) R,
+            // third = 3 (A2 B1 + A1 B2) R  (every factor is quadratic in its column: A3 = B3 = 0; along a single column: 0);
+            // A1 = p1_a, A2 = p2_a, B1 = w p1_b, B2 = p2_b (columns outside the spatial block contribute nothing)
             const int ca = pinn_dir_a(SH::dir(A, k)), cb = pinn_dir_b(SH::dir(A, k));
-            float first = 0.0f, second = 0.0f, cross = 2.0f;
+            const float wb = SH::FIXED ? 1.0f : pinn_dir_sb(SH::dir(A, k));
+            float first = 0.0f, second = 0.0f, cross = 2.0f * wb, third = 0.0f;
             bool both = true;
 #pragma unroll
             for (int t = 0; t < 2; ++t) {
@@ -740,7 +763,7 @@ PINN_DEVICE void pinn_point_stage(const PinnKArgs& A, const float (&net)[pinn_ns
                         if (j == c) { q1 = p1[j]; q2 = p2[j]; }
                         else rest *= p[j];
                     }
-                    first += q1 * rest;
+                    first += (t == 0 ? 1.0f : wb) * q1 * rest;
                     second += q2 * rest;
                 } else {
                     both = false;
@@ -750,9 +773,20 @@ PINN_DEVICE void pinn_point_stage(const PinnKArgs& A, const float (&net)[pinn_ns
 #pragma unroll
                 for (int j = 0; j < NIN; ++j) cross *= (j == ca || j == cb) ? p1[j] : p[j];
                 second += cross;
+                if (N3 > 0 && k < N3) {
+                    float rab = 3.0f, a1 = 0.0f, a2 = 0.0f, b1 = 0.0f, b2 = 0.0f;
+#pragma unroll
+                    for (int j = 0; j < NIN; ++j) {
+                        if (j == ca) { a1 = p1[j]; a2 = p2[j]; }
+                        else if (j == cb) { b1 = p1[j]; b2 = p2[j]; }
+                        else rab *= p[j];
+                    }
+                    third = rab * (a2 * wb * b1 + a1 * b2);
+                }
             }
             Pk[k] = first;
             Pkk[k] = second;
+            if (N3 > 0 && k < N3) Pkkk[k < N3 ? k : 0] = third;
         }
     }
     // ---- Q = net * P + bc ---------------------------------------------------------------------------------
@@ -772,7 +806,7 @@ PINN_DEVICE void pinn_point_stage(const PinnKArgs& A, const float (&net)[pinn_ns
         // Q''' = net''' P + 3 net'' P' + 3 net' P''
 #pragma unroll
         for (int k = 0; k < N3; ++k)
-            Q[J::idx3(k)] = net[J::idx3(k)] * P + 3.0f * (net[1 + ND + k] * Pk[k] + net[1 + k] * Pkk[k]);
+            Q[J::idx3(k)] = net[J::idx3(k)] * P + 3.0f * (net[1 + ND + k] * Pk[k] + net[1 + k] * Pkk[k]) + net[0] * Pkkk[k];
     }
     // ---- IC gate G = sigmoid(tau) - 1/2, tau = (t - t0) exp(-log_scale) -----------------------------------------
     float u[S];
@@ -786,7 +820,7 @@ PINN_DEVICE void pinn_point_stage(const PinnKArgs& A, const float (&net)[pinn_ns
     for (int k = 0; k < (N3 > 0 ? N3 : 1); ++k) { Gkkk[k] = 0.0f; dGkkk[k] = 0.0f; }
     if (SH::has_ic(A)) {
         const int tcol = SH::ndims(A) - 1;
-        const float es = expf(-A.params[A.off_ls]);
+        const float es = expf(-params_[A.off_ls]);
         const float tau = (x[tcol] - A.t0) * es;
         const float sg = pinn_sigmoidf(tau);
         float d1, d2;
@@ -797,14 +831,16 @@ PINN_DEVICE void pinn_point_stage(const PinnKArgs& A, const float (&net)[pinn_ns
 #pragma unroll
         for (int k = 0; k < ND; ++k) {
             if (pinn_dir_has(SH::dir(A, k), tcol)) {
-                Gk[k] = d1 * es; Gkk[k] = d2 * es * es;
-                dGk[k] = es * (-tau * d2 - d1);
+                // (wt: weight of the time column in the direction, -1 only as the second column of a minus diagonal; odd orders carry it)
+                const float wt = SH::FIXED ? 1.0f : pinn_dir_coef(SH::dir(A, k), tcol);
+                Gk[k] = wt * d1 * es; Gkk[k] = d2 * es * es;
+                dGk[k] = wt * es * (-tau * d2 - d1);
                 dGkk[k] = es * es * (-tau * d3 - 2.0f * d2);
                 if (k < N3) {
                     // G''' = s'''(tau) es^3 and its derivative with respect to log_scale (d tau / ds = -tau, d es / ds = -es)
                     const float d4 = pinn_act_d4(sg, d1, d2, PINN_ACT_SIGMOID);
-                    Gkkk[k] = d3 * es * es * es;
-                    dGkkk[k] = es * es * es * (-tau * d4 - 3.0f * d3);
+                    Gkkk[k] = wt * d3 * es * es * es;
+                    dGkkk[k] = wt * es * es * es * (-tau * d4 - 3.0f * d3);
                 }
             }
         }
@@ -857,7 +893,7 @@ PINN_DEVICE void pinn_point_stage(const PinnKArgs& A, const float (&net)[pinn_ns
         // trainable V(...) scalars: registers behind the aux rows; the adjoints of these registers are never cleared,
         // so they add up d(loss)/dV over all points this thread sees (summed over the tile's threads at the end of the kernel)
         const int vbase = S + SH::d(A) + A.n_aux;
-        for (int k = 0; k < A.n_vars; ++k) pregs[(vbase + k) * T] = A.params[A.off_extra + k];
+        for (int k = 0; k < A.n_vars; ++k) pregs[(vbase + k) * T] = params_[A.off_extra + k];
         const float r = pinn_prog_forward(A.prog, pregs, T);
         const float w = valid ? 2.0f * r * A.inv_n : 0.0f;
         pinn_prog_backward(A.prog, pregs, padj, T, w);          // seeded with d(loss)/dr: adjoints come out scaled
@@ -936,6 +972,7 @@ PINN_DEVICE void pinn_point_stage(const PinnKArgs& A, const float (&net)[pinn_ns
             out.gnet[J::idx3(k)] = g3 * P;
             out.gnet[1 + ND + k] += 3.0f * g3 * Pk[k];
             out.gnet[1 + k] += 3.0f * g3 * Pkk[k];
+            g0 += g3 * Pkkk[k];             // (third derivative of the box factor along a diagonal; 0 along a single column)
         }
         out.gnet[0] = g0;
     }
@@ -1069,9 +1106,11 @@ template <int HP, int ND, int N2, int MT, int LHC, int ACTC, bool COMB = false, 
 #ifndef PINN_WAVES_PER_SIMD
 #define PINN_WAVES_PER_SIMD 1
 #endif
-PINN_GLOBAL void PINN_LAUNCH_BOUNDS2((PinnCfg<HP, ND, N2, MT>::NTHREADS * ((VAR & 256) ? 2 : 1)),
-                                    (PinnCfg<HP, ND, N2, MT>::NW < 4 || (VAR & (2 | 256)) ? 2 : PINN_WAVES_PER_SIMD))
-pinn_tile_kernel(const PinnKArgs A) {
+PINN_DEVICE void pinn_tile_body(const PinnKArgs& A, const float* params_, float* partials_) {
+    // params_ / partials_: the parameter buffer the pass reads and the block of partial gradient rows it writes -- params_ / partials_ for
+    // an ordinary launch; the one-launch fit chunk hands over the workgroup's own parameter copy and the rows of the iteration's parity
+    // (the body of the tile kernel as a function: pinn_tile_kernel below runs it once per launch, pinn_fit_kernel.h -- a whole chunk of
+    //  fit iterations in one launch, round 5 -- once per iteration)
     using C = PinnCfg<HP, ND, N2, MT, (VAR & 512) != 0>;
     constexpr int S = C::S, NT = C::NT, NTW = C::NTW, NW = C::NW, T = C::T, LDA = C::LDA, NTHREADS = C::NTHREADS;
     constexpr bool DWG = (LHC < 0) || (VAR & 1), ONEBUF = C::ONEBUF, SKIPS = (VAR & 8) != 0;
@@ -1146,8 +1185,14 @@ pinn_tile_kernel(const PinnKArgs A) {
     //  no nested skips: exactly the kernels round 4 measured; ACTC -2 knows all sixteen codes and parks the outer skip of a nest. The
     //  second set spills 50 - 150 registers more at width 256, which the nets of the first set should not pay)
     constexpr bool ALLACT = ACTC == -2;
+    // tanh by its minimax polynomial below |z| = 0.45 (pinn_act): an instantiation of its own, ACTC = PINN_ACT_TANH | PINN_ACT_TANH_POLYBIT,
+    // picked by pinn_set_tanh_mode(PINN_TANH_ACCURATE). Same-box A/B on BASELINE config 2 (round 5, profiles/r05_headline_ab.txt): +2.5 % kernel
+    // time (the select per value costs the forward epilogues their packed fp32 code) for a trained-state gradient error of 0.6 - 1.2x the fp32
+    // reference's own instead of 1.7 - 1.9x (bench.py `parity_trained_state`). Not the default: the default form already meets the survey's bar.
+    constexpr int TPOLY = (ACTC >= 0 && (ACTC & PINN_ACT_TANH_POLYBIT)) ? PINN_ACT_TANH_POLYBIT : 0;
+    constexpr int ACTK = (ACTC >= 0) ? (ACTC & 0xff) : ACTC;          // the activation code proper
     auto act_at = [&](int a) -> int {
-        return (ACTC >= 0) ? ACTC : (pinn_act_code(A.act_codes, a) & ((SKIPS && !(VAR & 1024)) ? (ALLACT ? 15 : 7) : 1));
+        return (ACTC >= 0) ? ACTK : (pinn_act_code(A.act_codes, a) & ((SKIPS && !(VAR & 1024)) ? (ALLACT ? 15 : 7) : 1));
     };
     // skip connection ending / starting at activation a (or -1); slab slot of skip k
     auto skip_into = [&](int a) -> int {
@@ -1184,10 +1229,10 @@ pinn_tile_kernel(const PinnKArgs A) {
     // ---- one-time staging of the small layers and zeroing of the LDS accumulators -------------------------------
     for (int i = tid; i < HP * PINN_XS_LD; i += NTHREADS) {
         const int n = i / PINN_XS_LD, c = i % PINN_XS_LD;
-        W1s[i] = (c < d) ? A.params[n * d + c] : 0.0f;
+        W1s[i] = (c < d) ? params_[n * d + c] : 0.0f;
         accW1[i] = 0.0f;
     }
-    for (int i = tid; i < HP; i += NTHREADS) { b1s[i] = A.params[A.off_b1 + i]; WLs[i] = A.params[A.off_wl + i]; }
+    for (int i = tid; i < HP; i += NTHREADS) { b1s[i] = params_[A.off_b1 + i]; WLs[i] = params_[A.off_wl + i]; }
     if (tid == 0) tbar[0] = 0;
     for (int i = tid; i < PINN_MAX_LAYERS * HP; i += NTHREADS) accB[i] = 0.0f;
     float* WTs = TEAMS2 ? smem_all + 2 * C::TEAM_FLOATS : smem + C::O_WT;
@@ -1198,7 +1243,7 @@ pinn_tile_kernel(const PinnKArgs A) {
         float* wtw = const_cast<float*>(wtg);
         for (int i = tid; i < lh * HP * HP; i += NTHREADS) {
             const int l = i / (HP * HP), n = (i / HP) % HP, k = i % HP;
-            wtw[((size_t)l * HP + k) * HP + n] = A.params[A.off_wh + (size_t)l * A.hidden_stride + n * HP + k];
+            wtw[((size_t)l * HP + k) * HP + n] = params_[A.off_wh + (size_t)l * A.hidden_stride + n * HP + k];
         }
     }
     // WTs[l][k][n] = W_l[n][k]: coalesced global reads along k, one-time strided LDS writes. ALL loads of a thread are
@@ -1226,13 +1271,13 @@ pinn_tile_kernel(const PinnKArgs A) {
             for (int e = 0; e < WT_B; ++e) {
                 const int i = gtid + (e0 + e) * NTH_ALL;
                 const int l = i / (HP * HP), n = (i / HP) % HP, k = i % HP;
-                wreg[e] = (i < WT_TOTAL) ? A.params[A.off_wh + (size_t)l * A.hidden_stride + n * HP + k] : 0.0f;
+                wreg[e] = (i < WT_TOTAL) ? params_[A.off_wh + (size_t)l * A.hidden_stride + n * HP + k] : 0.0f;
             }
             wt_write(e0, wreg);
         }
     }
     if (!SLABL && !TEAMS2) for (int i = tid; i < PINN_MAX_REGS * T; i += NTHREADS) padj[i] = 0.0f;   // (team blocks end before the program registers)
-    const float bL = A.params[A.off_bl];
+    const float bL = params_[A.off_bl];
 
     // persistent per-lane accumulators
     f32x4 dW[LHREG][DWG ? 1 : NT][NTW];
@@ -1244,7 +1289,7 @@ pinn_tile_kernel(const PinnKArgs A) {
             for (int j = 0; j < NTW; ++j) dW[l][o][j] = f32x4{0.f, 0.f, 0.f, 0.f};
     // this lane's element of weight-gradient tile (o, j) of hidden layer li inside the workgroup's partial buffer
     auto dwg_ptr = [&](int li, int o, int j, int r) -> float* {
-        return A.partials + (size_t)PINN_BID * A.p_core + A.off_wh + (size_t)li * A.hidden_stride +
+        return partials_ + (size_t)PINN_BID * A.p_core + A.off_wh + (size_t)li * A.hidden_stride +
                (o * 16 + lq * 4 + r) * HP + (wave * NTW + j) * 16 + lr;
     };
     if (DWG && !WGX && train) {
@@ -1469,10 +1514,11 @@ pinn_tile_kernel(const PinnKArgs A) {
         // NTHREADS / T tiles per sweep; the rows land in A.aux and are read back (by the point-stage threads of the same
         // workgroup, hence the fence + the barrier below) at the top of each tile
         // (its registers live in the activation buffers, which nothing uses before the first tile, whenever they fit)
-        float* pp_regs = (A.pre_nregs * NTHREADS <= C::O_NET - C::O_BUFA) ? smem + C::O_BUFA + tid : nullptr;
+        const bool pp_lds = A.pre_nregs * NTHREADS <= C::O_NET - C::O_BUFA;
+        float* pp_regs = smem + C::O_BUFA + tid;
         for (long long tile = A.tile_begin + vbid + (long long)(tid / T) * vnblk; tile < ntiles; tile += (long long)(NTHREADS / T) * vnblk) {
             const long long gi = tile * T + tid % T;
-            if (gi < A.n_points) pinn_prepass_point(A.pre, A.xs + gi * d, d, A.aux, A.n_points, gi, pp_regs, NTHREADS);
+            if (gi < A.n_points) pinn_prepass_point(A.pre, A.xs + gi * d, d, A.aux, A.n_points, gi, pp_regs, NTHREADS, pp_lds);
         }
         PINN_FENCE_BLOCK();
     }
@@ -1518,18 +1564,21 @@ pinn_tile_kernel(const PinnKArgs A) {
         float* xs_t = xs_base + tile_parity * T * PINN_XS_LD;
         float* xs_next = xs_base + (tile_parity ^ 1) * T * PINN_XS_LD;
 #ifndef PINN_PTALL
-#define PINN_PTALL 0
+#define PINN_PTALL 1            // 1: the Dirichlet-box kernels with 16-point tiles (product), 2: every shape-specialised kernel (experiment), 0: off
 #endif
         // PTALL: every lane runs the point stage of ITS point(s) -- lane (lr, any lq, any wave) owns points mt * 16 + lr -- so the
-        // upstream gradient gnet is in the registers of every lane that needs it and the tile has one barrier less
-        constexpr bool PTALL = (PINN_PTALL != 0) && SPEC != 0;
+        // upstream gradient gnet is in the registers of every lane that needs it and the tile has one barrier and one LDS round trip
+        // less. Same-box A/B (round 5, profiles/r05_headline_ab.txt): -1.1 % on BASELINE config 2 (16-point tiles, Dirichlet box: the
+        // point stage is ~40 instructions), +6.8 % on config 4 (32-point tiles: two points per lane and the IC gate's exponentials in
+        // every wave) -- so only where the stage is small: PinnShape 1, one row tile, at most four waves per team
+        constexpr bool PTALL = (PINN_PTALL == 2 && SPEC != 0) || (PINN_PTALL == 1 && SPEC == 1 && MT == 1 && NW <= 4);
         PinnPointPre<ND, N2> ppre, ppre_all[PTALL ? MT : 1];
         if constexpr (PTALL) {
 #pragma unroll
             for (int mt = 0; mt < MT; ++mt)
-                pinn_point_prefetch<ND, N2, SPEC>(A, base + mt * 16 + lr, base + mt * 16 + lr < A.n_points, pregs, T, ppre_all[mt]);
+                pinn_point_prefetch<ND, N2, SPEC>(A, params_, base + mt * 16 + lr, base + mt * 16 + lr < A.n_points, pregs, T, ppre_all[mt]);
         } else {
-            if (tid < T) pinn_point_prefetch<ND, N2, SPEC>(A, base + tid, base + tid < A.n_points, pregs + tid, T, ppre);
+            if (tid < T) pinn_point_prefetch<ND, N2, SPEC>(A, params_, base + tid, base + tid < A.n_points, pregs + tid, T, ppre);
         }
         PH(0)
 
@@ -1554,12 +1603,12 @@ pinn_tile_kernel(const PinnKArgs A) {
                 for (int j = 0; j < NTW; ++j)
                     wall[q][j] = pinn_ld4(Wl + ((wave * NTW + j) * 16 + lr) * HP + 16 * q + 4 * lq);
         };
-        if (WPF && lh > 0) load_wall(A.params + A.off_wh);
+        if (WPF && lh > 0) load_wall(params_ + A.off_wh);
         pinn_s16x8 wsf[SPK][3];       // split-bf16: forward weight fragments of the NEXT hidden layer, one phase ahead
         if constexpr (SPLIT) {
             sp_weights(0, 0, wsf);
 #pragma unroll
-            for (int j = 0; j < NTW; ++j) biasn[j] = pinn_ld4(A.params + A.off_wh + HP * HP + unit0(j));
+            for (int j = 0; j < NTW; ++j) biasn[j] = pinn_ld4(params_ + A.off_wh + HP * HP + unit0(j));
         }
         f32x4 hskip[SKIPS ? NTW : 1][SKIPS ? MT : 1][S];      // activations carried by the open skip connection
         const int act0 = act_at(0);
@@ -1611,7 +1660,7 @@ pinn_tile_kernel(const PinnKArgs A) {
                     for (int k = 0; k < ND; ++k) z[1 + k] = pinn_dir_weight(W1s + n * PINN_XS_LD, SH::dir(A, k));
 #pragma unroll
                     for (int s = 1 + ND; s < S; ++s) z[s] = 0.0f;              // z_kk = z_kkk = 0 in the first layer
-                    pinn_jet_fwd<ND, N2, COMB>(z, act0, h, cw);
+                    pinn_jet_fwd<ND, N2, COMB>(z, act0 | TPOLY, h, cw);
 #pragma unroll
                     for (int s = 0; s < S; ++s) { hv[s][r] = h[s]; sv[s][r] = (s == 0) ? pinn_act_saved(h[0], z[0], act0) : z[s]; }
                     if (SRCPRE) z0v[r] = z[0];
@@ -1673,7 +1722,7 @@ pinn_tile_kernel(const PinnKArgs A) {
 
         // ---- (2) hidden layers: Z^T = W H^T (MFMA: A = weight fragment, B = activations), jets on accumulators --------
         for (int li = 0; li < lh; ++li) {
-            const float* Wl = A.params + A.off_wh + (size_t)li * A.hidden_stride;
+            const float* Wl = params_ + A.off_wh + (size_t)li * A.hidden_stride;
             const float* bl = Wl + HP * HP;
             const int act = act_at(li + 1), sk_in = skip_into(li + 1), sk_out = skip_from(li + 1);
             f32x4 acc[NTW][MT][S];
@@ -1778,7 +1827,7 @@ pinn_tile_kernel(const PinnKArgs A) {
 #pragma unroll
                             for (int s = 0; s < S; ++s) z[s] += hin[SKIPS ? s : 0][r];
                         }
-                        pinn_jet_fwd<ND, N2, COMB>(z, act, h, cw);
+                        pinn_jet_fwd<ND, N2, COMB>(z, act | TPOLY, h, cw);
 #pragma unroll
                         for (int s = 0; s < S; ++s) { hv[s][r] = h[s]; sv[s][r] = (s == 0) ? pinn_act_saved(h[0], z[0], act) : z[s]; }
                         if (SRCPRE) z0v[r] = z[0];
@@ -1892,7 +1941,7 @@ pinn_tile_kernel(const PinnKArgs A) {
                     net[s] = v;
                 }
                 PinnPointOut<ND, N2> po;
-                pinn_point_stage<ND, N2, false, COMB, SPEC>(A, net, xs_t + pt * PINN_XS_LD, base + pt, base + pt < A.n_points,
+                pinn_point_stage<ND, N2, false, COMB, SPEC>(A, params_, net, xs_t + pt * PINN_XS_LD, base + pt, base + pt < A.n_points,
                                                             pregs, padj, T, ppre_all[mt], po);
 #pragma unroll
                 for (int s = 0; s < S; ++s) gnet_r[PTALL ? mt : 0][s] = po.gnet[s];
@@ -1921,7 +1970,7 @@ pinn_tile_kernel(const PinnKArgs A) {
             }
 #endif
             PinnPointOut<ND, N2> po;
-            pinn_point_stage<ND, N2, SPEC == 0, COMB, SPEC>(A, net, xs_t + pt * PINN_XS_LD, base + pt, base + pt < A.n_points,
+            pinn_point_stage<ND, N2, SPEC == 0, COMB, SPEC>(A, params_, net, xs_t + pt * PINN_XS_LD, base + pt, base + pt < A.n_points,
                                      pregs + pt, padj + pt, T, ppre, po);
 #pragma unroll
             for (int s = 0; s < S; ++s) gnetb[s * T + pt] = po.gnet[s];
@@ -2154,7 +2203,7 @@ pinn_tile_kernel(const PinnKArgs A) {
             const int li = a - 1;
             pinn_s16x8 wsb[SPK][3];       // split-bf16: W^T fragments of this layer (L2 round trip behind the weight-gradient GEMM)
             if constexpr (SPLIT) sp_weights(li, 1, wsb);
-            const float* Wl = A.params + A.off_wh + (size_t)li * A.hidden_stride;
+            const float* Wl = params_ + A.off_wh + (size_t)li * A.hidden_stride;
             float wqall[WPF ? NQ : 1][NTW][4];
             if (WPF && !WTL) {
 #pragma unroll
@@ -2453,7 +2502,7 @@ pinn_tile_kernel(const PinnKArgs A) {
                                 accW1r[REGB ? c : 0][j] += gz[j][mt][0] * xs_t[(mt * 16 + lr) * PINN_XS_LD + c];
 #pragma unroll
                                 for (int k = 0; k < ND; ++k)
-                                    if (pinn_dir_has(SH::dir(A, k), c)) accW1r[REGB ? c : 0][j] += gz[j][mt][1 + k];
+                                    if (pinn_dir_has(SH::dir(A, k), c)) accW1r[REGB ? c : 0][j] += (SH::FIXED ? 1.0f : pinn_dir_coef(SH::dir(A, k), c)) * gz[j][mt][1 + k];
                             }
                         }
                     }
@@ -2465,7 +2514,7 @@ pinn_tile_kernel(const PinnKArgs A) {
                         v += gz[j][mt][0] * xs_t[(mt * 16 + lr) * PINN_XS_LD + c];
 #pragma unroll
                         for (int k = 0; k < ND; ++k)
-                            if (pinn_dir_has(SH::dir(A, k), c)) v += gz[j][mt][1 + k];
+                            if (pinn_dir_has(SH::dir(A, k), c)) v += (SH::FIXED ? 1.0f : pinn_dir_coef(SH::dir(A, k), c)) * gz[j][mt][1 + k];
                     }
                     v = pinn_row_sum16_v4(v);
                     if (lr == 0) {
@@ -2515,7 +2564,7 @@ pinn_tile_kernel(const PinnKArgs A) {
     // (two teams: ONE row per workgroup -- team 0 stores, team 1 adds on top behind a barrier)
     if (tid < T) { scal[tid * 4 + 0] = sum_loss; scal[tid * 4 + 1] = sum_ls; scal[tid * 4 + 2] = sum_bl; scal[tid * 4 + 3] = sum_ic; }
     PINN_SYNC();
-    float* part = A.partials + (size_t)PINN_BID * A.p_core;
+    float* part = partials_ + (size_t)PINN_BID * A.p_core;
     for (int round = 0; round < TEAMS; ++round) {
         if (team == round) {
             const bool add = round > 0;
@@ -2572,4 +2621,11 @@ pinn_tile_kernel(const PinnKArgs A) {
         }
         if (TEAMS2) { PINN_FENCE_BLOCK(); PINN_SYNC(); }
     }
+}
+
+template <int HP, int ND, int N2, int MT, int LHC, int ACTC, bool COMB = false, int VAR = 0>
+PINN_GLOBAL void PINN_LAUNCH_BOUNDS2((PinnCfg<HP, ND, N2, MT>::NTHREADS * ((VAR & 256) ? 2 : 1)),
+                                    (PinnCfg<HP, ND, N2, MT>::NW < 4 || (VAR & (2 | 256)) ? 2 : PINN_WAVES_PER_SIMD))
+pinn_tile_kernel(const PinnKArgs A) {
+    pinn_tile_body<HP, ND, N2, MT, LHC, ACTC, COMB, VAR>(A, A.params, A.partials);
 }

@@ -116,6 +116,8 @@ def bind(lib):
                                          vp, i32, vp, ctypes.c_size_t, vp, ctypes.c_size_t, vp]
     lib.pinn_fit_steps_graph.restype = i32
     lib.pinn_fit_ctrl_bytes.restype = ctypes.c_size_t
+    lib.pinn_set_tanh_mode.argtypes = [vp, i32]
+    lib.pinn_set_tanh_mode.restype = i32
     lib.pinn_set_gemm_mode.argtypes = [vp, i32]
     lib.pinn_set_gemm_mode.restype = i32
     lib.pinn_profile_tile.argtypes = [i32]
@@ -129,6 +131,7 @@ def bind(lib):
     lib.pinn_debug_wgx_chunk_bytes.argtypes = [vp, ctypes.c_longlong]
     lib.pinn_debug_max_wgs_per_cu.argtypes = [vp, ctypes.c_int]
     lib.pinn_debug_prepass_in_kernel.argtypes = [vp, ctypes.c_int]
+    lib.pinn_debug_fit_persistent.argtypes = [vp, ctypes.c_int]
     lib.pinn_last_launch_info.argtypes = [ctypes.POINTER(ctypes.c_int32)]
     lib.pinn_debug_fit_graph_stats.argtypes = [ctypes.POINTER(ctypes.c_int32)]
     for name in ('pinn_create', 'pinn_create_ex', 'pinn_destroy', 'pinn_layout', 'pinn_jet_forward', 'pinn_jet_forward_ws', 'pinn_jet_backward',
@@ -138,9 +141,9 @@ def bind(lib):
 
 
 ABI_SYMBOLS = ('pinn_create', 'pinn_create_ex', 'pinn_destroy', 'pinn_layout', 'pinn_workspace_bytes', 'pinn_jet_forward', 'pinn_jet_forward_ws',
-               'pinn_jet_backward', 'pinn_residual_step', 'pinn_residual_step_add', 'pinn_residual_adam_step', 'pinn_adam_step', 'pinn_adam_step_at', 'pinn_sample_points', 'pinn_fit_steps', 'pinn_fit_steps_graph', 'pinn_fit_ctrl_bytes', 'pinn_set_gemm_mode', 'pinn_profile_tile',
+               'pinn_jet_backward', 'pinn_residual_step', 'pinn_residual_step_add', 'pinn_residual_adam_step', 'pinn_adam_step', 'pinn_adam_step_at', 'pinn_sample_points', 'pinn_fit_steps', 'pinn_fit_steps_graph', 'pinn_fit_ctrl_bytes', 'pinn_set_gemm_mode', 'pinn_set_tanh_mode', 'pinn_profile_tile',
                'pinn_last_tile_ms', 'pinn_last_wgrad_ms', 'pinn_last_kernel_name', 'pinn_last_wgrad_kernel_name', 'pinn_debug_last_kernel',
-               'pinn_debug_prepass_in_kernel', 'pinn_debug_wgx_chunk_bytes', 'pinn_debug_max_wgs_per_cu', 'pinn_debug_fit_graph_stats', 'pinn_last_launch_info',
+               'pinn_debug_prepass_in_kernel', 'pinn_debug_wgx_chunk_bytes', 'pinn_debug_max_wgs_per_cu', 'pinn_debug_fit_persistent', 'pinn_debug_fit_graph_stats', 'pinn_last_launch_info',
                'pinn_last_error', 'pinn_backend')
 
 _LIB = None
@@ -215,6 +218,8 @@ class Net:
         # nested skips (another 'R' while one is open): their forward passes need scratch (include/pinn.h pinn_jet_forward_ws)
         self.nested = any(a[0] < b[0] < a[1] for a in skips for b in skips if a is not b)
         self._fwd_ws = None
+        # second set of full breadth kernels (pinn_inst.inc pinn_needs_allact): activation codes above 7 or nested skips
+        self.allact = self.nested or any(c > 7 for c in codes)
         domain = list(domain) if domain is not None else [(0.0, 1.0)] * ndims
         dims = (ctypes.c_int * len(layer_dims))(*layer_dims)
         lo = (ctypes.c_float * ndims)(*[float(d[0]) for d in domain])
@@ -233,10 +238,23 @@ class Net:
         self.layer_dims = list(layer_dims)
         self.ndims, self.nparams = ndims, nparams
         self.gemm_mode = 'fp32'
+        self.tanh_mode = 'fast'
         if os.environ.get('PYDENS_AMD_GEMM'):
             self.set_gemm_mode(os.environ['PYDENS_AMD_GEMM'])
+        if os.environ.get('PYDENS_AMD_FIT_PERSIST', '0') == '1':    # small fit chunks as ONE launch each instead of launch graphs (experiment:
+            self.lib.pinn_debug_fit_persistent(self.handle, 1)      # measured slower on MI355X, include/pinn.h)
+        if os.environ.get('PYDENS_AMD_TANH'):
+            self.set_tanh_mode(os.environ['PYDENS_AMD_TANH'])
         if os.environ.get('PYDENS_AMD_WGX_CHUNK_MB'):           # experiments: slab budget of the widths >= 128 (pinn_debug_wgx_chunk_bytes)
             self.lib.pinn_debug_wgx_chunk_bytes(self.handle, int(float(os.environ['PYDENS_AMD_WGX_CHUNK_MB']) * (1 << 20)))
+
+    def set_tanh_mode(self, mode):
+        """ 'fast' (default) or 'accurate' (polynomial tanh below |z| = 0.45 where the kernel has that form: include/pinn.h pinn_set_tanh_mode) """
+        codes = {'fast': 0, 'accurate': 1}
+        if mode not in codes:
+            raise ValueError(f'tanh mode {mode!r}: expected one of {sorted(codes)}')
+        self._raise(self.lib.pinn_set_tanh_mode(self.handle, codes[mode]))
+        self.tanh_mode = mode
 
     def set_gemm_mode(self, mode):
         """ 'fp32' (default: exact-fp32 MFMA) or 'bf16x3' (fp32 operands as three bf16, six products, fp32 accumulate: the

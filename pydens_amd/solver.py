@@ -147,6 +147,12 @@ class Solver:
         kernels elsewhere; include/pinn.h pinn_set_gemm_mode). Also settable for a whole process with PYDENS_AMD_GEMM. """
         self.model.net.set_gemm_mode(mode)
 
+    def set_tanh_mode(self, mode):
+        """ 'fast' (default) or 'accurate': tanh of small arguments by a minimax polynomial in the kernels that have that form (the
+        Poisson-box shape of BASELINE configs 1 / 2 at width 64) -- gradient error on trained models 0.6 - 1.2x the fp32 reference's own
+        instead of 1.7 - 1.9x, for +2.5 % kernel time (include/pinn.h pinn_set_tanh_mode). Process-wide: PYDENS_AMD_TANH. """
+        self.model.net.set_tanh_mode(mode)
+
     def _equation_of_the_network(self, net_value, *cols):
         """ custom forward(): the equation as a function of the BARE network's value (tagged: `D` finds its derivative streams)
         and the input columns -- u_hat = model.forward(points) is torch code around it (reference model_torch.py:437-447) """
@@ -168,7 +174,7 @@ class Solver:
         the start of a fit call whenever the cached lowering no longer reproduces the live callable) """
         self._eq = self._equation_of_the_network if self.custom_forward else self.equation
         self.spec, self.needs_x_grad = trace.discover(self._eq, self.ctx.run, self.model.total, self.device,
-                                                      hp=self.model.net.layout.hp)
+                                                      hp=self.model.net.layout.hp, allact=self.model.net.allact)
         if self.custom_forward:
             # torch code between the network and the equation: generic step path only
             self.needs_x_grad = True
@@ -269,6 +275,8 @@ class Solver:
         try:
             root = trace.symbolic(self.equation, self.ctx.run, total, variable_slot=self._variable_slot)
             ic_root = self._symbolic_initial_condition()
+            if self.spec.mixed3:
+                raise trace.TraceUnsupported('mixed third-order partials are assembled from several kernel calls (generic path)')
             plan = trace.lower_residual(root, self.spec, total, ic_root=ic_root)
             trace.combine_second_order(plan, self.spec)
             if not self._plan_matches(plan):
@@ -383,6 +391,8 @@ class Solver:
                 sc.tag(t, alpha)
         for ab, (ivv, iaa, ibb) in self.spec.mixed.items():      # u_ab = (u_vv - u_aa - u_bb) / 2
             sc.tag(0.5 * (full[ivv] - full[iaa] - full[ibb]), ab)
+        for alpha, (ip, im, i3, sign) in self.spec.mixed3.items():      # u_aab = (D3_{a+b} - D3_{a-b} - 2 u_bbb) / 6, u_abb: + D3_{a-b}, - 2 u_aaa
+            sc.tag((full[ip] + sign * full[im] - 2.0 * full[i3]) / 6.0, alpha)
         cols = []
         for c in range(total):
             col = xs[:, c:c + 1]
@@ -406,10 +416,11 @@ class Solver:
             def along(f, direction):
                 """ directional derivative of f over the SPATIAL columns of a direction (IC ignores t / parameters) """
                 total = None
-                for c in direction:
+                for c, weight in trace.dir_weights(direction):
                     if c < m.ndims_spatial and f is not None and f.requires_grad:
                         (g,) = torch.autograd.grad(f.sum(), cols[c], create_graph=True, retain_graph=True, allow_unused=True)
                         if g is not None:
+                            g = g if weight > 0 else -g
                             total = g if total is None else total + g
                 return total
             for k, direction in enumerate(spec.dirs):

@@ -36,8 +36,18 @@ class TraceUnsupported(Exception):
 # stream bookkeeping
 # ---------------------------------------------------------------------------------------------------------------
 def dir_code(direction):
-    """ ABI code of a differentiation direction: column a, or the diagonal e_a + e_b as a | (b + 1) << 4. """
-    return direction[0] if len(direction) == 1 else direction[0] | ((direction[1] + 1) << 4)
+    """ ABI code of a differentiation direction: column a, the diagonal e_a + e_b as a | (b + 1) << 4, or -- a third entry -1 --
+    the minus diagonal e_a - e_b with PINN_DIR_MINUS (0x100) on top (include/pinn.h). """
+    if len(direction) == 1:
+        return direction[0]
+    return direction[0] | ((direction[1] + 1) << 4) | (0x100 if len(direction) > 2 and direction[2] < 0 else 0)
+
+
+def dir_weights(direction):
+    """ [(column, weight)] of a direction tuple: (c,), (a, b) = e_a + e_b, (a, b, -1) = e_a - e_b """
+    if len(direction) == 1:
+        return [(direction[0], 1.0)]
+    return [(direction[0], 1.0), (direction[1], -1.0 if len(direction) > 2 and direction[2] < 0 else 1.0)]
 
 
 class StreamSpec:
@@ -52,8 +62,12 @@ class StreamSpec:
     (five directions, four separate second derivatives, ...) is served by several calls over `groups` of at most two
     directions each on the generic path: the streams of different directions are independent given the network, and the
     parameter gradient is linear in the upstream stream gradients, so forward and backward split by direction. """
-    def __init__(self, requested, hp=None):
+    def __init__(self, requested, hp=None, allact=False):
+        """ allact: the net runs on the SECOND set of full breadth kernels (activation codes above 7 or nested skips: pinn_inst.inc
+        PINN_ALLACT_SHAPES), which is built for the stream shapes of one or two directions per call (+ the combined second-order
+        stream over two or three directions): anything larger goes through direction groups on the generic path. """
         firsts, seconds, mixed, thirds = set(), set(), set(), set()
+        pairs3, mixed3 = set(), {}                   # mixed THIRD-order partials (round 5): column pairs, alpha -> (pair, doubled column)
         for alpha in requested:
             if len(alpha) == 1:
                 firsts.add(alpha[0])
@@ -63,17 +77,27 @@ class StreamSpec:
                 mixed.add(tuple(alpha)); seconds.update(alpha)
             elif len(alpha) == 3 and alpha[0] == alpha[1] == alpha[2]:
                 thirds.add(alpha[0]); seconds.add(alpha[0])
+            elif len(alpha) == 3 and len(set(alpha)) == 2:
+                # u_aab = (D3_{a+b} - D3_{a-b} - 2 u_bbb) / 6,  u_abb = (D3_{a+b} + D3_{a-b} - 2 u_aaa) / 6: third derivatives along both
+                # diagonals of the pair and along the column that occurs ONCE
+                a, b = sorted(set(alpha))
+                doubled = a if alpha.count(a) == 2 else b
+                single = b if doubled == a else a
+                pairs3.add((a, b)); mixed3[tuple(alpha)] = ((a, b), doubled)
+                thirds.add(single); seconds.add(single)
             elif len(alpha) > 2:
                 raise NotImplementedError(
-                    f'derivative multi-index {alpha}: the HIP kernels provide first and second derivatives incl. mixed '
-                    'partials, and third derivatives along single columns (u_xxx, any number of such columns); mixed '
-                    'third-order partials and orders above three are not built')
+                    f'derivative multi-index {alpha}: the HIP kernels provide first and second derivatives incl. mixed partials, third '
+                    'derivatives along single columns and mixed third-order partials of two columns (u_xxy); third-order partials of '
+                    'three different columns (u_xyz) and orders above three are not built')
         firsts |= seconds
-        # directions: third-order columns first, then the other second-order ones, the diagonals, the first-order rest
-        self.dirs = ([(c,) for c in sorted(thirds)] + [(c,) for c in sorted(seconds - thirds)] + sorted(mixed)
-                     + [(c,) for c in sorted(firsts - seconds)])
-        self.n3 = len(thirds)
-        self.n2 = len(seconds) + len(mixed)
+        # directions: third-order ones first (columns, then both diagonals of every pair a mixed third-order partial needs), then the
+        # other second-order columns, the remaining diagonals, the first-order rest
+        diag3 = [d for ab in sorted(pairs3) for d in (ab, ab + (-1,))]
+        self.dirs = ([(c,) for c in sorted(thirds)] + diag3 + [(c,) for c in sorted(seconds - thirds)]
+                     + [ab for ab in sorted(mixed) if ab not in pairs3] + [(c,) for c in sorted(firsts - seconds)])
+        self.n3 = len(thirds) + len(diag3)
+        self.n2 = len(seconds) + len(diag3) + len([ab for ab in mixed if ab not in pairs3])
         self.nd = len(self.dirs)
         self.n2p = self.n2 | (self.n3 << 3)          # packed count of the C-ABI (include/pinn.h)
         self.dir_cols = [dir_code(d) for d in self.dirs]
@@ -86,21 +110,33 @@ class StreamSpec:
                     self.index[(d[0], d[0])] = 1 + self.nd + k
                 if k < self.n3:
                     self.index[(d[0], d[0], d[0])] = 1 + self.nd + self.n2 + k
-            else:
+            elif len(d) == 2:
                 self.index[('d',) + d] = 1 + self.nd + k
+                if k < self.n3:
+                    self.index[('d3',) + d + (1,)] = 1 + self.nd + self.n2 + k
+            else:
+                self.index[('d3',) + d] = 1 + self.nd + self.n2 + k
         self.mixed = {ab: (self.index[('d',) + ab], self.index[(ab[0], ab[0])], self.index[(ab[1], ab[1])])
                       for ab in sorted(mixed)}
+        # alpha -> (stream of D3 along a + b, of D3 along a - b, of the pure third derivative it subtracts, sign of the minus-diagonal term)
+        self.mixed3 = {}
+        for alpha, ((a, b), doubled) in sorted(mixed3.items()):
+            single = b if doubled == a else a
+            self.mixed3[alpha] = (self.index[('d3', a, b, 1)], self.index[('d3', a, b, -1)], self.index[(single,) * 3],
+                                  -1.0 if doubled == a else 1.0)
         # can ONE kernel call produce all of it as separate streams?
         if self.n3 > 0:
             # third order in ONE call: one such direction, at most two directions in all, nothing else of second order (u_xxx-type
-            # equations: KdV in (x, t), third-order ODEs). Anything else with third derivatives along single columns (two
-            # third-order columns, a third-order column beside other second-order ones) goes through the groups below
+            # equations: KdV in (x, t), third-order ODEs). Anything else with third derivatives (two third-order columns, a
+            # third-order column beside other second-order ones, the diagonals of a mixed third-order partial) goes through the groups below
             self.single_call = self.n3 == 1 and self.n2 == 1 and self.nd <= 2
         else:
             self.single_call = (self.nd <= 3 and not (self.nd == 3 and self.n2 == 3 and hp == 256)) or \
                                (self.nd == 4 and self.n2 == 0)
+        if allact:
+            self.single_call = (self.nd <= 2) if self.n3 == 0 else (self.n3 == 1 and self.n2 == 1 and self.nd == 1)
         # ... or as [u, firsts, one combined second-order stream] (affine residuals only)
-        self.combinable = 2 <= self.nd <= MAX_DIRS and self.n2 >= 1 and self.n3 == 0
+        self.combinable = 2 <= self.nd <= (3 if allact else MAX_DIRS) and self.n2 >= 1 and self.n3 == 0
         # groups for the generic path: (direction codes, packed n2 of the group, stream index of each of the group's streams)
         self.groups = []
         if self.single_call:
@@ -160,7 +196,7 @@ def call_with_streams(sc, equation, *args):
         active_streams.reset(token)
 
 
-def discover(equation, ctx_run, n_inputs, device='cpu', hp=None):
+def discover(equation, ctx_run, n_inputs, device='cpu', hp=None, allact=False):
     """ fake run (reference model_torch.py:319-325): which streams does the equation request?
     Returns (StreamSpec, needs_x_grad). """
     sc = StreamContext(n_inputs)
@@ -172,7 +208,7 @@ def discover(equation, ctx_run, n_inputs, device='cpu', hp=None):
         xs.append(x)
     u = sc.tag(torch.rand((3, 1), device=device).requires_grad_(), ())
     ctx_run(call_with_streams, sc, equation, u, *xs)
-    return StreamSpec(sc.requested, hp=hp), sc.used_autograd_fallback
+    return StreamSpec(sc.requested, hp=hp, allact=allact), sc.used_autograd_fallback
 
 
 # ---------------------------------------------------------------------------------------------------------------

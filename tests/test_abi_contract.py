@@ -43,7 +43,9 @@ def test_create_rejects_what_the_kernels_do_not_instantiate(lib):
             _net(lib, dims, **kw)
         assert needle in str(err.value).lower(), str(err.value)
     with pytest.raises(NotImplementedError):
-        engine.Net([2, 8, 1], 'relu', 2, lib=lib)
+        engine.Net([2, 8, 1], 'hardswish', 2, lib=lib)           # (an activation outside the sixteen codes of include/pinn.h)
+    # round 5: ReLU & co. exist -- ReLU (code 7) with the first set of full breadth kernels, codes above 7 on the second set
+    assert not engine.Net([2, 8, 1], 'relu', 2, lib=lib).allact and engine.Net([2, 8, 1], 'elu', 2, lib=lib).allact
     bad = (ctypes.c_int * 3)(2, 8, 1)
     assert lib.pinn_create_ex(bad, 2, None, 0, None, None, 2, 0, 0, 0, None, None, 0.0, None) != 0
 

@@ -917,7 +917,8 @@ def test_third_order_streams_match_the_oracle(pa, emu_lib, which):
     assert np.abs(solver.predict(*xs) - oracle.predict(*xs)).max() < 2e-5
 
 
-@pytest.mark.parametrize('which', ['two_third_order_columns', 'third_beside_second'])
+@pytest.mark.parametrize('which', ['two_third_order_columns', 'third_beside_second', 'mixed_third_space', 'mixed_third_time',
+                                   'mixed_third_both'])
 def test_third_order_beyond_one_call_runs_in_direction_groups(pa, emu_lib, which):
     _direction_groups_case(pa, which, emu_kwargs(emu_lib))
 
@@ -931,6 +932,16 @@ def _direction_groups_case(pa, which, solver_kwargs):
     def problem(D):
         if which == 'two_third_order_columns':
             eq = lambda f, x, y, t: D(f, t) + 0.1 * D(D(D(f, x), x), x) - 0.2 * D(D(D(f, y), y), y) + f * D(f, x)
+        elif which == 'mixed_third_space':
+            # round 5: MIXED third-order partials -- u_xxy from third derivatives along x + y, x - y and y (trace.StreamSpec.mixed3);
+            # both columns inside the boundary factor (its third derivative along a diagonal is not zero), nested in another order
+            eq = lambda f, x, y, t: D(f, t) + 0.1 * D(D(D(f, x), x), y) + f * D(f, x)
+        elif which == 'mixed_third_time':
+            # u_xtt: the minus diagonal x - t carries the time column with weight -1 through the IC gate and its log_scale adjoint
+            eq = lambda f, x, y, t: D(D(D(f, t), x), t) * 0.05 + D(f, t) - D(D(f, y), y)
+        elif which == 'mixed_third_both':
+            # u_xxy and u_xyy of the same pair (they share the two diagonals), a mixed second-order partial of it as well
+            eq = lambda f, x, y, t: D(f, t) + 0.1 * D(D(D(f, x), y), x) - 0.07 * D(D(D(f, y), y), x) + 0.3 * D(D(f, x), y)
         else:
             eq = lambda f, x, y, t: D(f, t) + 0.1 * D(D(D(f, x), x), x) - D(D(f, y), y) + f * D(f, y)
         return eq, dict(ndims=3, boundary_condition=0.1, initial_condition=lambda x, y: x * y * (1 - x),
@@ -947,7 +958,9 @@ def _direction_groups_case(pa, which, solver_kwargs):
     eq_p, kw = problem(pa.D)
     solver = pa.Solver(eq_p, **kw, **solver_kwargs)
     assert solver.program is None and not solver.spec.single_call
-    assert [g[1] for g in solver.spec.groups] == ([9, 9, 0] if which == 'two_third_order_columns' else [9, 1])
+    want_groups = {'two_third_order_columns': [9, 9, 0], 'third_beside_second': [9, 1], 'mixed_third_space': [9, 9, 9, 1],
+                   'mixed_third_time': [9, 9, 9, 2], 'mixed_third_both': [9, 9, 9, 9, 0]}[which]      # (intermediate D(D(f, x), x) of a nest counts)
+    assert [g[1] for g in solver.spec.groups] == want_groups, solver.spec.groups
     load_params(solver, start)
     solver._generic_step(torch.from_numpy(pts[0].copy()).to(solver.device), ('equation',), [], torch.nn.MSELoss(), 1)
     lay = solver.model.net.layout
@@ -1214,3 +1227,38 @@ def test_results_do_not_depend_on_the_order_the_waves_run_in(pa, emu_lib, case, 
     want = run(0)
     for seed in (1,):           # (tools/emu_shuffle_check.py runs more seeds; a stalled wave costs the emulator many idle passes)
         assert np.array_equal(run(seed), want), seed
+
+
+def test_second_kernel_set_splits_large_stream_shapes_into_direction_groups(pa, emu_lib):
+    """ round 5: nets with activation codes above 7 / nested skips run on the SECOND set of full breadth kernels, built for the stream
+    shapes of one or two directions per call (pinn_inst.inc PINN_ALLACT_SHAPES). A non-affine equation over three differentiated
+    columns (separate second-order streams: shape (3, 2)) has no single-call kernel there: the tracer must say so and the generic
+    path must serve it through direction groups -- same trajectory as the oracle. The affine heat operator over the same columns
+    stays fused (ONE combined second-order stream over three directions is in the set). """
+    from oracle import pinn_oracle as po
+    net = dict(layout='fa fa f', features=[12, 12, 1], activation=['ELU', 'Mish'])
+
+    def problems(D):
+        nonaffine = lambda f, x, y, t: D(f, t) - (1.0 + f * f) * D(D(f, x), x) - D(D(f, y), y)
+        affine = lambda f, x, y, t: D(f, t) - 0.3 * D(D(f, x), x) - 0.2 * D(D(f, y), y) - 1.0
+        kw = dict(ndims=3, boundary_condition=0.1, initial_condition=lambda x, y: torch.sin(np.pi * x) * y, **net)
+        return (nonaffine, kw), (affine, kw)
+
+    pts = np.random.RandomState(12).rand(3, 24, 3).astype(np.float32)
+    for which, want_path in ((0, 'generic'), (1, 'fused')):
+        eq_o, kw = problems(po.D)[which]
+        oracle = po.OracleSolver(eq_o, **kw)
+        start = oracle.export_params()
+        oracle.fit(niters=3, batch_size=24, points=pts, lr=0.01)
+        eq_p, kw = problems(pa.D)[which]
+        solver = pa.Solver(eq_p, **kw, **emu_kwargs(emu_lib))
+        assert solver.model.net.allact
+        load_params(solver, start)
+        solver.fit(niters=3, batch_size=24, sampler=FixedBatches(pts), lr=0.01)
+        assert solver.last_fit_path == want_path, (solver.last_fit_path, solver.program_error)
+        if want_path == 'generic':
+            assert 'several kernel calls' in solver.program_error and len(solver.spec.groups) > 1
+        assert emu_lib.pinn_last_kernel_name().decode().split(',')[5] == '-2'
+        np.testing.assert_allclose([float(v) for v in solver.losses], [float(v) for v in oracle.losses], rtol=3e-5)
+        for got, want in zip(export_params(solver), oracle.export_params()):
+            assert params_close(got, want, 3e-5)

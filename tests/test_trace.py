@@ -36,12 +36,24 @@ def test_mixed_partials_take_a_diagonal_direction():
     plan = trace.lower_residual(trace.symbolic(eq, run, 2), spec, 2)
     assert trace.combine_second_order(plan, spec)
     np.testing.assert_allclose(plan.comb_w, [0.5, 1.5, 0.5])               # u_xy = (u_vv - u_xx - u_yy) / 2
-    # third order along ONE column is a stream of its own (packed count n2 | n3 << 3 = 9); mixed third-order partials are not built
+    # third order along ONE column is a stream of its own (packed count n2 | n3 << 3 = 9)
     spec3, _ = trace.discover(lambda f, x, t: D(f, t) + D(D(D(f, x), x), x), run, 2)
     assert (spec3.dirs, spec3.n2, spec3.n3, spec3.n2p, spec3.n_streams) == ([(0,), (1,)], 1, 1, 9, 5)
     assert spec3.index[(0, 0, 0)] == 4 and spec3.single_call
-    with pytest.raises(NotImplementedError, match='third'):
-        trace.discover(lambda f, x, y: D(D(D(f, x), x), y), run, 2)
+    # round 5: a MIXED third-order partial of two columns is assembled from third derivatives along both diagonals of the pair and along
+    # the column that occurs once: u_xxy = (D3_{x+y} - D3_{x-y} - 2 u_yyy) / 6; every third-order direction is a kernel call of its own
+    specm, _ = trace.discover(lambda f, x, y: D(D(D(f, x), x), y), run, 2)
+    assert specm.dirs == [(1,), (0, 1), (0, 1, -1), (0,)] and (specm.n3, specm.n2) == (3, 4) and not specm.single_call
+    assert specm.dir_cols == [1, 0 | (1 + 1) << 4, 0 | (1 + 1) << 4 | 0x100, 0]          # PINN_DIR_MINUS on the minus diagonal
+    ip, im, i3, sign = specm.mixed3[(0, 0, 1)]
+    assert (ip, im, i3, sign) == (specm.index[('d3', 0, 1, 1)], specm.index[('d3', 0, 1, -1)], specm.index[(1, 1, 1)], -1.0)
+    assert [g[1] for g in specm.groups] == [9, 9, 9, 1]
+    assert trace.discover(lambda f, x, y: D(D(D(f, y), x), y), run, 2)[0].mixed3[(0, 1, 1)][3] == 1.0     # u_xyy: + D3_{x-y}, - 2 u_xxx
+    # three different columns (u_xyz) and orders above three stay refused, loudly
+    with pytest.raises(NotImplementedError, match='three different columns'):
+        trace.discover(lambda f, x, y, z: D(D(D(f, x), y), z), run, 3)
+    with pytest.raises(NotImplementedError, match='orders above three'):
+        trace.discover(lambda f, x: D(D(D(D(f, x), x), x), x), run, 1)
     # 3 columns + 2 diagonals = 5 directions, each with a second derivative: more than one kernel call carries -> served
     # by several calls over groups of two directions (generic path), never refused
     spec, _ = trace.discover(lambda f, x, y, z: D(D(f, x), y) + D(D(f, y), z), run, 3)

@@ -119,7 +119,7 @@ pinn_chain_kernel(const PinnKArgs A) {
         const int ptid = role * 64 + lane;
         for (long long tile = A.tile_begin + vbid + (long long)(ptid / TW) * vnblk; tile < ntiles; tile += (long long)(128 / TW) * vnblk) {
             const long long gi = tile * TW + ptid % TW;
-            if (gi < A.n_points) pinn_prepass_point(A.pre, A.xs + gi * d, d, A.aux, A.n_points, gi, pp_regs, NTHREADS);
+            if (gi < A.n_points) pinn_prepass_point(A.pre, A.xs + gi * d, d, A.aux, A.n_points, gi, pp_regs, NTHREADS, pp_regs != nullptr);
         }
         PINN_FENCE_BLOCK();
     }
@@ -259,7 +259,7 @@ pinn_chain_kernel(const PinnKArgs A) {
 #pragma unroll
         for (int mt = 0; mt < MT; ++mt) {
             const long long g = base + mt * 16 + lr;
-            pinn_point_prefetch<ND, N2, SPEC>(A, g, g < A.n_points, nullptr, 0, ppre[mt]);
+            pinn_point_prefetch<ND, N2, SPEC>(A, A.params, g, g < A.n_points, nullptr, 0, ppre[mt]);
         }
 
         PH(0)
@@ -399,7 +399,7 @@ pinn_chain_kernel(const PinnKArgs A) {
         for (int mt = 0; mt < MT; ++mt) {
             const long long g = base + mt * 16 + lr;
             PinnPointOut<ND, N2> po;
-            pinn_point_stage<ND, N2, false, COMB, SPEC>(A, net[mt], x[mt], g, g < A.n_points, nullptr, nullptr, 0, ppre[mt], po);
+            pinn_point_stage<ND, N2, false, COMB, SPEC>(A, A.params, net[mt], x[mt], g, g < A.n_points, nullptr, nullptr, 0, ppre[mt], po);
 #pragma unroll
             for (int s = 0; s < S; ++s) gnet[mt][s] = po.gnet[s];
             if (lq == 0) { sum_loss += po.loss; sum_ls += po.g_ls; sum_bl += po.gnet[0]; }

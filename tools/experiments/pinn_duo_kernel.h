@@ -377,11 +377,11 @@ pinn_duo_kernel(const PinnKArgs A) {
             }
             PinnPointOut<ND, N2> po;
             PinnPointPre<ND, N2> ppre;
-            pinn_point_prefetch<ND, N2>(A, base + lr, base + lr < A.n_points, pregs + lr, T, ppre);
+            pinn_point_prefetch<ND, N2>(A, A.params, base + lr, base + lr < A.n_points, pregs + lr, T, ppre);
             const bool writer = (wave == 0 && lq == 0);
             // (residual PROGRAMS keep per-point registers in LDS and are run by the solo kernel; the host only sends
             //  affine residuals and external upstream gradients here)
-            pinn_point_stage<ND, N2, false>(A, net, xs_t + xb * T * PINN_XS_LD + lr * PINN_XS_LD, base + lr,
+            pinn_point_stage<ND, N2, false>(A, A.params, net, xs_t + xb * T * PINN_XS_LD + lr * PINN_XS_LD, base + lr,
                                      base + lr < A.n_points, pregs + lr, padj + lr, T, ppre, po);
             if (writer) { sum_loss += po.loss; sum_ls += po.g_ls; sum_bl += po.gnet[0]; }
             // stage the next tile's points (other xs buffer) and start fetching the one after
