@@ -31,6 +31,10 @@
  * Third order: wherever an entry point takes `n2`, the value may be PACKED as n2 | n3 << 3 -- n3 of the n2 second-order
  * directions (the first ones; columns or diagonals) also carry a third derivative, streams 1+nd+n2 .. nd+n2+n3, S = 1 + nd + n2 + n3
  * (built: one third-order direction with nd <= 2, i.e. u_xxx-type equations such as KdV; plain n2 < 8 means n3 = 0).
+ * Fourth order (round 5): n2 | n3 << 3 | n4 << 6 -- n4 of the n3 third-order directions (the first ones) also carry a fourth derivative,
+ * streams behind the third-order ones, S = 1 + nd + n2 + n3 + n4 (built: ONE such direction alone, packed value 73: u, u', u'', u''', u''''
+ * along a column or a diagonal -- beam, Kuramoto-Sivashinsky and biharmonic operators; the host assembles
+ * u_aabb = (D4_{a+b} + D4_{a-b} - 2 u_aaaa - 2 u_bbbb) / 12).
  */
 #ifndef PINN_H
 #define PINN_H

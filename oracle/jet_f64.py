@@ -421,3 +421,53 @@ def adam_update(p, g, m, v, step_no, lr=0.005, b1=0.9, b2=0.999, eps=1e-8):
     bc2 = 1 - b2 ** step_no
     denom = np.sqrt(v) / np.sqrt(bc2) + eps
     p[:] = p - (lr / bc1) * m / denom
+
+
+def act_d5(z, act):
+    """ fifth derivative of the activation (the reverse sweep of fourth-order streams needs it; round 5) -- the formulas of
+    pinn_kernel.h pinn_act_d5 in fp64; tests/test_activations.py holds them to torch's nested autograd. """
+    z = np.asarray(z, dtype=np.float64)
+    if act == 'tanh':
+        t2 = np.tanh(z) ** 2
+        return (1.0 - t2) * (16.0 - 120.0 * t2 + 120.0 * t2 * t2)
+    if act == 'sin':
+        return np.cos(z)
+    if act in ('identity', 'relu', 'leakyrelu'):
+        return np.zeros_like(z)
+    if act in ('elu', 'selu'):
+        s_, al = (1.0507009873554805, 1.6732632423543772) if act == 'selu' else (1.0, 1.0)
+        return np.where(z > 0, 0.0, s_ * al * np.exp(z))
+    if act == 'softsign':
+        return 120.0 / (1.0 + np.abs(z)) ** 6
+    if act == 'gelu':
+        phi = np.exp(-0.5 * z * z) / np.sqrt(2.0 * np.pi)
+        return phi * z * ((z * z - 11.0) * z * z + 18.0)
+    sg = 1.0 / (1.0 + np.exp(-z))
+    a, q = sg * (1.0 - sg), 1.0 - 2.0 * sg
+    s4, s5 = a * q * (q * q - 8.0 * a), a * (q ** 4 - 22.0 * a * q * q + 16.0 * a * a)
+    if act == 'sigmoid':
+        return s5
+    if act == 'softplus':
+        return s4
+    if act in ('silu', 'swish'):
+        return z * s5 + 5.0 * s4
+    if act == 'logsigmoid':
+        return -s4
+    if act == 'tanhshrink':
+        u, u1, u2, u3, u4, u5 = z, 1.0, 0.0, 0.0, 0.0, 0.0
+    elif act == 'gelu_tanh':
+        k, c = 0.7978845608028654, 0.044715
+        u, u1, u2, u3, u4, u5 = k * (z + c * z ** 3), k * (1.0 + 3.0 * c * z * z), 6.0 * k * c * z, 6.0 * k * c, 0.0, 0.0
+    elif act == 'mish':
+        u, u1, u2, u3, u4, u5 = np.logaddexp(0.0, z), sg, a, a * q, a * (q * q - 2.0 * a), s4
+    else:
+        raise ValueError(act)
+    T = np.tanh(u)
+    T2 = T * T
+    a1 = 1.0 - T2
+    a2, a3, a4, a5 = -2.0 * T * a1, a1 * (6.0 * T2 - 2.0), a1 * T * (16.0 - 24.0 * T2), a1 * (16.0 - 120.0 * T2 + 120.0 * T2 * T2)
+    t4 = a4 * u1 ** 4 + 6.0 * a3 * u1 ** 2 * u2 + a2 * (4.0 * u1 * u3 + 3.0 * u2 ** 2) + a1 * u4
+    t5 = a5 * u1 ** 5 + 10.0 * a4 * u1 ** 3 * u2 + a3 * (15.0 * u1 * u2 ** 2 + 10.0 * u1 ** 2 * u3) + a2 * (10.0 * u2 * u3 + 5.0 * u1 * u4) + a1 * u5
+    if act == 'tanhshrink':
+        return -t5
+    return (0.5 if act == 'gelu_tanh' else 1.0) * (z * t5 + 5.0 * t4)

@@ -124,8 +124,9 @@ launch_fn launcher_for(int hp) {
 int pick_n2(int nd, int n2) {
     // (nd = 4: first derivatives only; its second-order form exists as ONE combined stream, `comb`)
     static const int avail[5][5] = {{1, 0, 0, 0, 0}, {1, 1, 0, 0, 0}, {1, 0, 1, 0, 0}, {0, 0, 1, 1, 0}, {1, 0, 0, 0, 0}};
-    if (pinn_n3(n2) > 0)            // packed count with third-order streams: exact instantiations only
-        return ((nd == 1 || nd == 2) && n2 == 9) ? n2 : -1;
+    if (pinn_n3(n2) > 0 || pinn_n4(n2) > 0)     // packed count with third- / fourth-order streams: exact instantiations only
+        return (((nd == 1 || nd == 2) && n2 == 9) || (nd == 1 && n2 == 73)) ? n2 : -1;       // 73 = 1 | 1 << 3 | 1 << 6: u, u', u'', u''', u''''
+    if (n2 > 7) return -1;
     if (nd < 0 || nd > 4 || n2 < 0 || n2 > nd) return -1;
     for (int k = n2; k <= nd; ++k)
         if (avail[nd][k]) return k;
@@ -179,7 +180,7 @@ int make_plan(const pinn_net* net, int64_t n_points, int nd, int n2, Plan* plan,
     if (!plan->fn) return fail("no kernel for padded hidden width %d (supported: 16, 32, 64, 128, 256)", net->lay.hp);
     plan->n2k = comb ? 1 : pick_n2(nd, n2);
     if (comb && (n2 != 1 || nd < 2 || nd > 4)) return fail("combined second-order stream needs n2 == 1 and nd in {2, 3, 4}");
-    if (plan->n2k < 0) return fail("unsupported derivative spec nd=%d n2=%d n3=%d (nd <= 3 with n2 <= nd, nd = 4 with n2 = 0 / one combined second-order stream, or one third-order direction with nd <= 2)", nd, pinn_n2(n2), pinn_n3(n2));
+    if (plan->n2k < 0) return fail("unsupported derivative spec nd=%d n2=%d n3=%d n4=%d (nd <= 3 with n2 <= nd, nd = 4 with n2 = 0 / one combined second-order stream, one third-order direction with nd <= 2, or one fourth-order direction alone)", nd, pinn_n2(n2), pinn_n3(n2), pinn_n4(n2));
     PinnKArgs probe;
     if (hint) {
         probe = *hint;
@@ -294,8 +295,8 @@ void typical_step_args(const pinn_net* net, PinnKArgs* a, int64_t n, int nd, int
 }
 
 int check_dirs(const pinn_net* net, const int* dir_cols, int nd, int n2p) {
-    const int n2 = pinn_n2(n2p), n3 = pinn_n3(n2p);       // packed count: seconds | thirds << 3 (include/pinn.h)
-    if (nd < 0 || nd > PINN_MAX_DIRS || n2 > nd || n3 > n2 || n2p < 0) return fail("bad derivative spec nd=%d n2=%d n3=%d", nd, n2, n3);
+    const int n2 = pinn_n2(n2p), n3 = pinn_n3(n2p), n4 = pinn_n4(n2p);       // packed count: seconds | thirds << 3 | fourths << 6 (include/pinn.h)
+    if (nd < 0 || nd > PINN_MAX_DIRS || n2 > nd || n3 > n2 || n4 > n3 || n2p < 0) return fail("bad derivative spec nd=%d n2=%d n3=%d n4=%d", nd, n2, n3, n4);
     for (int k = 0; k < nd; ++k) {
         // direction code: column a, or the diagonal e_a +- e_b as a | (b + 1) << 4 | PINN_DIR_MINUS (include/pinn.h)
         if (!dir_cols || dir_cols[k] < 0 || dir_cols[k] > 511) return fail("dir_cols[%d] out of range", k);

@@ -57,7 +57,8 @@ PINN_GLOBAL void PINN_LAUNCH_BOUNDS2((PinnWgCfg<HP, ND, N2, MT, SPLIT>::NTHREADS
 pinn_wgrad_kernel(const PinnKArgs A) {
     using W = PinnWgCfg<HP, ND, N2, MT, SPLIT>;
     using C = typename W::C;
-    constexpr int N2n = pinn_n2(N2), N3n = pinn_n3(N2);           // (N2 is the packed count, pinn_kernel.h)
+    constexpr int N2n = pinn_n2(N2), N3n = pinn_n3(N2), N4n = pinn_n4(N2);     // (N2 is the packed count, pinn_kernel.h)
+    constexpr bool KEEP0 = (HEAVY || N4n > 0) && N3n > 0;          // keep what was saved of the value stream (d3 / d4 of any activation)
     constexpr int S = W::S, NTW = W::NTW, NTHREADS = W::NTHREADS, LDK = W::LDK, AM = W::AM, BN = W::BN, OPER = W::OPER;
     const int tid = PINN_TID, lane = tid & 63, wave = tid >> 6;
     const int lr = lane & 15, lq = lane >> 4;
@@ -127,7 +128,8 @@ pinn_wgrad_kernel(const PinnKArgs A) {
         // running sum_k c_k z_k^2 for the combined second-order stream, else z_k^2 of the N2 directions that have one)
         f32x4 d1v[NTW], d2v[NTW], zz[(COMB || N2n == 0) ? 1 : N2n][NTW];
         f32x4 z1v[N3n > 0 ? N3n : 1][NTW], z2v[N3n > 0 ? N3n : 1][NTW];      // first / second streams of the third-order directions
-        f32x4 s0v[(HEAVY && N3n > 0) ? NTW : 1];                              // HEAVY: what was saved of the value stream (third derivative of any activation)
+        f32x4 s0v[KEEP0 ? NTW : 1];                                           // what was saved of the value stream (third / fourth derivative of the activation)
+        f32x4 z3v[N4n > 0 ? N4n : 1][NTW];                                    // third streams of the fourth-order directions
         auto transform = [&](int s, const f32x4 (&svr)[NTW], f32x4 (&hv)[NTW], const f32x4 (&skr)[SKIPS ? NTW : 1]) {
 #pragma unroll
             for (int j = 0; j < NTW; ++j) {
@@ -138,7 +140,7 @@ pinn_wgrad_kernel(const PinnKArgs A) {
                         pinn_act_d12(svr[j][r], act, d1, d2);
                         d1v[j][r] = d1; d2v[j][r] = d2;
                         hv[j][r] = pinn_act_value(svr[j][r], act);
-                        if (HEAVY && N3n > 0) s0v[(HEAVY && N3n > 0) ? j : 0][r] = svr[j][r];
+                        if (KEEP0) s0v[KEEP0 ? j : 0][r] = svr[j][r];
                         if (COMB) zz[0][j][r] = 0.0f;
                     } else if (s <= ND) {
                         hv[j][r] = d1v[j][r] * svr[j][r];
@@ -149,14 +151,22 @@ pinn_wgrad_kernel(const PinnKArgs A) {
                         const float q = zz[(COMB || N2n == 0) ? 0 : s - 1 - ND][j][r];
                         hv[j][r] = fmaf(d2v[j][r], q, d1v[j][r] * svr[j][r]);
                         if (s - 1 - ND < N3n) z2v[N3n > 0 ? s - 1 - ND : 0][j][r] = svr[j][r];
-                    } else {
+                    } else if (s <= ND + N2n + N3n) {
                         // third order: h3 = a1 z3 + 3 a2 z1 z2 + a3 z1^3 with the activation's derivatives a1, a2, a3; a3 from
                         // a1 (tanh: a1 (4 - 6 a1), sigmoid: a1 (1 - 6 a1); HEAVY: any activation, from what was saved of the value stream)
                         const int k = N3n > 0 ? s - 1 - ND - N2n : 0;
                         const float d1 = d1v[j][r], d2 = d2v[j][r], z1 = z1v[k][j][r], z2 = z2v[k][j][r];
-                        const float d3 = HEAVY ? pinn_act_d3(s0v[(HEAVY && N3n > 0) ? j : 0][r], d1, d2, act)
+                        const float d3 = KEEP0 ? pinn_act_d3(s0v[KEEP0 ? j : 0][r], d1, d2, act)
                                                : (act == PINN_ACT_TANH) ? d1 * (4.0f - 6.0f * d1) : d1 * (1.0f - 6.0f * d1);
                         hv[j][r] = d1 * svr[j][r] + 3.0f * d2 * z1 * z2 + d3 * z1 * z1 * z1;
+                        if (N4n > 0 && k < N4n) z3v[N4n > 0 ? (k < N4n ? k : 0) : 0][j][r] = svr[j][r];
+                    } else {
+                        // fourth order (round 5): h4 = a1 z4 + a2 (4 z1 z3 + 3 z2^2) + 6 a3 z1^2 z2 + a4 z1^4
+                        const int k = N4n > 0 ? s - 1 - ND - N2n - N3n : 0;
+                        const float d1 = d1v[j][r], d2 = d2v[j][r], z1 = z1v[k][j][r], z2 = z2v[k][j][r], z3 = z3v[k][j][r];
+                        const float sv0 = s0v[KEEP0 ? j : 0][r];
+                        const float d3 = pinn_act_d3(sv0, d1, d2, act), d4 = pinn_act_d4(sv0, d1, d2, act);
+                        hv[j][r] = d1 * svr[j][r] + d2 * (4.0f * z1 * z3 + 3.0f * z2 * z2) + 6.0f * d3 * z1 * z1 * z2 + d4 * z1 * z1 * z1 * z1;
                     }
                 }
                 if (SKIPS && sk_in >= 0) hv[j] += skr[SKIPS ? j : 0];

@@ -307,7 +307,7 @@ class Net:
         _check(params, 'params'); _check(xs, 'xs'); _check(ic_streams, 'ic_streams')
         n = xs.shape[0]
         dirs, nd = self._dirs(dir_cols)
-        s = 1 + nd + (n2 & 7) + (n2 >> 3)                # n2 may be packed: seconds | thirds << 3 (include/pinn.h)
+        s = 1 + nd + (n2 & 7) + ((n2 >> 3) & 7) + (n2 >> 6)       # n2 may be packed: seconds | thirds << 3 | fourths << 6 (include/pinn.h)
         if out is None:
             out = torch.empty((s, n), dtype=torch.float32, device=xs.device)
         _check(out, 'out')

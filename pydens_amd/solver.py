@@ -275,8 +275,8 @@ class Solver:
         try:
             root = trace.symbolic(self.equation, self.ctx.run, total, variable_slot=self._variable_slot)
             ic_root = self._symbolic_initial_condition()
-            if self.spec.mixed3:
-                raise trace.TraceUnsupported('mixed third-order partials are assembled from several kernel calls (generic path)')
+            if self.spec.mixed3 or self.spec.n4 > 0:
+                raise trace.TraceUnsupported('mixed third-order partials / fourth-order derivatives run on the generic path')
             plan = trace.lower_residual(root, self.spec, total, ic_root=ic_root)
             trace.combine_second_order(plan, self.spec)
             if not self._plan_matches(plan):
@@ -391,6 +391,8 @@ class Solver:
                 sc.tag(t, alpha)
         for ab, (ivv, iaa, ibb) in self.spec.mixed.items():      # u_ab = (u_vv - u_aa - u_bb) / 2
             sc.tag(0.5 * (full[ivv] - full[iaa] - full[ibb]), ab)
+        for alpha, (ip, im, ia, ib) in self.spec.mixed4.items():         # u_aabb = (D4_{a+b} + D4_{a-b} - 2 u_aaaa - 2 u_bbbb) / 12
+            sc.tag((full[ip] + full[im] - 2.0 * full[ia] - 2.0 * full[ib]) / 12.0, alpha)
         for alpha, (ip, im, i3, sign) in self.spec.mixed3.items():      # u_aab = (D3_{a+b} - D3_{a-b} - 2 u_bbb) / 6, u_abb: + D3_{a-b}, - 2 u_aaa
             sc.tag((full[ip] + sign * full[im] - 2.0 * full[i3]) / 6.0, alpha)
         cols = []
@@ -436,6 +438,10 @@ class Solver:
                             g3 = along(g2, direction)
                             if g3 is not None:
                                 out[1 + spec.nd + spec.n2 + k] = g3.view(-1, 1)
+                                if k < spec.n4:
+                                    g4 = along(g3, direction)
+                                    if g4 is not None:
+                                        out[1 + spec.nd + spec.n2 + spec.n3 + k] = g4.view(-1, 1)
         if not create_graph:
             out = [None if t is None else t.detach() for t in out]
         return out

@@ -66,8 +66,9 @@ class StreamSpec:
         """ allact: the net runs on the SECOND set of full breadth kernels (activation codes above 7 or nested skips: pinn_inst.inc
         PINN_ALLACT_SHAPES), which is built for the stream shapes of one or two directions per call (+ the combined second-order
         stream over two or three directions): anything larger goes through direction groups on the generic path. """
-        firsts, seconds, mixed, thirds = set(), set(), set(), set()
+        firsts, seconds, mixed, thirds, fourths = set(), set(), set(), set(), set()
         pairs3, mixed3 = set(), {}                   # mixed THIRD-order partials (round 5): column pairs, alpha -> (pair, doubled column)
+        pairs4 = set()                               # mixed FOURTH-order partials u_aabb: column pairs
         for alpha in requested:
             if len(alpha) == 1:
                 firsts.add(alpha[0])
@@ -85,37 +86,55 @@ class StreamSpec:
                 single = b if doubled == a else a
                 pairs3.add((a, b)); mixed3[tuple(alpha)] = ((a, b), doubled)
                 thirds.add(single); seconds.add(single)
+            elif len(alpha) == 4 and len(set(alpha)) == 1:
+                fourths.add(alpha[0]); thirds.add(alpha[0]); seconds.add(alpha[0])
+            elif len(alpha) == 4 and len(set(alpha)) == 2 and alpha.count(alpha[0]) == 2:
+                # u_aabb = (D4_{a+b} + D4_{a-b} - 2 u_aaaa - 2 u_bbbb) / 12: fourth derivatives along both diagonals and both columns
+                a, b = sorted(set(alpha))
+                pairs4.add((a, b))
+                for c in (a, b):
+                    fourths.add(c); thirds.add(c); seconds.add(c)
             elif len(alpha) > 2:
                 raise NotImplementedError(
-                    f'derivative multi-index {alpha}: the HIP kernels provide first and second derivatives incl. mixed partials, third '
-                    'derivatives along single columns and mixed third-order partials of two columns (u_xxy); third-order partials of '
-                    'three different columns (u_xyz) and orders above three are not built')
+                    f'derivative multi-index {alpha}: the HIP kernels provide derivatives up to fourth order along single columns, mixed second- '
+                    'and third-order partials of two columns (u_xy, u_xxy) and the symmetric mixed fourth-order one (u_xxyy); partials of three '
+                    'different columns (u_xyz), u_xxxy and orders above four are not built')
         firsts |= seconds
-        # directions: third-order ones first (columns, then both diagonals of every pair a mixed third-order partial needs), then the
-        # other second-order columns, the remaining diagonals, the first-order rest
-        diag3 = [d for ab in sorted(pairs3) for d in (ab, ab + (-1,))]
-        self.dirs = ([(c,) for c in sorted(thirds)] + diag3 + [(c,) for c in sorted(seconds - thirds)]
+        pairs3 |= pairs4                             # (a pair with a fourth-order diagonal carries the third-order ones anyway)
+        # directions: fourth-order ones first, then the third-order ones (columns, then both diagonals of every pair a mixed third- /
+        # fourth-order partial needs), then the other second-order columns, the remaining diagonals, the first-order rest
+        def diag_pair(ab):
+            return [ab, ab + (-1,)]
+        d4_dirs = [(c,) for c in sorted(fourths)] + [d for ab in sorted(pairs4) for d in diag_pair(ab)]
+        d3_dirs = [(c,) for c in sorted(thirds - fourths)] + [d for ab in sorted(pairs3 - pairs4) for d in diag_pair(ab)]
+        self.dirs = (d4_dirs + d3_dirs + [(c,) for c in sorted(seconds - thirds)]
                      + [ab for ab in sorted(mixed) if ab not in pairs3] + [(c,) for c in sorted(firsts - seconds)])
-        self.n3 = len(thirds) + len(diag3)
-        self.n2 = len(seconds) + len(diag3) + len([ab for ab in mixed if ab not in pairs3])
+        self.n4 = len(d4_dirs)
+        self.n3 = self.n4 + len(d3_dirs)
+        self.n2 = self.n3 + len(seconds - thirds) + len([ab for ab in mixed if ab not in pairs3])
         self.nd = len(self.dirs)
-        self.n2p = self.n2 | (self.n3 << 3)          # packed count of the C-ABI (include/pinn.h)
+        self.n2p = self.n2 | (self.n3 << 3) | (self.n4 << 6)      # packed count of the C-ABI (include/pinn.h); only meaningful per group when large
         self.dir_cols = [dir_code(d) for d in self.dirs]
-        self.n_streams = 1 + self.nd + self.n2 + self.n3
+        self.n_streams = 1 + self.nd + self.n2 + self.n3 + self.n4
         self.index = {(): 0}
         for k, d in enumerate(self.dirs):
+            base2, base3, base4 = 1 + self.nd + k, 1 + self.nd + self.n2 + k, 1 + self.nd + self.n2 + self.n3 + k
             if len(d) == 1:
                 self.index[(d[0],)] = 1 + k
                 if k < self.n2:
-                    self.index[(d[0], d[0])] = 1 + self.nd + k
+                    self.index[(d[0],) * 2] = base2
                 if k < self.n3:
-                    self.index[(d[0], d[0], d[0])] = 1 + self.nd + self.n2 + k
-            elif len(d) == 2:
-                self.index[('d',) + d] = 1 + self.nd + k
-                if k < self.n3:
-                    self.index[('d3',) + d + (1,)] = 1 + self.nd + self.n2 + k
+                    self.index[(d[0],) * 3] = base3
+                if k < self.n4:
+                    self.index[(d[0],) * 4] = base4
             else:
-                self.index[('d3',) + d] = 1 + self.nd + self.n2 + k
+                sign = -1 if len(d) > 2 else 1
+                if sign > 0:
+                    self.index[('d',) + d[:2]] = base2
+                if k < self.n3:
+                    self.index[('d3',) + d[:2] + (sign,)] = base3
+                if k < self.n4:
+                    self.index[('d4',) + d[:2] + (sign,)] = base4
         self.mixed = {ab: (self.index[('d',) + ab], self.index[(ab[0], ab[0])], self.index[(ab[1], ab[1])])
                       for ab in sorted(mixed)}
         # alpha -> (stream of D3 along a + b, of D3 along a - b, of the pure third derivative it subtracts, sign of the minus-diagonal term)
@@ -124,8 +143,14 @@ class StreamSpec:
             single = b if doubled == a else a
             self.mixed3[alpha] = (self.index[('d3', a, b, 1)], self.index[('d3', a, b, -1)], self.index[(single,) * 3],
                                   -1.0 if doubled == a else 1.0)
+        # (a, a, b, b) -> streams of D4 along a + b, a - b, u_aaaa, u_bbbb
+        self.mixed4 = {(a, a, b, b): (self.index[('d4', a, b, 1)], self.index[('d4', a, b, -1)], self.index[(a,) * 4], self.index[(b,) * 4])
+                       for a, b in sorted(pairs4)}
         # can ONE kernel call produce all of it as separate streams?
-        if self.n3 > 0:
+        if self.n4 > 0:
+            # fourth order in ONE call: that direction alone (u'''' = f(x) beams, u_t-free fourth-order ODEs); anything else in groups
+            self.single_call = self.n4 == 1 and self.nd == 1
+        elif self.n3 > 0:
             # third order in ONE call: one such direction, at most two directions in all, nothing else of second order (u_xxx-type
             # equations: KdV in (x, t), third-order ODEs). Anything else with third derivatives (two third-order columns, a
             # third-order column beside other second-order ones, the diagonals of a mixed third-order partial) goes through the groups below
@@ -133,7 +158,7 @@ class StreamSpec:
         else:
             self.single_call = (self.nd <= 3 and not (self.nd == 3 and self.n2 == 3 and hp == 256)) or \
                                (self.nd == 4 and self.n2 == 0)
-        if allact:
+        if allact and self.n4 == 0:
             self.single_call = (self.nd <= 2) if self.n3 == 0 else (self.n3 == 1 and self.n2 == 1 and self.nd == 1)
         # ... or as [u, firsts, one combined second-order stream] (affine residuals only)
         self.combinable = 2 <= self.nd <= (3 if allact else MAX_DIRS) and self.n2 >= 1 and self.n3 == 0
@@ -142,15 +167,17 @@ class StreamSpec:
         if self.single_call:
             chunks = [list(range(self.nd))] if self.nd else [[]]
         else:
-            # every third-order column in a call of its own (the third-order kernels carry one such column), the rest in pairs
+            # every third- / fourth-order direction in a call of its own (those kernels carry one such direction), the rest in pairs
             rest = list(range(self.n3, self.nd))
             chunks = [[k] for k in range(self.n3)] + [rest[i:i + 2] for i in range(0, len(rest), 2)]
         for ks in chunks:
             n2g = sum(1 for k in ks if k < self.n2)
             n3g = sum(1 for k in ks if k < self.n3)
+            n4g = sum(1 for k in ks if k < self.n4)
             idx = ([0] + [1 + k for k in ks] + [1 + self.nd + k for k in ks if k < self.n2]
-                   + [1 + self.nd + self.n2 + k for k in ks if k < self.n3])
-            self.groups.append(([self.dir_cols[k] for k in ks], n2g | (n3g << 3), idx))
+                   + [1 + self.nd + self.n2 + k for k in ks if k < self.n3]
+                   + [1 + self.nd + self.n2 + self.n3 + k for k in ks if k < self.n4])
+            self.groups.append(([self.dir_cols[k] for k in ks], n2g | (n3g << 3) | (n4g << 6), idx))
 
     def __repr__(self):
         return f'StreamSpec(dirs={self.dirs}, n2={self.n2})'

@@ -1262,3 +1262,71 @@ def test_second_kernel_set_splits_large_stream_shapes_into_direction_groups(pa, 
         np.testing.assert_allclose([float(v) for v in solver.losses], [float(v) for v in oracle.losses], rtol=3e-5)
         for got, want in zip(export_params(solver), oracle.export_params()):
             assert params_close(got, want, 3e-5)
+
+
+def _fourth_order_problems(D, torch, which):
+    if which == 'beam_1d':            # u'''' + u = f(x) on a clamped interval (beam on an elastic foundation): ONE kernel call carries u .. u'''' (packed 73)
+        # (the `+ f` matters to the TEST: without it the last bias has an exactly zero gradient and Adam turns fp noise into +-lr steps)
+        eq = lambda f, x: D(D(D(D(f, x), x), x), x) + f - 24.0 * torch.cos(2.0 * x)
+        return eq, dict(ndims=1, boundary_condition=0.1, layout='fa fa f', features=[16, 16, 1], activation='Tanh')
+    if which in ('beam_wide', 'beam_wide_sin'):      # widths >= 128: streamed weight gradients (pinn_wgrad_kernel rebuilds h'''' from the saved jets)
+        eq = lambda f, x: D(D(D(D(f, x), x), x), x) + f - 24.0 * torch.cos(2.0 * x)
+        acts = ['Tanh', 'Sigmoid', 'Tanh'] if which == 'beam_wide' else ['Sin', 'Softplus', 'Tanh']
+        return eq, dict(ndims=1, boundary_condition=0.1, layout='fa fa fa f', features=[72, 72, 72, 1], activation=acts)
+    if which == 'kuramoto_sivashinsky':   # u_t + u_xxxx + u_xx + u u_x in (x, t): fourth-order direction in a group of its own, IC gate + BC
+        eq = lambda f, x, t: D(f, t) + 0.02 * D(D(D(D(f, x), x), x), x) + 0.1 * D(D(f, x), x) + f * D(f, x)
+        return eq, dict(ndims=2, boundary_condition=0.0, initial_condition=lambda x: torch.sin(np.pi * x), layout='fa fa f', features=[20, 20, 1],
+                        activation='Tanh')
+    if which == 'time_fourth':        # fourth derivative along the TIME column: the gate's fourth derivative and its log_scale adjoint (sigmoid's fifth)
+        eq = lambda f, x, t: 0.05 * D(D(D(D(f, t), t), t), t) + D(f, x) - f
+        return eq, dict(ndims=2, boundary_condition=0.2, initial_condition=0.7, layout='fa fa f', features=[16, 16, 1], activation='Sigmoid')
+    if which == 'biharmonic':         # u_xxxx + 2 u_xxyy + u_yyyy = f: the mixed one from fourth derivatives along x + y and x - y
+        eq = lambda f, x, y: D(D(D(D(f, x), x), x), x) + 2.0 * D(D(D(D(f, x), x), y), y) + D(D(D(D(f, y), y), y), y) - torch.sin(np.pi * x) * y
+        return eq, dict(ndims=2, boundary_condition=0.0, layout='fa fa f', features=[16, 16, 1], activation='Tanh')
+    # activations of the second kernel set, a skip connection and an identity layer: every fifth derivative formula on the reverse sweep
+    eq = lambda f, x: D(D(D(D(f, x), x), x), x) + D(D(f, x), x) - torch.exp(-x)
+    return eq, dict(ndims=1, boundary_condition=0.3, layout='faR fa f+a fa f', features=[12, 12, 12, 12, 1], activation=['Mish', 'Softsign', 'GELU', 'SiLU'])
+
+
+@pytest.mark.parametrize('which', ['beam_1d', 'kuramoto_sivashinsky', 'time_fourth', 'biharmonic', 'any_activation', 'beam_wide', 'beam_wide_sin'])
+def test_fourth_order_streams_match_the_oracle(pa, emu_lib, which):
+    _fourth_order_case(pa, which, emu_kwargs(emu_lib))
+
+
+def _fourth_order_case(pa, which, solver_kwargs):
+    """ round 5: u_xxxx-type equations (the reference nests D to any order, model_torch.py:174-178) -- a fourth Taylor coefficient per
+    direction in the jets, the ansatz product rules to fourth order (box factor incl. its mixed fourth derivative along a diagonal, IC
+    gate and its log_scale adjoint), the reverse sweep with the activation's FIFTH derivative; one fourth-order direction per kernel call,
+    generic step path. Four nested fp32 autograd sweeps of the reference are noisy: the fp64 oracle arbitrates. """
+    from oracle import pinn_oracle as po
+    eq_o, kw = _fourth_order_problems(po.D, torch, which)
+    oracle32 = po.OracleSolver(eq_o, **kw)
+    oracle = po.OracleSolver(eq_o, dtype=torch.float64, **kw)
+    start = oracle32.export_params()
+    oracle.import_params(start)
+    d = kw['ndims']
+    pts = np.random.RandomState(14).rand(3, 40, d).astype(np.float32)
+    ev32, g32 = oracle32.evaluate(pts[0]), oracle32.export_grads()
+    ev, g_want = oracle.evaluate(pts[0]), oracle.export_grads()
+    oracle.fit(niters=3, batch_size=40, points=pts, lr=0.01)
+    eq_p, kw = _fourth_order_problems(pa.D, torch, which)
+    solver = pa.Solver(eq_p, **kw, **solver_kwargs)
+    assert solver.spec.n4 >= 1 and solver.program is None
+    want_groups = {'beam_1d': [73], 'kuramoto_sivashinsky': [73, 0], 'time_fourth': [73, 0], 'biharmonic': [73, 73, 73, 73], 'any_activation': [73], 'beam_wide': [73], 'beam_wide_sin': [73]}[which]
+    assert [g[1] for g in solver.spec.groups] == want_groups, solver.spec.groups
+    load_params(solver, start)
+    solver._generic_step(torch.from_numpy(pts[0].copy()).to(solver.device), ('equation',), [], torch.nn.MSELoss(), 1)
+    lay = solver.model.net.layout
+    loss = float(solver.grads[lay.off_loss])
+    assert abs(loss - ev['loss']) <= max(2 * abs(ev32['loss'] - ev['loss']), 1e-5 * ev['loss']), (loss, ev['loss'], ev32['loss'])
+    for got, want, w32 in zip(export_grads(solver), g_want, g32):
+        if want is not None:
+            err = np.linalg.norm(np.asarray(got, dtype=np.float64) - want)
+            assert err <= max(2 * np.linalg.norm(np.asarray(w32, dtype=np.float64) - want), 1e-4 * np.linalg.norm(want)), (which, err)
+    solver.fit(niters=3, batch_size=40, sampler=FixedBatches(pts), lr=0.01)
+    assert solver.last_fit_path == 'generic'
+    np.testing.assert_allclose([float(v) for v in solver.losses], [float(v) for v in oracle.losses], rtol=1e-4)
+    for got, want in zip(export_params(solver), oracle.export_params()):
+        assert params_close(got, want, 2e-4, atol=2e-5)
+    xs = [pts[0][:, i] for i in range(d)]
+    assert np.abs(solver.predict(*xs) - oracle.predict(*xs)).max() < 2e-5

@@ -840,6 +840,12 @@ def test_residual_programs_on_one_combined_stream_on_the_gpu(pa, which):
     te._combined_program_case(pa, which, {})
 
 
+@pytest.mark.parametrize('which', ['beam_1d', 'kuramoto_sivashinsky', 'time_fourth', 'biharmonic', 'any_activation', 'beam_wide', 'beam_wide_sin'])
+def test_fourth_order_streams_on_the_gpu(pa, which):
+    import test_emu_engine as te
+    te._fourth_order_case(pa, which, {})
+
+
 @pytest.mark.parametrize('which', ['two_third_order_columns', 'third_beside_second', 'mixed_third_space', 'mixed_third_time', 'mixed_third_both'])
 def test_third_order_direction_groups_on_the_gpu(pa, which):
     """ equations with more third-order content than one kernel call carries: generic path, one call per third-order column """
@@ -1087,9 +1093,10 @@ def test_fit_chunks_as_launch_graphs_follow_the_eager_loop_bit_for_bit(pa, name,
     assert np.array_equal(p0, p1) and np.array_equal(m0, m1)
 
 
-@pytest.mark.parametrize('which', ['cfg1', 'ode_default_net', 'heat_callable_ic', 'program_with_variable', 'one_point'])
+@pytest.mark.parametrize('which', ['cfg1', 'ode_default_net', 'program_with_variable'])
 def test_fit_chunk_as_one_launch_follows_the_eager_loop(pa, which, monkeypatch):
-    """ round 5: narrow nets at the reference's batch sizes run a whole chunk of fit iterations -- sampling, tile
+    """ round 5 (OPT-IN, PYDENS_AMD_FIT_PERSIST=1: measured slower than launch-graph replay on MI355X, profiles/r05_small_fit_rate.txt):
+    narrow nets at the reference's batch sizes can run a whole chunk of fit iterations -- sampling, tile
     body, the sum of the partial rows, Adam -- in ONE launch (pinn_fit_kernel.h: the workgroups of the grid meet once per iteration in
     a device-scope arrive / wait, every workgroup keeps its own copy of parameters and Adam state). Same tile -> workgroup map, same
     summation order, same Adam scalars, same Philox counters as the eager loop: every loss, every parameter, the Adam moments and the

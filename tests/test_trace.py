@@ -52,8 +52,17 @@ def test_mixed_partials_take_a_diagonal_direction():
     # three different columns (u_xyz) and orders above three stay refused, loudly
     with pytest.raises(NotImplementedError, match='three different columns'):
         trace.discover(lambda f, x, y, z: D(D(D(f, x), y), z), run, 3)
-    with pytest.raises(NotImplementedError, match='orders above three'):
-        trace.discover(lambda f, x: D(D(D(D(f, x), x), x), x), run, 1)
+    # round 5: fourth order along a column (one direction with second, third and fourth derivative: packed count 1 | 1 << 3 | 1 << 6 = 73) and
+    # the symmetric mixed one, u_xxyy = (D4_{x+y} + D4_{x-y} - 2 u_xxxx - 2 u_yyyy) / 12
+    spec4, _ = trace.discover(lambda f, x: D(D(D(D(f, x), x), x), x), run, 1)
+    assert (spec4.dirs, spec4.n2, spec4.n3, spec4.n4, spec4.n2p, spec4.n_streams, spec4.single_call) == ([(0,)], 1, 1, 1, 73, 5, True)
+    specb, _ = trace.discover(lambda f, x, y: D(D(D(D(f, x), x), y), y), run, 2)
+    assert specb.dirs[:4] == [(0,), (1,), (0, 1), (0, 1, -1)] and specb.n4 == 4 and [g[1] for g in specb.groups] == [73, 73, 73, 73]
+    assert specb.mixed4[(0, 0, 1, 1)] == (specb.index[('d4', 0, 1, 1)], specb.index[('d4', 0, 1, -1)], specb.index[(0,) * 4], specb.index[(1,) * 4])
+    with pytest.raises(NotImplementedError, match='orders above four'):
+        trace.discover(lambda f, x: D(D(D(D(D(f, x), x), x), x), x), run, 1)
+    with pytest.raises(NotImplementedError, match='u_xxxy'):
+        trace.discover(lambda f, x, y: D(D(D(D(f, x), x), x), y), run, 2)
     # 3 columns + 2 diagonals = 5 directions, each with a second derivative: more than one kernel call carries -> served
     # by several calls over groups of two directions (generic path), never refused
     spec, _ = trace.discover(lambda f, x, y, z: D(D(f, x), y) + D(D(f, y), z), run, 3)
