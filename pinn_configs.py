@@ -80,6 +80,35 @@ def make_config(name, D, torch, V=None):
                                        layout='faR fa f+a R fa fa+ f', features=[24, 24, 24, 24, 24, 1],
                                        activation=['Sin', 'Tanh', 'SiLU', 'Tanh', 'Sigmoid']),
                     n_points=4096, low=[0, 0], high=[1, 1])
+    if name == 'nested_acts':
+        # breadth fixture (round 5): a skip connection INSIDE a skip connection ('R .. R .. + .. +': the reference's layout letters nest,
+        # model_torch.py:142-156) and the torch-default activation forms of the second kernel set; viscous Burgers with IC + BC
+        def equation(f, x, t):
+            return D(f, t) + f * D(f, x) - 0.05 * D(D(f, x), x)
+        return dict(equation=equation,
+                    solver_kwargs=dict(ndims=2, boundary_condition=0.1, initial_condition=lambda x: torch.sin(PI * x) * x,
+                                       layout='faR faR fa fa+ fa+ fa f', features=[24, 24, 24, 24, 24, 24, 1],
+                                       activation=['ELU', 'Mish', 'Softsign', 'SELU', 'LogSigmoid', 'LeakyReLU']),
+                    n_points=4096, low=[0, 0], high=[1, 1])
+    if name == 'mixed3':
+        # breadth fixture (round 5): MIXED third derivatives u_xxy and u_xyy (nested D in any order, model_torch.py:174-178) next to a
+        # first derivative in t: third Taylor coefficients along x + y and x - y, polarised
+        def equation(f, x, y, t):
+            return D(f, t) + D(D(D(f, x), x), y) - 0.5 * D(D(D(f, x), y), y) + f * D(f, x) - 0.1 * D(D(f, y), y)
+        return dict(equation=equation,
+                    solver_kwargs=dict(ndims=3, boundary_condition=0.2,
+                                       initial_condition=lambda x, y: torch.sin(PI * x) * y, layout='fa fa fa f',
+                                       features=[24, 24, 24, 1], activation='Tanh'),
+                    n_points=4096, low=[0, 0, 0], high=[1, 1, 1])
+    if name == 'biharm':
+        # breadth fixture (round 5): the biharmonic operator u_xxxx + 2 u_xxyy + u_yyyy -- fourth derivatives, the mixed one from the
+        # fourth Taylor coefficients along x + y and x - y
+        def equation(f, x, y):
+            return (D(D(D(D(f, x), x), x), x) + 2.0 * D(D(D(D(f, x), x), y), y) + D(D(D(D(f, y), y), y), y)
+                    - 10.0 * torch.sin(PI * x) * torch.sin(PI * y))
+        return dict(equation=equation,
+                    solver_kwargs=dict(ndims=2, boundary_condition=0.0, layout='fa fa f', features=[24, 24, 1], activation='Tanh'),
+                    n_points=4096, low=[0, 0], high=[1, 1])
     # ---- breadth workloads: timed by `bench.py --workload ...`, not BASELINE configs -----------------------
     if name in ('skip128', 'skip256', 'sin64', 'sin128', 'gelu256', 'program', 'generic'):
         def poisson(f, x, y):

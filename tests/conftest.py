@@ -10,6 +10,10 @@ if ROOT not in sys.path:
 
 GOLDEN_DIR = os.path.join(ROOT, 'tests', 'golden')
 GOLDEN_NAMES = ('cfg1', 'cfg2', 'cfg3', 'cfg4', 'cfg5', 'ode_sigmoid', 'mixed', 'heat3d', 'kdv', 'resnet3')
+# round 5 breadth fixtures (nested skips + second-set activations, mixed third order, fourth order): the restatement is pinned on them like
+# on the others; the fp64 jet restatement (oracle/jet_f64.py) does not go there -- the KERNELS are checked against them directly
+# (tests/test_golden_extras.py; -m gpu twin in test_gpu_parity.py)
+GOLDEN_EXTRA = ('nested_acts', 'mixed3', 'biharm')
 
 
 def pytest_configure(config):
@@ -30,7 +34,7 @@ class Golden:
         self.predict, self.losses, self.lr = z['predict'], z['losses'], float(z['lr'])
 
 
-@pytest.fixture(params=GOLDEN_NAMES)
+@pytest.fixture(params=GOLDEN_NAMES + GOLDEN_EXTRA)
 def golden(request):
     return Golden(request.param)
 

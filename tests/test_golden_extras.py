@@ -1,0 +1,111 @@
+""" The round-5 breadth features against fixtures generated from the UNMODIFIED reference (oracle/make_golden.py, tests/golden/):
+
+    nested_acts   skip connection inside a skip connection, ELU / Mish / Softsign / SELU / LogSigmoid / LeakyReLU, Burgers with IC + BC
+    mixed3        u_xxy and u_xyy next to u_t (third Taylor coefficients along x + y and x - y)
+    biharm        u_xxxx + 2 u_xxyy + u_yyyy (fourth Taylor coefficients, the mixed one polarised)
+
+The restatement (oracle/pinn_oracle.py) is pinned on them by tests/test_oracle_vs_golden.py (same `golden` fixture). Here the KERNELS
+are: predict, loss, every parameter gradient and the K-step Adam trajectory of `Solver.fit`. The survey's bar (1e-5 gradients, 2e-5
+trajectory) against the fp32 fixture -- and, where three or four nested fp32 autograd sweeps of the REFERENCE are the noisy side, the
+fp64 arbiter of SURVEY 8c item 5: the restatement evaluated in float64 on the fixture's parameters and points. """
+import numpy as np
+import pytest
+import torch
+
+import pinn_configs as pc
+from conftest import GOLDEN_EXTRA, Golden
+from helpers import (FixedBatches, GRAD_RTOL, close_or_arbitrated, export_grads, export_params, load_params, make_solver,
+                     record_margin)
+from test_emu_engine import emu_kwargs, emu_lib, pa          # noqa: F401  (fixtures)
+
+EXPECT = {  # name: (fit path, [packed second/third/fourth-order counts of the kernel calls], second kernel set?)
+    'nested_acts': ('fused', None, True),
+    'mixed3': ('generic', None, False),
+    'biharm': ('generic', [73, 73, 73, 73], False),
+}
+FIT_RTOL = 2e-5
+
+
+def oracle64(name, g):
+    from oracle import pinn_oracle as po
+    cfg = pc.make_config(name, po.D, torch)
+    o = po.OracleSolver(cfg['equation'], dtype=torch.float64, **cfg['solver_kwargs'])
+    o.import_params(g.params)
+    return o
+
+
+def golden_extra_case(pa, name, solver_kwargs, test='golden_extra'):
+    g = Golden(name)
+    path, groups, allact = EXPECT[name]
+    _, solver = make_solver(name, pa, **solver_kwargs)
+    load_params(solver, g.params)
+    net = solver.model.net
+    assert net.allact == allact and net.nested == (name == 'nested_acts')
+    if groups is not None:
+        assert [grp[1] for grp in solver.spec.groups] == groups, solver.spec.groups
+    pts = g.points
+    d = pts.shape[2]
+    pred = solver.predict(*[pts[1][:, i] for i in range(d)])
+    assert np.abs(pred[:, 0] - g.predict).max() <= 1e-5 * max(1.0, np.abs(g.predict).max())
+
+    cache = {}
+
+    def f64():
+        if not cache:
+            o = oracle64(name, g)
+            cache['ev'] = o.evaluate(pts[0])
+            cache['grads'] = o.export_grads()
+            o.fit(niters=len(g.losses), batch_size=pts.shape[1], points=pts, lr=g.lr)
+            cache['losses'] = np.array([float(v) for v in o.losses])
+            cache['finals'] = o.export_params()
+        return cache
+
+    # one evaluation on batch 0: loss and the gradient of every parameter tensor
+    xs = torch.from_numpy(pts[0].copy()).to(solver.device)
+    if path == 'fused':
+        assert solver.program is not None, solver.program_error
+        solver._fused_step(xs, 1)
+    else:
+        assert solver.program is None
+        solver._generic_step(xs, ('equation',), [], torch.nn.MSELoss(), 1)
+    lay = net.layout
+    loss = float(solver.grads[lay.off_loss])
+    ok, err, arb = close_or_arbitrated([loss], [g.loss0], lambda: [f64()['ev']['loss']], 1e-5)
+    record_margin(test, name, 'loss', err, 1e-5, arb)
+    assert ok, (loss, g.loss0)
+    for i, (got, want) in enumerate(zip(export_grads(solver), g.grads)):
+        if want is None:
+            assert float(np.abs(got).max()) == 0.0
+            continue
+        ok, err, arb = close_or_arbitrated(got, want, lambda i=i: f64()['grads'][i], GRAD_RTOL)
+        record_margin(test, f'{name}[{i}]', 'grad', err, GRAD_RTOL, arb)
+        assert ok, (name, i, err)
+
+    # the K Adam steps of the fixture through Solver.fit
+    load_params(solver, g.params)
+    solver.fit(niters=len(g.losses), batch_size=pts.shape[1], sampler=FixedBatches(pts), lr=g.lr)
+    assert solver.last_fit_path == path
+    losses = np.array([float(v) for v in solver.losses])
+    for k, (got, want) in enumerate(zip(losses, g.losses)):
+        ok, err, arb = close_or_arbitrated([got], [want], lambda k=k: [f64()['losses'][k]], FIT_RTOL)
+        record_margin(test, f'{name} step {k}', 'loss_k', err, FIT_RTOL, arb)
+        assert ok, (name, k, got, want)
+    for i, (got, want) in enumerate(zip(export_params(solver), g.finals)):
+        ok, err, arb = close_or_arbitrated(got, want, lambda i=i: f64()['finals'][i], FIT_RTOL, atol=3e-7)
+        record_margin(test, f'{name}[{i}]', 'final', err, FIT_RTOL, arb)
+        assert ok, (name, i, err)
+
+
+@pytest.mark.parametrize('name', GOLDEN_EXTRA)
+def test_emulated_kernels_match_reference_golden(pa, emu_lib, name):          # noqa: F811
+    golden_extra_case(pa, name, emu_kwargs(emu_lib), test='emu_golden_extra')
+
+
+@pytest.mark.parametrize('name', GOLDEN_EXTRA)
+def test_fixture_is_not_degenerate(name):
+    """ a fixture that pins nothing would pass everything: the loss moves over the K steps and no gradient tensor is zero """
+    g = Golden(name)
+    assert abs(g.losses[-1] - g.losses[0]) > 1e-3 * g.losses[0]
+    for want in g.grads:
+        if want is not None:
+            assert float(np.abs(want).max()) > 1e-6

@@ -840,6 +840,14 @@ def test_residual_programs_on_one_combined_stream_on_the_gpu(pa, which):
     te._combined_program_case(pa, which, {})
 
 
+@pytest.mark.parametrize('name', ['nested_acts', 'mixed3', 'biharm'])
+def test_breadth_features_match_reference_golden_on_the_gpu(pa, name):
+    """ round 5 breadth (nested skips + second-set activations, mixed third order, fourth order) against the fixtures generated from the
+    unmodified reference: predict, loss, gradients, K-step trajectory (tests/test_golden_extras.py holds the case) """
+    import test_golden_extras as tg
+    tg.golden_extra_case(pa, name, {}, test='gpu_golden_extra')
+
+
 @pytest.mark.parametrize('which', ['beam_1d', 'kuramoto_sivashinsky', 'time_fourth', 'biharmonic', 'any_activation', 'beam_wide', 'beam_wide_sin'])
 def test_fourth_order_streams_on_the_gpu(pa, which):
     import test_emu_engine as te
