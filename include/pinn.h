@@ -333,12 +333,20 @@ int pinn_debug_wgx_chunk_bytes(pinn_t* net, long long bytes);
  *                                 restores the default, 4): tests run the same step at 1 and at several workgroups per CU; affects
  *                                 pinn_workspace_bytes (partial rows, slabs), so set it first. Returns the previous bound (-1: null). */
 int pinn_debug_max_wgs_per_cu(pinn_t* net, int cap);
-/*   pinn_debug_fit_persistent     0: pinn_fit_steps_graph never runs a chunk as ONE launch (pinn_fit_kernel: narrow nets, grids of at most
- *                                 64 resident workgroups); 1 switches it on. Off by default: on MI355X the device-scope arrive / wait between
- *                                 workgroups on different XCDs (L2 write-back + invalidate per iteration) costs more than the two launch gaps of
- *                                 a replayed launch graph -- 22 - 37 us against 16 - 17 us per iteration (profiles/r05_small_fit_rate.txt).
- *                                 Returns the previous setting (-1: null). */
-int pinn_debug_fit_persistent(pinn_t* net, int enable);
+/*   pinn_debug_fit_persistent     how pinn_fit_steps_graph runs a chunk of a NARROW net (hidden width <= 32) as ONE launch (pinn_fit_kernel.h):
+ *                                 2 (default): the one-CU form -- one hardware workgroup of up to eight virtual workgroups with parameters, Adam
+ *                                   state, partial rows and batch resident in LDS; the iteration's only synchronisation is a workgroup
+ *                                   barrier -- for batches of at most `rounds` sweeps of those virtual workgroups (pinn_debug_fit_onecu_rounds,
+ *                                   default 1: up to 7 - 8 tiles, e.g. BASELINE config 1's 100 points: 13.5 us per iteration against 14.7 us as
+ *                                   launch graphs; a second sweep adds ~4.5 us and loses); larger batches replay launch graphs;
+ *                                 1: the grid form (at most 64 resident workgroups, one device-scope arrive / wait per iteration). On MI355X
+ *                                   that wait crosses the XCDs' L2s (write-back + invalidate per iteration) and costs more than the two launch
+ *                                   gaps of a replayed launch graph -- 21 - 34 us against 15 - 19 us per iteration (profiles/r05_small_fit_rate.txt);
+ *                                 0: never (launch graphs / eager loop).
+ *                                 Returns the previous setting (-1: null).
+ *   pinn_debug_fit_onecu_rounds   see above; rounds >= 1, returns the previous value */
+int pinn_debug_fit_persistent(pinn_t* net, int mode);
+int pinn_debug_fit_onecu_rounds(pinn_t* net, int rounds);
 /*   pinn_debug_fit_graph_stats    out[0] chunks replayed as launch graphs so far, out[1] graphs captured, out[2] captures the runtime
  *                                 refused (those chunks ran eagerly), out[3] the HIP error code of the last refusal */
 int pinn_debug_fit_graph_stats(int32_t out[4]);

@@ -87,7 +87,9 @@ struct pinn_net {
     int fit_graph_k;
     // diagnostics of THIS descriptor (pinn_debug_*: tests run one net at 1 workgroup per CU, with a separate pre-pass launch, with a
     // tiny slab budget -- a second Solver in the same process keeps its own planning)
-    int fit_persistent;             // pinn_debug_fit_persistent (default 0: measured slower than launch-graph replay on MI355X): small fit chunks as ONE launch
+    int fit_persistent;             // pinn_debug_fit_persistent: small fit chunks as ONE launch. 2 (default): the one-CU form for batches of a few tiles;
+                                    // 1: the grid form (measured slower than launch-graph replay on MI355X); 0: never
+    int fit_onecu_rounds;           // one-CU form: at most this many sweeps of its virtual workgroups per iteration (pinn_debug_fit_onecu_rounds)
     int max_per_cu;                 // pinn_debug_max_wgs_per_cu (default 4)
     int prepass_in_kernel;          // pinn_debug_prepass_in_kernel (default 1)
     size_t wgx_chunk_bytes;         // pinn_debug_wgx_chunk_bytes (default PINN_WGX_CHUNK_DEFAULT)
@@ -418,10 +420,17 @@ int pinn_debug_wgx_chunk_bytes(pinn_t* net, long long bytes) {
     return 0;
 }
 
+int pinn_debug_fit_onecu_rounds(pinn_t* net, int rounds) {
+    if (!net) return -1;
+    const int before = net->fit_onecu_rounds;
+    if (rounds >= 1) net->fit_onecu_rounds = rounds;
+    return before;
+}
+
 int pinn_debug_fit_persistent(pinn_t* net, int enable) {
     if (!net) return -1;
     const int before = net->fit_persistent;
-    net->fit_persistent = enable ? 1 : 0;
+    net->fit_persistent = (enable == 1 || enable == 2) ? enable : 0;
     return before;
 }
 
@@ -541,7 +550,7 @@ int pinn_create_ex(const int* layer_dims, int n_layers, const int* acts, int n_s
     pinn_net* net = new (std::nothrow) pinn_net();
     if (!net) return fail("out of memory");
     memset(net, 0, sizeof(*net));
-    net->fit_persistent = 0; net->max_per_cu = 4; net->prepass_in_kernel = 1; net->wgx_chunk_bytes = PINN_WGX_CHUNK_DEFAULT;
+    net->fit_persistent = 2; net->fit_onecu_rounds = 1; net->max_per_cu = 4; net->prepass_in_kernel = 1; net->wgx_chunk_bytes = PINN_WGX_CHUNK_DEFAULT;
     net->n_layers = n_layers; net->act = act; net->ndims = ndims; net->nparams = nparams;
     for (int a = 0; a + 1 < n_layers; ++a) {
         net->act_codes[a >> 4] |= (unsigned long long)acts[a] << (4 * (a & 15));
@@ -601,6 +610,7 @@ size_t pinn_workspace_bytes(const pinn_t* net, int64_t n_points, int nd, int n2)
     if (!net) return 0;
     size_t need = 0;
     bool any = false;
+    size_t slab_per_wg_max = 0;
     // every form a step of this derivative spec may take: separate second-order streams (affine residual, residual program, the
     // generic path's backward call) and ONE combined second-order stream (affine or program: trace.py lowers to it from a single
     // second derivative on -- `u_t + u_y + u_z = nu u_xx` in four variables exists in that form only), each planned
@@ -624,12 +634,15 @@ size_t pinn_workspace_bytes(const pinn_t* net, int64_t n_points, int nd, int n2)
                          align256(plan.slab_bytes()) + align256(plan.gz_bytes()) +
                          align256((size_t)plan.grid * plan.wt_floats_per_wg * sizeof(float));
         if (v > need) need = v;
+        if (plan.slab_vec4_per_wg > slab_per_wg_max) slab_per_wg_max = plan.slab_vec4_per_wg;
     }
     if (!any) return 0;
     // (narrow nets: partial rows of both parities and the private (parameters, exp_avg, exp_avg_sq) of every workgroup of a one-launch fit
     //  chunk, pinn_fit_kernel.h -- 5 x 16 x p_total floats at most)
+    //  (+ the saved-jet slabs of the one-CU form's virtual workgroups: at most eight)
     const size_t persist = net->lay.hp <= 32 ? align256(2 * (size_t)PINN_FIT_MAX_WGS * net->lay.p_total * sizeof(float)) +
-                                               align256(3 * (size_t)PINN_FIT_MAX_WGS * net->lay.p_total * sizeof(float)) + 512 : 0;
+                                               align256(3 * (size_t)PINN_FIT_MAX_WGS * net->lay.p_total * sizeof(float)) + 512 +
+                                               align256(8 * slab_per_wg_max * sizeof(f32x4)) : 0;
     return need + align256((size_t)PINN_MAX_AUX * (size_t)n_points * sizeof(float)) + wt_workspace_bytes(net) +
            wsp_workspace_bytes(net) + 256 + persist;
 }
@@ -755,33 +768,44 @@ static int run_train(pinn_t* net, PinnKArgs* a, const Plan& plan, int nd, float*
     if (g_profile && !pe) return fail("hipEventCreate failed");
     if (pe) pe->have_wgrad = false;
 #endif
-#ifndef PINN_EMU
     if (g_fit_persist.active) {
-        // a whole chunk of fit iterations in ONE launch (pinn_fit_kernel.h): the step must be one pass of a non-streamed kernel on a grid
-        // of resident workgroups, the instantiation must carry the kernel, the scratch for rows / private states must fit behind `need`
+        // a whole chunk of fit iterations in ONE launch (pinn_fit_kernel.h): the step must be one pass of a non-streamed kernel, the
+        // instantiation must carry the kernel, the scratch for rows / private states must fit behind `need`. Mode 2: the one-CU form
+        // (virtual workgroups, no device-scope wait) for batches of at most fit_onecu_rounds sweeps of its virtual workgroups; mode 1:
+        // the grid form (every workgroup resident).
         g_fit_persist.done = 0;
-        long long has = 0;
+        long long has[3] = {0, 0, 0};
         const size_t pc = (size_t)net->lay.p_total;
-        const size_t rows_b = align256(2 * (size_t)plan.grid * pc * sizeof(float)), state_b = align256(3 * (size_t)plan.grid * pc * sizeof(float));
-        if (!plan.wgx && !plan.wt_global && !plan.split && plan.chunk_tiles >= plan.ntiles && plan.grid <= PINN_FIT_MAX_WGS && !g_profile &&
-            plan.fn(nd, plan.n2k, a, plan.grid, stream, 3, &has) == 0 && has && workspace_bytes >= need + rows_b + state_b + 256 && adam &&
-            (!aux_bytes || net->prepass_in_kernel)) {
+        bool ok = !plan.wgx && !plan.wt_global && !plan.split && plan.chunk_tiles >= plan.ntiles && !g_profile && adam &&
+                  (!aux_bytes || net->prepass_in_kernel) && plan.fn(nd, plan.n2k, a, plan.grid, stream, 3, has) == 0 && has[0];
+        const int vw = (int)has[1];
+        const bool onecu = ok && net->fit_persistent == 2 && vw >= 2 && vw <= 8 && plan.ntiles <= (int64_t)vw * net->fit_onecu_rounds;
+        const bool gridform = ok && net->fit_persistent == 1 && plan.grid <= PINN_FIT_MAX_WGS;
+        const int rows = onecu ? vw : plan.grid, states = onecu ? 1 : plan.grid;
+        const size_t rows_b = align256(2 * (size_t)rows * pc * sizeof(float)), state_b = align256(3 * (size_t)states * pc * sizeof(float));
+        const size_t slab1_b = onecu ? align256((size_t)vw * plan.slab_vec4_per_wg * sizeof(f32x4)) : 0;      // the virtual workgroups' own slabs
+        if ((onecu || gridform) && workspace_bytes >= need + rows_b + state_b + 256 + slab1_b) {
             PinnFitP& P = g_fit_persist.p;
             P.rows = reinterpret_cast<float*>(ws + need);
             P.state = reinterpret_cast<float*>(ws + need + rows_b);
             P.sync = reinterpret_cast<unsigned*>(ws + need + rows_b + state_b);
+            if (onecu && a->slab) a->slab = reinterpret_cast<f32x4*>(ws + need + rows_b + state_b + 256);
             P.params = adam->params; P.m = adam->m; P.v = adam->v; P.mask = adam->mask; P.step_ptr = adam->step_ptr; P.grads = grads;
             P.b1 = adam->b1; P.b2 = adam->b2; P.eps = adam->eps; P.off_loss = net->lay.off_loss;
-            if (hipMemsetAsync(P.sync, 0, 256, (hipStream_t)stream) != hipSuccess) return fail("hipMemsetAsync failed");
+#ifdef PINN_EMU
+            memset(P.sync, 0, 256);
+#else
+            if (!onecu && hipMemsetAsync(P.sync, 0, 256, (hipStream_t)stream) != hipSuccess) return fail("hipMemsetAsync failed");
+#endif
             set_tile_range(a, plan, 0, plan.ntiles);
-            const int rc = plan.fn(nd, plan.n2k, a, plan.grid, stream, 2, reinterpret_cast<long long*>(&P));
+            const int rc = plan.fn(nd, plan.n2k, a, onecu ? 1 : plan.grid, stream, onecu ? 4 : 2, reinterpret_cast<long long*>(&P));
             note_launch(plan);
+            if (rc == 1) return 0;               // (this instantiation has no such form after all: the caller falls back)
             if (rc) return fail("fit kernel launch failed (%d)", rc);
             g_fit_persist.done = 1;
         }
         return 0;
     }
-#endif
     // one pass (any non-WGX kernel; a WGX batch whose slabs fit the net's wgx_chunk_bytes) or chunk by chunk: tile kernel ->
     // weight-gradient kernel -> reduction of the partial rows, later chunks ADD into `grads`, Adam rides in the last reduction
     for (int64_t t0 = 0; t0 < plan.ntiles || t0 == 0; t0 += plan.chunk_tiles) {
@@ -1029,19 +1053,13 @@ int pinn_fit_steps_graph(pinn_t* net, const pinn_residual_t* residual, float* pa
                          size_t ctrl_bytes, void* stream) {
     if (!net || !residual || !xs || !loss_history || !kind || !a || !b || !dir_cols) return fail("null argument");
     if (k_steps < 0 || step0 < 1) return fail("k_steps must be >= 0 and step0 >= 1");
-#ifdef PINN_EMU
-    (void)ctrl; (void)ctrl_bytes;
-    return pinn_fit_steps(net, residual, params, xs, n_points, kind, a, b, seed, call_index0, dir_cols, nd, n2, ic_const, grads, exp_avg,
-                          exp_avg_sq, mask, step_ptr, step0, lr, beta1, beta2, eps, loss_history, k_steps, workspace, workspace_bytes, stream);
-#else
-    // narrow nets, grids of a few resident workgroups: the whole chunk -- any length up to PINN_FIT_CHUNK_MAX -- as ONE launch
-    // (pinn_fit_kernel.h); bit-identical to the eager loop below
+    // narrow nets, batches of a few tiles: the whole chunk -- any length up to PINN_FIT_CHUNK_MAX -- as ONE launch (pinn_fit_kernel.h);
+    // the eager loop's trajectory to fp32 round-off
     if (net->fit_persistent && net->lay.hp <= 32 && ctrl && ctrl_bytes >= sizeof(PinnFitCtrl) && k_steps >= 1 && k_steps <= PINN_FIT_CHUNK_MAX &&
         !g_profile && !g_phase_prof && residual && params && grads && exp_avg && exp_avg_sq && step_ptr) {
         PinnNextBatch spec_probe = {nullptr, 0, {}, 0u, 0u, 0ull};
         if (fit_next_spec(net, xs, n_points, kind, a, b, seed, &spec_probe) == 0) {
             PinnFitCtrl* dctrl = reinterpret_cast<PinnFitCtrl*>(ctrl);
-            hipStream_t hs = (hipStream_t)stream;
             PinnFitCtrlArgs ca;
             ca.c.call_index0 = call_index0; ca.c.loss_base = loss_history; ca.c.step0 = step0; ca.c.pad = 0;
             ca.c.k0 = (unsigned)(seed & 0xffffffffull); ca.c.k1 = (unsigned)(seed >> 32);
@@ -1053,8 +1071,14 @@ int pinn_fit_steps_graph(pinn_t* net, const pinn_residual_t* residual, float* pa
             PinnFitP& P = g_fit_persist.p;
             P.ctrl = dctrl; P.k_steps = k_steps; P.xs = xs; P.n = (long long)n_points; P.spec = spec_probe.spec;
             g_fit_persist.active = 1;
-            hipLaunchKernelGGL(pinn_fit_ctrl_kernel, dim3(1), dim3(128), 0, hs, dctrl, ca);
-            const int rc = (hipGetLastError() != hipSuccess) ? fail("control-block launch failed")
+#ifdef PINN_EMU
+            emu::launch(1, 128, 0, [&] { pinn_fit_ctrl_kernel(dctrl, ca); });
+            const int rc0 = 0;
+#else
+            hipLaunchKernelGGL(pinn_fit_ctrl_kernel, dim3(1), dim3(128), 0, (hipStream_t)stream, dctrl, ca);
+            const int rc0 = (hipGetLastError() != hipSuccess) ? fail("control-block launch failed") : 0;
+#endif
+            const int rc = rc0 ? rc0
                            : pinn_residual_adam_step(net, residual, params, xs, n_points, dir_cols, nd, n2, nullptr, ic_const, grads, exp_avg,
                                                      exp_avg_sq, mask, step_ptr, step0, lr, beta1, beta2, eps, loss_history, workspace,
                                                      workspace_bytes, stream);
@@ -1064,6 +1088,10 @@ int pinn_fit_steps_graph(pinn_t* net, const pinn_residual_t* residual, float* pa
             if (did) { ++g_fit_graph_stats[0]; return 0; }          // (counted with the replayed chunks: one launch for the chunk)
         }
     }
+#ifdef PINN_EMU
+    return pinn_fit_steps(net, residual, params, xs, n_points, kind, a, b, seed, call_index0, dir_cols, nd, n2, ic_const, grads, exp_avg,
+                          exp_avg_sq, mask, step_ptr, step0, lr, beta1, beta2, eps, loss_history, k_steps, workspace, workspace_bytes, stream);
+#else
     // the graph pays where launch gaps are a visible share of an iteration; chunks that do not qualify run the eager loop
     // (only whole chunks: the tail of a fit would capture a graph of its own that nothing replays)
     if (k_steps != PINN_FIT_CHUNK_MAX || !ctrl || ctrl_bytes < sizeof(PinnFitCtrl) || g_profile || g_phase_prof)

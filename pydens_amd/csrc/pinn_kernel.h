@@ -648,14 +648,15 @@ PINN_DEVICE float pinn_prog_forward(const pinn_program_t& pg, float* regs, int T
 // `regs` / T: the register file -- LDS of the workgroup (register r of this thread at regs[r * T], T = threads) when the
 // program's registers fit the free activation buffers, else null: private memory (scratch; 10x the latency per access).
 PINN_DEVICE void pinn_prepass_point(const pinn_program_t& pg, const float* x, int d, float* aux, long long n, long long gi,
-                                    float* regs, int T, bool in_lds = true) {
-    float priv[PINN_MAX_REGS];                 // private (scratch): the program indexes it at run time
-    // (`in_lds` instead of a null test of `regs`: comparing an LDS-derived generic pointer with null makes hipcc 7.2 emit
-    //  `v_cmp_ne_u32 0, src_shared_base` -- "Illegal instruction detected" -- once this body sits inside pinn_fit_kernel's loop)
-    if (!in_lds) { regs = priv; T = 1; }
+                                    float* regs, int T) {
+    // `regs`: from ONE address space per call site (round 5: a select between the LDS carve and a private array made every register
+    // access a flat instruction; the tile kernels now always find room in LDS -- fewer points per sweep if need be -- and whoever wants
+    // private registers calls pinn_prepass_point_private)
     for (int c = 0; c < d; ++c) regs[c * T] = x[c];
+    unsigned w_next = pg.n_ops > 0 ? pg.code[0] : 0u;          // (the next op word is fetched one op ahead: a scalar load per op otherwise)
     for (int i = 0; i < pg.n_ops; ++i) {
-        const unsigned w = pg.code[i];
+        const unsigned w = w_next;
+        if (i + 1 < pg.n_ops) w_next = pg.code[i + 1];
         const int op = w & 255, dst = (w >> 8) & 255, a = (w >> 16) & 255, b = (w >> 24) & 255;
         if (op == PINN_OP_STORE) { aux[(long long)b * n + gi] = regs[a * T]; continue; }
         const float xa = (op == PINN_OP_CONST) ? 0.0f : regs[a * T];
@@ -681,6 +682,11 @@ PINN_DEVICE void pinn_prepass_point(const pinn_program_t& pg, const float* x, in
         }
         regs[dst * T] = y;
     }
+}
+
+PINN_DEVICE void pinn_prepass_point_private(const pinn_program_t& pg, const float* x, int d, float* aux, long long n, long long gi) {
+    float priv[PINN_MAX_REGS];                 // private (scratch): the program indexes it at run time
+    pinn_prepass_point(pg, x, d, aux, n, gi, priv, 1);
 }
 
 // reverse sweep: adj[] must be zero on entry for every register; adj[result] is seeded with `seed`.
@@ -763,7 +769,8 @@ struct PinnPointPre {
 
 template <int ND, int N2P, int SPEC = 0>
 PINN_DEVICE void pinn_point_prefetch(const PinnKArgs& A, const float* params_, long long gidx, bool valid, float* pregs, int T,
-                                     PinnPointPre<ND, N2P>& pre) {
+                                     PinnPointPre<ND, N2P>& pre, const float* aux_) {
+    // aux_: the rows of the x-only pre-pass -- A.aux, or the LDS copy of the one-CU fit chunk (pinn_fit_kernel.h)
     constexpr int S = pinn_ns(ND, N2P);
     using SH = PinnShape<SPEC, ND>;
     const long long gi = valid ? gidx : 0;
@@ -772,13 +779,13 @@ PINN_DEVICE void pinn_point_prefetch(const PinnKArgs& A, const float* params_, l
     for (int s = 0; s < S; ++s) { pre.cs[s] = 0.0f; pre.ic[s] = 0.0f; }
     if (SH::mode(A) == PINN_MODE_STEP) {
         if (SH::res_kind(A) == PINN_RES_AFFINE) {
-            if (A.src_row >= 0) pre.src = A.aux[(long long)A.src_row * A.n_points + gi];
+            if (A.src_row >= 0) pre.src = aux_[(long long)A.src_row * A.n_points + gi];
 #pragma unroll
             for (int s = 0; s < S; ++s)
                 if (s < SH::s_user(A))
-                    pre.cs[s] = (SH::coef_row(A, s) >= 0) ? A.aux[(long long)SH::coef_row(A, s) * A.n_points + gi] : A.coef[s];
+                    pre.cs[s] = (SH::coef_row(A, s) >= 0) ? aux_[(long long)SH::coef_row(A, s) * A.n_points + gi] : A.coef[s];
         } else {
-            for (int m = 0; m < A.n_aux; ++m) pregs[(S + SH::d(A) + m) * T] = A.aux[(long long)m * A.n_points + gi];
+            for (int m = 0; m < A.n_aux; ++m) pregs[(S + SH::d(A) + m) * T] = aux_[(long long)m * A.n_points + gi];
         }
     }
     if (SH::has_ic(A)) {
@@ -790,7 +797,7 @@ PINN_DEVICE void pinn_point_prefetch(const PinnKArgs& A, const float* params_, l
             // callable IC lowered into the x-only pre-pass (value + derivative streams as aux rows / constants)
 #pragma unroll
             for (int s = 0; s < S; ++s)
-                if (s < SH::s_user(A)) pre.ic[s] = (A.ic_row[s] >= 0) ? A.aux[(long long)A.ic_row[s] * A.n_points + gi] : A.ic_cst[s];
+                if (s < SH::s_user(A)) pre.ic[s] = (A.ic_row[s] >= 0) ? aux_[(long long)A.ic_row[s] * A.n_points + gi] : A.ic_cst[s];
         } else {
             pre.ic[0] = (SPEC == 0 && A.ic_var1 > 0) ? params_[A.off_extra + A.ic_var1 - 1] : A.ic_const;
         }
@@ -1114,7 +1121,7 @@ PINN_DEVICE void pinn_point_stage(const PinnKArgs& A, const float* params_, cons
 #if defined(PINN_PROFILE_PHASES) && !defined(PINN_EMU)
 #define PH_DECL long long ph_acc[16] = {0}; long long ph_last = __builtin_readcyclecounter();
 #define PH(i) { PINN_SCHED_BARRIER(); const long long ph_now = __builtin_readcyclecounter(); ph_acc[i] += ph_now - ph_last; ph_last = ph_now; PINN_SCHED_BARRIER(); }
-#define PH_FLUSH if (A.prof && lane == 0) { for (int i = 0; i < 16; ++i) A.prof[((size_t)PINN_BID * NW + wave) * 16 + i] = ph_acc[i]; }
+#define PH_FLUSH if (A.prof && lane == 0) { for (int i = 0; i < 16; ++i) A.prof[((size_t)rowid * NW + wave) * 16 + i] = ph_acc[i]; }
 #else
 #define PH_DECL
 #define PH(i)
@@ -1206,6 +1213,9 @@ PINN_DEVICE f32x4 pinn_row_sum16_v4(f32x4 v) {
     return v;
 }
 
+#if defined(PINN_FIT_PROF) && !defined(PINN_EMU)
+static __device__ long long g_pinn_fitprof[8];
+#endif
 // VAR (experiment bits): 1 = accumulate dW in the partial buffer although the layer count is static, 2 = two waves per
 // SIMD (two workgroups per CU), 4 = no whole-layer weight prefetch; 8 = layout breadth: Sin / identity activations and
 // skip connections ('R ... +' layouts; the skipped activations ride in registers through the forward half and in extra
@@ -1221,19 +1231,31 @@ PINN_DEVICE f32x4 pinn_row_sum16_v4(f32x4 v) {
 // 512 = SPLIT: the hidden-layer GEMMs on v_mfma_f32_16x16x32_bf16 with every fp32 operand split exactly into three bf16 (round 3;
 // pinn_set_gemm_mode). 1024 (with 8) = the breadth kernel for skip connections over Tanh / Sigmoid layers only:
 // one-bit activation codes, no skips that start in front of an activation.
-template <int HP, int ND, int N2, int MT, int LHC, int ACTC, bool COMB = false, int VAR = 0>
+// VW > 1 (round 5, pinn_fit_kernel.h only): VW VIRTUAL workgroups in one hardware workgroup -- each with its own LDS block, slab, tile
+// stream and partial row, exactly the workgroups of a grid of VW (times the hardware grid), but on ONE CU, so that whatever follows the
+// pass (the sum over the partial rows, Adam) needs a workgroup barrier and not a device-scope one. Narrow nets only (one or two waves
+// per virtual workgroup); the barriers inside the tile loop become wave-local (one wave: LDS executes a wave's accesses in order) or an
+// arrival counter in the virtual workgroup's own LDS block (two waves), so the virtual workgroups run their tiles independently; the
+// barriers in front of and behind the loop stay hardware barriers (every virtual workgroup passes them once per call).
+template <int HP, int ND, int N2, int MT, int LHC, int ACTC, bool COMB = false, int VAR = 0, int VW = 1>
 // occupancy hint: the fused kernel of a 64/128-wide net wants the whole register file of a SIMD (one wave per SIMD,
 // no spills); narrower nets (1-2 waves per workgroup) run several workgroups per CU
 #ifndef PINN_WAVES_PER_SIMD
 #define PINN_WAVES_PER_SIMD 1
 #endif
-PINN_DEVICE void pinn_tile_body(const PinnKArgs& A, const float* params_, float* partials_) {
-    // params_ / partials_: the parameter buffer the pass reads and the block of partial gradient rows it writes -- params_ / partials_ for
-    // an ordinary launch; the one-launch fit chunk hands over the workgroup's own parameter copy and the rows of the iteration's parity
+PINN_DEVICE void pinn_tile_body(const PinnKArgs& A, const float* params_, float* partials_, const float* xs_in, float* aux_in, int rstride_in) {
+    // params_ / partials_ / xs_ / aux_: the parameter buffer the pass reads, the block of partial gradient rows it writes, the batch and the
+    // rows of the x-only pre-pass -- A.params / A.partials / A.xs / A.aux for an ordinary launch; the one-launch fit chunk hands over the
+    // workgroup's own copies (the one-CU form: in LDS); rstride_: the row stride of partials_ (A.p_core / rounded up to 16 bytes)
     // (the body of the tile kernel as a function: pinn_tile_kernel below runs it once per launch, pinn_fit_kernel.h -- a whole chunk of
     //  fit iterations in one launch, round 5 -- once per iteration)
     using C = PinnCfg<HP, ND, N2, MT, (VAR & 512) != 0>;
     constexpr int S = C::S, NT = C::NT, NTW = C::NTW, NW = C::NW, T = C::T, LDA = C::LDA, NTHREADS = C::NTHREADS;
+    // (only the one-CU fit chunk has copies of its own: everybody else reads the launch arguments where they are needed -- as values
+    //  carried through the whole kernel the three cost BASELINE config 2's kernel 0.8 %, same-box A/B)
+    const float* xs_ = (VW > 1) ? xs_in : A.xs;
+    float* aux_ = (VW > 1) ? aux_in : A.aux;
+    const int rstride_ = (VW > 1) ? rstride_in : A.p_core;
     constexpr bool DWG = (LHC < 0) || (VAR & 1), ONEBUF = C::ONEBUF, SKIPS = (VAR & 8) != 0;
     constexpr int LHREG = DWG ? 1 : PINN_LHMAX;            // layers with register-resident dW accumulators
     // VAR 64: saved jets in LDS instead of the global slab (no slab traffic at all); W^T then lives in the workgroup's own
@@ -1241,7 +1263,9 @@ PINN_DEVICE void pinn_tile_body(const PinnKArgs& A, const float* params_, float*
     constexpr bool SLABL = (VAR & 64) != 0;
     constexpr bool WGX = (VAR & 128) != 0;
     constexpr bool TEAMS2 = (VAR & 256) != 0;
-    constexpr int TEAMS = TEAMS2 ? 2 : 1;
+    constexpr bool VWG = VW > 1;                           // virtual workgroups (above): `team` is the virtual workgroup's index
+    constexpr int TEAMS = TEAMS2 ? 2 : VW;
+    static_assert(!VWG || (!TEAMS2 && !(VAR & (2 | 64 | 128 | 512)) && NW <= 2 && HP <= 32), "virtual workgroups: the narrow nets' plain kernels");
     // VAR 512: split-bf16 GEMMs. Every hidden-layer GEMM (forward, data gradient, weight gradient) runs on
     // v_mfma_f32_16x16x32_bf16 with both operands split exactly into hi + mid + lo bf16 and the six products a_i b_j,
     // i + j <= 2, accumulated in fp32 (pinn_mfma_split6): 6 x 16 cycles of the matrix pipe per K = 32 instead of 8 x 32 cycles
@@ -1277,6 +1301,8 @@ PINN_DEVICE void pinn_tile_body(const PinnKArgs& A, const float* params_, float*
     static_assert(!SLABL || (((VAR >> 4) & 3) != 0 && LHC >= 1 && !(VAR & 8) && !(VAR & 1) && C::slabl_fits(LHC)),
                   "slab-in-LDS kernels: shape-specialised, static depth, no skips, and the jets must fit");
     constexpr bool WTL = !SPLIT && ((C::wt_fits(LHC) && !SLABL && !(VAR & 2)) || TEAMS2);        // transposed hidden weights staged in LDS
+    // (virtual workgroups: C::wt_fits(LHC) of ONE block is the launcher's condition for the shared copy as well -- pinn_inst.inc sizes
+    //  VW so that VW blocks + W^T fit)
     // widths >= 128: the data-gradient A operand comes from a transposed copy of the weights in global memory (one b128 per
     // K quad like the forward GEMM) instead of four strided global_load_dword per quad
     // (VAR 2, two workgroups per CU: W^T of both does not fit the LDS beside the activation buffers)
@@ -1285,9 +1311,10 @@ PINN_DEVICE void pinn_tile_body(const PinnKArgs& A, const float* params_, float*
     using SH = PinnShape<SPEC, ND>;
     // two teams: everything below is written in TEAM-local terms (tid, wave, LDS block, virtual block index); the teams meet
     // at the barriers only (same trip counts by construction) and in the shared W^T
-    const int gtid = PINN_TID, team = TEAMS2 ? gtid / NTHREADS : 0;
-    const int tid = TEAMS2 ? gtid % NTHREADS : gtid, lane = tid & 63, wave = tid >> 6;
+    const int gtid = PINN_TID, team = (TEAMS2 || VWG) ? gtid / NTHREADS : 0;
+    const int tid = (TEAMS2 || VWG) ? gtid % NTHREADS : gtid, lane = tid & 63, wave = tid >> 6;
     const int vbid = PINN_BID * TEAMS + team, vnblk = PINN_NBLK * TEAMS;
+    const int rowid = VWG ? vbid : PINN_BID;               // partial row (two teams share their workgroup's, virtual workgroups own one each)
     const int lr = lane & 15, lq = lane >> 4;
     const int lh = (LHC >= 0) ? LHC : A.lh;
     // activation of index a (0: first layer ... lh: last hidden layer)
@@ -1331,7 +1358,9 @@ PINN_DEVICE void pinn_tile_body(const PinnKArgs& A, const float* params_, float*
     const bool train = SH::mode(A) != PINN_MODE_FORWARD;
 
     PINN_SMEM(smem_all);
-    float* smem = smem_all + team * C::TEAM_FLOATS;            // (one team: the whole block)
+    // (virtual workgroups of a kernel with program registers carry them in their block; W^T sits once behind all blocks)
+    constexpr int TEAM_FLOATS = (VWG && ((VAR >> 4) & 3) == 0) ? C::SMEM_FLOATS : C::TEAM_FLOATS;
+    float* smem = smem_all + team * TEAM_FLOATS;               // (one team: the whole block)
     float* xs_base = smem + C::O_XS;
     float* W1s = smem + C::O_W1;
     float* b1s = smem + C::O_B1;
@@ -1347,6 +1376,13 @@ PINN_DEVICE void pinn_tile_body(const PinnKArgs& A, const float* params_, float*
     float* pregs = smem + C::O_PREG;
     float* padj = smem + C::O_PADJ;
 
+    // -DPINN_FIT_PROF (experiment builds, pinn_fit_kernel.h): clock ticks of thread 0 between marks of this function
+#if defined(PINN_FIT_PROF) && !defined(PINN_EMU)
+    long long fpb_last = __builtin_readcyclecounter();
+#define FPB(i) if (PINN_TID == 0 && PINN_BID == 0) { const long long fpb_now = __builtin_readcyclecounter(); g_pinn_fitprof[i] += fpb_now - fpb_last; fpb_last = fpb_now; }
+#else
+#define FPB(i)
+#endif
     // ---- one-time staging of the small layers and zeroing of the LDS accumulators -------------------------------
     for (int i = tid; i < HP * PINN_XS_LD; i += NTHREADS) {
         const int n = i / PINN_XS_LD, c = i % PINN_XS_LD;
@@ -1356,7 +1392,7 @@ PINN_DEVICE void pinn_tile_body(const PinnKArgs& A, const float* params_, float*
     for (int i = tid; i < HP; i += NTHREADS) { b1s[i] = params_[A.off_b1 + i]; WLs[i] = params_[A.off_wl + i]; }
     if (tid == 0) tbar[0] = 0;
     for (int i = tid; i < PINN_MAX_LAYERS * HP; i += NTHREADS) accB[i] = 0.0f;
-    float* WTs = TEAMS2 ? smem_all + 2 * C::TEAM_FLOATS : smem + C::O_WT;
+    float* WTs = (TEAMS2 || VWG) ? smem_all + TEAMS * TEAM_FLOATS : smem + C::O_WT;
     const float* wtg = A.wt + (SLABL ? (size_t)PINN_BID * (size_t)lh * HP * HP : (size_t)0);
     if (SLABL && train) {
         // wt[l][k][n] = W_l[n][k] in this workgroup's scratch: coalesced reads along k, strided fire-and-forget writes;
@@ -1397,7 +1433,8 @@ PINN_DEVICE void pinn_tile_body(const PinnKArgs& A, const float* params_, float*
             wt_write(e0, wreg);
         }
     }
-    if (!SLABL && !TEAMS2) for (int i = tid; i < PINN_MAX_REGS * T; i += NTHREADS) padj[i] = 0.0f;   // (team blocks end before the program registers)
+    if (!SLABL && !TEAMS2 && !(VWG && ((VAR >> 4) & 3) != 0))
+        for (int i = tid; i < PINN_MAX_REGS * T; i += NTHREADS) padj[i] = 0.0f;   // (team blocks end before the program registers)
     const float bL = params_[A.off_bl];
 
     // persistent per-lane accumulators
@@ -1410,7 +1447,7 @@ PINN_DEVICE void pinn_tile_body(const PinnKArgs& A, const float* params_, float*
             for (int j = 0; j < NTW; ++j) dW[l][o][j] = f32x4{0.f, 0.f, 0.f, 0.f};
     // this lane's element of weight-gradient tile (o, j) of hidden layer li inside the workgroup's partial buffer
     auto dwg_ptr = [&](int li, int o, int j, int r) -> float* {
-        return partials_ + (size_t)PINN_BID * A.p_core + A.off_wh + (size_t)li * A.hidden_stride +
+        return partials_ + (size_t)rowid * rstride_ + A.off_wh + (size_t)li * A.hidden_stride +
                (o * 16 + lq * 4 + r) * HP + (wave * NTW + j) * 16 + lr;
     };
     if (DWG && !WGX && train) {
@@ -1617,7 +1654,7 @@ PINN_DEVICE void pinn_tile_body(const PinnKArgs& A, const float* params_, float*
             const int i = tid + e * NTHREADS;
             const int pt = i / PINN_XS_LD, c = i % PINN_XS_LD;
             const long long g = tile * T + pt;
-            xpre[e] = (i < T * PINN_XS_LD && c < d && tile < ntiles && g < A.n_points) ? A.xs[g * d + c] : 0.0f;
+            xpre[e] = (i < T * PINN_XS_LD && c < d && tile < ntiles && g < A.n_points) ? xs_[g * d + c] : 0.0f;
         }
     };
     auto store_points = [&](float* dst) {
@@ -1630,24 +1667,32 @@ PINN_DEVICE void pinn_tile_body(const PinnKArgs& A, const float* params_, float*
     // the points live in a double-buffered LDS tile: tile k reads buffer k&1 while the points of tile k+1 are written
     // to the other one in the middle of tile k (several barriers away from both its last reader and its first reader),
     // so neither the staging nor the end of a tile needs a barrier of its own
+    FPB(0)
     if (A.pre.n_ops > 0) {
         // x-only pre-pass (source terms, variable coefficients) for the points of this workgroup's own tiles, all threads,
         // NTHREADS / T tiles per sweep; the rows land in A.aux and are read back (by the point-stage threads of the same
         // workgroup, hence the fence + the barrier below) at the top of each tile
-        // (its registers live in the activation buffers, which nothing uses before the first tile, whenever they fit)
-        const bool pp_lds = A.pre_nregs * NTHREADS <= C::O_NET - C::O_BUFA;
+        // (its registers live in the activation buffers, which nothing uses before the first tile: as many points per sweep as their
+        //  registers fit -- a tile's worth always does)
+        static_assert(PINN_MAX_REGS * T <= C::O_NET - C::O_BUFA, "the activation buffers hold the pre-pass registers of one tile");
+        int pp_lanes = NTHREADS;
+        while (A.pre_nregs * pp_lanes > C::O_NET - C::O_BUFA) pp_lanes -= T;
         float* pp_regs = smem + C::O_BUFA + tid;
-        for (long long tile = A.tile_begin + vbid + (long long)(tid / T) * vnblk; tile < ntiles; tile += (long long)(NTHREADS / T) * vnblk) {
-            const long long gi = tile * T + tid % T;
-            if (gi < A.n_points) pinn_prepass_point(A.pre, A.xs + gi * d, d, A.aux, A.n_points, gi, pp_regs, NTHREADS, pp_lds);
+        if (tid < pp_lanes) {
+            for (long long tile = A.tile_begin + vbid + (long long)(tid / T) * vnblk; tile < ntiles; tile += (long long)(pp_lanes / T) * vnblk) {
+                const long long gi = tile * T + tid % T;
+                if (gi < A.n_points) pinn_prepass_point(A.pre, xs_ + gi * d, d, aux_, A.n_points, gi, pp_regs, pp_lanes);
+            }
         }
         PINN_FENCE_BLOCK();
     }
+    FPB(1)
     fetch_points(A.tile_begin + vbid);
     store_points(xs_base);
     fetch_points(A.tile_begin + vbid + vnblk);
     PINN_SYNC();
     PH_DECL
+    FPB(2)
 
     int tile_parity = 0;
     // (two-team kernels with team 1 running one barrier behind team 0, so that its vector phases meet team 0's GEMM phases:
@@ -1659,10 +1704,12 @@ PINN_DEVICE void pinn_tile_body(const PinnKArgs& A, const float* params_, float*
 #ifndef PINN_TEAM_FLAGS
 #define PINN_TEAM_FLAGS 0
 #endif
-    constexpr bool TEAM_FLAGS = TEAMS2 && ((PINN_TEAM_FLAGS & (SPLIT ? 1 : 2)) != 0);
+    constexpr bool TEAM_FLAGS = (TEAMS2 && ((PINN_TEAM_FLAGS & (SPLIT ? 1 : 2)) != 0)) || (VWG && NW > 1);
     int tb_round = 0;
     auto tsync = [&]() {
-        if constexpr (TEAM_FLAGS) {
+        if constexpr (VWG && NW == 1) {
+            PINN_WAVE_SYNC();
+        } else if constexpr (TEAM_FLAGS) {
             tb_round += NW;
             pinn_flag_arrive(tbar, lane == 0);
             while (pinn_flag_load(tbar) < tb_round) PINN_SPIN_PAUSE();
@@ -1673,8 +1720,9 @@ PINN_DEVICE void pinn_tile_body(const PinnKArgs& A, const float* params_, float*
     };
     // (two teams: both run as many rounds as team 0 has tiles -- a team without a tile in the last round works on an empty
     //  one: zero points, every sample invalid, contributions zero -- so that the barriers match)
-    for (long long tile0 = A.tile_begin + (long long)PINN_BID * TEAMS; tile0 < ntiles; tile0 += vnblk, tile_parity ^= 1) {
-        const long long tile = tile0 + team;
+    // (virtual workgroups: no hardware barrier in here, so each runs over its own tiles only)
+    for (long long tile0 = A.tile_begin + (VWG ? (long long)vbid : (long long)PINN_BID * TEAMS); tile0 < ntiles; tile0 += vnblk, tile_parity ^= 1) {
+        const long long tile = VWG ? tile0 : tile0 + team;
         const long long base = tile * T;
         if (WGX && train) {
             // (debug flag 4, timing experiments only: every tile writes the first tile's slab -- stores stay in L2)
@@ -1697,9 +1745,9 @@ PINN_DEVICE void pinn_tile_body(const PinnKArgs& A, const float* params_, float*
         if constexpr (PTALL) {
 #pragma unroll
             for (int mt = 0; mt < MT; ++mt)
-                pinn_point_prefetch<ND, N2, SPEC>(A, params_, base + mt * 16 + lr, base + mt * 16 + lr < A.n_points, pregs, T, ppre_all[mt]);
+                pinn_point_prefetch<ND, N2, SPEC>(A, params_, base + mt * 16 + lr, base + mt * 16 + lr < A.n_points, pregs, T, ppre_all[mt], aux_);
         } else {
-            if (tid < T) pinn_point_prefetch<ND, N2, SPEC>(A, params_, base + tid, base + tid < A.n_points, pregs + tid, T, ppre);
+            if (tid < T) pinn_point_prefetch<ND, N2, SPEC>(A, params_, base + tid, base + tid < A.n_points, pregs + tid, T, ppre, aux_);
         }
         PH(0)
 
@@ -2651,43 +2699,54 @@ PINN_DEVICE void pinn_tile_body(const PinnKArgs& A, const float* params_, float*
         }
         PH(15)
     }
+    FPB(3)
     if (TEAM_FLAGS) PINN_SYNC();       // (the arrival counter shares its LDS slot with `scal`, written below)
     PH_FLUSH
 
     if (!train) return;
     if (REGB) {
-        // one row reduction for everything the lanes summed privately; each (wave, j, lq) owns its units: plain LDS adds
+        // one row reduction for everything the lanes summed privately; each (wave, j, lq) owns its units. Plain LDS STORES: with
+        // register accumulators nothing else writes these slots (they were zeroed in the prologue; the per-tile LDS adds belong to
+        // the kernels without REGB and to the columns c >= W1R) -- as read-modify-writes these were ~20 dependent LDS round trips
+        // at the end of every workgroup (phase clocks of the one-CU fit chunk: 6.1 K ticks of a 30 K tick pass over one tile)
 #pragma unroll
         for (int j = 0; j < NTW; ++j) {
 #pragma unroll
             for (int a = 0; a <= PINN_LHMAX; ++a) {
                 if (a <= lh) {
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) {
-                        const float t = pinn_row_sum16(accBr[REGB && a < NBR ? a : 0][j][r]);
-                        if (lr == 0) accB[a * HP + unit0(j) + r] += t;
-                    }
+                    const f32x4 t = pinn_row_sum16_v4(accBr[REGB && a < NBR ? a : 0][j]);
+                    if (lr == 0) pinn_st4(accB + a * HP + unit0(j), t);
                 }
             }
 #pragma unroll
             for (int c = 0; c < W1R; ++c) {
                 if (c < d) {
+                    const f32x4 t = pinn_row_sum16_v4(accW1r[REGB ? c : 0][j]);
+                    if (lr == 0) {
 #pragma unroll
-                    for (int r = 0; r < 4; ++r) {
-                        const float t = pinn_row_sum16(accW1r[REGB ? c : 0][j][r]);
-                        if (lr == 0) accW1[(unit0(j) + r) * PINN_XS_LD + c] += t;
+                        for (int r = 0; r < 4; ++r) accW1[(unit0(j) + r) * PINN_XS_LD + c] = t[r];
                     }
                 }
             }
         }
     }
+    FPB(4)
     // ---- write this workgroup's partial gradient ---------------------------------------------------------------
     // (two teams: ONE row per workgroup -- team 0 stores, team 1 adds on top behind a barrier)
-    if (tid < T) { scal[tid * 4 + 0] = sum_loss; scal[tid * 4 + 1] = sum_ls; scal[tid * 4 + 2] = sum_bl; scal[tid * 4 + 3] = sum_ic; }
+    // the per-point sums of the point-stage lanes (tid < T: rows of wave 0) -> every lane of wave 0, by row and wave sums (as LDS slots
+    // summed by thread 0 these were 48 serial LDS reads at the end of every workgroup: 5 K ticks)
+    static_assert(T <= 64, "the point-stage lanes sit in wave 0");
+    float tot_loss = (tid < T) ? sum_loss : 0.0f, tot_ls = (tid < T) ? sum_ls : 0.0f, tot_bl = (tid < T) ? sum_bl : 0.0f,
+          tot_ic = (tid < T) ? sum_ic : 0.0f;
+    if (wave == 0) {
+        tot_loss = pinn_row_sum16(tot_loss); tot_ls = pinn_row_sum16(tot_ls); tot_bl = pinn_row_sum16(tot_bl); tot_ic = pinn_row_sum16(tot_ic);
+        if (T > 16) { tot_loss = pinn_rows_sum(tot_loss); tot_ls = pinn_rows_sum(tot_ls); tot_bl = pinn_rows_sum(tot_bl); tot_ic = pinn_rows_sum(tot_ic); }
+    }
+    (void)scal;
     PINN_SYNC();
-    float* part = partials_ + (size_t)PINN_BID * A.p_core;
-    for (int round = 0; round < TEAMS; ++round) {
-        if (team == round) {
+    float* part = partials_ + (size_t)rowid * rstride_;
+    for (int round = 0; round < (VWG ? 1 : TEAMS); ++round) {
+        if (VWG || team == round) {
             const bool add = round > 0;
             auto put = [&](float* p, float v) { *p = add ? *p + v : v; };
 #pragma unroll
@@ -2718,11 +2777,9 @@ PINN_DEVICE void pinn_tile_body(const PinnKArgs& A, const float* params_, float*
                 }
             }
             if (tid == 0) {
-                float l0 = 0.0f, l1 = 0.0f, l2 = 0.0f;
-                for (int i = 0; i < T; ++i) { l0 += scal[i * 4]; l1 += scal[i * 4 + 1]; l2 += scal[i * 4 + 2]; }
-                put(part + A.off_loss, l0);
-                put(part + A.off_ls, l1);
-                put(part + A.off_bl, l2);
+                put(part + A.off_loss, tot_loss);
+                put(part + A.off_ls, tot_ls);
+                put(part + A.off_bl, tot_bl);
                 if (!add)
                     for (int i = A.off_loss + 1; i < A.p_core; ++i) part[i] = 0.0f;
                 if (SPEC == 0 && SH::mode(A) == PINN_MODE_STEP && A.res_kind == PINN_RES_PROGRAM) {
@@ -2734,19 +2791,18 @@ PINN_DEVICE void pinn_tile_body(const PinnKArgs& A, const float* params_, float*
                     }
                 }
                 if (SPEC == 0 && A.ic_var1 > 0 && SH::mode(A) == PINN_MODE_STEP) {
-                    float l3 = 0.0f;
-                    for (int i = 0; i < T; ++i) l3 += scal[i * 4 + 3];
-                    part[A.off_extra + A.ic_var1 - 1] += l3;
+                    part[A.off_extra + A.ic_var1 - 1] += tot_ic;
                 }
             }
         }
         if (TEAMS2) { PINN_FENCE_BLOCK(); PINN_SYNC(); }
     }
+    FPB(5)
 }
 
 template <int HP, int ND, int N2, int MT, int LHC, int ACTC, bool COMB = false, int VAR = 0>
 PINN_GLOBAL void PINN_LAUNCH_BOUNDS2((PinnCfg<HP, ND, N2, MT>::NTHREADS * ((VAR & 256) ? 2 : 1)),
                                     (PinnCfg<HP, ND, N2, MT>::NW < 4 || (VAR & (2 | 256)) ? 2 : PINN_WAVES_PER_SIMD))
 pinn_tile_kernel(const PinnKArgs A) {
-    pinn_tile_body<HP, ND, N2, MT, LHC, ACTC, COMB, VAR>(A, A.params, A.partials);
+    pinn_tile_body<HP, ND, N2, MT, LHC, ACTC, COMB, VAR>(A, A.params, A.partials, A.xs, A.aux, A.p_core);
 }

@@ -132,6 +132,8 @@ def bind(lib):
     lib.pinn_debug_max_wgs_per_cu.argtypes = [vp, ctypes.c_int]
     lib.pinn_debug_prepass_in_kernel.argtypes = [vp, ctypes.c_int]
     lib.pinn_debug_fit_persistent.argtypes = [vp, ctypes.c_int]
+    if hasattr(lib, 'pinn_debug_fit_onecu_rounds'):              # (experiment builds of older sources, tools/variant.sh, lack the knob)
+        lib.pinn_debug_fit_onecu_rounds.argtypes = [vp, ctypes.c_int]
     lib.pinn_last_launch_info.argtypes = [ctypes.POINTER(ctypes.c_int32)]
     lib.pinn_debug_fit_graph_stats.argtypes = [ctypes.POINTER(ctypes.c_int32)]
     for name in ('pinn_create', 'pinn_create_ex', 'pinn_destroy', 'pinn_layout', 'pinn_jet_forward', 'pinn_jet_forward_ws', 'pinn_jet_backward',
@@ -143,7 +145,7 @@ def bind(lib):
 ABI_SYMBOLS = ('pinn_create', 'pinn_create_ex', 'pinn_destroy', 'pinn_layout', 'pinn_workspace_bytes', 'pinn_jet_forward', 'pinn_jet_forward_ws',
                'pinn_jet_backward', 'pinn_residual_step', 'pinn_residual_step_add', 'pinn_residual_adam_step', 'pinn_adam_step', 'pinn_adam_step_at', 'pinn_sample_points', 'pinn_fit_steps', 'pinn_fit_steps_graph', 'pinn_fit_ctrl_bytes', 'pinn_set_gemm_mode', 'pinn_set_tanh_mode', 'pinn_profile_tile',
                'pinn_last_tile_ms', 'pinn_last_wgrad_ms', 'pinn_last_kernel_name', 'pinn_last_wgrad_kernel_name', 'pinn_debug_last_kernel',
-               'pinn_debug_prepass_in_kernel', 'pinn_debug_wgx_chunk_bytes', 'pinn_debug_max_wgs_per_cu', 'pinn_debug_fit_persistent', 'pinn_debug_fit_graph_stats', 'pinn_last_launch_info',
+               'pinn_debug_prepass_in_kernel', 'pinn_debug_wgx_chunk_bytes', 'pinn_debug_max_wgs_per_cu', 'pinn_debug_fit_persistent', 'pinn_debug_fit_onecu_rounds', 'pinn_debug_fit_graph_stats', 'pinn_last_launch_info',
                'pinn_last_error', 'pinn_backend')
 
 _LIB = None
@@ -241,8 +243,12 @@ class Net:
         self.tanh_mode = 'fast'
         if os.environ.get('PYDENS_AMD_GEMM'):
             self.set_gemm_mode(os.environ['PYDENS_AMD_GEMM'])
-        if os.environ.get('PYDENS_AMD_FIT_PERSIST', '0') == '1':    # small fit chunks as ONE launch each instead of launch graphs (experiment:
-            self.lib.pinn_debug_fit_persistent(self.handle, 1)      # measured slower on MI355X, include/pinn.h)
+        # small fit chunks of narrow nets as ONE launch each (include/pinn.h pinn_debug_fit_persistent): '2' one-CU form for batches of a few
+        # tiles (the default), '1' grid form (measured slower than launch graphs on MI355X), '0' never
+        if os.environ.get('PYDENS_AMD_FIT_PERSIST') in ('0', '1', '2'):
+            self.lib.pinn_debug_fit_persistent(self.handle, int(os.environ['PYDENS_AMD_FIT_PERSIST']))
+        if os.environ.get('PYDENS_AMD_FIT_ROUNDS'):
+            self.lib.pinn_debug_fit_onecu_rounds(self.handle, int(os.environ['PYDENS_AMD_FIT_ROUNDS']))
         if os.environ.get('PYDENS_AMD_TANH'):
             self.set_tanh_mode(os.environ['PYDENS_AMD_TANH'])
         if os.environ.get('PYDENS_AMD_WGX_CHUNK_MB'):           # experiments: slab budget of the widths >= 128 (pinn_debug_wgx_chunk_bytes)

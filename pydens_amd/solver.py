@@ -714,6 +714,7 @@ class Solver:
             done[0] = it + 1
 
     FIT_CHUNK = 128             # iterations per pinn_fit_steps call (progress bar / KeyboardInterrupt granularity)
+    FIT_CTRL_ON_HOST = False    # (tests on the CPU emulator: the control block of pinn_fit_steps_graph in host memory)
     GRAPH_MAX_BATCH = 4096      # batches up to this size replay their chunks as one launch graph (+16 % at batch 100, +1 % at 4 096)
 
     def _device_columns(self, sampler):
@@ -745,7 +746,7 @@ class Solver:
         # small batches (the latency regime): each chunk as ONE replayable launch graph; the control block the kernels read their
         # per-iteration values from belongs to the solver (include/pinn.h pinn_fit_steps_graph)
         ctrl = None
-        if batch <= self.GRAPH_MAX_BATCH and xs.is_cuda and os.environ.get('PYDENS_AMD_FIT_GRAPH', '1') != '0':
+        if batch <= self.GRAPH_MAX_BATCH and (xs.is_cuda or self.FIT_CTRL_ON_HOST) and os.environ.get('PYDENS_AMD_FIT_GRAPH', '1') != '0':
             if getattr(self, '_fit_ctrl', None) is None or self._fit_ctrl.device != xs.device:
                 self._fit_ctrl = torch.zeros(int(model.net.lib.pinn_fit_ctrl_bytes()) + 64, dtype=torch.uint8, device=xs.device)
             ctrl = self._fit_ctrl

@@ -1330,3 +1330,63 @@ def _fourth_order_case(pa, which, solver_kwargs):
         assert params_close(got, want, 2e-4, atol=2e-5)
     xs = [pts[0][:, i] for i in range(d)]
     assert np.abs(solver.predict(*xs) - oracle.predict(*xs)).max() < 2e-5
+
+
+# ---- a chunk of fit iterations as ONE launch on ONE CU (pinn_fit_kernel.h, round 5) ---------------------------------------------------
+def _one_launch_problem(pa, which, kw):
+    """ -> (solver, sampler, batch): narrow nets at the reference's own batch sizes """
+    if which in ('cfg1', 'one_point'):
+        return make_solver('cfg1', pa, **kw)[1], None, (100 if which == 'cfg1' else 1)
+    if which == 'ode_16':                      # generic kernel of width 16 (program registers in every virtual workgroup's LDS block), 25 tiles
+        eq = lambda f, x: pa.D(f, x) - 2 * np.pi * torch.cos(2 * np.pi * x)
+        return pa.Solver(eq, ndims=1, initial_condition=0.5, layout='fa fa f', features=[10, 12, 1], activation='Tanh', **kw), None, 400
+    if which == 'ode_default_net':             # tutorial cells 28-31: default net (20, 30 units -> width 32: TWO waves per virtual workgroup)
+        eq = lambda f, x, e: pa.D(f, x) - e * np.pi * torch.cos(e * np.pi * x)
+        return (pa.Solver(eq, ndims=1, initial_condition=2.0, nparams=1, **kw),
+                pa.NumpySampler('u') & pa.NumpySampler('u', low=.5, high=5.5), 100)
+    if which == 'program_with_variable':       # residual program with a trainable coefficient
+        eq = lambda f, x, y: pa.D(pa.D(f, x), x) + pa.D(pa.D(f, y), y) + pa.V('k', data=torch.Tensor([1.5])) * f * f - torch.sin(np.pi * (x + y))
+        return pa.Solver(eq, ndims=2, boundary_condition=1, layout='fa fa f', features=[16, 16, 1], activation='Tanh', **kw), None, 90
+    assert which == 'skip_sin'                 # breadth kernel: skip connection, Sin / Tanh / Sigmoid
+    eq = lambda f, x, y: pa.D(pa.D(f, x), x) + pa.D(pa.D(f, y), y) - torch.sin(np.pi * (x + y))
+    return pa.Solver(eq, ndims=2, boundary_condition=1, layout='faR fa fa+ f', features=[16, 16, 16, 1], activation=['Sin', 'Tanh', 'Sigmoid'], **kw), None, 60
+
+
+def _one_launch_case(pa, which, kw, monkeypatch, mode, niters, lib, rounds=4):
+    """ Solver.fit with every chunk as one launch (mode 2: one hardware workgroup of virtual workgroups on one CU, mode 1: a grid with a
+    device-scope wait) against the eager loop: same Philox batches, same Adam scalars; the sums over the partial rows may group the tiles
+    differently (another number of rows) and the tile pass is compiled into another kernel (FMA contraction): fp32 round-off apart. """
+    def run(m):
+        monkeypatch.setenv('PYDENS_AMD_FIT_PERSIST', str(m))
+        monkeypatch.setenv('PYDENS_AMD_FIT_ROUNDS', str(rounds))
+        monkeypatch.setenv('PYDENS_AMD_FIT_GRAPH', '1')
+        torch.manual_seed(31)
+        solver, sampler, batch = _one_launch_problem(pa, which, kw)
+        assert solver.model.net.layout.hp <= 32
+        st0 = (ctypes.c_int32 * 4)()
+        lib.pinn_debug_fit_graph_stats(st0)
+        solver.fit(niters=niters[0], batch_size=batch, sampler=sampler, lr=0.005)
+        solver.fit(niters=niters[1], batch_size=batch, sampler=sampler, lr=0.005, optimizer=None)      # continues
+        assert solver.last_fit_path == 'fused', solver.program_error
+        st = (ctypes.c_int32 * 4)()
+        lib.pinn_debug_fit_graph_stats(st)
+        return (np.array([float(v) for v in solver.losses]), solver.model.flat.detach().cpu().numpy().copy(),
+                solver.optimizer.exp_avg.cpu().numpy().copy(), solver.optimizer.exp_avg_sq.cpu().numpy().copy(),
+                int(solver.optimizer.step_count.item()), solver.grads.cpu().numpy().copy(), lib.pinn_last_kernel_name().decode(), st[0] - st0[0])
+    l0, p0, m0, v0, t0, g0, k0, n0 = run(0)
+    l1, p1, m1, v1, t1, g1, k1, n1 = run(mode)
+    assert k0.startswith('pinn_tile_kernel<'), k0
+    assert k1.startswith('pinn_fit_kernel<') and (k1.endswith(',1>') == (mode == 1)), k1
+    chunks = sum((n + 127) // 128 for n in niters)
+    assert n1 >= chunks                          # every chunk went out as one launch (n0: the chunks the eager run replayed as launch graphs)
+    assert t0 == t1 == sum(niters) and np.isfinite(l1).all()
+    np.testing.assert_allclose(l1[:8], l0[:8], rtol=2e-6)
+    np.testing.assert_allclose(l1, l0, rtol=2e-4)
+    assert params_close(p1, p0, 2e-4) and params_close(m1, m0, 2e-3, atol=1e-7) and params_close(v1, v0, 2e-3, atol=1e-9)
+    assert params_close(g1, g0, 5e-3, atol=1e-6)
+
+
+@pytest.mark.parametrize('which', ['cfg1', 'one_point', 'ode_16', 'ode_default_net', 'program_with_variable', 'skip_sin'])
+def test_fit_chunk_on_one_cu_follows_the_eager_loop(pa, emu_lib, which, monkeypatch):
+    monkeypatch.setattr(pa.Solver, 'FIT_CTRL_ON_HOST', True)
+    _one_launch_case(pa, which, emu_kwargs(emu_lib), monkeypatch, 2, (5, 3), emu_lib)

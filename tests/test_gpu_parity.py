@@ -1101,56 +1101,17 @@ def test_fit_chunks_as_launch_graphs_follow_the_eager_loop_bit_for_bit(pa, name,
     assert np.array_equal(p0, p1) and np.array_equal(m0, m1)
 
 
-@pytest.mark.parametrize('which', ['cfg1', 'ode_default_net', 'program_with_variable'])
-def test_fit_chunk_as_one_launch_follows_the_eager_loop(pa, which, monkeypatch):
-    """ round 5 (OPT-IN, PYDENS_AMD_FIT_PERSIST=1: measured slower than launch-graph replay on MI355X, profiles/r05_small_fit_rate.txt):
-    narrow nets at the reference's batch sizes can run a whole chunk of fit iterations -- sampling, tile
-    body, the sum of the partial rows, Adam -- in ONE launch (pinn_fit_kernel.h: the workgroups of the grid meet once per iteration in
-    a device-scope arrive / wait, every workgroup keeps its own copy of parameters and Adam state). Same tile -> workgroup map, same
-    summation order, same Adam scalars, same Philox counters as the eager loop: every loss, every parameter, the Adam moments and the
-    step counter must follow the eager loop to fp32 round-off, over whole chunks, a short tail and a second fit that continues. """
-    def build():
-        if which == 'cfg1':
-            return make_solver('cfg1', pa)[1], None, 100
-        if which == 'one_point':
-            return make_solver('cfg1', pa)[1], None, 1
-        if which == 'ode_default_net':            # tutorial cells 28-31: default net (20, 30 units -> width 32), two-column sampler
-            eq = lambda f, x, e: pa.D(f, x) - e * np.pi * torch.cos(e * np.pi * x)
-            return (pa.Solver(eq, ndims=1, initial_condition=2.0, nparams=1),
-                    pa.NumpySampler('u') & pa.NumpySampler('u', low=.5, high=5.5), 700)
-        if which == 'heat_callable_ic':           # tutorial cells 37-40 on a net of 30 / 24 units (width 32), 900 points (57 tiles): callable IC in the pre-pass
-            eq = lambda f, x, y, t, a: pa.D(pa.D(f, x), x) + pa.D(pa.D(f, y), y) - a * pa.D(f, t)
-            return (pa.Solver(eq, ndims=3, nparams=1, initial_condition=lambda x, y: 10 * x * y * (1 - x) * (1 - y), boundary_condition=0,
-                              layout='fafaf', features=[30, 24, 1], activation='Sigmoid'),
-                    pa.NumpySampler('u', dim=2) & pa.NumpySampler('u', low=0, high=.5) & pa.NumpySampler('u', low=.1, high=4), 900)
-        eq = lambda f, x, y: pa.D(pa.D(f, x), x) + pa.D(pa.D(f, y), y) + pa.V('k', data=torch.Tensor([1.5])) * f * f - torch.sin(np.pi * (x + y))
-        return pa.Solver(eq, ndims=2, boundary_condition=1, layout='fa fa f', features=[16, 16, 1], activation='Tanh'), None, 300
-
-    def run(persist):
-        monkeypatch.setenv('PYDENS_AMD_FIT_PERSIST', '1' if persist else '0')
-        monkeypatch.setenv('PYDENS_AMD_FIT_GRAPH', '1')
-        torch.manual_seed(31)
-        solver, sampler, batch = build()
-        assert solver.model.net.layout.hp <= 32
-        solver.fit(niters=300, batch_size=batch, sampler=sampler, lr=0.005)                      # 128 + 128 + 44
-        solver.fit(niters=130, batch_size=batch, sampler=sampler, lr=0.005, optimizer=None)      # continues
-        assert solver.last_fit_path == 'fused', solver.program_error
-        st = (ctypes.c_int32 * 4)()
-        solver.model.net.lib.pinn_debug_fit_graph_stats(st)
-        return (np.array([float(v) for v in solver.losses]), solver.model.flat.detach().cpu().numpy().copy(),
-                solver.optimizer.exp_avg.cpu().numpy().copy(), solver.optimizer.exp_avg_sq.cpu().numpy().copy(),
-                int(solver.optimizer.step_count.item()), solver.grads.cpu().numpy().copy(),
-                solver.model.net.lib.pinn_last_kernel_name().decode(), st[0])
-    l0, p0, m0, v0, t0, g0, k0, n0 = run(False)
-    l1, p1, m1, v1, t1, g1, k1, n1 = run(True)
-    assert k1.startswith('pinn_fit_kernel<') and k0.startswith('pinn_tile_kernel<'), (k0, k1)
-    assert n1 - n0 >= 5                          # five chunks went out as one launch each
-    assert t0 == t1 == 430 and np.isfinite(l1).all()
-    # same batches (Philox counters), same sums, same Adam -- but the tile pass is compiled into another kernel, where hipcc contracts
-    # multiply-adds where it sees fit: the first iterations agree to the last bit or two, 430 Adam steps later the losses to ~1e-6
-    np.testing.assert_allclose(l1[:8], l0[:8], rtol=2e-6)
-    np.testing.assert_allclose(l1, l0, rtol=2e-4)
-    assert params_close(p1, p0, 2e-4) and params_close(m1, m0, 2e-3, atol=1e-7) and params_close(g1, g0, 5e-3, atol=1e-6)
+@pytest.mark.parametrize('mode,which', [(2, 'cfg1'), (2, 'ode_16'), (2, 'ode_default_net'), (2, 'program_with_variable'),
+                                        (2, 'skip_sin'), (1, 'cfg1'), (1, 'ode_default_net'), (1, 'program_with_variable')])
+def test_fit_chunk_as_one_launch_follows_the_eager_loop(pa, mode, which, monkeypatch):
+    """ round 5: narrow nets at the reference's batch sizes run a whole chunk of fit iterations -- sampling, tile body,
+    the sum of the partial rows, Adam -- in ONE launch (pinn_fit_kernel.h). Mode 2 (default for batches of a few tiles): ONE hardware
+    workgroup of up to eight virtual workgroups on one CU, a workgroup barrier per iteration. Mode 1 (opt-in, measured slower than
+    launch-graph replay, profiles/r05_small_fit_rate.txt): the workgroups of a grid meet once per iteration in a device-scope arrive /
+    wait. Same Adam scalars and Philox counters as the eager loop: every loss, every parameter, the Adam moments and the step counter
+    follow it to fp32 round-off, over whole chunks, a short tail and a second fit that continues. """
+    import test_emu_engine as te
+    te._one_launch_case(pa, which, {}, monkeypatch, mode, (300, 130), pa.engine.load_library())
 
 
 @pytest.mark.parametrize('which', ['cfg2_forced_generic', 'tensor_variable'])

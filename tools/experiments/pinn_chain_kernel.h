@@ -115,11 +115,15 @@ pinn_chain_kernel(const PinnKArgs A) {
     if (A.pre.n_ops > 0) {
         // x-only pre-pass (source term of the residual) for the points of this pair's own tiles, both waves, 128 / TW tiles per
         // sweep; its registers live in the ring (unused before the first tile) whenever they fit
-        float* pp_regs = (A.pre_nregs * NTHREADS <= NP * C::SCR_W) ? smem + C::O_SCR + tid : nullptr;
+        const bool pp_in_lds = A.pre_nregs * NTHREADS <= NP * C::SCR_W;
+        float* pp_regs = smem + C::O_SCR + tid;
         const int ptid = role * 64 + lane;
         for (long long tile = A.tile_begin + vbid + (long long)(ptid / TW) * vnblk; tile < ntiles; tile += (long long)(128 / TW) * vnblk) {
             const long long gi = tile * TW + ptid % TW;
-            if (gi < A.n_points) pinn_prepass_point(A.pre, A.xs + gi * d, d, A.aux, A.n_points, gi, pp_regs, NTHREADS, pp_regs != nullptr);
+            if (gi < A.n_points) {
+                if (pp_in_lds) pinn_prepass_point(A.pre, A.xs + gi * d, d, A.aux, A.n_points, gi, pp_regs, NTHREADS);
+                else pinn_prepass_point_private(A.pre, A.xs + gi * d, d, A.aux, A.n_points, gi);
+            }
         }
         PINN_FENCE_BLOCK();
     }
@@ -259,7 +263,7 @@ pinn_chain_kernel(const PinnKArgs A) {
 #pragma unroll
         for (int mt = 0; mt < MT; ++mt) {
             const long long g = base + mt * 16 + lr;
-            pinn_point_prefetch<ND, N2, SPEC>(A, A.params, g, g < A.n_points, nullptr, 0, ppre[mt]);
+            pinn_point_prefetch<ND, N2, SPEC>(A, A.params, g, g < A.n_points, nullptr, 0, ppre[mt], A.aux);
         }
 
         PH(0)

@@ -377,7 +377,7 @@ pinn_duo_kernel(const PinnKArgs A) {
             }
             PinnPointOut<ND, N2> po;
             PinnPointPre<ND, N2> ppre;
-            pinn_point_prefetch<ND, N2>(A, A.params, base + lr, base + lr < A.n_points, pregs + lr, T, ppre);
+            pinn_point_prefetch<ND, N2>(A, A.params, base + lr, base + lr < A.n_points, pregs + lr, T, ppre, A.aux);
             const bool writer = (wave == 0 && lq == 0);
             // (residual PROGRAMS keep per-point registers in LDS and are run by the solo kernel; the host only sends
             //  affine residuals and external upstream gradients here)

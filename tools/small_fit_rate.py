@@ -1,9 +1,10 @@
 """ Solver.fit rates in the reference's own regime (tutorials: batches of 100 .. 1 500 points, nets of 10 .. 40 units): iterations / s with
-the chunk of iterations as ONE launch (pinn_fit_kernel.h, round 5) and -- PYDENS_AMD_FIT_PERSIST=0 -- as launch graphs (round 4).
-One fresh process per line: python tools/small_fit_rate.py  (runs itself once per case and setting) """
+the chunk of iterations as ONE launch (pinn_fit_kernel.h, round 5: PYDENS_AMD_FIT_PERSIST=2 one hardware workgroup of virtual workgroups
+on one CU -- here for ANY number of sweeps, PYDENS_AMD_FIT_ROUNDS=1000, to see where it stops paying; =1 a grid with a device-scope wait)
+and -- =0 -- as launch graphs (round 4). One fresh process per line: python tools/small_fit_rate.py  (runs itself once per case and setting) """
 import os, subprocess, sys, time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-CASES = ('cfg1', 'ode_tanh', 'poisson_10', 'ode_family', 'heat_sigmoid')
+CASES = ('cfg1', 'cfg1_256', 'ode_tanh', 'poisson_10', 'ode_family', 'heat_sigmoid')
 
 if len(sys.argv) > 1:
     sys.path.insert(0, ROOT)
@@ -11,12 +12,16 @@ if len(sys.argv) > 1:
     import pinn_configs as pc
     import pydens_amd as pa
     name, iters = sys.argv[1], int(sys.argv[2])
+    if os.environ.get('SMALL_FIT_LIB'):       # an experiment build of the library (tools/variant.sh) instead of the product
+        import ctypes
+        from pydens_amd import engine
+        engine._LIB = engine.bind(ctypes.CDLL(os.environ['SMALL_FIT_LIB']))
     D = pa.D
     torch.manual_seed(0)
     sampler = None
-    if name == 'cfg1':
+    if name in ('cfg1', 'cfg1_256'):      # BASELINE config 1 (README.md:36-53) at its 100 points; at 256 points (16 tiles: two sweeps of 8)
         cfg = pc.make_config('cfg1', pa.D, torch)
-        solver, batch = pa.Solver(cfg['equation'], **cfg['solver_kwargs']), 100
+        solver, batch = pa.Solver(cfg['equation'], **cfg['solver_kwargs']), (100 if name == 'cfg1' else 256)
     elif name == 'ode_tanh':              # tutorial cells 12-14
         solver, batch = pa.Solver(lambda f, x: D(f, x) - 2 * np.pi * torch.cos(2 * np.pi * x), ndims=1, initial_condition=.5, activation='Tanh',
                                   layout='fafaf', features=[12, 10, 1]), 400
@@ -41,10 +46,16 @@ if len(sys.argv) > 1:
           f'{solver.model.net.lib.pinn_last_kernel_name().decode()}  loss {float(solver.losses[300]):.4g} -> {float(solver.losses[-1]):.4g}')
     sys.exit(0)
 
-for persist in ('1', '0'):
-    print(f'# PYDENS_AMD_FIT_PERSIST={persist}: ' + ('chunks of up to 128 iterations as ONE launch each' if persist == '1' else 'launch graphs of 128-iteration chunks (round 4)'), flush=True)
+TITLES = {'2': 'the product default: a chunk of up to 128 iterations as ONE launch on ONE CU where the batch is one sweep of its virtual workgroups, launch graphs otherwise',
+          '2any': 'chunks as ONE launch on ONE CU for ANY number of sweeps (PYDENS_AMD_FIT_ROUNDS=1000): where the one-CU form stops paying',
+          '1': 'chunks as ONE launch of a grid of workgroups (device-scope wait per iteration)',
+          '0': 'launch graphs of 128-iteration chunks (round 4)'}
+for persist in ('2', '2any', '1', '0'):
+    print(f'# PYDENS_AMD_FIT_PERSIST={persist[0]}: ' + TITLES[persist], flush=True)
+    env = dict(os.environ, PYDENS_AMD_FIT_PERSIST=persist[0])
+    if persist == '2any':
+        env['PYDENS_AMD_FIT_ROUNDS'] = '1000'
     for name in CASES:
-        out = subprocess.run([sys.executable, os.path.abspath(__file__), name, '12800'], capture_output=True, text=True,
-                             env=dict(os.environ, PYDENS_AMD_FIT_PERSIST=persist))
+        out = subprocess.run([sys.executable, os.path.abspath(__file__), name, '12800'], capture_output=True, text=True, env=env)
         lines = [l for l in out.stdout.splitlines() if l.startswith(name)]
         print('\n'.join(lines) if lines else f'{name}: FAILED\n{out.stdout[-300:]}\n{out.stderr[-600:]}', flush=True)
