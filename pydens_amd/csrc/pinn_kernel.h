@@ -1311,7 +1311,10 @@ PINN_DEVICE void pinn_tile_body(const PinnKArgs& A, const float* params_, float*
     using SH = PinnShape<SPEC, ND>;
     // two teams: everything below is written in TEAM-local terms (tid, wave, LDS block, virtual block index); the teams meet
     // at the barriers only (same trip counts by construction) and in the shared W^T
-    const int gtid = PINN_TID, team = (TEAMS2 || VWG) ? gtid / NTHREADS : 0;
+    // (the team index is wave-uniform -- NTHREADS is a multiple of 64 -- and the compiler should know: tile index, LDS block, slab and
+    //  partial row derived from it then live in scalar registers instead of 64-bit vector pairs. Round 5: the two-team kernel of BASELINE
+    //  config 2 reloaded two such pairs from scratch in the middle of every tile)
+    const int gtid = PINN_TID, team = (TEAMS2 || VWG) ? pinn_wave_uniform(gtid / NTHREADS) : 0;
     const int tid = (TEAMS2 || VWG) ? gtid % NTHREADS : gtid, lane = tid & 63, wave = tid >> 6;
     const int vbid = PINN_BID * TEAMS + team, vnblk = PINN_NBLK * TEAMS;
     const int rowid = VWG ? vbid : PINN_BID;               // partial row (two teams share their workgroup's, virtual workgroups own one each)
