@@ -516,6 +516,11 @@ class _Emitter:
     def __init__(self, first_temp, reuse=False):
         self.first_temp, self.code, self.consts, self.memo, self._cidx = first_temp, [], [], {}, {}
         self.reuse = reuse
+        # the memo is keyed by id(node): every visited node is kept alive here, or a node created later (the derivatives of a callable
+        # IC, emitted after the residual's own rows) can be handed the id of a temporary that is gone -- and with it that temporary's
+        # register. (Round 5: the tutorial's heat equation with a parameter column lost its lowered IC that way -- the validation against
+        # the callable caught it, the fit fell back to torch autograd per iteration: 470 us instead of ~20 us per iteration)
+        self._alive = []
 
     def const_slot(self, v):
         key = float(np.float32(v))
@@ -550,6 +555,7 @@ class _Emitter:
                 rb = self.visit(node.args[1], leaf)
                 reg = self.emit(node.op, ra, rb)
         self.memo[key] = reg
+        self._alive.append(node)
         return reg
 
     def finish(self):

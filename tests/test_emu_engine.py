@@ -1390,3 +1390,26 @@ def _one_launch_case(pa, which, kw, monkeypatch, mode, niters, lib, rounds=4):
 def test_fit_chunk_on_one_cu_follows_the_eager_loop(pa, emu_lib, which, monkeypatch):
     monkeypatch.setattr(pa.Solver, 'FIT_CTRL_ON_HOST', True)
     _one_launch_case(pa, which, emu_kwargs(emu_lib), monkeypatch, 2, (5, 3), emu_lib)
+
+
+def test_callable_ic_beside_a_parameter_column_is_lowered(pa, emu_lib):
+    """ tutorial cells 37-40 (heat equation with the diffusivity as a sampled parameter, callable IC): the IC and its derivative streams
+    must join the x-only pre-pass -- no torch autograd per iteration. Round 5 regression: the tracer's emitter memoised registers by
+    id(node) without keeping the nodes; the temporaries of the coefficient row (-a) died, the IC's derivative nodes were handed their
+    ids and registers, the validation against the callable refused the lowering, and every iteration paid ~0.45 ms of torch autograd. """
+    eq = lambda f, x, y, t, a: pa.D(pa.D(f, x), x) + pa.D(pa.D(f, y), y) - a * pa.D(f, t)
+    solver = pa.Solver(eq, ndims=3, nparams=1, initial_condition=lambda x, y: 10 * x * y * (1 - x) * (1 - y), boundary_condition=0,
+                       layout='fafaf', features=[30, 24, 1], activation='Sigmoid', **emu_kwargs(emu_lib))
+    assert solver.program is not None, solver.program_error
+    assert solver.ic_lowering_error is None and solver.residual_plan.ic_row is not None
+    assert not solver._needs_ic_streams()
+    sampler = pa.NumpySampler('u', dim=2) & pa.NumpySampler('u', low=0, high=.5) & pa.NumpySampler('u', low=.1, high=4)
+    assert solver._device_columns(sampler) is not None
+    # and the lowered rows are the callable's streams (the validation the solver ran, once more, on other points)
+    from pydens_amd import trace
+    pts = torch.rand((9, 4), dtype=torch.float32) * 0.5 + 0.2
+    want = solver._ic_stream_tensor(pts, solver.residual_plan.comb_w).double().numpy()
+    got = trace.run_ic_numpy(solver.residual_plan, pts.numpy().astype(np.float64))
+    assert np.allclose(got, want, rtol=1e-5, atol=1e-6)
+    solver.fit(niters=3, batch_size=40, sampler=sampler, lr=0.005)
+    assert solver.last_fit_path == 'fused' and np.isfinite([float(v) for v in solver.losses]).all()
