@@ -37,6 +37,10 @@ if os.environ.get('PINN_WIDE_SPLIT_FLAGS'):
 if os.environ.get('PINN_SPLIT_FLAGS'):
     import json
     SPLIT_FLAGS = {int(k): v for k, v in json.loads(os.environ['PINN_SPLIT_FLAGS']).items()}
+OWN_FLAGS = {1: []}                              # pinn_inst.inc PINN_INST_OWN=1: BASELINE config 2's fp32 kernel (default scheduler)
+if os.environ.get('PINN_OWN_FLAGS'):             # experiment builds: JSON list of flags for that unit
+    import json
+    OWN_FLAGS = {1: json.loads(os.environ['PINN_OWN_FLAGS'])}
 if os.environ.get('PINN_WIDTH_FLAGS'):          # experiment builds: JSON {width: [flags]} replaces the table above
     import json
     WIDTH_FLAGS = {int(k): v for k, v in json.loads(os.environ['PINN_WIDTH_FLAGS']).items()}
@@ -109,6 +113,11 @@ def _build(force, verbose, extra_flags, widths):
         obj = os.path.join(OBJ, f'inst_hp64_split{which}.o')
         jobs.append((obj, [hipcc, *FLAGS, *flags, *extra_flags, '-DPINN_INST_HP=64', f'-DPINN_INST_SPLIT={which}', '-c',
                            os.path.join(HERE, 'pinn_inst.inc'), '-o', obj]))
+    # the fp32 kernel of BASELINE config 2: a unit of its own, because it wants the DEFAULT instruction scheduler while the rest of width 64
+    # (BASELINE config 4's kernel above all) wants iterative-ilp -- same-box A/B, profiles/r05_headline_ab2.txt (pinn_inst.inc PINN_INST_OWN)
+    obj = os.path.join(OBJ, 'inst_hp64_own1.o')
+    jobs.append((obj, [hipcc, *FLAGS, *OWN_FLAGS[1], *extra_flags, '-DPINN_INST_HP=64', '-DPINN_INST_OWN=1', '-c',
+                       os.path.join(HERE, 'pinn_inst.inc'), '-o', obj]))
     for hp in (128, 256):                 # the split-bf16 WGX tile kernels of BASELINE configs 3 / 5
         obj = os.path.join(OBJ, f'inst_hp{hp}_split.o')
         jobs.append((obj, [hipcc, *FLAGS, *WIDE_SPLIT_FLAGS.get(hp, []), *extra_flags, f'-DPINN_INST_HP={hp}', '-DPINN_INST_SPLIT=1',

@@ -47,6 +47,8 @@ def build(force=False, extra_flags=(), tag='', widths=(64,)):
                   os.path.join(BUILD, f'inst_hp64_split{n}.o')] for n in (1, 2)]
         jobs += [[CXX, *FLAGS, f'-DPINN_INST_HP={hp}', '-DPINN_INST_SPLIT=1', '-c', os.path.join(CSRC, 'pinn_inst.inc'), '-o',
                   os.path.join(BUILD, f'inst_hp{hp}_split.o')] for hp in (128, 256)]
+        jobs.append([CXX, *FLAGS, '-DPINN_INST_HP=64', '-DPINN_INST_OWN=1', '-c', os.path.join(CSRC, 'pinn_inst.inc'), '-o',
+                     os.path.join(BUILD, 'inst_hp64_own1.o')])          # (BASELINE config 2's fp32 kernel: a unit of its own in the product build)
         jobs += [[CXX, *FLAGS, f'-DPINN_INST_HP={hp}', f'-DPINN_INST_ALLACT={part}', '-c', os.path.join(CSRC, 'pinn_inst.inc'), '-o',
                   os.path.join(BUILD, f'inst_hp{hp}_allact{part}.o')] for hp in WIDTHS for part in ((1, 2) if hp >= 128 else (1,))]
         jobs.append([CXX, *FLAGS, '-c', os.path.join(CSRC, 'pinn_abi.cpp'), '-o', os.path.join(BUILD, 'abi.o')])
@@ -73,6 +75,7 @@ def build(force=False, extra_flags=(), tag='', widths=(64,)):
     if not split_here:
         objs += [os.path.join(BUILD, f'inst_hp64_split{n}.o') for n in (1, 2)]
     objs += [os.path.join(BUILD, f'inst_hp{hp}_split.o') for hp in (128, 256)]
+    objs.append(os.path.join(BUILD, 'inst_hp64_own1.o'))
     objs += [os.path.join(BUILD, f'inst_hp{hp}_allact{part}.o') for hp in WIDTHS for part in ((1, 2) if hp >= 128 else (1,))]   # (second set of full breadth kernels: the default build's)
     objs += [os.path.join(BUILD, 'abi.o'), os.path.join(BUILD, 'emu_runtime.o')]
     _run([CXX, '-shared', '-fPIC', *objs, '-o', tout])

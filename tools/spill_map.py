@@ -21,6 +21,13 @@ cmd = ['/opt/rocm/bin/hipcc', *build.FLAGS, *build.WIDTH_FLAGS.get(hp, []), f'-D
 if not (os.environ.get('SPILL_MAP_REUSE') and os.path.exists(asm)):
     subprocess.run(cmd, check=True, stderr=subprocess.DEVNULL)
 text = open(asm).read()
+if hp == 64:        # BASELINE config 2's fp32 kernel lives in a unit of its own (pinn_inst.inc PINN_INST_OWN, build.OWN_FLAGS)
+    asm2 = f'/tmp/spill_map_{hp}_own1.s'
+    cmd2 = ['/opt/rocm/bin/hipcc', *build.FLAGS, *build.OWN_FLAGS[1], f'-DPINN_INST_HP={hp}', '-DPINN_INST_OWN=1', '--cuda-device-only', '-S', '-o', asm2,
+            os.path.join(HERE, 'pydens_amd', 'csrc', 'pinn_inst.inc')]
+    if not (os.environ.get('SPILL_MAP_REUSE') and os.path.exists(asm2)):
+        subprocess.run(cmd2, check=True, stderr=subprocess.DEVNULL)
+    text += '\n' + open(asm2).read()
 spills = {m.group(1): int(m.group(2)) for m in re.finditer(r'\.name:\s+(\S+)\n(?:.*\n)*?\s+\.vgpr_spill_count:\s+(\d+)', text)}
 lines = text.split('\n')
 rows = []
