@@ -37,6 +37,9 @@ if os.environ.get('PINN_WIDE_SPLIT_FLAGS'):
 if os.environ.get('PINN_SPLIT_FLAGS'):
     import json
     SPLIT_FLAGS = {int(k): v for k, v in json.loads(os.environ['PINN_SPLIT_FLAGS']).items()}
+if os.environ.get('PINN_SPLIT_EXTRA_FLAGS'):     # experiment builds: JSON list of flags ADDED to both width-64 split units
+    import json
+    SPLIT_FLAGS = {k: v + json.loads(os.environ['PINN_SPLIT_EXTRA_FLAGS']) for k, v in SPLIT_FLAGS.items()}
 OWN_FLAGS = {1: []}                              # pinn_inst.inc PINN_INST_OWN=1: BASELINE config 2's fp32 kernel (default scheduler)
 if os.environ.get('PINN_OWN_FLAGS'):             # experiment builds: JSON list of flags for that unit
     import json
