@@ -1413,3 +1413,42 @@ def test_callable_ic_beside_a_parameter_column_is_lowered(pa, emu_lib):
     assert np.allclose(got, want, rtol=1e-5, atol=1e-6)
     solver.fit(niters=3, batch_size=40, sampler=sampler, lr=0.005)
     assert solver.last_fit_path == 'fused' and np.isfinite([float(v) for v in solver.losses]).all()
+
+
+def _wide_prepass_case(pa, kw):
+    """ an x-only pre-pass whose program keeps more registers alive than the activation buffers hold for a whole workgroup of points:
+    width 16, no derivative streams (S = 1: 768 floats of buffers, 64 threads -> room for 12 registers per lane), a source term with ten
+    shared sub-terms (16 registers) -- the kernel then runs the pre-pass over fewer points per sweep (48 lanes) instead of falling back to
+    private registers (round 5: the select between the two made every register access a flat instruction) """
+    from oracle import pinn_oracle as po
+    from pydens_amd import trace
+
+    def mk(D):
+        def eq(f, x, y):
+            ts = [torch.sin((i + 1) * x) if i % 2 else torch.cos((i + 1) * y) for i in range(10)]
+            src = ts[0] * ts[9]
+            for i in range(1, 10):
+                src = src + ts[i] * ts[9 - i]
+            return f - 0.1 * src
+        return eq
+    net = dict(ndims=2, boundary_condition=0.3, layout='fa fa f', features=[12, 12, 1], activation='Tanh')
+    torch.manual_seed(3)
+    oracle = po.OracleSolver(mk(po.D), **net)
+    solver = pa.Solver(mk(pa.D), **net, **kw)
+    assert solver.program is not None, solver.program_error
+    code, _ = solver.residual_plan.pre
+    two_reg = {trace.OPS[k] for k in ('ADD', 'SUB', 'MUL', 'DIV')}
+    nregs = 1 + max(max(w[1], w[2] if w[0] != trace.OPS['CONST'] else 0, w[3] if w[0] in two_reg else 0) for w in code)
+    assert nregs > 12, nregs                       # more than a 64-thread sweep has room for
+    load_params(solver, oracle.export_params())
+    pts = np.random.RandomState(5).rand(3, 100, 2).astype(np.float32)
+    oracle.fit(niters=3, batch_size=100, points=pts, lr=0.01)
+    solver.fit(niters=3, batch_size=100, sampler=FixedBatches(pts), lr=0.01)
+    assert solver.last_fit_path == 'fused'
+    np.testing.assert_allclose([float(v) for v in solver.losses], [float(v) for v in oracle.losses], rtol=2e-5)
+    for got, want in zip(export_params(solver), oracle.export_params()):
+        assert params_close(got, want, 2e-5)
+
+
+def test_prepass_with_more_registers_than_a_full_sweep_holds(pa, emu_lib):
+    _wide_prepass_case(pa, emu_kwargs(emu_lib))

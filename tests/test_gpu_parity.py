@@ -840,6 +840,11 @@ def test_residual_programs_on_one_combined_stream_on_the_gpu(pa, which):
     te._combined_program_case(pa, which, {})
 
 
+def test_prepass_with_more_registers_than_a_full_sweep_holds_on_the_gpu(pa):
+    import test_emu_engine as te
+    te._wide_prepass_case(pa, {})
+
+
 @pytest.mark.parametrize('name', ['nested_acts', 'mixed3', 'biharm'])
 def test_breadth_features_match_reference_golden_on_the_gpu(pa, name):
     """ round 5 breadth (nested skips + second-set activations, mixed third order, fourth order) against the fixtures generated from the
