@@ -1452,3 +1452,23 @@ def _wide_prepass_case(pa, kw):
 
 def test_prepass_with_more_registers_than_a_full_sweep_holds(pa, emu_lib):
     _wide_prepass_case(pa, emu_kwargs(emu_lib))
+
+
+def test_fit_chunk_that_does_not_fit_one_cu_keeps_the_other_paths(pa, emu_lib, monkeypatch):
+    """ the one-CU fit chunk keeps parameters, Adam state and one partial row per virtual workgroup in LDS: a narrow but DEEP net
+    (width 32, seven hidden layers: ~7 K parameters) does not fit beside the virtual workgroups' blocks -- the launcher declines and
+    the chunk runs as before (launch graphs on the GPU, the eager loop here), same trajectory as with the form switched off """
+    monkeypatch.setattr(pa.Solver, 'FIT_CTRL_ON_HOST', True)
+    eq = lambda f, x: pa.D(f, x) - 2 * np.pi * torch.cos(2 * np.pi * x)
+
+    def run(mode):
+        monkeypatch.setenv('PYDENS_AMD_FIT_PERSIST', str(mode))
+        torch.manual_seed(5)
+        solver = pa.Solver(eq, ndims=1, initial_condition=0.5, layout='fa' * 7 + 'f', features=[32] * 7 + [1], activation='Tanh',
+                           **emu_kwargs(emu_lib))
+        solver.fit(niters=4, batch_size=40, lr=0.005)
+        return np.array([float(v) for v in solver.losses]), emu_lib.pinn_last_kernel_name().decode()
+    l0, k0 = run(0)
+    l2, k2 = run(2)
+    assert k0.startswith('pinn_tile_kernel<') and k2.startswith('pinn_tile_kernel<'), (k0, k2)
+    assert np.array_equal(l0, l2)
