@@ -64,13 +64,20 @@ PINN_HOST_DEVICE inline void pinn_adam_scalars(double t, float lr, float b1, flo
     *bc2_sqrt = (float)sqrt(bc2);
 }
 
-PINN_DEVICE void pinn_adam_update(float* params, float gi, float* m, float* v, long long i, float step_size, float bc2_sqrt,
-                                  float b1, float b2, float eps) {
-    const float mi = m[i] + (1.0f - b1) * (gi - m[i]);       // exp_avg.lerp_(grad, 1 - beta1)
-    const float vi = fmaf(1.0f - b2, gi * gi, b2 * v[i]);    // exp_avg_sq.mul_(beta2).addcmul_(grad, grad, 1 - beta2)
+// (the arithmetic of one Adam update on operands already in registers: ONE expression tree for every caller, so that every path
+//  rounds -- and contracts multiply-adds -- the same way)
+PINN_DEVICE void pinn_adam_apply(float* params, float* m, float* v, long long i, float gi, float m_old, float v_old, float p_old,
+                                 float step_size, float bc2_sqrt, float b1, float b2, float eps) {
+    const float mi = m_old + (1.0f - b1) * (gi - m_old);     // exp_avg.lerp_(grad, 1 - beta1)
+    const float vi = fmaf(1.0f - b2, gi * gi, b2 * v_old);   // exp_avg_sq.mul_(beta2).addcmul_(grad, grad, 1 - beta2)
     m[i] = mi; v[i] = vi;
     const float denom = sqrtf(vi) / bc2_sqrt + eps;
-    params[i] -= step_size * (mi / denom);
+    params[i] = p_old - step_size * (mi / denom);
+}
+
+PINN_DEVICE void pinn_adam_update(float* params, float gi, float* m, float* v, long long i, float step_size, float bc2_sqrt,
+                                  float b1, float b2, float eps) {
+    pinn_adam_apply(params, m, v, i, gi, m[i], v[i], params[i], step_size, bc2_sqrt, b1, b2, eps);
 }
 
 #ifndef PINN_REDUCE_PB
@@ -179,18 +186,43 @@ pinn_reduce_kernel(const float* partials, int n_wg, int p_core, float* grads, in
     constexpr int PB = PINN_REDUCE_PB, CH = 1024 / PB;        // PB parameters x CH chunks of workgroups per block
     const int pl = tid % PB, ch = tid / PB;
     const int p = PINN_BID * PB + pl;
+    // the operands of the final lanes' Adam update do not depend on the sums: fetched up front, so that their round trip runs under the
+    // row loads instead of behind the barrier (round 5: this kernel took 8 us on BASELINE config 2 -- 4 % of the step -- for 13 MB;
+    // it was a chain of dependent round trips: row after row, then the mask, then m / v / the parameter)
+    const bool fin = tid < PB && p < p_core;
+    bool upd = false;
+    float g_old = 0.0f, m_old = 0.0f, v_old = 0.0f, p_old = 0.0f;
+    if (fin) {
+        if (accumulate) g_old = grads[p];
+        if (do_adam) {
+            upd = !mask || mask[p];
+            if (upd) { m_old = m[p]; v_old = v[p]; p_old = params[p]; }
+        }
+    }
+    // the rows of this thread's chunk, eight loads in flight at a time, summed in ascending row order (as before)
     float s = 0.0f;
-    if (p < p_core)
-        for (int w = ch; w < n_wg; w += CH) s += partials[(size_t)w * p_core + p];
+    if (p < p_core) {
+        for (int w0 = ch; w0 < n_wg; w0 += 8 * CH) {
+            float r[8];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const int w = w0 + j * CH;
+                r[j] = (w < n_wg) ? partials[(size_t)w * p_core + p] : 0.0f;
+            }
+#pragma unroll
+            for (int j = 0; j < 8; ++j)
+                if (w0 + j * CH < n_wg) s += r[j];
+        }
+    }
     red[ch * PB + pl] = s;
     PINN_SYNC();
-    if (tid < PB && p < p_core) {
+    if (fin) {
         float t = 0.0f;
         for (int c = 0; c < CH; ++c) t += red[c * PB + tid];
-        if (accumulate) t += grads[p];
+        if (accumulate) t += g_old;
         grads[p] = t;
         if (loss_out && p == off_loss) loss_out[0] = t;
-        if (do_adam && (!mask || mask[p])) pinn_adam_update(params, t, m, v, p, step_size, bc2_sqrt, b1, b2, eps);
+        if (upd) pinn_adam_apply(params, m, v, p, t, m_old, v_old, p_old, step_size, bc2_sqrt, b1, b2, eps);
     }
     if (do_adam && PINN_BID == 0 && tid == 0) step_ptr[0] = step_value;
     // fit chunks: this iteration's tile kernel is through with the batch buffer -- the batch of the next iteration is drawn here
