@@ -20,6 +20,35 @@ def pytest_configure(config):
     config.addinivalue_line('markers', 'gpu: needs a real MI355X (run with -m gpu on the GPU box)')
 
 
+@pytest.hookimpl(tryfirst=True)
+def pytest_cmdline_main(config):
+    """ the CPU tier (`-m "not gpu"`: ~330 tests, most of them the product kernels on the fiber emulator) takes 16 minutes on one core and
+    under 4 on six: where pytest-xdist is installed, no GPU is in sight and nobody asked for a worker count, run it on several workers
+    (what `-n 6` does: the options xdist's own hook would set). The GPU tier stays serial -- one device, timing-sensitive tests, and the
+    driver records which libraries the test PROCESS loaded. PYDENS_AMD_TEST_WORKERS=0 switches this off, =N picks the count. """
+    want = os.environ.get('PYDENS_AMD_TEST_WORKERS', '')
+    if want == '0' or not hasattr(config.option, 'numprocesses') or config.option.numprocesses is not None:
+        return None                                     # no xdist, switched off, or an explicit -n on the command line
+    if getattr(config.option, 'collectonly', False) or getattr(config.option, 'usepdb', False):
+        return None
+    if hasattr(config, 'workerinput'):
+        return None                                     # (an xdist worker itself)
+    try:
+        import torch
+        if torch.cuda.is_available():
+            return None
+    except ImportError:
+        return None
+    n = int(want) if want.isdigit() else min(6, os.cpu_count() or 1)
+    if n < 2:
+        return None
+    config.option.numprocesses = n
+    config.option.tx = ['popen'] * n
+    if getattr(config.option, 'dist', 'no') == 'no':
+        config.option.dist = 'load'
+    return None
+
+
 class Golden:
     """ One `tests/golden/<name>.npz` fixture (made by oracle/make_golden.py from the unmodified reference). """
     def __init__(self, name):

@@ -38,6 +38,14 @@ def _fresh(out, deps):
 def build(force=False, extra_flags=(), tag='', widths=(64,)):
     """ extra_flags / tag: a second library with other build knobs (e.g. -DPINN_CHAIN=1) for the kernel instantiations of
     `widths`, kept beside the default one and sharing every other object with it """
+    import fcntl
+    os.makedirs(BUILD, exist_ok=True)
+    with open(os.path.join(BUILD, '.lock'), 'w') as lock:        # several test workers (pytest-xdist) may ask at once: one builds
+        fcntl.flock(lock, fcntl.LOCK_EX)
+        return _build(force, extra_flags, tag, widths)
+
+
+def _build(force, extra_flags, tag, widths):
     deps = _deps()
     if not (not force and _fresh(OUT, deps)):
         os.makedirs(BUILD, exist_ok=True)
