@@ -1472,3 +1472,30 @@ def test_fit_chunk_that_does_not_fit_one_cu_keeps_the_other_paths(pa, emu_lib, m
     l2, k2 = run(2)
     assert k0.startswith('pinn_tile_kernel<') and k2.startswith('pinn_tile_kernel<'), (k0, k2)
     assert np.array_equal(l0, l2)
+
+
+def test_first_layer_gradient_in_registers_and_in_lds_side_by_side(pa, emu_lib):
+    """ a static-depth kernel with register accumulators (<64,2,2,..,3,TANH>: two separate second-order streams, x-dependent coefficient) on
+    FIVE input columns: the first four columns of dW1 and the bias gradients are summed per lane and stored once at the end of the
+    workgroup (plain LDS stores since round 5), the fifth column is added in LDS tile by tile -- both land in the same rows """
+    from oracle import pinn_oracle as po
+
+    def mk(D):
+        return lambda f, x, y, a, b, c: (1 + x) * D(D(f, x), x) + a * D(D(f, y), y) - b * torch.sin(np.pi * (x + y)) + 0.2 * c
+    net = dict(ndims=2, nparams=3, boundary_condition=0.5, layout='fa fa fa fa f', features=[64, 64, 64, 64, 1], activation='Tanh')
+    torch.manual_seed(3)
+    oracle = po.OracleSolver(mk(po.D), **net)
+    solver = pa.Solver(mk(pa.D), **net, **emu_kwargs(emu_lib))
+    load_params(solver, oracle.export_params())
+    pts = (np.random.RandomState(5).rand(70, 5) * np.array([1, 1, 2, 1, 1]) + np.array([0, 0, 1, 0, 0])).astype(np.float32)
+    ev, g_want = oracle.evaluate(pts), oracle.export_grads()
+    solver._fused_step(torch.from_numpy(pts.copy()), 1)
+    assert emu_lib.pinn_last_kernel_name().decode() == 'pinn_tile_kernel<64,2,2,1,3,0,false,0>'
+    lay = solver.model.net.layout
+    assert abs(float(solver.grads[lay.off_loss]) - ev['loss']) <= 1e-5 * ev['loss']
+    grads = export_grads(solver)
+    for c in range(5):
+        assert rel_l2(grads[0][:, c], g_want[0][:, c]) < 1e-5, c
+    for got, want in zip(grads, g_want):
+        if want is not None:
+            assert grad_close(got, want)
