@@ -372,6 +372,12 @@ def _s_mul(a, b):
     return b if _is_const(a, 1.0) else a if _is_const(b, 1.0) else Sym.make('MUL', a, b)
 
 
+def _keep(memo, node):
+    """ the memo dictionaries of this module are keyed by id(node): every memoised node is kept alive beside its entry, or a node built
+    later could be handed the id -- and the memoised answer -- of one that is gone (round 5: that is how the emitter lost a callable IC) """
+    memo.setdefault('_alive', []).append(node)
+
+
 def _differentiate(node, col, memo):
     """ symbolic d(node)/d(input column `col`): streams step to the next derivative stream (`D` of the field), x-only
     sub-expressions differentiate in closed form, everything else by the chain rule. """
@@ -433,6 +439,7 @@ def _differentiate(node, col, memo):
         else:
             raise TraceUnsupported(f'D through {op}')
     memo[key] = out
+    _keep(memo, node)
     return out
 
 
@@ -472,6 +479,7 @@ def _depends_on_inputs(node, memo):
     key = id(node)
     if key not in memo:
         memo[key] = node.kind == 'input' or any(_depends_on_inputs(a, memo) for a in node.args)
+        _keep(memo, node)
     return memo[key]
 
 
@@ -610,6 +618,7 @@ def _uses_streams(node, memo):
     if key not in memo:
         # (expressions of trainable variables stay in the main program too: the pre-pass has no reverse sweep)
         memo[key] = node.kind in ('stream', 'var') or any(_uses_streams(a, memo) for a in node.args)
+        _keep(memo, node)
     return memo[key]
 
 
@@ -647,6 +656,7 @@ def _affine(node, spec, memo):
             elif node.op == 'DIV' and not parts[1][0]:
                 out = ({k: v / parts[1][1] for k, v in parts[0][0].items()}, parts[0][1] / parts[1][1])
     memo[key] = out
+    _keep(memo, node)
     return out
 
 
@@ -689,6 +699,7 @@ def _second_order_split(node, spec, memo):
                 scale = 1.0 / float(node.args[1].value)
                 out = ({k: v * scale for k, v in parts[0][0].items()}, _s_mul(Sym('const', value=scale), parts[0][1]))
     memo[key] = out
+    _keep(memo, node)
     return out
 
 
