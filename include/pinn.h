@@ -157,6 +157,14 @@ typedef struct pinn_residual {
     int ic_rows;
     int ic_row[PINN_MAX_STREAMS];
     float ic_cst[PINN_MAX_STREAMS];
+    /* round 6: the x-only pre-pass `pre` is evaluated in DOUBLE precision -- input columns promoted exactly, constant k read from
+     * pre_consts64[k] (pre.consts[k] is its fp32 rounding, kept for inspection), every operation and elementary function in fp64,
+     * ONE rounding to fp32 when a STORE writes an aux row. Why: source terms like e*pi*cos(e*pi*x) (README.md:78-79) evaluated in fp32
+     * carry a SYSTEMATIC error (fl32(pi) != pi moves the argument of the cosine by 3e-8 relative; at arguments of 15 that is 5e-7 in
+     * every point, same sign) which survives the sum over the batch in gradients that are cancelling sums -- BASELINE config 4's
+     * d(loss)/d(b_L) came out 1.1 - 1.4e-5 from the fp64 oracle for that reason alone (the fp32 reference: 0.5 - 1e-5, same cause;
+     * tools/cfg4_bl_probe.py). The pre-pass is a handful of operations per point, once per step. */
+    double pre_consts64[PINN_MAX_CONSTS];
 } pinn_residual_t;
 
 /* Descriptor of network + ansatz.  Replaces ConvBlockModel.__init__/TorchModel.__init__ bookkeeping

@@ -163,6 +163,7 @@ struct Plan {
     int wgx, grid2;                 // grid2: workgroups of the weight-gradient kernel
     int wt_global;                  // the kernel reads the transposed global copy of the hidden weights (pinn_transpose_kernel)
     int split;                      // split-bf16 kernel: reads the bf16 fragment copy of the hidden weights (pinn_wsplit_kernel)
+    int prepass_floats_per_lane;    // LDS floats per point of a tile the in-kernel pre-pass may use for its (double) registers; 0: no in-kernel pre-pass
     wgrad_fn wfn;
     size_t gz_vec4_per_tile;
     int64_t chunk_tiles;            // tiles per pass through the two kernels
@@ -201,7 +202,7 @@ int make_plan(const pinn_net* net, int64_t n_points, int nd, int n2, Plan* plan,
     probe.mode = mode;
     probe.res_kind = res_kind;
     probe.comb = comb;
-    long long info[12] = {0, 0, 0, 1, 1, 0, 0, 0, 0, 0, 1, 0};
+    long long info[16] = {0, 0, 0, 1, 1, 0, 0, 0, 0, 0, 1, 0, 0, 0, 0, 0};
     if (plan->fn(nd, plan->n2k, &probe, 0, nullptr, 1, info))
         return fail("no kernel instantiation for width %d with nd=%d n2=%d%s", net->lay.hp, nd, plan->n2k, comb ? " (combined)" : "");
     plan->smem = (size_t)info[0];
@@ -223,6 +224,7 @@ int make_plan(const pinn_net* net, int64_t n_points, int nd, int n2, Plan* plan,
     plan->wgx = (mode != PINN_MODE_FORWARD && info[6]) ? 1 : 0;
     plan->wt_global = (int)info[9];
     plan->split = (int)info[11];
+    plan->prepass_floats_per_lane = (int)info[12];
     plan->grid2 = 0; plan->wfn = nullptr; plan->gz_vec4_per_tile = 0; plan->chunk_tiles = wg_tiles;
     if (plan->wgx) {
         plan->wfn = wgrad_launcher_for(net->lay.hp);
@@ -319,7 +321,7 @@ struct AdamArgs {
 int launch_reduce(const float* partials, int n_wg, int p_core, float* grads, int accumulate, void* stream,
                   const AdamArgs* adam = nullptr) {
     const int blocks = (p_core + PINN_REDUCE_PB - 1) / PINN_REDUCE_PB;
-    const size_t smem = 1024 * sizeof(float);
+    const size_t smem = 1024 * sizeof(double);      // (the chunk sums cross the LDS in double: pinn_reduce_kernel)
     AdamArgs z = {nullptr, nullptr, nullptr, nullptr, nullptr, 0, 0.f, 0.f, 0.f, 0.f, nullptr, -1};
     const AdamArgs& a = adam ? *adam : z;
     const int do_adam = adam ? 1 : 0;
@@ -687,7 +689,7 @@ int pinn_jet_forward_ws(pinn_t* net, const float* params, const float* xs, int64
 
 static int run_train(pinn_t* net, PinnKArgs* a, const Plan& plan, int nd, float* grads, int accumulate, void* workspace,
                      size_t workspace_bytes, void* stream, const pinn_program_t* pre = nullptr,
-                     const AdamArgs* adam = nullptr) {
+                     const AdamArgs* adam = nullptr, const double* pre_consts64 = nullptr) {
     const size_t part_bytes = align256((size_t)plan.rows() * net->lay.p_total * sizeof(float));
     const size_t slab_bytes = align256(plan.slab_bytes());
     const size_t aux_bytes = (pre && a->n_aux > 0) ? align256((size_t)a->n_aux * (size_t)a->n_points * sizeof(float)) : 0;
@@ -711,22 +713,28 @@ static int run_train(pinn_t* net, PinnKArgs* a, const Plan& plan, int nd, float*
     if (aux_bytes) {
         float* aux = reinterpret_cast<float*>(ws + part_bytes + slab_bytes);
         a->aux = aux;
-        if (net->prepass_in_kernel) {
+        // the pre-pass runs in fp64 (include/pinn.h, pinn_residual_t::pre_consts64): its constants unrounded
+        PinnPreConsts pc64;
+        for (int k = 0; k < PINN_MAX_CONSTS; ++k) pc64.v[k] = pre_consts64 ? pre_consts64[k] : (double)pre->consts[k];
+        int nregs = a->d;
+        for (int i = 0; i < pre->n_ops; ++i) {
+            const uint32_t w = pre->code[i];
+            const int op = w & 255, dst = (w >> 8) & 255;
+            if (op != PINN_OP_STORE && dst + 1 > nregs) nregs = dst + 1;
+        }
+        // in the kernel its registers are doubles in the (not yet used) LDS activation buffers: one tile's worth of points must fit --
+        // always, except for a long program in front of the narrowest one-stream kernels, which takes the separate launch
+        if (net->prepass_in_kernel && 2 * nregs <= plan.prepass_floats_per_lane) {
             a->pre = *pre;          // evaluated in the prologue of the tile kernel: one launch (and one dependent-launch gap) less
-            int nregs = a->d;
-            for (int i = 0; i < pre->n_ops; ++i) {
-                const uint32_t w = pre->code[i];
-                const int op = w & 255, dst = (w >> 8) & 255;
-                if (op != PINN_OP_STORE && dst + 1 > nregs) nregs = dst + 1;
-            }
+            a->pre_consts64 = pc64;
             a->pre_nregs = nregs;
         } else {
             const int blocks = (int)((a->n_points + 255) / 256);
 #ifdef PINN_EMU
-            emu::launch(blocks, 256, 0, [&] { pinn_aux_kernel(a->xs, a->n_points, a->d, *pre, aux); });
+            emu::launch(blocks, 256, 0, [&] { pinn_aux_kernel(a->xs, a->n_points, a->d, *pre, pc64, aux); });
 #else
             hipLaunchKernelGGL(pinn_aux_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, a->xs, a->n_points, a->d,
-                               *pre, aux);
+                               *pre, pc64, aux);
             if (hipGetLastError() != hipSuccess) return fail("pre-pass kernel launch failed");
 #endif
         }
@@ -947,7 +955,7 @@ static int residual_step_impl(pinn_t* net, const pinn_residual_t* residual, cons
     a.mode = PINN_MODE_STEP;
     a.inv_n = inv_n_global;
     if (make_plan(net, n_points, nd, n2, &plan, PINN_MODE_STEP, residual->kind, comb, &a)) return 1;      // with the call's own arguments
-    return run_train(net, &a, plan, nd, grads, accumulate, workspace, workspace_bytes, stream, &residual->pre, adam);
+    return run_train(net, &a, plan, nd, grads, accumulate, workspace, workspace_bytes, stream, &residual->pre, adam, residual->pre_consts64);
 }
 
 int pinn_residual_step(pinn_t* net, const pinn_residual_t* residual, const float* params, const float* xs,

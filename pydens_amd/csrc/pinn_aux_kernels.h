@@ -16,38 +16,11 @@
 // outside the tile kernel (one thread per point, registers in private memory; N * a-few-ops, microseconds).
 // ------------------------------------------------------------------------------------------------------------
 PINN_AUX_GLOBAL void PINN_LAUNCH_BOUNDS(256)
-pinn_aux_kernel(const float* xs, long long n, int d, pinn_program_t pg, float* aux) {
+pinn_aux_kernel(const float* xs, long long n, int d, pinn_program_t pg, PinnPreConsts c64, float* aux) {
     const long long i = (long long)PINN_BID * 256 + PINN_TID;
     if (i >= n) return;
-    float regs[PINN_MAX_REGS];
-    for (int c = 0; c < d; ++c) regs[c] = xs[i * d + c];
-    for (int k = 0; k < pg.n_ops; ++k) {
-        const unsigned w = pg.code[k];
-        const int op = w & 255, dst = (w >> 8) & 255, a = (w >> 16) & 255, b = (w >> 24) & 255;
-        if (op == PINN_OP_STORE) { aux[(long long)b * n + i] = regs[a]; continue; }
-        const float x = (op == PINN_OP_CONST) ? 0.0f : regs[a];
-        float y;
-        switch (op) {
-            case PINN_OP_CONST: y = pg.consts[a]; break;
-            case PINN_OP_ADD: y = x + regs[b]; break;
-            case PINN_OP_SUB: y = x - regs[b]; break;
-            case PINN_OP_MUL: y = x * regs[b]; break;
-            case PINN_OP_DIV: y = x / regs[b]; break;
-            case PINN_OP_NEG: y = -x; break;
-            case PINN_OP_SIN: y = sinf(x); break;
-            case PINN_OP_COS: y = cosf(x); break;
-            case PINN_OP_EXP: y = expf(x); break;
-            case PINN_OP_LOG: y = logf(x); break;
-            case PINN_OP_TANH: y = tanhf(x); break;
-            case PINN_OP_SQRT: y = sqrtf(x); break;
-            case PINN_OP_POW: y = powf(x, pg.consts[b]); break;
-            case PINN_OP_ABS: y = fabsf(x); break;
-            case PINN_OP_SIGMOID: y = 1.0f / (1.0f + expf(-x)); break;
-            case PINN_OP_RECIP: y = 1.0f / x; break;
-            default: y = x; break;
-        }
-        regs[dst] = y;
-    }
+    double regs[PINN_MAX_REGS];                 // private (scratch): the program indexes it at run time; fp64 like the in-kernel form
+    pinn_prepass_point(pg, c64, xs + i * d, d, aux, n, i, regs, 1);
 }
 
 // ------------------------------------------------------------------------------------------------------------
@@ -199,8 +172,12 @@ pinn_reduce_kernel(const float* partials, int n_wg, int p_core, float* grads, in
             if (upd) { m_old = m[p]; v_old = v[p]; p_old = params[p]; }
         }
     }
-    // the rows of this thread's chunk, eight loads in flight at a time, summed in ascending row order (as before)
-    float s = 0.0f;
+    // the rows of this thread's chunk, eight loads in flight at a time, summed in ascending row order (as before) -- in DOUBLE since
+    // round 6: a gradient entry that is a cancelling sum over the batch (BASELINE config 4's d loss / d b_L: sum of |terms| 850 x the
+    // result) walks through prefix sums far larger than its total, and every fp32 add of this loop rounded at THEIR magnitude: 5e-6
+    // relative on that entry from the 256 rows alone (tools/cfg4_bl_probe.py). One rounding to fp32 at the end instead; the adds are
+    // free beside the row loads.
+    double s = 0.0;
     if (p < p_core) {
         for (int w0 = ch; w0 < n_wg; w0 += 8 * CH) {
             float r[8];
@@ -211,15 +188,17 @@ pinn_reduce_kernel(const float* partials, int n_wg, int p_core, float* grads, in
             }
 #pragma unroll
             for (int j = 0; j < 8; ++j)
-                if (w0 + j * CH < n_wg) s += r[j];
+                if (w0 + j * CH < n_wg) s += (double)r[j];
         }
     }
-    red[ch * PB + pl] = s;
+    double* red64 = reinterpret_cast<double*>(red);
+    red64[ch * PB + pl] = s;
     PINN_SYNC();
     if (fin) {
-        float t = 0.0f;
-        for (int c = 0; c < CH; ++c) t += red[c * PB + tid];
-        if (accumulate) t += g_old;
+        double t64 = 0.0;
+        for (int c = 0; c < CH; ++c) t64 += red64[c * PB + tid];
+        if (accumulate) t64 += (double)g_old;
+        const float t = (float)t64;
         grads[p] = t;
         if (loss_out && p == off_loss) loss_out[0] = t;
         if (upd) pinn_adam_apply(params, m, v, p, t, m_old, v_old, p_old, step_size, bc2_sqrt, b1, b2, eps);

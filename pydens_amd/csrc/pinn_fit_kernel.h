@@ -176,7 +176,7 @@ pinn_fit_kernel(const PinnKArgs A0, const PinnFitP P) {
         // (the R row loads of a parameter are independent: issued eight at a time, summed in ascending row order -- the first form of
         //  this loop waited for one L2 round trip per row and made the iteration 2.6x SLOWER than two launches: 43 us against 16)
         for (int p0 = gtid; p0 < pc; p0 += 4 * NTH) {
-            float t[4] = {0.0f, 0.0f, 0.0f, 0.0f};
+            double t64[4] = {0.0, 0.0, 0.0, 0.0};      // (double like pinn_reduce_kernel's sums: one rounding per entry)
             for (int c0 = 0; c0 < R; c0 += 8) {
                 float r[8][4];
 #pragma unroll
@@ -189,8 +189,11 @@ pinn_fit_kernel(const PinnKArgs A0, const PinnFitP P) {
 #pragma unroll
                 for (int j = 0; j < 8; ++j)
 #pragma unroll
-                    for (int q = 0; q < 4; ++q) t[q] += r[j][q];
+                    for (int q = 0; q < 4; ++q) t64[q] += (double)r[j][q];
             }
+            float t[4];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) t[q] = (float)t64[q];
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
                 const int p = p0 + q * NTH;

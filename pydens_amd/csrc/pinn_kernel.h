@@ -73,6 +73,9 @@ PINN_HOST_DEVICE constexpr int pinn_ns(int nd, int n2p) { return 1 + nd + (n2p &
 constexpr int PINN_LHMAX = 4;      // hidden->hidden layers whose dW accumulators live in registers
 constexpr int PINN_XS_LD = PINN_MAX_INPUTS;
 
+// constants of the x-only pre-pass in double precision (pinn_residual_t::pre_consts64)
+struct PinnPreConsts { double v[PINN_MAX_CONSTS]; };
+
 struct PinnKArgs {
     const float* params;
     const float* xs;             // [N][d]
@@ -124,6 +127,7 @@ struct PinnKArgs {
     int pre_nregs;               // registers the pre-pass program touches (inputs included)
     pinn_program_t pre;          // n_ops > 0: the tile kernel evaluates the pre-pass itself for the points of its own tiles
                                  // (kernel prologue) instead of a separate launch in front of it
+    PinnPreConsts pre_consts64;  // ... in fp64, with these constants (round 6)
 };
 
 template <int HP_, int ND_, int N2_, int MT_ = 1, bool SPLIT_ = false>
@@ -165,6 +169,8 @@ struct PinnCfg {
     static constexpr int BUF_FLOATS = SPLIT ? 3 * SP_PLANE_BYTES / 4 : S * T * LDA;
     static constexpr int O_BUFB = ONEBUF ? O_BUFA : O_BUFA + BUF_FLOATS;
     static constexpr int O_NET = O_BUFB + BUF_FLOATS;           // [NW][S][T] per-wave partial dot products
+    // floats of the activation buffers per point of a tile: where the in-kernel pre-pass keeps its (double) registers
+    static constexpr int PREPASS_FLOATS_PER_LANE = (O_NET - O_BUFA) / T;
     static constexpr int O_GNET = O_NET + NW * S * T;
     static constexpr int O_ACCB = O_GNET + S * T;
     static constexpr int O_ACCW1 = O_ACCB + PINN_MAX_LAYERS * HP;   // bias-gradient rows for any depth
@@ -645,48 +651,53 @@ PINN_DEVICE float pinn_prog_forward(const pinn_program_t& pg, float* regs, int T
 
 // x-only pre-pass of ONE point inside the tile kernel: registers 0..d-1 = the input columns, PINN_OP_STORE writes a
 // register to aux row b (read back by the same thread in pinn_point_prefetch). Same arithmetic as pinn_aux_kernel.
-// `regs` / T: the register file -- LDS of the workgroup (register r of this thread at regs[r * T], T = threads) when the
-// program's registers fit the free activation buffers, else null: private memory (scratch; 10x the latency per access).
-PINN_DEVICE void pinn_prepass_point(const pinn_program_t& pg, const float* x, int d, float* aux, long long n, long long gi,
-                                    float* regs, int T) {
+// Round 6: in DOUBLE precision -- the columns promoted exactly, the constants unrounded (c64), every operation and elementary
+// function in fp64, one rounding to fp32 at the STORE. In fp32 a source term like e pi cos(e pi x) carries a systematic error (the
+// rounded pi moves the cosine's argument the same way in every point) that survives the batch sum of gradients that are cancelling
+// sums: BASELINE config 4's d(loss)/d(b_L) was 1.1 - 1.4e-5 from the fp64 oracle for that reason alone (include/pinn.h,
+// tools/cfg4_bl_probe.py). A handful of operations per point and step.
+// `regs` / T: the register file -- LDS of the workgroup (register r of this thread at regs[r * T], T = threads; the host checked
+// that a tile's worth of points fits, run_train) or private memory (pinn_aux_kernel: T = 1).
+PINN_DEVICE double pinn_prepass_op(int op, double xa, double xb, double cb) {
+    switch (op) {
+        case PINN_OP_ADD: return xa + xb;
+        case PINN_OP_SUB: return xa - xb;
+        case PINN_OP_MUL: return xa * xb;
+        case PINN_OP_DIV: return xa / xb;
+        case PINN_OP_NEG: return -xa;
+        case PINN_OP_SIN: return sin(xa);
+        case PINN_OP_COS: return cos(xa);
+        case PINN_OP_EXP: return exp(xa);
+        case PINN_OP_LOG: return log(xa);
+        case PINN_OP_TANH: return tanh(xa);
+        case PINN_OP_SQRT: return sqrt(xa);
+        case PINN_OP_POW: return pow(xa, cb);
+        case PINN_OP_ABS: return fabs(xa);
+        case PINN_OP_SIGMOID: return 1.0 / (1.0 + exp(-xa));
+        case PINN_OP_RECIP: return 1.0 / xa;
+        default: return xa;    // COPY
+    }
+}
+PINN_DEVICE void pinn_prepass_point(const pinn_program_t& pg, const PinnPreConsts& c64, const float* x, int d, float* aux, long long n,
+                                    long long gi, double* regs, int T) {
     // `regs`: from ONE address space per call site (round 5: a select between the LDS carve and a private array made every register
-    // access a flat instruction; the tile kernels now always find room in LDS -- fewer points per sweep if need be -- and whoever wants
-    // private registers calls pinn_prepass_point_private)
-    for (int c = 0; c < d; ++c) regs[c * T] = x[c];
+    // access a flat instruction)
+    for (int c = 0; c < d; ++c) regs[c * T] = (double)x[c];
     unsigned w_next = pg.n_ops > 0 ? pg.code[0] : 0u;          // (the next op word is fetched one op ahead: a scalar load per op otherwise)
     for (int i = 0; i < pg.n_ops; ++i) {
         const unsigned w = w_next;
         if (i + 1 < pg.n_ops) w_next = pg.code[i + 1];
         const int op = w & 255, dst = (w >> 8) & 255, a = (w >> 16) & 255, b = (w >> 24) & 255;
-        if (op == PINN_OP_STORE) { aux[(long long)b * n + gi] = regs[a * T]; continue; }
-        const float xa = (op == PINN_OP_CONST) ? 0.0f : regs[a * T];
-        float y;
-        switch (op) {
-            case PINN_OP_CONST: y = pg.consts[a]; break;
-            case PINN_OP_ADD: y = xa + regs[b * T]; break;
-            case PINN_OP_SUB: y = xa - regs[b * T]; break;
-            case PINN_OP_MUL: y = xa * regs[b * T]; break;
-            case PINN_OP_DIV: y = xa / regs[b * T]; break;
-            case PINN_OP_NEG: y = -xa; break;
-            case PINN_OP_SIN: y = sinf(xa); break;
-            case PINN_OP_COS: y = cosf(xa); break;
-            case PINN_OP_EXP: y = expf(xa); break;
-            case PINN_OP_LOG: y = logf(xa); break;
-            case PINN_OP_TANH: y = tanhf(xa); break;
-            case PINN_OP_SQRT: y = sqrtf(xa); break;
-            case PINN_OP_POW: y = powf(xa, pg.consts[b]); break;
-            case PINN_OP_ABS: y = fabsf(xa); break;
-            case PINN_OP_SIGMOID: y = pinn_sigmoidf(xa); break;
-            case PINN_OP_RECIP: y = 1.0f / xa; break;
-            default: y = xa; break;    // COPY
-        }
-        regs[dst * T] = y;
+        if (op == PINN_OP_STORE) { aux[(long long)b * n + gi] = (float)regs[a * T]; continue; }
+        if (op == PINN_OP_CONST) { regs[dst * T] = c64.v[a]; continue; }
+        const bool b_is_reg = op == PINN_OP_ADD || op == PINN_OP_SUB || op == PINN_OP_MUL || op == PINN_OP_DIV;
+        regs[dst * T] = pinn_prepass_op(op, regs[a * T], b_is_reg ? regs[b * T] : 0.0, op == PINN_OP_POW ? c64.v[b] : 0.0);
     }
 }
 
-PINN_DEVICE void pinn_prepass_point_private(const pinn_program_t& pg, const float* x, int d, float* aux, long long n, long long gi) {
-    float priv[PINN_MAX_REGS];                 // private (scratch): the program indexes it at run time
-    pinn_prepass_point(pg, x, d, aux, n, gi, priv, 1);
+PINN_DEVICE void pinn_prepass_point_private(const pinn_program_t& pg, const PinnPreConsts& c64, const float* x, int d, float* aux, long long n, long long gi) {
+    double priv[PINN_MAX_REGS];                // private (scratch): the program indexes it at run time
+    pinn_prepass_point(pg, c64, x, d, aux, n, gi, priv, 1);
 }
 
 // reverse sweep: adj[] must be zero on entry for every register; adj[result] is seeded with `seed`.
@@ -1207,6 +1218,13 @@ PINN_DEVICE f32x4 pinn_mfma_split6(const pinn_s16x8 (&a)[3], const pinn_s16x8 (&
 // chain pays two wait states between its dependent steps; pinn_port.h)
 // (batching the four DPP chains step-major, pinn_row_sum16_n, measured no difference on the tile kernels: the second wave per SIMD
 //  already covers the wait states -- DESIGN.md section 6a)
+// a double across lanes as two 32-bit moves (end-of-workgroup sums of the head scalars)
+PINN_DEVICE double pinn_shfl_xor_f64(double v, int mask) {
+    const unsigned long long b = __builtin_bit_cast(unsigned long long, v);
+    const unsigned lo = __builtin_bit_cast(unsigned, pinn_shfl_xor(__builtin_bit_cast(float, (unsigned)(b & 0xffffffffull)), mask));
+    const unsigned hi = __builtin_bit_cast(unsigned, pinn_shfl_xor(__builtin_bit_cast(float, (unsigned)(b >> 32)), mask));
+    return __builtin_bit_cast(double, ((unsigned long long)hi << 32) | (unsigned long long)lo);
+}
 PINN_DEVICE f32x4 pinn_row_sum16_v4(f32x4 v) {
 #pragma unroll
     for (int r = 0; r < 4; ++r) v[r] = pinn_row_sum16(v[r]);
@@ -1677,14 +1695,16 @@ PINN_DEVICE void pinn_tile_body(const PinnKArgs& A, const float* params_, float*
         // workgroup, hence the fence + the barrier below) at the top of each tile
         // (its registers live in the activation buffers, which nothing uses before the first tile: as many points per sweep as their
         //  registers fit -- a tile's worth always does)
-        static_assert(PINN_MAX_REGS * T <= C::O_NET - C::O_BUFA, "the activation buffers hold the pre-pass registers of one tile");
+        // (round 6: DOUBLE registers -- two floats each; the host sends a program whose registers do not fit a tile's worth of points
+        //  through the separate launch instead, PinnCfg::PREPASS_FLOATS_PER_LANE / run_train)
+        static_assert(C::O_BUFA % 2 == 0 && C::TEAM_FLOATS % 2 == 0 && C::SMEM_FLOATS % 2 == 0, "double registers of the pre-pass: 8-byte aligned");
         int pp_lanes = NTHREADS;
-        while (A.pre_nregs * pp_lanes > C::O_NET - C::O_BUFA) pp_lanes -= T;
-        float* pp_regs = smem + C::O_BUFA + tid;
+        while (pp_lanes > T && 2 * A.pre_nregs * pp_lanes > C::O_NET - C::O_BUFA) pp_lanes -= T;
+        double* pp_regs = reinterpret_cast<double*>(smem + C::O_BUFA) + tid;
         if (tid < pp_lanes) {
             for (long long tile = A.tile_begin + vbid + (long long)(tid / T) * vnblk; tile < ntiles; tile += (long long)(pp_lanes / T) * vnblk) {
                 const long long gi = tile * T + tid % T;
-                if (gi < A.n_points) pinn_prepass_point(A.pre, xs_ + gi * d, d, aux_, A.n_points, gi, pp_regs, pp_lanes);
+                if (gi < A.n_points) pinn_prepass_point(A.pre, A.pre_consts64, xs_ + gi * d, d, aux_, A.n_points, gi, pp_regs, pp_lanes);
             }
         }
         PINN_FENCE_BLOCK();
@@ -1721,6 +1741,25 @@ PINN_DEVICE void pinn_tile_body(const PinnKArgs& A, const float* params_, float*
             PINN_SYNC();
         }
     };
+    // PINN_TEAM_SKEW (round 6): team 1 of an exact-fp32 two-team kernel runs SKEW barriers behind team 0 -- it passes SKEW empty
+    // barriers in front of its first tile, team 0 as many behind its last one, so every hardware barrier still sees all eight waves.
+    // With SKEW = half a tile's barriers a team's vector phases (first layer, jet epilogues' tails, point stage, activation reverse +
+    // staging) meet the other team's GEMM phases on the SIMD they share instead of its vector phases: the latency of one hides under
+    // the MFMA issue of the other (fp32 MFMA and VALU share the issue port -- the sum of both is the floor -- but a wave that waits
+    // for LDS, a transcendental or a barrier issues nothing). Not for the split-bf16 kernels (their packed
+    // fp32 code must never run under the partner's bf16-MFMA phase).
+    // PINN_NOTOPB: no barrier behind the epilogue of the LAST hidden layer -- it writes nothing to LDS (its activations stay in
+    // registers), the head dot's partial sums go to `netp`, whose last readers (the previous tile's point stage) are a tile away.
+#ifndef PINN_TEAM_SKEW
+#define PINN_TEAM_SKEW 0
+#endif
+#ifndef PINN_NOTOPB
+#define PINN_NOTOPB 0
+#endif
+    constexpr int SKEW = (TEAMS2 && !SPLIT) ? PINN_TEAM_SKEW : 0;
+    constexpr bool NOTOPB = PINN_NOTOPB != 0;
+    if (SKEW > 0 && team == 1)
+        for (int i = 0; i < SKEW; ++i) tsync();
     // (two teams: both run as many rounds as team 0 has tiles -- a team without a tile in the last round works on an empty
     //  one: zero points, every sample invalid, contributions zero -- so that the barriers match)
     // (virtual workgroups: no hardware barrier in here, so each runs over its own tiles only)
@@ -2054,7 +2093,7 @@ PINN_DEVICE void pinn_tile_body(const PinnKArgs& A, const float* params_, float*
                 }
             }
             PH(4)
-            tsync();
+            if (!(NOTOPB && li + 1 == lh)) tsync();
             PH(5)
             float* tmp = cur; cur = nxt; nxt = tmp;
         }
@@ -2702,6 +2741,8 @@ PINN_DEVICE void pinn_tile_body(const PinnKArgs& A, const float* params_, float*
         }
         PH(15)
     }
+    if (SKEW > 0 && team == 0)
+        for (int i = 0; i < SKEW; ++i) tsync();
     FPB(3)
     if (TEAM_FLAGS) PINN_SYNC();       // (the arrival counter shares its LDS slot with `scal`, written below)
     PH_FLUSH
@@ -2739,11 +2780,19 @@ PINN_DEVICE void pinn_tile_body(const PinnKArgs& A, const float* params_, float*
     // the per-point sums of the point-stage lanes (tid < T: rows of wave 0) -> every lane of wave 0, by row and wave sums (as LDS slots
     // summed by thread 0 these were 48 serial LDS reads at the end of every workgroup: 5 K ticks)
     static_assert(T <= 64, "the point-stage lanes sit in wave 0");
-    float tot_loss = (tid < T) ? sum_loss : 0.0f, tot_ls = (tid < T) ? sum_ls : 0.0f, tot_bl = (tid < T) ? sum_bl : 0.0f,
-          tot_ic = (tid < T) ? sum_ic : 0.0f;
+    // (round 6: across the lanes in DOUBLE, one rounding to fp32 per row -- d loss / d b_L and d loss / d log_scale are sums of signed
+    //  per-point terms that cancel, BASELINE config 4's to 1 / 850 of the sum of their magnitudes; with fp32 row sums the lane tree alone
+    //  put 3 - 4e-6 relative onto that entry, tools/cfg4_bl_probe.py. Once per workgroup: the cost does not show)
+    float tot_loss = 0.0f, tot_ls = 0.0f, tot_bl = 0.0f, tot_ic = 0.0f;
     if (wave == 0) {
-        tot_loss = pinn_row_sum16(tot_loss); tot_ls = pinn_row_sum16(tot_ls); tot_bl = pinn_row_sum16(tot_bl); tot_ic = pinn_row_sum16(tot_ic);
-        if (T > 16) { tot_loss = pinn_rows_sum(tot_loss); tot_ls = pinn_rows_sum(tot_ls); tot_bl = pinn_rows_sum(tot_bl); tot_ic = pinn_rows_sum(tot_ic); }
+        double t64[4] = {(tid < T) ? (double)sum_loss : 0.0, (tid < T) ? (double)sum_ls : 0.0, (tid < T) ? (double)sum_bl : 0.0,
+                         (tid < T) ? (double)sum_ic : 0.0};
+#pragma unroll
+        for (int mask = 1; mask < (T > 16 ? 64 : 16); mask <<= 1) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) t64[i] += pinn_shfl_xor_f64(t64[i], mask);
+        }
+        tot_loss = (float)t64[0]; tot_ls = (float)t64[1]; tot_bl = (float)t64[2]; tot_ic = (float)t64[3];
     }
     (void)scal;
     PINN_SYNC();

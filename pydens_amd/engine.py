@@ -58,7 +58,7 @@ class Residual(ctypes.Structure):
                 ('src_const', ctypes.c_float), ('src_row', ctypes.c_int),
                 ('combined', ctypes.c_int), ('comb_w', ctypes.c_float * MAX_DIRS), ('n_vars', ctypes.c_int),
                 ('ic_var1', ctypes.c_int), ('ic_rows', ctypes.c_int), ('ic_row', ctypes.c_int * MAX_STREAMS),
-                ('ic_cst', ctypes.c_float * MAX_STREAMS)]
+                ('ic_cst', ctypes.c_float * MAX_STREAMS), ('pre_consts64', ctypes.c_double * MAX_CONSTS)]
 
     @classmethod
     def build(cls, kind, n_aux, pre, program=None, coef=(), coef_row=(), src_const=0.0, src_row=-1, comb_w=None, n_vars=0,
@@ -66,6 +66,9 @@ class Residual(ctypes.Structure):
         res = cls()
         res.kind, res.n_aux, res.n_vars = kind, n_aux, n_vars
         res.pre = Program.from_lists(*pre) if pre is not None else Program()
+        if pre is not None:                         # the pre-pass runs in fp64: its constants unrounded (include/pinn.h)
+            for i, c in enumerate(pre[1]):
+                res.pre_consts64[i] = float(c)
         res.program = Program.from_lists(*program) if program is not None else Program()
         for i in range(MAX_STREAMS):
             res.coef[i] = coef[i] if i < len(coef) else 0.0

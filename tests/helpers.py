@@ -90,10 +90,17 @@ def record_margin(test, case, quantity, achieved, bound, arbitrated=False):
     MARGINS.append((test, str(case), quantity, float(achieved), float(bound), bool(arbitrated)))
 
 
-def close_or_arbitrated(got, want32, want64_fn, rtol, atol=1e-9, k=2.0, note=None):
+def close_or_arbitrated(got, want32, want64_fn, rtol, atol=1e-9, k=2.0, note=None, adam_move=None):
     """ |got - ref32| <= rtol |ref32| (+ floor) -- or, where the reference's own fp32 arithmetic is the noisy side, the survey's arbiter:
     |got - f64| <= max(k |ref32 - f64|, rtol |f64| + floor). `want64_fn()` is only evaluated when the first test fails. Returns
-    (ok, achieved relative error, arbitrated). """
+    (ok, achieved relative error, arbitrated).
+    adam_move (PARAMETERS after a few Adam steps only; = lr * steps, the farthest Adam can move an entry): Adam's update is
+    g / sqrt(g^2)-like, so an entry whose gradient sits at the fp32 noise level of the batch sum (a cancelling sum near zero) turns that
+    noise into a move of a fraction of lr -- in the fp32 reference and in the kernels alike, in different entries and by different amounts
+    (round 6, `fa faR f+a fa f` GELU/Sin/Sigmoid/GELU on the Poisson problem: ONE of 1 287 entries of W2 2.2e-4 off the fp64
+    trajectory in the kernels' run, the reference's worst entry 6.6e-5 off). The k = 2 rule on the L2 norm then compares two draws of
+    one heavy-tailed noise. So in the arbitrated branch the 1 + n / 512 entries farthest from fp64 are set aside on BOTH sides, each of
+    them bounded by 2 % of adam_move, and the rule is applied to the rest. """
     a = np.asarray(got, dtype=np.float64).ravel()
     b = np.asarray(want32, dtype=np.float64).ravel()
     floor = atol * np.sqrt(a.size)
@@ -101,5 +108,12 @@ def close_or_arbitrated(got, want32, want64_fn, rtol, atol=1e-9, k=2.0, note=Non
     if err <= rtol * scale + floor:
         return True, err / max(scale, 1e-30), False
     c = np.asarray(want64_fn(), dtype=np.float64).ravel()
-    err64, ref64, scale64 = float(np.linalg.norm(a - c)), float(np.linalg.norm(b - c)), float(np.linalg.norm(c))
-    return err64 <= max(k * ref64, rtol * scale64 + floor), err64 / max(scale64, 1e-30), True
+    ea, eb = np.abs(a - c), np.abs(b - c)
+    outliers_ok = True
+    if adam_move is not None and a.size >= 64:
+        n_out = 1 + a.size // 512
+        ia, ib = np.argsort(ea)[-n_out:], np.argsort(eb)[-n_out:]
+        outliers_ok = float(ea[ia].max()) <= 0.02 * adam_move
+        ea, eb = np.delete(ea, ia), np.delete(eb, ib)
+    err64, ref64, scale64 = float(np.linalg.norm(ea)), float(np.linalg.norm(eb)), float(np.linalg.norm(c))
+    return outliers_ok and err64 <= max(k * ref64, rtol * scale64 + floor), err64 / max(scale64, 1e-30), True

@@ -62,7 +62,7 @@ def _ev(tree, env):
 LOSS_RTOL, PARAM_RTOL = 2e-5, 2e-5          # SURVEY 8c items 2 - 4 (were 5e-5 / 2e-4)
 
 
-def _fit_close(test, case, solver, oracle32, oracle64_fn, param_atol=2e-6):
+def _fit_close(test, case, solver, oracle32, oracle64_fn, param_atol=2e-6, adam_move=None):
     """ losses and final parameters of a short Adam trajectory against the fp32 oracle at the survey's bar; a case the reference's own
     fp32 arithmetic cannot hold is arbitrated by the fp64 oracle stepped from the same start:
     |ours - f64| <= max(2 |ref32 - f64|, bar). Adam turns the fp32 noise of a SMALL gradient entry into a move of size lr, hence the
@@ -79,7 +79,7 @@ def _fit_close(test, case, solver, oracle32, oracle64_fn, param_atol=2e-6):
     assert ok, (case, got_l, want_l, err)
     p64 = None
     for i, (got, ref) in enumerate(zip(export_params(solver), oracle32.export_params())):
-        ok, err, a = close_or_arbitrated(got, ref, lambda i=i: o64().export_params()[i], PARAM_RTOL, atol=param_atol)
+        ok, err, a = close_or_arbitrated(got, ref, lambda i=i: o64().export_params()[i], PARAM_RTOL, atol=param_atol, adam_move=adam_move)
         record_margin(test, case, 'parameters', err, PARAM_RTOL, a)
         assert ok, (case, i, err)
 
@@ -149,7 +149,7 @@ def _run(pa, extra, n_trees, batch, fused=True, third=False):
             for got, ref in zip(export_params(solver), oracle.export_params()):
                 assert params_close(got, ref, 2e-4, atol=1e-5), tree
         else:
-            _fit_close('random_equations_' + ('fused' if fused else 'generic'), tree, solver, oracle, oracle64)
+            _fit_close('random_equations_' + ('fused' if fused else 'generic'), tree, solver, oracle, oracle64, adam_move=2 * 0.01)
         kinds['program' if solver.residual_plan.kind == 0 else 'affine'] += 1
     assert (kinds['program'] >= 5 and kinds['affine'] >= 5) or (third and sum(kinds.values()) >= 10), kinds
 
@@ -252,7 +252,7 @@ def _run_layouts(pa, extra, n_nets, batch, wide=False):
         oracle.fit(niters=2, batch_size=batch, points=pts, lr=0.01)
         solver.fit(niters=2, batch_size=batch, sampler=FixedBatches(pts), lr=0.01)
         assert solver.last_fit_path == 'fused', (net, solver.program_error)
-        _fit_close('random_layouts' + ('_wide' if wide else ''), net, solver, oracle, oracle64)
+        _fit_close('random_layouts' + ('_wide' if wide else ''), net, solver, oracle, oracle64, adam_move=2 * 0.01)
         grid = [np.linspace(0.1, 0.9, 5).astype(np.float32)] * 2
         assert np.abs(solver.predict(*grid) - oracle.predict(*grid)).max() < 2e-5, net
         seen.add(('R' in net['layout'], isinstance(net['activation'], list)))
@@ -343,7 +343,7 @@ def _run_problems(pa, extra, n_problems, max_batch):
         want = [float(v) for v in oracle.losses]
         if not np.all(np.isfinite(want)):
             continue
-        _fit_close('random_problem_shapes', (trial, batch), solver, oracle, oracle64)
+        _fit_close('random_problem_shapes', (trial, batch), solver, oracle, oracle64, adam_move=2 * 0.01)
         paths.add(solver.last_fit_path)
     assert 'fused' in paths
 

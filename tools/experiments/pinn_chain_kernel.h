@@ -115,15 +115,12 @@ pinn_chain_kernel(const PinnKArgs A) {
     if (A.pre.n_ops > 0) {
         // x-only pre-pass (source term of the residual) for the points of this pair's own tiles, both waves, 128 / TW tiles per
         // sweep; its registers live in the ring (unused before the first tile) whenever they fit
-        const bool pp_in_lds = A.pre_nregs * NTHREADS <= NP * C::SCR_W;
-        float* pp_regs = smem + C::O_SCR + tid;
+        // (round 6: the pre-pass is fp64 and the host only hands it to kernels that report LDS room for its double registers -- this
+        //  experiment kernel reports none, so the separate launch runs and this block stays a fallback with private registers)
         const int ptid = role * 64 + lane;
         for (long long tile = A.tile_begin + vbid + (long long)(ptid / TW) * vnblk; tile < ntiles; tile += (long long)(128 / TW) * vnblk) {
             const long long gi = tile * TW + ptid % TW;
-            if (gi < A.n_points) {
-                if (pp_in_lds) pinn_prepass_point(A.pre, A.xs + gi * d, d, A.aux, A.n_points, gi, pp_regs, NTHREADS);
-                else pinn_prepass_point_private(A.pre, A.xs + gi * d, d, A.aux, A.n_points, gi);
-            }
+            if (gi < A.n_points) pinn_prepass_point_private(A.pre, A.pre_consts64, A.xs + gi * d, d, A.aux, A.n_points, gi);
         }
         PINN_FENCE_BLOCK();
     }

@@ -8,7 +8,7 @@
 CFG=${1:-cfg2}; TAG=${2:-prof}; SUF=${3:-}; shift 3 2>/dev/null; EXTRA="$@"; OUT=/root/repo/gpurun_out/$TAG/prof_$CFG$SUF; mkdir -p $OUT
 export TMPDIR=/tmp; cd /tmp
 STEPS=30; WARM=5; case $CFG in cfg3|cfg5) STEPS=24; WARM=4;; esac    # (wide configs: enough launches that the first-touch launches of the 12 GB slabs do not weigh on AverageNs)
-CMD="python /root/repo/bench.py --workload $CFG --no-cpu-baseline --no-strong --no-side --no-parity --no-cold --steps $STEPS --warmup $WARM $EXTRA"
+CMD="python /root/repo/bench.py --workload $CFG --no-cpu-baseline --no-strong --no-side --no-parity --no-cold --no-configs --steps $STEPS --warmup $WARM $EXTRA"
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -- $CMD > $OUT/trace.log 2>&1
 rocprofv3 --kernel-trace --output-format csv --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_MFMA SQ_INSTS_VALU SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY GRBM_GUI_ACTIVE -d $OUT/pmc1 -- $CMD > $OUT/pmc1.log 2>&1
 rocprofv3 --kernel-trace --output-format csv --pmc FETCH_SIZE -d $OUT/pmc2 -- $CMD > $OUT/pmc2.log 2>&1
