@@ -187,6 +187,12 @@ int pinn_create_ex(const int* layer_dims, int n_layers, const int* acts, int n_s
                    const int* skip_dst, int ndims, int nparams, int has_bc, int has_ic, const float* dom_lo,
                    const float* dom_hi, float bc_value, pinn_t** out);
 int pinn_destroy(pinn_t* net);
+/* Round 6: the ONE parameter some torch activation modules carry, per activation index a = 0 .. n_layers-2 -- nn.LeakyReLU(negative_slope),
+ * nn.ELU(alpha), nn.Softplus(beta) (threshold stays 20) -- for nets built from module INSTANCES configured away from torch's defaults
+ * (the reference hands instances through to the block, model_torch.py:150, :164-168). par[a] of an activation that takes none must be 0.
+ * Without this call every activation has its torch default (0.01 / 1 / 1). Forward values, all derivative orders and the reverse sweep
+ * use it (full breadth kernels; oracle/jet_f64.py act_derivs states the formulas). */
+int pinn_set_act_params(pinn_t* net, const float* par, int n);
 /* pinn_jet_forward (below) with caller-owned scratch: a net with NESTED skip connections parks the jets of its outer skip in global
  * memory between 'R' and '+', in a value-only forward pass too; `workspace` of pinn_workspace_bytes(net, n_points, nd, n2) bytes
  * (16-byte aligned) covers it. Nets without nested skips ignore the workspace; pinn_jet_forward on a nested net fails with a message. */
@@ -354,6 +360,11 @@ int pinn_debug_max_wgs_per_cu(pinn_t* net, int cap);
  *                                 Returns the previous setting (-1: null).
  *   pinn_debug_fit_onecu_rounds   see above; rounds >= 1, returns the previous value */
 int pinn_debug_fit_persistent(pinn_t* net, int mode);
+/* Round 6: the grid form (mode 1) waits device-wide once per iteration with a BOUNDED spin; on a timeout every workgroup
+ * returns without writing parameters, Adam state or losses back. The launcher now checks that the whole grid is resident before it picks
+ * the form, and this call -- it synchronises with the device -- returns 1 (and sets pinn_last_error) if the last grid-form chunk of the
+ * calling thread timed out, 0 otherwise, -1 if the flag could not be read. `Solver.fit` calls it behind every grid-form fit and raises. */
+int pinn_fit_chunk_status(void);
 int pinn_debug_fit_onecu_rounds(pinn_t* net, int rounds);
 /*   pinn_debug_fit_graph_stats    out[0] chunks replayed as launch graphs so far, out[1] graphs captured, out[2] captures the runtime
  *                                 refused (those chunks ran eagerly), out[3] the HIP error code of the last refusal */

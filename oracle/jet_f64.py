@@ -16,8 +16,21 @@ e_a + e_b (mixed partials: u_ab = (u_vv - u_aa - u_bb) / 2).
 import numpy as np
 
 
+def act_param(act):
+    """ 'name' or 'name:value' -> (name, value or None): the one parameter a LeakyReLU (negative_slope) / ELU (alpha) / Softplus (beta)
+    module may carry (round 6; pinn_kernel.h PinnAct, include/pinn.h pinn_set_act_params) """
+    base, _, value = str(act).partition(':')
+    return base, (float(value) if value else None)
+
+
 def act_derivs(z, act, fourth=False):
     """ activation value and its first three (four) derivatives. """
+    act, par = act_param(act)
+    if act == 'softplus' and par is not None and par != 1.0:
+        # softplus_beta(z) = softplus(beta z) / beta: derivative n is beta^(n-1) times derivative n of softplus at beta z
+        out = act_derivs(par * np.asarray(z, dtype=np.float64), 'softplus', fourth=True)
+        scaled = (out[0] / par, out[1], par * out[2], par ** 2 * out[3], par ** 3 * out[4])
+        return scaled if fourth else scaled[:4]
     if act == 'tanh':
         t = np.tanh(z)
         d1 = 1.0 - t * t
@@ -64,12 +77,12 @@ def act_derivs(z, act, fourth=False):
         d3 = phi * z * (z2 - 4.0)
         d4 = phi * ((7.0 - z2) * z2 - 4.0)
     elif act in ('relu', 'leakyrelu'):             # torch: slope 0 / 0.01 (the defaults) on z <= 0, derivative taken as in torch (z > 0 ? 1 : slope)
-        slope = 0.0 if act == 'relu' else 0.01
+        slope = 0.0 if act == 'relu' else (0.01 if par is None else par)
         t = np.where(z > 0, z, slope * z)
         d1 = np.where(z > 0, 1.0, slope)
         d2 = d3 = d4 = np.zeros_like(z)
     elif act in ('elu', 'selu'):                   # s (z > 0 ? z : alpha (e^z - 1)); ELU: s = alpha = 1
-        s_, al = (1.0507009873554805, 1.6732632423543772) if act == 'selu' else (1.0, 1.0)
+        s_, al = (1.0507009873554805, 1.6732632423543772) if act == 'selu' else (1.0, 1.0 if par is None else par)
         e = s_ * al * np.exp(z)
         t = np.where(z > 0, s_ * z, s_ * al * np.expm1(z))
         d1 = np.where(z > 0, s_, e)
@@ -427,6 +440,9 @@ def act_d5(z, act):
     """ fifth derivative of the activation (the reverse sweep of fourth-order streams needs it; round 5) -- the formulas of
     pinn_kernel.h pinn_act_d5 in fp64; tests/test_activations.py holds them to torch's nested autograd. """
     z = np.asarray(z, dtype=np.float64)
+    act, par = act_param(act)
+    if act == 'softplus' and par is not None and par != 1.0:
+        return par ** 4 * act_d5(par * z, 'softplus')
     if act == 'tanh':
         t2 = np.tanh(z) ** 2
         return (1.0 - t2) * (16.0 - 120.0 * t2 + 120.0 * t2 * t2)
@@ -435,7 +451,7 @@ def act_d5(z, act):
     if act in ('identity', 'relu', 'leakyrelu'):
         return np.zeros_like(z)
     if act in ('elu', 'selu'):
-        s_, al = (1.0507009873554805, 1.6732632423543772) if act == 'selu' else (1.0, 1.0)
+        s_, al = (1.0507009873554805, 1.6732632423543772) if act == 'selu' else (1.0, 1.0 if par is None else par)
         return np.where(z > 0, 0.0, s_ * al * np.exp(z))
     if act == 'softsign':
         return 120.0 / (1.0 + np.abs(z)) ** 6

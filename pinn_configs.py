@@ -90,6 +90,18 @@ def make_config(name, D, torch, V=None):
                                        layout='faR faR fa fa+ fa+ fa f', features=[24, 24, 24, 24, 24, 24, 1],
                                        activation=['ELU', 'Mish', 'Softsign', 'SELU', 'LogSigmoid', 'LeakyReLU']),
                     n_points=4096, low=[0, 0], high=[1, 1])
+    if name == 'act_params':
+        # breadth fixture (round 6): activation module INSTANCES configured away from torch's defaults -- the reference hands them through
+        # to the block (model_torch.py:150 "Sequence of callables, str", :164-168) -- LeakyReLU(negative_slope), ELU(alpha), Softplus(beta);
+        # viscous Burgers with IC + BC (second derivatives: the parameters enter every derivative order of the jets)
+        def equation(f, x, t):
+            return D(f, t) + f * D(f, x) - 0.05 * D(D(f, x), x)
+        nn = torch.nn
+        return dict(equation=equation,
+                    solver_kwargs=dict(ndims=2, boundary_condition=0.1, initial_condition=lambda x: torch.sin(PI * x) * x,
+                                       layout='fa fa fa fa f', features=[24, 24, 24, 24, 1],
+                                       activation=[nn.Softplus(beta=2.0), nn.ELU(alpha=0.5), nn.LeakyReLU(0.2), nn.Softplus(beta=0.5)]),
+                    n_points=4096, low=[0, 0], high=[1, 1])
     if name == 'mixed3':
         # breadth fixture (round 5): MIXED third derivatives u_xxy and u_xyy (nested D in any order, model_torch.py:174-178) next to a
         # first derivative in t: third Taylor coefficients along x + y and x - y, polarised

@@ -140,8 +140,16 @@ def _build(force, verbose, extra_flags, widths):
             from pydens_amd.csrc import asm_guard
             src = cmd[cmd.index('-c') + 1]
             flags = [c for c in cmd[1:] if c not in ('-c', src, '-o', obj)]
-            guard_report[os.path.basename(obj)] = asm_guard.compile_guarded(hipcc, flags, src, obj, verbose=verbose)
-            return obj
+            try:
+                guard_report[os.path.basename(obj)] = asm_guard.compile_guarded(hipcc, flags, src, obj, verbose=verbose)
+                return obj
+            except FileNotFoundError as err:
+                # no assembler / linker / bundler beside this hipcc (a ROCm install laid out differently): the unit is compiled the
+                # ordinary way -- LOUDLY: the split-bf16 kernels then lack the structural exclusion of DESIGN.md section 6.2
+                # (their two teams stay phase-locked, which is what protected them before round 5)
+                import warnings
+                warnings.warn(f'pydens_amd build: {err}; compiling {os.path.basename(obj)} WITHOUT the packed-fp32 assembly guard')
+                guard_report[os.path.basename(obj)] = {'unguarded': str(err)}
         if verbose:
             print(' '.join(cmd), flush=True)
         res = subprocess.run(cmd, capture_output=True, text=True)

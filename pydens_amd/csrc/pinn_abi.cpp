@@ -74,6 +74,7 @@ struct pinn_net {
     pinn_layout_t lay;
     int n_layers, act, ndims, nparams, has_bc, has_ic, nsp;      // act: uniform activation code or -1
     unsigned long long act_codes[2];                              // 4 bits per activation index (pinn_act_code)
+    float act_par[PINN_MAX_LAYERS];                               // parameter of activation a (pinn_set_act_params; torch's defaults at creation)
     int n_skips, skip_src[PINN_MAX_SKIPS], skip_dst[PINN_MAX_SKIPS], skip_pre, skip_src_pre, skip_outer;
     int dims[PINN_MAX_LAYERS + 1];
     float lo[PINN_MAX_INPUTS], hi[PINN_MAX_INPUTS], bc_value;
@@ -192,6 +193,7 @@ int make_plan(const pinn_net* net, int64_t n_points, int nd, int n2, Plan* plan,
         probe.lh = net->lay.lh;
         probe.act = net->act;
         probe.act_codes[0] = net->act_codes[0]; probe.act_codes[1] = net->act_codes[1];
+        for (int i = 0; i < PINN_MAX_LAYERS; ++i) probe.act_par[i] = net->act_par[i];
         probe.n_skips = net->n_skips;
         probe.skip_pre = net->skip_pre;
         probe.skip_src_pre = net->skip_src_pre;
@@ -261,6 +263,7 @@ void fill_args(const pinn_net* net, PinnKArgs* a, const float* params, const flo
     const pinn_layout_t& L = net->lay;
     a->params = params; a->xs = xs; a->ic_streams = ic_streams; a->n_points = n;
     a->lh = L.lh; a->d = L.d; a->act = net->act; a->act_codes[0] = net->act_codes[0]; a->act_codes[1] = net->act_codes[1];
+    for (int i = 0; i < PINN_MAX_LAYERS; ++i) a->act_par[i] = net->act_par[i];
     a->n_skips = net->n_skips;
     a->skip_pre = net->skip_pre;
     a->skip_src_pre = net->skip_src_pre;
@@ -392,6 +395,28 @@ int pinn_debug_set_flags(int flags) { g_pinn_debug_flags = flags; return 0; }
 
 int pinn_debug_last_kernel(void) { return g_pinn_last_kernel; }
 
+// torch's default of the one parameter an activation module may carry
+static float pinn_act_default_param(int code) {
+    return code == PINN_ACT_LEAKYRELU ? 0.01f : (code == PINN_ACT_ELU || code == PINN_ACT_SOFTPLUS) ? 1.0f : 0.0f;
+}
+
+int pinn_set_act_params(pinn_t* net, const float* par, int n) {
+    if (!net || !par) return fail("null argument");
+    if (n != net->n_layers - 1) return fail("pinn_set_act_params: %d values for %d activations", n, net->n_layers - 1);
+    for (int a = 0; a < n; ++a) {
+        const int code = pinn_act_code(net->act_codes, a);
+        const bool takes = code == PINN_ACT_LEAKYRELU || code == PINN_ACT_ELU || code == PINN_ACT_SOFTPLUS;
+        if (!takes && par[a] != 0.0f) return fail("pinn_set_act_params: activation %d (code %d) takes no parameter", a, code);
+        if (code == PINN_ACT_SOFTPLUS && !(par[a] > 0.0f)) return fail("pinn_set_act_params: Softplus beta must be positive (activation %d: %g)", a, par[a]);
+        if (!(par[a] == par[a]) || par[a] > 1e30f || par[a] < -1e30f) return fail("pinn_set_act_params: activation %d: parameter is not finite", a);
+    }
+    for (int a = 0; a < n; ++a) {
+        const int code = pinn_act_code(net->act_codes, a);
+        if (code == PINN_ACT_LEAKYRELU || code == PINN_ACT_ELU || code == PINN_ACT_SOFTPLUS) net->act_par[a] = par[a];
+    }
+    return 0;
+}
+
 int pinn_set_tanh_mode(pinn_t* net, int mode) {
     if (!net) return fail("null argument");
     if (mode != PINN_TANH_FAST && mode != PINN_TANH_ACCURATE) return fail("unknown tanh mode %d", mode);
@@ -427,6 +452,22 @@ int pinn_debug_fit_onecu_rounds(pinn_t* net, int rounds) {
     const int before = net->fit_onecu_rounds;
     if (rounds >= 1) net->fit_onecu_rounds = rounds;
     return before;
+}
+
+// the GRID form of the one-launch fit chunk (pinn_debug_fit_persistent 1) waits device-wide once per iteration with a bounded spin; a
+// workgroup that gives up raises a flag and the whole grid returns WITHOUT writing parameters / losses back (pinn_fit_kernel.h). The host
+// cannot see that from the launch: this call synchronises with the device and reads the flag of the last such chunk.
+static thread_local unsigned* g_fit_last_sync = nullptr;
+int pinn_fit_chunk_status(void) {
+    if (!g_fit_last_sync) return 0;
+#ifdef PINN_EMU
+    return (int)g_fit_last_sync[1];
+#else
+    unsigned host[2] = {0u, 0u};
+    if (hipMemcpy(host, g_fit_last_sync, sizeof(host), hipMemcpyDeviceToHost) != hipSuccess) { fail("pinn_fit_chunk_status: hipMemcpy failed"); return -1; }
+    if (host[1] != 0u) { fail("one-launch fit chunk (grid form) timed out at its device-wide wait: the chunk's iterations were NOT applied"); return 1; }
+    return 0;
+#endif
 }
 
 int pinn_debug_fit_persistent(pinn_t* net, int enable) {
@@ -557,6 +598,7 @@ int pinn_create_ex(const int* layer_dims, int n_layers, const int* acts, int n_s
     for (int a = 0; a + 1 < n_layers; ++a) {
         net->act_codes[a >> 4] |= (unsigned long long)acts[a] << (4 * (a & 15));
         if (acts[a] != act) net->act = -1;
+        net->act_par[a] = pinn_act_default_param(acts[a]);
     }
     net->n_skips = n_skips;
     for (int k = 0; k < n_skips; ++k) { net->skip_src[k] = src_of[k]; net->skip_dst[k] = dst_of[k]; }
@@ -811,6 +853,7 @@ static int run_train(pinn_t* net, PinnKArgs* a, const Plan& plan, int nd, float*
             if (rc == 1) return 0;               // (this instantiation has no such form after all: the caller falls back)
             if (rc) return fail("fit kernel launch failed (%d)", rc);
             g_fit_persist.done = 1;
+            g_fit_last_sync = onecu ? nullptr : P.sync;        // (grid form: its timeout flag, read back by pinn_fit_chunk_status)
         }
         return 0;
     }

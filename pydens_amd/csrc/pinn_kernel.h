@@ -54,6 +54,16 @@ PINN_HOST_DEVICE inline int pinn_act_code(const unsigned long long (&codes)[2], 
     return (int)((codes[a >> 4] >> (4 * (a & 15))) & 15ull);
 }
 
+// an activation as the jet functions see it: its code (PINN_ACT_*) and the ONE parameter some of torch's modules carry -- round 6:
+// nn.LeakyReLU(negative_slope), nn.ELU(alpha), nn.Softplus(beta) configured away from their defaults (the reference hands module
+// instances through, model_torch.py:150; pinn_set_act_params). Converts to and from the plain code, so code that only compares
+// codes is written as before; a kernel whose activation is a compile-time constant carries no parameter at all.
+struct PinnAct {
+    int c; float p;
+    PINN_HOST_DEVICE PinnAct(int code = 0, float par = 0.0f) : c(code), p(par) {}
+    PINN_HOST_DEVICE operator int() const { return c; }
+};
+
 // timing-experiment bits (kernels skip loads / stores / barriers; include/pinn.h): compiled into -DPINN_DEBUG_ABI builds only
 // (tools/variant.sh), the product kernels carry none of these paths
 #ifdef PINN_DEBUG_ABI
@@ -96,6 +106,7 @@ struct PinnKArgs {
     long long n_points;
     int lh, d, act, mode;        // act: the activation code shared by every layer, or -1 when they differ (act_codes)
     unsigned long long act_codes[2];   // 4 bits per activation index a = 0..lh (a = 0: first layer): pinn_act_code
+    float act_par[PINN_MAX_LAYERS];    // parameter of activation a (LeakyReLU negative_slope / ELU alpha / Softplus beta; pinn_set_act_params)
     int n_skips;                 // skip connections 'R ... +': h_out[skip_dst] += h_out[skip_src] (activation indices)
     int skip_src[PINN_MAX_SKIPS], skip_dst[PINN_MAX_SKIPS];
     int skip_pre;                // bit k: skip k ends IN FRONT of the activation ('R fa f+ a': z[skip_dst] += h_out[skip_src])
@@ -251,9 +262,10 @@ PINN_DEVICE void pinn_sincos(float x, float& sn, float& cs) {
 // (bit 8 of the code handed to pinn_act / pinn_jet_fwd: tanh of small arguments by its minimax polynomial -- the kernels that can pay
 //  for it, see PTALL in the tile kernel; every other function sees the plain code)
 #define PINN_ACT_TANH_POLYBIT 0x100
-PINN_DEVICE float pinn_act(float z, int act_) {
-    const bool poly = (act_ & PINN_ACT_TANH_POLYBIT) != 0;
-    const int act = act_ & 0xff;
+PINN_DEVICE float pinn_act(float z, PinnAct act_) {
+    const bool poly = (act_.c & PINN_ACT_TANH_POLYBIT) != 0;
+    const int act = act_.c & 0xff;
+    const float par = act_.p;                   // LeakyReLU negative_slope / ELU alpha / Softplus beta
     if (PINN_ABL & 32) return 0.5f * z;
     if (act == PINN_ACT_TANH) {
         // sign(z) (1 - t)/(1 + t) with t = e^{-2|z|} (symmetric, no overflow) for small |z|; 1 - 2t/(1 + t) where the unit saturates
@@ -280,13 +292,13 @@ PINN_DEVICE float pinn_act(float z, int act_) {
     }
     if (act == PINN_ACT_SIGMOID) return pinn_rcp(1.0f + pinn_exp2(z * -1.4426950408889634f));
     if (act == PINN_ACT_SIN) { float sn, cs; pinn_sincos(z, sn, cs); return sn; }
-    if (act == PINN_ACT_SOFTPLUS) return z > 20.0f ? z : log1pf(expf(z));           // torch.nn.Softplus (beta 1, threshold 20)
+    if (act == PINN_ACT_SOFTPLUS) return par * z > 20.0f ? z : log1pf(expf(par * z)) / par;    // torch.nn.Softplus (beta, threshold 20)
     if (act == PINN_ACT_SILU) return z / (1.0f + expf(-z));
     if (act == PINN_ACT_GELU) return 0.5f * z * (1.0f + erff(z * 0.70710678118654752f));   // torch.nn.GELU (erf form)
     // round 5: the torch-default forms of the other common `nn` activations (include/pinn.h)
     if (act == PINN_ACT_RELU) return z > 0.0f ? z : 0.0f;
-    if (act == PINN_ACT_LEAKYRELU) return z > 0.0f ? z : 0.01f * z;
-    if (act == PINN_ACT_ELU) return z > 0.0f ? z : expm1f(z);
+    if (act == PINN_ACT_LEAKYRELU) return z > 0.0f ? z : par * z;
+    if (act == PINN_ACT_ELU) return z > 0.0f ? z : par * expm1f(z);
     if (act == PINN_ACT_SELU) return 1.0507009873554805f * (z > 0.0f ? z : 1.6732632423543772f * expm1f(z));
     if (act == PINN_ACT_SOFTSIGN) return z / (1.0f + fabsf(z));
     if (act == PINN_ACT_GELU_TANH) return 0.5f * z * (1.0f + tanhf(0.7978845608028654f * (z + 0.044715f * z * z * z)));
@@ -299,7 +311,7 @@ PINN_DEVICE float pinn_act(float z, int act_) {
 // pre-activation (sin, softplus, SiLU, GELU: their derivatives are functions of z)
 PINN_DEVICE bool pinn_act_keeps_z(int act) { return act == PINN_ACT_SIN || act >= PINN_ACT_SOFTPLUS; }
 PINN_DEVICE float pinn_act_saved(float v, float z, int act) { return pinn_act_keeps_z(act) ? z : v; }
-PINN_DEVICE float pinn_act_value(float saved, int act) { return pinn_act_keeps_z(act) ? pinn_act(saved, act) : saved; }
+PINN_DEVICE float pinn_act_value(float saved, PinnAct act) { return pinn_act_keeps_z(act) ? pinn_act(saved, act) : saved; }
 // derivatives 1..4 of the z-keeping smooth activations, from z. With s = sigmoid(z), a = s (1 - s), q = 1 - 2 s (so that
 // s' = a, a' = a q, q' = -2 a) and phi = exp(-z^2 / 2) / sqrt(2 pi), Phi' = phi, phi' = -z phi:
 //   softplus: s | a | a q | a (q^2 - 2 a)
@@ -317,12 +329,14 @@ PINN_DEVICE void pinn_tanh_chain(float T, float u1, float u2, float u3, float u4
 // tests/test_activations.py holds both to torch's nested autograd): piecewise ones as autograd differentiates them (kinks: the
 // z > 0 branch decides, every higher derivative of a linear piece is 0), GELU-tanh and Mish as z F(z) with F built on tanh(u(z)):
 // (z F)^(n) = z F^(n) + n F^(n-1)
-PINN_DEVICE void pinn_act_zderivs_ext(float z, int act, float& d1, float& d2, float& d3, float& d4) {
+PINN_DEVICE void pinn_act_zderivs_ext(float z, PinnAct act_, float& d1, float& d2, float& d3, float& d4) {
+    const int act = act_.c;
+    const float par = act_.p;
     d2 = 0.0f; d3 = 0.0f; d4 = 0.0f;
     if (act == PINN_ACT_RELU) { d1 = z > 0.0f ? 1.0f : 0.0f; return; }
-    if (act == PINN_ACT_LEAKYRELU) { d1 = z > 0.0f ? 1.0f : 0.01f; return; }
+    if (act == PINN_ACT_LEAKYRELU) { d1 = z > 0.0f ? 1.0f : par; return; }
     if (act == PINN_ACT_ELU || act == PINN_ACT_SELU) {
-        const float sc = act == PINN_ACT_SELU ? 1.0507009873554805f : 1.0f, al = act == PINN_ACT_SELU ? 1.6732632423543772f : 1.0f;
+        const float sc = act == PINN_ACT_SELU ? 1.0507009873554805f : 1.0f, al = act == PINN_ACT_SELU ? 1.6732632423543772f : par;
         if (z > 0.0f) { d1 = sc; return; }
         const float e = sc * al * expf(z);
         d1 = e; d2 = e; d3 = e; d4 = e;
@@ -359,27 +373,30 @@ PINN_DEVICE void pinn_act_zderivs_ext(float z, int act, float& d1, float& d2, fl
     const float sc = gelu ? 0.5f : 1.0f, f0 = gelu ? 0.5f * (1.0f + T) : T;
     d1 = f0 + sc * z * t1; d2 = sc * (z * t2 + 2.0f * t1); d3 = sc * (z * t3 + 3.0f * t2); d4 = sc * (z * t4 + 4.0f * t3);
 }
-PINN_DEVICE void pinn_act_zderivs(float z, int act, float& d1, float& d2, float& d3, float& d4) {
-    if (act >= PINN_ACT_RELU) { pinn_act_zderivs_ext(z, act, d1, d2, d3, d4); return; }
+PINN_DEVICE void pinn_act_zderivs(float z, PinnAct act_, float& d1, float& d2, float& d3, float& d4) {
+    const int act = act_.c;
+    if (act >= PINN_ACT_RELU) { pinn_act_zderivs_ext(z, act_, d1, d2, d3, d4); return; }
     if (act == PINN_ACT_GELU) {
         const float phi = 0.3989422804014327f * expf(-0.5f * z * z), Phi = 0.5f * (1.0f + erff(z * 0.70710678118654752f));
         const float z2 = z * z;
         d1 = Phi + z * phi; d2 = phi * (2.0f - z2); d3 = phi * z * (z2 - 4.0f); d4 = phi * ((7.0f - z2) * z2 - 4.0f);
         return;
     }
-    const float sg = 1.0f / (1.0f + expf(-z)), a = sg * (1.0f - sg), q = 1.0f - 2.0f * sg;
+    // (softplus_beta(z) = log(1 + e^{beta z}) / beta: derivative n is beta^{n-1} s^{(n-1)}(beta z))
+    const float be = act == PINN_ACT_SOFTPLUS ? act_.p : 1.0f;
+    const float sg = 1.0f / (1.0f + expf(-be * z)), a = sg * (1.0f - sg), q = 1.0f - 2.0f * sg;
     const float a3 = a * (q * q - 2.0f * a), a4 = a * q * (q * q - 8.0f * a);       // s''' and s''''
-    if (act == PINN_ACT_SOFTPLUS) { d1 = sg; d2 = a; d3 = a * q; d4 = a3; }
+    if (act == PINN_ACT_SOFTPLUS) { d1 = sg; d2 = be * a; d3 = be * be * a * q; d4 = be * be * be * a3; }
     else { d1 = sg + z * a; d2 = 2.0f * a + z * a * q; d3 = 3.0f * a * q + z * a3; d4 = 4.0f * a3 + z * a4; }   // SiLU
 }
-PINN_DEVICE void pinn_act_d12(float sv, int act, float& d1, float& d2) {
+PINN_DEVICE void pinn_act_d12(float sv, PinnAct act, float& d1, float& d2) {
     if (act == PINN_ACT_TANH) { d1 = 1.0f - sv * sv; d2 = -2.0f * sv * d1; }
     else if (act == PINN_ACT_SIGMOID) { d1 = sv * (1.0f - sv); d2 = d1 * (1.0f - 2.0f * sv); }
     else if (act == PINN_ACT_SIN) { float sn; pinn_sincos(sv, sn, d1); d2 = -sn; }
     else if (act >= PINN_ACT_SOFTPLUS) { float d3, d4; pinn_act_zderivs(sv, act, d1, d2, d3, d4); }
     else { d1 = 1.0f; d2 = 0.0f; }
 }
-PINN_DEVICE float pinn_act_d3(float sv, float d1, float d2, int act) {
+PINN_DEVICE float pinn_act_d3(float sv, float d1, float d2, PinnAct act) {
     if (act == PINN_ACT_TANH) return d1 * (6.0f * sv * sv - 2.0f);
     if (act == PINN_ACT_SIGMOID) {
         const float q = 1.0f - 2.0f * sv;
@@ -391,7 +408,7 @@ PINN_DEVICE float pinn_act_d3(float sv, float d1, float d2, int act) {
 }
 
 // fourth derivative from the activation value (reverse sweep of third-order streams)
-PINN_DEVICE float pinn_act_d4(float sv, float d1, float d2, int act) {
+PINN_DEVICE float pinn_act_d4(float sv, float d1, float d2, PinnAct act) {
     if (act == PINN_ACT_TANH) return d1 * sv * (16.0f - 24.0f * sv * sv);
     if (act == PINN_ACT_SIGMOID) {
         const float q = 1.0f - 2.0f * sv;                        // with a = s(1 - s): s2 = a q, s3 = a (q^2 - 2 a), s4 = a q (q^2 - 8 a)
@@ -406,7 +423,8 @@ PINN_DEVICE float pinn_act_d4(float sv, float d1, float d2, int act) {
 // the z-keeping ones from the pre-activation: sigmoid's derivatives s1 = a, s2 = a q, s3 = a (q^2 - 2 a), s4 = a q (q^2 - 8 a),
 // s5 = a (q^4 - 22 a q^2 + 16 a^2) give softplus (s4), SiLU (z s5 + 5 s4), LogSigmoid (-s4); GELU z Phi: phi (z^5 - 11 z^3 + 18 z);
 // GELU-tanh / Mish / Tanhshrink: Faa di Bruno's fifth term on tanh(u(z)), tanh^(5) = T1 (16 - 120 T^2 + 120 T^4)
-PINN_DEVICE float pinn_act_d5(float sv, float d1, float d2, int act) {
+PINN_DEVICE float pinn_act_d5(float sv, float d1, float d2, PinnAct act_) {
+    const int act = act_.c;
     if (act == PINN_ACT_TANH) { const float t2 = sv * sv; return d1 * (16.0f + t2 * (-120.0f + 120.0f * t2)); }
     if (act == PINN_ACT_SIGMOID) {
         const float q = 1.0f - 2.0f * sv, q2 = q * q;
@@ -417,7 +435,7 @@ PINN_DEVICE float pinn_act_d5(float sv, float d1, float d2, int act) {
     const float z = sv;
     if (act == PINN_ACT_RELU || act == PINN_ACT_LEAKYRELU) return 0.0f;
     if (act == PINN_ACT_ELU || act == PINN_ACT_SELU) {
-        const float sc = act == PINN_ACT_SELU ? 1.0507009873554805f : 1.0f, al = act == PINN_ACT_SELU ? 1.6732632423543772f : 1.0f;
+        const float sc = act == PINN_ACT_SELU ? 1.0507009873554805f : 1.0f, al = act == PINN_ACT_SELU ? 1.6732632423543772f : act_.p;
         return z > 0.0f ? 0.0f : sc * al * expf(z);
     }
     if (act == PINN_ACT_SOFTSIGN) { const float a = 1.0f / (1.0f + fabsf(z)), a2 = a * a; return 120.0f * a2 * a2 * a2; }
@@ -425,9 +443,10 @@ PINN_DEVICE float pinn_act_d5(float sv, float d1, float d2, int act) {
         const float phi = 0.3989422804014327f * expf(-0.5f * z * z), z2 = z * z;
         return phi * z * ((z2 - 11.0f) * z2 + 18.0f);
     }
-    const float sg = 1.0f / (1.0f + expf(-z)), a = sg * (1.0f - sg), q = 1.0f - 2.0f * sg, q2 = q * q;
+    const float be = act == PINN_ACT_SOFTPLUS ? act_.p : 1.0f;
+    const float sg = 1.0f / (1.0f + expf(-be * z)), a = sg * (1.0f - sg), q = 1.0f - 2.0f * sg, q2 = q * q;
     const float s4 = a * q * (q2 - 8.0f * a), s5 = a * (q2 * q2 - 22.0f * a * q2 + 16.0f * a * a);
-    if (act == PINN_ACT_SOFTPLUS) return s4;
+    if (act == PINN_ACT_SOFTPLUS) return be * be * be * be * s4;
     if (act == PINN_ACT_SILU) return z * s5 + 5.0f * s4;
     if (act == PINN_ACT_LOGSIGMOID) return -s4;
     // tanh(u(z)): u = z (Tanhshrink), k (z + c z^3) (GELU-tanh), softplus(z) (Mish)
@@ -487,11 +506,11 @@ struct PinnJet {
 
 // forward jet of one (point, unit): z[S] pre-activations -> h[S] activations
 template <int ND, int N2P, bool COMB = false>
-PINN_DEVICE void pinn_jet_fwd(const float (&z)[pinn_ns(ND, N2P)], int act_, float (&h)[pinn_ns(ND, N2P)], const float* cw = nullptr) {
+PINN_DEVICE void pinn_jet_fwd(const float (&z)[pinn_ns(ND, N2P)], PinnAct act_, float (&h)[pinn_ns(ND, N2P)], const float* cw = nullptr) {
     using J = PinnJet<ND, N2P, COMB>;
     constexpr int N2 = J::N2, N3 = J::N3, N4 = J::N4;
     const float v = pinn_act(z[0], act_);
-    const int act = act_ & 0xff;                // (PINN_ACT_TANH_POLYBIT concerns the value only)
+    const PinnAct act(act_.c & 0xff, act_.p);   // (PINN_ACT_TANH_POLYBIT concerns the value only)
     float d1, d2;
     pinn_act_d12(pinn_act_saved(v, z[0], act), act, d1, d2);
     h[0] = v;
@@ -524,7 +543,7 @@ PINN_DEVICE void pinn_jet_fwd(const float (&z)[pinn_ns(ND, N2P)], int act_, floa
 
 // activations h[S] recomputed from the saved form (v, z_k, z_kk)
 template <int ND, int N2P, bool COMB = false>
-PINN_DEVICE void pinn_jet_recompute(const float (&sv)[pinn_ns(ND, N2P)], int act, float (&h)[pinn_ns(ND, N2P)],
+PINN_DEVICE void pinn_jet_recompute(const float (&sv)[pinn_ns(ND, N2P)], PinnAct act, float (&h)[pinn_ns(ND, N2P)],
                                     const float* cw = nullptr) {
     using J = PinnJet<ND, N2P, COMB>;
     constexpr int N2 = J::N2, N3 = J::N3, N4 = J::N4;
@@ -558,7 +577,7 @@ PINN_DEVICE void pinn_jet_recompute(const float (&sv)[pinn_ns(ND, N2P)], int act
 
 // reverse jet: gh[S] = dL/dh streams -> gz[S] = dL/dz streams
 template <int ND, int N2P, bool COMB = false>
-PINN_DEVICE void pinn_jet_bwd(const float (&gh)[pinn_ns(ND, N2P)], const float (&sv)[pinn_ns(ND, N2P)], int act,
+PINN_DEVICE void pinn_jet_bwd(const float (&gh)[pinn_ns(ND, N2P)], const float (&sv)[pinn_ns(ND, N2P)], PinnAct act,
                               float (&gz)[pinn_ns(ND, N2P)], const float* cw = nullptr) {
     using J = PinnJet<ND, N2P, COMB>;
     constexpr int N2 = J::N2, N3 = J::N3, N4 = J::N4;
@@ -658,6 +677,29 @@ PINN_DEVICE float pinn_prog_forward(const pinn_program_t& pg, float* regs, int T
 // tools/cfg4_bl_probe.py). A handful of operations per point and step.
 // `regs` / T: the register file -- LDS of the workgroup (register r of this thread at regs[r * T], T = threads; the host checked
 // that a tile's worth of points fits, run_train) or private memory (pinn_aux_kernel: T = 1).
+// sin and cos of a double for the pre-pass: Cody-Waite reduction with pi/2 in two parts (fdlibm's medium path: k * pio2_1 is exact for
+// |k| < 2^20), fdlibm's kernel polynomials on [-pi/4, pi/4] (1e-16) -- a third of the instructions of ocml's sin / cos, which carry the
+// large-argument reduction; beyond |x| = 1e5 the library functions take over. (The fp64 pre-pass cost the one-launch fit chunk of BASELINE
+// config 1 -- 100 points, 13.9 us per iteration -- most of 1.3 us per iteration with the library forms: profiles/r06_small_fit_rate.txt.)
+PINN_DEVICE void pinn_sincos_f64(double x, double& sn, double& cs) {
+    const double kf = rint(x * 6.36619772367581382433e-01);
+    double r = fma(-kf, 1.57079632673412561417e+00, x);
+    r = fma(-kf, 6.07710050650619224932e-11, r);
+    const int k = (int)kf;
+    const double z = r * r;
+    const double sp = fma(z * r, fma(z, fma(z, fma(z, fma(z, fma(z, 1.58969099521155010221e-10, -2.50507602534068634195e-08),
+                                    2.75573137070700676789e-06), -1.98412698298579493134e-04), 8.33333333332248946124e-03),
+                                    -1.66666666666666324348e-01), r);
+    const double cp = fma(z * z, fma(z, fma(z, fma(z, fma(z, fma(z, -1.13596475577881948265e-11, 2.08757232129817482790e-09),
+                                    -2.75573143513906633035e-07), 2.48015872894767294178e-05), -1.38888888888741095749e-03),
+                                    4.16666666666666019037e-02), fma(-0.5, z, 1.0));
+    const double a = (k & 1) ? cp : sp, b = (k & 1) ? sp : cp;
+    sn = (k & 2) ? -a : a;
+    cs = ((k + 1) & 2) ? -b : b;
+}
+PINN_DEVICE double pinn_sin_f64(double x) { if (!(fabs(x) < 1e5)) return sin(x); double s, c; pinn_sincos_f64(x, s, c); return s; }
+PINN_DEVICE double pinn_cos_f64(double x) { if (!(fabs(x) < 1e5)) return cos(x); double s, c; pinn_sincos_f64(x, s, c); return c; }
+
 PINN_DEVICE double pinn_prepass_op(int op, double xa, double xb, double cb) {
     switch (op) {
         case PINN_OP_ADD: return xa + xb;
@@ -665,8 +707,8 @@ PINN_DEVICE double pinn_prepass_op(int op, double xa, double xb, double cb) {
         case PINN_OP_MUL: return xa * xb;
         case PINN_OP_DIV: return xa / xb;
         case PINN_OP_NEG: return -xa;
-        case PINN_OP_SIN: return sin(xa);
-        case PINN_OP_COS: return cos(xa);
+        case PINN_OP_SIN: return pinn_sin_f64(xa);
+        case PINN_OP_COS: return pinn_cos_f64(xa);
         case PINN_OP_EXP: return exp(xa);
         case PINN_OP_LOG: return log(xa);
         case PINN_OP_TANH: return tanh(xa);
@@ -818,7 +860,10 @@ PINN_DEVICE void pinn_point_prefetch(const PinnKArgs& A, const float* params_, l
 template <int ND, int N2P, bool WITH_PROGRAMS = true, bool COMB = false, int SPEC = 0>
 PINN_DEVICE void pinn_point_stage(const PinnKArgs& A, const float* params_, const float (&net)[pinn_ns(ND, N2P)], const float* x /*[d]*/,
                                   long long gidx, bool valid, float* pregs, float* padj, int T,
-                                  const PinnPointPre<ND, N2P>& pre, PinnPointOut<ND, N2P>& out) {
+                                  const PinnPointPre<ND, N2P>& pre, PinnPointOut<ND, N2P>& out, float es_in = -1.0f) {
+    // es_in >= 0: exp(-log_scale), computed ONCE per launch by the caller (PINN_GATE_FAST: the gate's sigmoid then also takes the hardware
+    // exp / rcp the activations use -- the serial point stage of the shape-specialised kernels is a chain of dependent instructions that
+    // three of a team's four waves wait for)
     constexpr int S = pinn_ns(ND, N2P), N2 = pinn_n2(N2P), N3 = pinn_n3(N2P), N4 = pinn_n4(N2P);
     using J = PinnJet<ND, N2P, COMB>;
     using SH = PinnShape<SPEC, ND>;
@@ -929,9 +974,9 @@ PINN_DEVICE void pinn_point_stage(const PinnKArgs& A, const float* params_, cons
     for (int k = 0; k < (N4 > 0 ? N4 : 1); ++k) { G4[k] = 0.0f; dG4[k] = 0.0f; }
     if (SH::has_ic(A)) {
         const int tcol = SH::ndims(A) - 1;
-        const float es = expf(-params_[A.off_ls]);
+        const float es = es_in >= 0.0f ? es_in : expf(-params_[A.off_ls]);
         const float tau = (x[tcol] - A.t0) * es;
-        const float sg = pinn_sigmoidf(tau);
+        const float sg = es_in >= 0.0f ? pinn_rcp(1.0f + pinn_exp2(tau * -1.4426950408889634f)) : pinn_sigmoidf(tau);
         float d1, d2;
         pinn_act_d12(sg, PINN_ACT_SIGMOID, d1, d2);
         const float d3 = pinn_act_d3(sg, d1, d2, PINN_ACT_SIGMOID);
@@ -1218,13 +1263,6 @@ PINN_DEVICE f32x4 pinn_mfma_split6(const pinn_s16x8 (&a)[3], const pinn_s16x8 (&
 // chain pays two wait states between its dependent steps; pinn_port.h)
 // (batching the four DPP chains step-major, pinn_row_sum16_n, measured no difference on the tile kernels: the second wave per SIMD
 //  already covers the wait states -- DESIGN.md section 6a)
-// a double across lanes as two 32-bit moves (end-of-workgroup sums of the head scalars)
-PINN_DEVICE double pinn_shfl_xor_f64(double v, int mask) {
-    const unsigned long long b = __builtin_bit_cast(unsigned long long, v);
-    const unsigned lo = __builtin_bit_cast(unsigned, pinn_shfl_xor(__builtin_bit_cast(float, (unsigned)(b & 0xffffffffull)), mask));
-    const unsigned hi = __builtin_bit_cast(unsigned, pinn_shfl_xor(__builtin_bit_cast(float, (unsigned)(b >> 32)), mask));
-    return __builtin_bit_cast(double, ((unsigned long long)hi << 32) | (unsigned long long)lo);
-}
 PINN_DEVICE f32x4 pinn_row_sum16_v4(f32x4 v) {
 #pragma unroll
     for (int r = 0; r < 4; ++r) v[r] = pinn_row_sum16(v[r]);
@@ -1360,9 +1398,13 @@ PINN_DEVICE void pinn_tile_body(const PinnKArgs& A, const float* params_, float*
     // reference's own instead of 1.7 - 1.9x (bench.py `parity_trained_state`). Not the default: the default form already meets the survey's bar.
     constexpr int TPOLY = (ACTC >= 0 && (ACTC & PINN_ACT_TANH_POLYBIT)) ? PINN_ACT_TANH_POLYBIT : 0;
     constexpr int ACTK = (ACTC >= 0) ? (ACTC & 0xff) : ACTC;          // the activation code proper
-    auto act_at = [&](int a) -> int {
-        return (ACTC >= 0) ? ACTK : (pinn_act_code(A.act_codes, a) & ((SKIPS && !(VAR & 1024)) ? (ALLACT ? 15 : 7) : 1));
+    // (the parameter of a configured LeakyReLU / ELU / Softplus travels with the code in the full breadth kernels -- round 6)
+    auto act_at = [&](int a) -> PinnAct {
+        if (ACTC >= 0) return PinnAct(ACTK);
+        constexpr bool FULL = SKIPS && !(VAR & 1024);
+        return PinnAct(pinn_act_code(A.act_codes, a) & (FULL ? (ALLACT ? 15 : 7) : 1), FULL ? A.act_par[a] : 0.0f);
     };
+    auto with_poly = [&](PinnAct a) -> PinnAct { return PinnAct(a.c | TPOLY, a.p); };
     // skip connection ending / starting at activation a (or -1); slab slot of skip k
     auto skip_into = [&](int a) -> int {
         int k = -1;
@@ -1753,9 +1795,30 @@ PINN_DEVICE void pinn_tile_body(const PinnKArgs& A, const float* params_, float*
 #ifndef PINN_TEAM_SKEW
 #define PINN_TEAM_SKEW 0
 #endif
+    // round 6 micro-structure knobs of the shape-specialised kernels (same-box A/B: profiles/r06_headline_ab.txt):
+    // PINN_PT_WAVE_SPREAD  the point-stage threads of team t sit in wave t: the two teams' serial point stages (one thread per point)
+    //                      then run on DIFFERENT SIMDs instead of time-slicing SIMD 0, which hosts wave 0 of both teams
+    // PINN_GATE_FAST       exp(-log_scale) once per launch, the IC gate's sigmoid on v_exp_f32 / v_rcp_f32
+    // PINN_BIAS_EARLY_LD   the LDS read of the bias / first-layer gradient rows issued in front of the arithmetic whose row sums they
+    //                      receive (inside the `lr == 0` region the read's round trip sat between the sums and the write)
+#ifndef PINN_PT_WAVE_SPREAD
+#define PINN_PT_WAVE_SPREAD 0
+#endif
+#ifndef PINN_GATE_FAST
+#define PINN_GATE_FAST 1
+#endif
+#ifndef PINN_BIAS_EARLY_LD
+#define PINN_BIAS_EARLY_LD 0
+#endif
 #ifndef PINN_NOTOPB
 #define PINN_NOTOPB 0
 #endif
+    // the threads of the serial point stage: lanes [0, T) of wave PTW of the team
+    const int ptw = (TEAMS2 && PINN_PT_WAVE_SPREAD) ? team : 0;            // (wave-uniform)
+    const int ptid = tid - 64 * ptw;
+    const bool pt_thread = ptid >= 0 && ptid < T;
+    // exp(-log_scale) of the IC gate, once per launch (PINN_GATE_FAST; negative: the point stage computes it itself)
+    const float es_gate = (PINN_GATE_FAST && SPEC != 0 && SH::has_ic(A)) ? expf(-params_[A.off_ls]) : -1.0f;
     constexpr int SKEW = (TEAMS2 && !SPLIT) ? PINN_TEAM_SKEW : 0;
     constexpr bool NOTOPB = PINN_NOTOPB != 0;
     if (SKEW > 0 && team == 1)
@@ -1789,7 +1852,7 @@ PINN_DEVICE void pinn_tile_body(const PinnKArgs& A, const float* params_, float*
             for (int mt = 0; mt < MT; ++mt)
                 pinn_point_prefetch<ND, N2, SPEC>(A, params_, base + mt * 16 + lr, base + mt * 16 + lr < A.n_points, pregs, T, ppre_all[mt], aux_);
         } else {
-            if (tid < T) pinn_point_prefetch<ND, N2, SPEC>(A, params_, base + tid, base + tid < A.n_points, pregs + tid, T, ppre, aux_);
+            if (pt_thread) pinn_point_prefetch<ND, N2, SPEC>(A, params_, base + ptid, base + ptid < A.n_points, pregs + ptid, T, ppre, aux_);
         }
         PH(0)
 
@@ -1822,7 +1885,7 @@ PINN_DEVICE void pinn_tile_body(const PinnKArgs& A, const float* params_, float*
             for (int j = 0; j < NTW; ++j) biasn[j] = pinn_ld4(params_ + A.off_wh + HP * HP + unit0(j));
         }
         f32x4 hskip[SKIPS ? NTW : 1][SKIPS ? MT : 1][S];      // activations carried by the open skip connection
-        const int act0 = act_at(0);
+        const PinnAct act0 = act_at(0);
         const bool src_pre0 = SRCPRE && skip_from(0) >= 0 && ((A.skip_src_pre >> skip_from(0)) & 1);
         // ---- (1) first layer on the VALU: z0 = W1 x + b1, z_k = W1[:, col_k], z_kk = 0 ------------------------
 #pragma unroll
@@ -1871,7 +1934,7 @@ PINN_DEVICE void pinn_tile_body(const PinnKArgs& A, const float* params_, float*
                     for (int k = 0; k < ND; ++k) z[1 + k] = pinn_dir_weight(W1s + n * PINN_XS_LD, SH::dir(A, k));
 #pragma unroll
                     for (int s = 1 + ND; s < S; ++s) z[s] = 0.0f;              // z_kk = z_kkk = 0 in the first layer
-                    pinn_jet_fwd<ND, N2, COMB>(z, act0 | TPOLY, h, cw);
+                    pinn_jet_fwd<ND, N2, COMB>(z, with_poly(act0), h, cw);
 #pragma unroll
                     for (int s = 0; s < S; ++s) { hv[s][r] = h[s]; sv[s][r] = (s == 0) ? pinn_act_saved(h[0], z[0], act0) : z[s]; }
                     if (SRCPRE) z0v[r] = z[0];
@@ -1935,7 +1998,8 @@ PINN_DEVICE void pinn_tile_body(const PinnKArgs& A, const float* params_, float*
         for (int li = 0; li < lh; ++li) {
             const float* Wl = params_ + A.off_wh + (size_t)li * A.hidden_stride;
             const float* bl = Wl + HP * HP;
-            const int act = act_at(li + 1), sk_in = skip_into(li + 1), sk_out = skip_from(li + 1);
+            const PinnAct act = act_at(li + 1);
+            const int sk_in = skip_into(li + 1), sk_out = skip_from(li + 1);
             f32x4 acc[NTW][MT][S];
 #pragma unroll
             for (int j = 0; j < NTW; ++j)
@@ -2038,7 +2102,7 @@ PINN_DEVICE void pinn_tile_body(const PinnKArgs& A, const float* params_, float*
 #pragma unroll
                             for (int s = 0; s < S; ++s) z[s] += hin[SKIPS ? s : 0][r];
                         }
-                        pinn_jet_fwd<ND, N2, COMB>(z, act | TPOLY, h, cw);
+                        pinn_jet_fwd<ND, N2, COMB>(z, with_poly(act), h, cw);
 #pragma unroll
                         for (int s = 0; s < S; ++s) { hv[s][r] = h[s]; sv[s][r] = (s == 0) ? pinn_act_saved(h[0], z[0], act) : z[s]; }
                         if (SRCPRE) z0v[r] = z[0];
@@ -2153,14 +2217,14 @@ PINN_DEVICE void pinn_tile_body(const PinnKArgs& A, const float* params_, float*
                 }
                 PinnPointOut<ND, N2> po;
                 pinn_point_stage<ND, N2, false, COMB, SPEC>(A, params_, net, xs_t + pt * PINN_XS_LD, base + pt, base + pt < A.n_points,
-                                                            pregs, padj, T, ppre_all[mt], po);
+                                                            pregs, padj, T, ppre_all[mt], po, es_gate);
 #pragma unroll
                 for (int s = 0; s < S; ++s) gnet_r[PTALL ? mt : 0][s] = po.gnet[s];
-                if (wave == 0 && lq == 0) { sum_loss += po.loss; sum_ls += po.g_ls; sum_bl += po.gnet[0]; }     // (one lane per point counts)
+                if (wave == ptw && lq == 0) { sum_loss += po.loss; sum_ls += po.g_ls; sum_bl += po.gnet[0]; }     // (one lane per point counts)
             }
         } else
-        if (tid < T) {
-            const int pt = tid;
+        if (pt_thread) {
+            const int pt = ptid;
             float net[S];
 #pragma unroll
             for (int s = 0; s < S; ++s) {
@@ -2182,7 +2246,7 @@ PINN_DEVICE void pinn_tile_body(const PinnKArgs& A, const float* params_, float*
 #endif
             PinnPointOut<ND, N2> po;
             pinn_point_stage<ND, N2, SPEC == 0, COMB, SPEC>(A, params_, net, xs_t + pt * PINN_XS_LD, base + pt, base + pt < A.n_points,
-                                     pregs + pt, padj + pt, T, ppre, po);
+                                     pregs + pt, padj + pt, T, ppre, po, es_gate);
 #pragma unroll
             for (int s = 0; s < S; ++s) gnetb[s * T + pt] = po.gnet[s];
             sum_loss += po.loss; sum_ls += po.g_ls; sum_bl += po.gnet[0];
@@ -2250,7 +2314,7 @@ PINN_DEVICE void pinn_tile_body(const PinnKArgs& A, const float* params_, float*
         //          accumulators are addressed statically (they must stay in registers) ----------------------------
         auto act_reverse = [&](int a, f32x4 (&gz)[NTW][MT][S], f32x4 (&bacc)[NTW]) {
             // gz_a = jet-reverse(gh, saved_a);  db_a += sum_pt gz_a,0 (DPP row sum over the 16 points of the lane row)
-            const int act = act_at(a);
+            const PinnAct act = act_at(a);
             if (SKIPS) {
                 // h_out(a) feeds a later '+': its gradient arrives through the skip slot; h_out(a) = act(z_a) + skipped
                 // activations: the whole gradient is handed down the skip (slot re-used: its activations are consumed)
@@ -2278,6 +2342,10 @@ PINN_DEVICE void pinn_tile_body(const PinnKArgs& A, const float* params_, float*
 #pragma unroll
             for (int j = 0; j < NTW; ++j) {
                 f32x4 bsum = f32x4{0.f, 0.f, 0.f, 0.f};
+                // (PINN_BIAS_EARLY_LD: the row this wave adds its bias-gradient sums to, read by every lane -- a broadcast -- in front of the
+                //  jet arithmetic; only this wave writes these units, and LDS executes a wave's accesses in order)
+                f32x4 bold = f32x4{0.f, 0.f, 0.f, 0.f};
+                if (PINN_BIAS_EARLY_LD && !REGB) bold = pinn_ld4(accB + a * HP + unit0(j));
 #pragma unroll
                 for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
@@ -2306,7 +2374,7 @@ PINN_DEVICE void pinn_tile_body(const PinnKArgs& A, const float* params_, float*
                     bsum = pinn_row_sum16_v4(bsum);
                     if (lr == 0) {
                         float* dst = accB + a * HP + unit0(j);
-                        pinn_st4(dst, pinn_ld4(dst) + bsum);
+                        pinn_st4(dst, (PINN_BIAS_EARLY_LD ? bold : pinn_ld4(dst)) + bsum);
                     }
                 }
             }
@@ -2334,7 +2402,7 @@ PINN_DEVICE void pinn_tile_body(const PinnKArgs& A, const float* params_, float*
             //  the data-gradient GEMM and to HBM for that kernel)
             f32x4 hv[NTW][MT][S];               // (WGX: never touched)
             if (!SVPF) load_saved(a - 1, svn);
-            const int act = act_at(a - 1);
+            const PinnAct act = act_at(a - 1);
             int sk_prev = skip_into(a - 1);
             if (SKIPS && sk_prev >= 0 && ((A.skip_pre >> sk_prev) & 1)) sk_prev = -1;      // (joined in front of the activation: h_out = act(z))
 #pragma unroll
@@ -2720,6 +2788,11 @@ PINN_DEVICE void pinn_tile_body(const PinnKArgs& A, const float* params_, float*
                 }
                 for (int c = REGB ? W1R : 0; c < d; ++c) {
                     f32x4 v = f32x4{0.f, 0.f, 0.f, 0.f};
+                    float old_e[4] = {0.f, 0.f, 0.f, 0.f};
+                    if (PINN_BIAS_EARLY_LD) {
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) old_e[r] = accW1[(unit0(j) + r) * PINN_XS_LD + c];
+                    }
 #pragma unroll
                     for (int mt = 0; mt < MT; ++mt) {
                         v += gz[j][mt][0] * xs_t[(mt * 16 + lr) * PINN_XS_LD + c];
@@ -2732,7 +2805,7 @@ PINN_DEVICE void pinn_tile_body(const PinnKArgs& A, const float* params_, float*
                         // (all four reads first: written element by element these are four LDS round trips in a row)
                         float old[4];
 #pragma unroll
-                        for (int r = 0; r < 4; ++r) old[r] = accW1[(unit0(j) + r) * PINN_XS_LD + c];
+                        for (int r = 0; r < 4; ++r) old[r] = PINN_BIAS_EARLY_LD ? old_e[r] : accW1[(unit0(j) + r) * PINN_XS_LD + c];
 #pragma unroll
                         for (int r = 0; r < 4; ++r) accW1[(unit0(j) + r) * PINN_XS_LD + c] = old[r] + v[r];
                     }
@@ -2784,13 +2857,13 @@ PINN_DEVICE void pinn_tile_body(const PinnKArgs& A, const float* params_, float*
     //  per-point terms that cancel, BASELINE config 4's to 1 / 850 of the sum of their magnitudes; with fp32 row sums the lane tree alone
     //  put 3 - 4e-6 relative onto that entry, tools/cfg4_bl_probe.py. Once per workgroup: the cost does not show)
     float tot_loss = 0.0f, tot_ls = 0.0f, tot_bl = 0.0f, tot_ic = 0.0f;
-    if (wave == 0) {
-        double t64[4] = {(tid < T) ? (double)sum_loss : 0.0, (tid < T) ? (double)sum_ls : 0.0, (tid < T) ? (double)sum_bl : 0.0,
-                         (tid < T) ? (double)sum_ic : 0.0};
+    if (wave == ptw) {
+        double t64[4] = {pt_thread ? (double)sum_loss : 0.0, pt_thread ? (double)sum_ls : 0.0, pt_thread ? (double)sum_bl : 0.0,
+                         pt_thread ? (double)sum_ic : 0.0};
 #pragma unroll
-        for (int mask = 1; mask < (T > 16 ? 64 : 16); mask <<= 1) {
-#pragma unroll
-            for (int i = 0; i < 4; ++i) t64[i] += pinn_shfl_xor_f64(t64[i], mask);
+        for (int i = 0; i < 4; ++i) {
+            t64[i] = pinn_row_sum16_f64(t64[i]);                 // (DPP on both halves; no LDS round trips: the one-launch fit chunk of the
+            if (T > 16) t64[i] = pinn_rows_total_f64(t64[i]);    //  narrow nets passes here once per ITERATION)
         }
         tot_loss = (float)t64[0]; tot_ls = (float)t64[1]; tot_bl = (float)t64[2]; tot_ic = (float)t64[3];
     }
@@ -2828,7 +2901,7 @@ PINN_DEVICE void pinn_tile_body(const PinnKArgs& A, const float* params_, float*
                     if (lr == 0) put(part + A.off_wl + unit0(j) + r, v);
                 }
             }
-            if (tid == 0) {
+            if (tid == 64 * ptw) {                  // (lane 0 of the team's point-stage wave holds the totals)
                 put(part + A.off_loss, tot_loss);
                 put(part + A.off_ls, tot_ls);
                 put(part + A.off_bl, tot_bl);

@@ -118,6 +118,34 @@ PINN_DEVICE float pinn_row_sum16(float v) {
     v += __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, v), 0x140, 0xF, 0xF, true));
     return v;
 }
+// ... of a DOUBLE (the head scalars' end-of-workgroup sums, round 6): the two halves through the same DPP moves -- no LDS round trip
+PINN_DEVICE double pinn_dpp_f64(double v, const int ctrl) {
+    const unsigned long long b = __builtin_bit_cast(unsigned long long, v);
+    int lo = (int)(unsigned)(b & 0xffffffffull), hi = (int)(unsigned)(b >> 32);
+    switch (ctrl) {     // (the control word must be an immediate)
+        case 0: lo = __builtin_amdgcn_mov_dpp(lo, 0xB1, 0xF, 0xF, true); hi = __builtin_amdgcn_mov_dpp(hi, 0xB1, 0xF, 0xF, true); break;
+        case 1: lo = __builtin_amdgcn_mov_dpp(lo, 0x4E, 0xF, 0xF, true); hi = __builtin_amdgcn_mov_dpp(hi, 0x4E, 0xF, 0xF, true); break;
+        case 2: lo = __builtin_amdgcn_mov_dpp(lo, 0x141, 0xF, 0xF, true); hi = __builtin_amdgcn_mov_dpp(hi, 0x141, 0xF, 0xF, true); break;
+        default: lo = __builtin_amdgcn_mov_dpp(lo, 0x140, 0xF, 0xF, true); hi = __builtin_amdgcn_mov_dpp(hi, 0x140, 0xF, 0xF, true); break;
+    }
+    return __builtin_bit_cast(double, ((unsigned long long)(unsigned)hi << 32) | (unsigned long long)(unsigned)lo);
+}
+PINN_DEVICE double pinn_row_sum16_f64(double v) {
+    v += pinn_dpp_f64(v, 0); v += pinn_dpp_f64(v, 1); v += pinn_dpp_f64(v, 2); v += pinn_dpp_f64(v, 3);
+    return v;
+}
+// v equal within each 16-lane row -> the sum over the four rows, in every lane (v_readlane: wave-uniform values, no LDS)
+PINN_DEVICE double pinn_rows_total_f64(double v) {
+    const unsigned long long b = __builtin_bit_cast(unsigned long long, v);
+    const int lo = (int)(unsigned)(b & 0xffffffffull), hi = (int)(unsigned)(b >> 32);
+    double t = 0.0;
+#pragma unroll
+    for (int row = 0; row < 4; ++row) {
+        const unsigned l = (unsigned)__builtin_amdgcn_readlane(lo, 16 * row), h = (unsigned)__builtin_amdgcn_readlane(hi, 16 * row);
+        t += __builtin_bit_cast(double, ((unsigned long long)h << 32) | (unsigned long long)l);
+    }
+    return t;
+}
 // the same for N values at once, step-major: N independent adds per DPP step (a lone chain pays two wait states between its
 // dependent DPP steps)
 template <int N>

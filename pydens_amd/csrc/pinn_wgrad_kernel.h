@@ -88,7 +88,7 @@ pinn_wgrad_kernel(const PinnKArgs A) {
 
     for (int li = 0; li < lh; ++li) {
         // layer a = li + 1: A operand gz_a, B operand h_{a-1} = h of activation index li
-        const int act = pinn_act_code(A.act_codes, li) & (HEAVY ? (ALLACT ? 15 : 7) : 1);
+        const PinnAct act(pinn_act_code(A.act_codes, li) & (HEAVY ? (ALLACT ? 15 : 7) : 1), HEAVY ? A.act_par[li] : 0.0f);
         int sk_in = -1;                   // skip that joins behind activation li
         if (SKIPS) for (int i = 0; i < A.n_skips; ++i) if (A.skip_dst[i] == li && !((A.skip_pre >> i) & 1)) sk_in = i;
         f32x4 acc[AM][BN];

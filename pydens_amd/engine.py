@@ -95,6 +95,7 @@ def bind(lib):
     lib.pinn_create_ex.argtypes = [ip, i32, ip, i32, ip, ip, i32, i32, i32, i32, ctypes.POINTER(f32), ctypes.POINTER(f32),
                                    f32, ctypes.POINTER(vp)]
     lib.pinn_destroy.argtypes = [vp]
+    lib.pinn_set_act_params.argtypes = [vp, ctypes.POINTER(f32), i32]
     lib.pinn_layout.argtypes = [vp, ctypes.POINTER(Layout)]
     lib.pinn_workspace_bytes.argtypes = [vp, i64, i32, i32]
     lib.pinn_workspace_bytes.restype = ctypes.c_size_t
@@ -135,6 +136,8 @@ def bind(lib):
     lib.pinn_debug_max_wgs_per_cu.argtypes = [vp, ctypes.c_int]
     lib.pinn_debug_prepass_in_kernel.argtypes = [vp, ctypes.c_int]
     lib.pinn_debug_fit_persistent.argtypes = [vp, ctypes.c_int]
+    lib.pinn_fit_chunk_status.argtypes = []
+    lib.pinn_fit_chunk_status.restype = ctypes.c_int
     if hasattr(lib, 'pinn_debug_fit_onecu_rounds'):              # (experiment builds of older sources, tools/variant.sh, lack the knob)
         lib.pinn_debug_fit_onecu_rounds.argtypes = [vp, ctypes.c_int]
     lib.pinn_last_launch_info.argtypes = [ctypes.POINTER(ctypes.c_int32)]
@@ -148,7 +151,7 @@ def bind(lib):
 ABI_SYMBOLS = ('pinn_create', 'pinn_create_ex', 'pinn_destroy', 'pinn_layout', 'pinn_workspace_bytes', 'pinn_jet_forward', 'pinn_jet_forward_ws',
                'pinn_jet_backward', 'pinn_residual_step', 'pinn_residual_step_add', 'pinn_residual_adam_step', 'pinn_adam_step', 'pinn_adam_step_at', 'pinn_sample_points', 'pinn_fit_steps', 'pinn_fit_steps_graph', 'pinn_fit_ctrl_bytes', 'pinn_set_gemm_mode', 'pinn_set_tanh_mode', 'pinn_profile_tile',
                'pinn_last_tile_ms', 'pinn_last_wgrad_ms', 'pinn_last_kernel_name', 'pinn_last_wgrad_kernel_name', 'pinn_debug_last_kernel',
-               'pinn_debug_prepass_in_kernel', 'pinn_debug_wgx_chunk_bytes', 'pinn_debug_max_wgs_per_cu', 'pinn_debug_fit_persistent', 'pinn_debug_fit_onecu_rounds', 'pinn_debug_fit_graph_stats', 'pinn_last_launch_info',
+               'pinn_debug_prepass_in_kernel', 'pinn_debug_wgx_chunk_bytes', 'pinn_debug_max_wgs_per_cu', 'pinn_debug_fit_persistent', 'pinn_fit_chunk_status', 'pinn_set_act_params', 'pinn_debug_fit_onecu_rounds', 'pinn_debug_fit_graph_stats', 'pinn_last_launch_info',
                'pinn_last_error', 'pinn_backend')
 
 _LIB = None
@@ -215,6 +218,16 @@ class Net:
         names = [activation] * n_hidden if isinstance(activation, str) else list(activation)
         if len(names) != n_hidden:
             raise ValueError(f'{n_hidden} hidden layers need {n_hidden} activations, got {names}')
+        # 'Name:value': an activation with its one parameter (LeakyReLU negative_slope / ELU alpha / Softplus beta; include/pinn.h
+        # pinn_set_act_params) -- what model._activation_name makes of a module instance configured away from torch's default
+        par_default = {'leakyrelu': 0.01, 'elu': 1.0, 'softplus': 1.0}
+        pars = []
+        for i, name in enumerate(names):
+            base, _, value = str(name).partition(':')
+            if value and base.lower() not in par_default:
+                raise NotImplementedError(f'activation {name!r}: only LeakyReLU, ELU and Softplus take a parameter')
+            pars.append(float(value) if value else par_default.get(base.lower(), 0.0))
+            names[i] = base
         codes = [ACT_CODES.get(str(name).lower()) for name in names]
         if None in codes:
             raise NotImplementedError(f'activation {names[codes.index(None)]!r}: the HIP kernels implement '
@@ -237,6 +250,9 @@ class Net:
                                      int(has_ic), lo, hi, float(bc_value), ctypes.byref(handle))
         self._raise(rc)
         self.handle = handle
+        self.act_params = pars
+        if any(p != par_default.get(str(n).lower(), 0.0) for p, n in zip(pars, names)):
+            self._raise(self.lib.pinn_set_act_params(self.handle, (ctypes.c_float * max(1, n_hidden))(*pars), n_hidden))
         lay = Layout()
         self._raise(self.lib.pinn_layout(self.handle, ctypes.byref(lay)))
         self.layout = lay

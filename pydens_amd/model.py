@@ -111,18 +111,22 @@ class FlatLinear(nn.Module):
 
 def _activation_name(act):
     """ what `getattr(nn, activation)()` / a module class / a module instance / a torch function names (model_torch.py:159, :164-168) ->
-    the kernels' activation name. The kernels implement the torch-DEFAULT form of each; an instance configured otherwise is refused. """
+    the kernels' activation name (`Name:value` for a LeakyReLU / ELU / Softplus instance with a non-default negative_slope / alpha / beta). """
     if isinstance(act, str):
         return act
     if isinstance(act, type):
         return act.__name__
     if isinstance(act, nn.Module):
-        defaults = {nn.Softplus: dict(beta=1, threshold=20), nn.LeakyReLU: dict(negative_slope=0.01), nn.ELU: dict(alpha=1.0)}
-        for cls, want in defaults.items():
+        # instances configured away from torch's defaults (round 6): the ONE parameter of LeakyReLU / ELU / Softplus travels with the name
+        # as 'Name:value' (engine.Net -> pinn_set_act_params); Softplus' threshold stays 20
+        if isinstance(act, nn.Softplus) and float(act.threshold) != 20.0:
+            raise NotImplementedError(f'nn.Softplus(threshold={act.threshold}): the HIP kernels implement threshold 20 (any beta)')
+        for cls, key, default in ((nn.Softplus, 'beta', 1.0), (nn.LeakyReLU, 'negative_slope', 0.01), (nn.ELU, 'alpha', 1.0)):
             if isinstance(act, cls):
-                got = {k: getattr(act, k) for k in want}
-                if any(float(got[k]) != float(v) for k, v in want.items()):
-                    raise NotImplementedError(f'nn.{cls.__name__} with {got}: the HIP kernels implement the default form ({want}) only')
+                value = float(getattr(act, key))
+                if cls is nn.Softplus and not value > 0.0:
+                    raise NotImplementedError(f'nn.Softplus(beta={value}): beta must be positive')
+                return cls.__name__ if value == default else f'{cls.__name__}:{value!r}'
         if isinstance(act, nn.GELU) and getattr(act, 'approximate', 'none') != 'none':
             if act.approximate != 'tanh':
                 raise NotImplementedError(f'nn.GELU(approximate={act.approximate!r}) is not implemented by the HIP kernels')
@@ -254,7 +258,9 @@ class KernelBlock(nn.Sequential):
 class ConvBlockModel(TorchModel):
     """ reference model_torch.py:130-172 for fully connected layouts. """
     def __init__(self, ndims, initial_condition=None, boundary_condition=None, domain=(0, 1), nparams=0,
-                 layout='fafaf', features=(20, 30, 1), activation='Sigmoid', device=None, lib=None, **kwargs):
+                 layout='fafaf', features=(20, 30, 1), activation='Sigmoid', device=None, _lib=None, **kwargs):
+        # (`_lib`: TEST HOOK, not part of the reference's surface -- the CPU test tier hands over the emulator build of the same C-ABI,
+        #  tools/ an experiment build; the product loads pydens_amd/libpinn_hip.so itself and refuses anything but the gfx950 backend)
         features = kwargs.pop('units', features)                  # README.md:41-42 spells it `units`
         super().__init__(ndims=ndims, initial_condition=initial_condition, boundary_condition=boundary_condition,
                          domain=domain, nparams=nparams, **kwargs)
@@ -270,7 +276,7 @@ class ConvBlockModel(TorchModel):
         bare = self.custom_forward
         self.net = engine.Net(self.layer_dims, act_names, ndims, nparams,
                               has_bc=boundary_condition is not None and not bare, bc_value=(boundary_condition or 0.0) if not bare else 0.0,
-                              has_ic=initial_condition is not None and not bare, domain=self.domain, lib=lib, skips=skips)
+                              has_ic=initial_condition is not None and not bare, domain=self.domain, lib=_lib, skips=skips)
         lay = self.net.layout
         # flat kernel buffer; PyTorch-default nn.Linear init drawn in the reference's order
         # (fake inputs first, model_torch.py:167, then the layers of Block, :168)

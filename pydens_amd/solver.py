@@ -765,6 +765,10 @@ class Solver:
                                         adam.exp_avg_sq, adam.mask, adam.step_count, adam.t + 1, adam.lr, adam.betas, adam.eps,
                                         history[it:it + k], k, dir_cols=spec.dir_cols, n2=n2, ic_const=model.kernel_ic_const(),
                                         stream=stream, ctrl=ctrl)
+                    if os.environ.get('PYDENS_AMD_FIT_PERSIST') == '1' and model.net.lib.pinn_fit_chunk_status() != 0:
+                        # the opt-in GRID form of the one-launch chunk gave up at its device-wide wait: nothing of the chunk was applied
+                        # (include/pinn.h pinn_fit_chunk_status; the check synchronises with the device once per chunk)
+                        raise RuntimeError('libpinn: ' + model.net.lib.pinn_last_error().decode())
                 except BaseException:
                     # the library stopped inside the chunk (or an interrupt landed around the call): the device knows how many
                     # Adam steps it applied -- the host's step number and the batch counters follow IT, so that a later

@@ -531,7 +531,10 @@ class _Emitter:
         self._alive = []
 
     def const_slot(self, v):
-        key = float(np.float32(v))
+        # (unrounded: the x-only pre-pass runs in fp64 and reads its constants as doubles -- pinn_residual_t::pre_consts64; the fp32
+        #  main program gets them rounded once, when engine.Program stores them. Rounded to fp32 HERE, round 6's first fp64 pre-pass
+        #  still carried half of the systematic error of fl32(pi) in e pi cos(e pi x): tools/cfg4_bl_probe.py)
+        key = float(v)
         if key not in self._cidx:
             if len(self.consts) >= MAX_CONSTS:
                 raise TraceUnsupported('too many constants')

@@ -82,6 +82,18 @@ static inline float pinn_rows_sum(float x) {
     return x;
 }
 static inline float pinn_row_sum16(float v) { return emu::row_sum16(v); }
+// (doubles across lanes: two 32-bit exchanges per step, like the device's DPP / readlane forms in pinn_port.h)
+static inline double pinn_emu_shfl_xor_f64(double v, int mask) {
+    unsigned long long b; memcpy(&b, &v, 8);
+    unsigned lo = (unsigned)(b & 0xffffffffull), hi = (unsigned)(b >> 32);
+    float flo, fhi; memcpy(&flo, &lo, 4); memcpy(&fhi, &hi, 4);
+    flo = emu::shfl_xor(flo, mask); fhi = emu::shfl_xor(fhi, mask);
+    memcpy(&lo, &flo, 4); memcpy(&hi, &fhi, 4);
+    b = ((unsigned long long)hi << 32) | lo;
+    double r; memcpy(&r, &b, 8); return r;
+}
+static inline double pinn_row_sum16_f64(double v) { for (int m = 1; m < 16; m <<= 1) v += pinn_emu_shfl_xor_f64(v, m); return v; }
+static inline double pinn_rows_total_f64(double v) { v += pinn_emu_shfl_xor_f64(v, 16); v += pinn_emu_shfl_xor_f64(v, 32); return v; }
 template <int N> static inline void pinn_row_sum16_n(float (&v)[N]) {
     for (int i = 0; i < N; ++i) v[i] = emu::row_sum16(v[i]);
 }

@@ -50,6 +50,23 @@ def test_create_rejects_what_the_kernels_do_not_instantiate(lib):
     assert lib.pinn_create_ex(bad, 2, None, 0, None, None, 2, 0, 0, 0, None, None, 0.0, None) != 0
 
 
+def test_activation_parameters_are_validated(lib):
+    """ pinn_set_act_params (round 6): one value per activation, only where the activation takes one, Softplus beta positive """
+    from pydens_amd import engine
+    net = engine.Net([2, 8, 8, 1], ['LeakyReLU:0.2', 'Softplus:2.0'], 2, lib=lib)
+    assert net.act_params == [0.2, 2.0] and net.allact
+    f3 = ctypes.c_float * 3
+    assert lib.pinn_set_act_params(net.handle, f3(0.2, 2.0, 0.0), 3) != 0 and 'activations' in _err(lib)          # wrong count
+    f2 = ctypes.c_float * 2
+    assert lib.pinn_set_act_params(net.handle, f2(0.2, -1.0), 2) != 0 and 'beta' in _err(lib)
+    assert lib.pinn_set_act_params(net.handle, f2(0.3, 1.5), 2) == 0
+    tanh = engine.Net([2, 8, 8, 1], 'tanh', 2, lib=lib)
+    assert lib.pinn_set_act_params(tanh.handle, f2(0.5, 0.0), 2) != 0 and 'takes no parameter' in _err(lib)
+    assert lib.pinn_set_act_params(tanh.handle, f2(0.0, 0.0), 2) == 0
+    with pytest.raises(NotImplementedError):
+        engine.Net([2, 8, 1], 'Tanh:0.5', 2, lib=lib)
+
+
 def test_layout_is_consistent(lib):
     net = _net(lib, (3, 20, 20, 20, 1), ndims=2, nparams=1)
     lay = net.layout

@@ -17,7 +17,10 @@ class _Sin(nn.Module):
 
 MODULES = {'sin': _Sin(), 'tanh': nn.Tanh(), 'sigmoid': nn.Sigmoid(), 'softplus': nn.Softplus(), 'silu': nn.SiLU(), 'gelu': nn.GELU(),
            'relu': nn.ReLU(), 'leakyrelu': nn.LeakyReLU(), 'elu': nn.ELU(), 'selu': nn.SELU(), 'softsign': nn.Softsign(),
-           'tanhshrink': nn.Tanhshrink(), 'logsigmoid': nn.LogSigmoid(), 'gelu_tanh': nn.GELU(approximate='tanh'), 'mish': nn.Mish()}
+           'tanhshrink': nn.Tanhshrink(), 'logsigmoid': nn.LogSigmoid(), 'gelu_tanh': nn.GELU(approximate='tanh'), 'mish': nn.Mish(),
+           # round 6: module instances configured away from torch's defaults ('name:value', pinn_set_act_params)
+           'leakyrelu:0.2': nn.LeakyReLU(0.2), 'elu:0.5': nn.ELU(alpha=0.5), 'softplus:2.0': nn.Softplus(beta=2), 'softplus:0.5': nn.Softplus(beta=0.5),
+           'elu:1.7': nn.ELU(alpha=1.7)}
 
 
 @pytest.mark.parametrize('name', sorted(MODULES))
@@ -50,8 +53,12 @@ def test_activation_names_the_host_accepts():
                         (nn.Softplus(), 'Softplus'), (torch.sin, 'Sin'), (F.logsigmoid, 'LogSigmoid'), (nn.Tanhshrink, 'Tanhshrink')]:
         name = _activation_name(given)
         assert name == want and name.lower() in ACT_CODES, (given, name)
-    # the kernels implement torch's DEFAULT form of each: an instance configured otherwise is refused loudly, not approximated
-    for bad in (nn.LeakyReLU(0.2), nn.ELU(alpha=0.5), nn.Softplus(beta=2), nn.PReLU()):
+    # round 6: LeakyReLU / ELU / Softplus instances carry their one parameter with the name
+    for given, want in [(nn.LeakyReLU(0.2), 'LeakyReLU:0.2'), (nn.ELU(alpha=0.5), 'ELU:0.5'), (nn.Softplus(beta=2), 'Softplus:2.0'),
+                        (nn.ELU(alpha=1.0), 'ELU')]:
+        assert _activation_name(given) == want
+    # what the kernels do not implement is refused loudly, not approximated
+    for bad in (nn.Softplus(threshold=5), nn.Softplus(beta=-1), nn.PReLU()):
         with pytest.raises(NotImplementedError):
             name = _activation_name(bad)
             if name.lower() not in ACT_CODES:

@@ -36,7 +36,7 @@ def test_chain_kernel_matches_the_oracle(chain_lib, name, n):
     torch.manual_seed(0)
     co, cp = pc.make_config(name, po.D, torch), pc.make_config(name, pa.D, torch)
     oracle = po.OracleSolver(co['equation'], **co['solver_kwargs'])
-    solver = pa.Solver(cp['equation'], **cp['solver_kwargs'], lib=chain_lib, device='cpu')
+    solver = pa.Solver(cp['equation'], **cp['solver_kwargs'], _lib=chain_lib, device='cpu')
     load_params(solver, oracle.export_params())
     pts = pc.sample_points(co, n, seed=3, steps=3)
     oracle.fit(niters=3, batch_size=n, points=pts, lr=0.01)
@@ -64,7 +64,7 @@ def test_experiment_build_knobs_keep_parity():
         pts = pc.sample_points(co, n, seed=5, steps=2)
         runs = []
         for lib in libs:
-            solver = pa.Solver(cp['equation'], **cp['solver_kwargs'], lib=lib, device='cpu')
+            solver = pa.Solver(cp['equation'], **cp['solver_kwargs'], _lib=lib, device='cpu')
             load_params(solver, oracle.export_params())
             solver.fit(niters=2, batch_size=n, sampler=FixedBatches(pts), lr=0.01)
             assert solver.last_fit_path == 'fused'

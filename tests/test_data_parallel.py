@@ -57,7 +57,7 @@ def _problem(path, pa, lib):
     from helpers import make_solver
     if path in ('fused', 'generic', 'fused_uneven', 'generic_uneven', 'fused_1003', 'generic_1003'):
         g = Golden('cfg1')
-        _, solver = make_solver('cfg1', pa, lib=lib, device='cpu')
+        _, solver = make_solver('cfg1', pa, _lib=lib, device='cpu')
         if path.startswith('generic'):
             solver.program = None
         # `_uneven`: 99 points per iteration on two ranks -- shares of 50 and 49 points, weighted by the GLOBAL count
@@ -75,7 +75,7 @@ def _problem(path, pa, lib):
         torch.manual_seed(5)
         eq = lambda f, x, t: pa.D(f, t) - 0.1 * pa.D(pa.D(f, x), x) + f * f
         solver = pa.Solver(eq, ndims=2, boundary_condition=0.2, initial_condition=lambda x: torch.sin(np.pi * x), model=Scaled,
-                           layout='fa fa f', features=[12, 10, 1], activation='Tanh', lib=lib, device='cpu')
+                           layout='fa fa f', features=[12, 10, 1], activation='Tanh', _lib=lib, device='cpu')
         rng = np.random.RandomState(6)
         start = [np.asarray(rng.randn(*p.shape) * 0.5, dtype=np.float32) for p in export_params_of(solver)]
         return solver, rng.rand(3, 32, 2).astype(np.float32), dict(lr=0.02), start
@@ -85,7 +85,7 @@ def _problem(path, pa, lib):
     torch.manual_seed(21)
     eq, con = _variable_problem(pa.D, pa.V, torch)
     solver = pa.Solver(eq, constraints=con, ndims=1, initial_condition=1, layout='fafaf', features=[12, 10, 1],
-                       activation='Tanh', lib=lib, device='cpu')
+                       activation='Tanh', _lib=lib, device='cpu')
     solver.use_fused = path == 'constraint_fused'
     rng = np.random.RandomState(3)
     start = [np.asarray(rng.randn(*p.shape) * 0.5, dtype=np.float32) for p in export_params_of(solver)]

@@ -88,11 +88,11 @@ def emu_lib():
 @pytest.mark.parametrize('name', sorted(CASES))
 def test_edge_shape_on_the_emulated_kernels(name, emu_lib):
     import pydens_amd as pa
-    kernel = _run(pa, name, dict(lib=emu_lib, device='cpu'), batch=37 if 'width_100' not in name else 19)
+    kernel = _run(pa, name, dict(_lib=emu_lib, device='cpu'), batch=37 if 'width_100' not in name else 19)
     if 'two_teams' in name:
         assert kernel.rstrip('>').endswith(('272', '304')), kernel                               # VAR 16 | 256, 48 | 256
-        _run(pa, name, dict(lib=emu_lib, device='cpu'), batch=5)                                 # less than one tile
-        _run(pa, name, dict(lib=emu_lib, device='cpu'), batch=97)                                # 7 / 4 tiles on 2 x 2 teams
+        _run(pa, name, dict(_lib=emu_lib, device='cpu'), batch=5)                                 # less than one tile
+        _run(pa, name, dict(_lib=emu_lib, device='cpu'), batch=97)                                # 7 / 4 tiles on 2 x 2 teams
 
 
 @pytest.mark.gpu

@@ -2,7 +2,7 @@
 (tests/emu): same pinn_kernel.h / pinn_abi.cpp as libpinn_hip.so, compiled for the host with an emulated
 v_mfma_f32_16x16x4_f32, barriers and DPP row sums. What they pin here, without a GPU: tile indexing, lane maps,
 the reverse sweep, the residual interpreter, Adam, the Python host (Solver/D/V/tracer) and the data-parallel path.
-The product never loads this library (it is injected with `lib=`); the GPU parity tests are in test_gpu_parity.py. """
+The product never loads this library (it is injected with the private `_lib=` test hook); the GPU parity tests are in test_gpu_parity.py. """
 import ctypes
 import os
 import sys
@@ -34,7 +34,7 @@ def pa():
 
 
 def emu_kwargs(lib):
-    return dict(lib=lib, device='cpu')
+    return dict(_lib=lib, device='cpu')
 
 
 @pytest.mark.parametrize('name', ['cfg1', 'cfg2', 'cfg3', 'cfg4', 'ode_sigmoid', 'mixed', 'heat3d', 'kdv', 'resnet3'])

@@ -163,7 +163,7 @@ def test_random_equations_on_the_emulated_kernels(path):
     import build_emu
     import pydens_amd as pa
     from pydens_amd import engine
-    _run(pa, dict(lib=engine.bind(ctypes.CDLL(build_emu.build())), device='cpu'), n_trees=40, batch=23, fused=path == 'fused')
+    _run(pa, dict(_lib=engine.bind(ctypes.CDLL(build_emu.build())), device='cpu'), n_trees=40, batch=23, fused=path == 'fused')
 
 
 @pytest.mark.gpu
@@ -182,7 +182,7 @@ def test_random_third_order_equations_on_the_emulated_kernels(path):
     import build_emu
     import pydens_amd as pa
     from pydens_amd import engine
-    _run(pa, dict(lib=engine.bind(ctypes.CDLL(build_emu.build())), device='cpu'), n_trees=40, batch=23, fused=path == 'fused', third=True)
+    _run(pa, dict(_lib=engine.bind(ctypes.CDLL(build_emu.build())), device='cpu'), n_trees=40, batch=23, fused=path == 'fused', third=True)
 
 
 @pytest.mark.gpu
@@ -267,7 +267,7 @@ def test_random_layouts_on_the_emulated_kernels():
     import build_emu
     import pydens_amd as pa
     from pydens_amd import engine
-    _run_layouts(pa, dict(lib=engine.bind(ctypes.CDLL(build_emu.build())), device='cpu'), n_nets=20, batch=21)
+    _run_layouts(pa, dict(_lib=engine.bind(ctypes.CDLL(build_emu.build())), device='cpu'), n_nets=20, batch=21)
 
 
 @pytest.mark.gpu
@@ -355,7 +355,7 @@ def test_random_problem_shapes_on_the_emulated_kernels():
     import build_emu
     import pydens_amd as pa
     from pydens_amd import engine
-    _run_problems(pa, dict(lib=engine.bind(ctypes.CDLL(build_emu.build())), device='cpu'), n_problems=6, max_batch=65)
+    _run_problems(pa, dict(_lib=engine.bind(ctypes.CDLL(build_emu.build())), device='cpu'), n_problems=6, max_batch=65)
 
 
 @pytest.mark.gpu

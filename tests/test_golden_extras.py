@@ -22,6 +22,7 @@ EXPECT = {  # name: (fit path, [packed second/third/fourth-order counts of the k
     'nested_acts': ('fused', None, True),
     'mixed3': ('generic', None, False),
     'biharm': ('generic', [73, 73, 73, 73], False),
+    'act_params': ('fused', None, True),        # round 6: Softplus(beta) / ELU(alpha) / LeakyReLU(negative_slope) instances
 }
 FIT_RTOL = 2e-5
 

@@ -412,6 +412,7 @@ def test_layout_breadth_matches_the_oracle(pa, net, which):
     pts = np.random.RandomState(10).rand(3, 700, 2).astype(np.float32)
     start = oracle.export_params()
     oracle.fit(niters=3, batch_size=700, points=pts, lr=0.01)
+    arb = {}
     for path in ('fused', 'generic'):
         solver = pa.Solver(eq_p, **kw)
         assert solver.program is not None, solver.program_error
@@ -421,12 +422,24 @@ def test_layout_breadth_matches_the_oracle(pa, net, which):
         solver.fit(niters=3, batch_size=700, sampler=FixedBatches(pts), lr=0.01)
         assert solver.last_fit_path == path
         np.testing.assert_allclose([float(v) for v in solver.losses], [float(v) for v in oracle.losses], rtol=3e-5)
-        for got, want in zip(export_params(solver), oracle.export_params()):
+        for i, (got, want) in enumerate(zip(export_params(solver), oracle.export_params())):
             # (three Adam steps of size lr = 0.01: from the second step on an entry moves by lr * f(g2 / g1), so the
             #  1e-4-level relative noise two fp32 implementations have on SMALL gradient entries of a second-order residual
             #  shows up as ~3e-6 absolute per entry, whatever the entry's own size -- hence the absolute term; a wrong
-            #  update rule is off by lr * O(0.1 .. 1) = 1e-3 .. 1e-2. The losses above are the sharp check.)
-            assert params_close(got, want, 3e-5, atol=2e-5)
+            #  update rule is off by lr * O(0.1 .. 1) = 1e-3 .. 1e-2. The losses above are the sharp check.
+            #  Round 6: where the fp32 reference is the noisy side the fp64 trajectory arbitrates, like in the fuzz sweeps --
+            #  `skip_to_top_wide` on the Poisson problem tripped the plain bound when the pre-pass constants stopped being
+            #  rounded to fp32: a change of the source term in its last bits, amplified by Adam in entries with near-zero gradient)
+            def o64(i=i):
+                if 'o' not in arb:
+                    o = po.OracleSolver(eq_o, dtype=torch.float64, **te._layout_problems(po.D, torch, which, te.LAYOUTS[net])[1])
+                    o.import_params(start)
+                    o.fit(niters=3, batch_size=700, points=pts, lr=0.01)
+                    arb['o'] = o.export_params()
+                return arb['o'][i]
+            ok, err, arbitrated = close_or_arbitrated(got, want, o64, 3e-5, atol=2e-5, adam_move=3 * 0.01)
+            record_margin('layout_breadth', (which, net, path, i), 'parameters', err, 3e-5, arbitrated)
+            assert ok, (which, net, path, i, err)
     xs = [pts[0][:, i] for i in range(2)]
     assert np.abs(solver.predict(*xs) - oracle.predict(*xs)).max() < 2e-5
 
@@ -866,7 +879,7 @@ def test_prepass_with_more_registers_than_a_full_sweep_holds_on_the_gpu(pa):
     te._wide_prepass_case(pa, {})
 
 
-@pytest.mark.parametrize('name', ['nested_acts', 'mixed3', 'biharm'])
+@pytest.mark.parametrize('name', ['nested_acts', 'mixed3', 'biharm', 'act_params'])
 def test_breadth_features_match_reference_golden_on_the_gpu(pa, name):
     """ round 5 breadth (nested skips + second-set activations, mixed third order, fourth order) against the fixtures generated from the
     unmodified reference: predict, loss, gradients, K-step trajectory (tests/test_golden_extras.py holds the case) """

@@ -16,7 +16,7 @@ sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), 'emu
 def kw():
     import build_emu
     from pydens_amd import engine
-    return dict(lib=engine.bind(ctypes.CDLL(build_emu.build())), device='cpu')
+    return dict(_lib=engine.bind(ctypes.CDLL(build_emu.build())), device='cpu')
 
 
 def _ode(pa):

@@ -71,7 +71,7 @@ def test_solver_draws_default_and_product_samplers_with_the_kernel(emu_net):
     import pydens_amd as pa
     torch.manual_seed(3)
     solver = pa.Solver(lambda u, x, e: pa.D(u, x) - e * torch.cos(e * x), ndims=1, nparams=1, initial_condition=2.0,
-                       layout='faf', features=[8, 1], activation='Tanh', lib=emu_net.lib, device='cpu')
+                       layout='faf', features=[8, 1], activation='Tanh', _lib=emu_net.lib, device='cpu')
     xs = solver._sample(500, None)
     want = philox.sample_points(500, [(0, 0.0, 1.0)] * 2, solver._sample_seed, 0)
     assert np.array_equal(xs.numpy(), want) and solver._sample_calls == 1

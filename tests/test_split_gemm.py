@@ -33,7 +33,7 @@ def pa():
 @pytest.mark.parametrize('name', ['cfg2', 'cfg4', 'cfg3', 'cfg5'])
 def test_split_kernels_follow_the_reference_goldens(pa, emu_lib, name):
     g = Golden(name)
-    _, solver = make_solver(name, pa, gemm='bf16x3', lib=emu_lib, device='cpu')
+    _, solver = make_solver(name, pa, gemm='bf16x3', _lib=emu_lib, device='cpu')
     load_params(solver, g.params)
     xs = torch.from_numpy(g.points[0].copy())
     solver._fused_step(xs, 1)
@@ -61,7 +61,7 @@ def test_split_kernels_follow_the_reference_goldens(pa, emu_lib, name):
 def test_split_kernels_on_ragged_batches(pa, emu_lib, name, n):
     """ tail tiles, a lone team, empty rounds of the second team: the split kernel against the exact one on the same points """
     torch.manual_seed(3)
-    cfg, solver = make_solver(name, pa, lib=emu_lib, device='cpu')
+    cfg, solver = make_solver(name, pa, _lib=emu_lib, device='cpu')
     pts = torch.from_numpy(pc.sample_points(cfg, n, seed=21))
     out = {}
     for gemm in ('fp32', 'bf16x3'):
@@ -78,7 +78,7 @@ def test_shapes_without_a_split_kernel_keep_the_fp32_kernels(pa, emu_lib):
     """ the mode is a request: nets / problems the split kernels are not built for run the exact kernels, unchanged """
     for name in ('cfg1', 'ode_sigmoid'):
         g = Golden(name)
-        _, solver = make_solver(name, pa, lib=emu_lib, device='cpu')
+        _, solver = make_solver(name, pa, _lib=emu_lib, device='cpu')
         load_params(solver, g.params)
         xs = torch.from_numpy(g.points[0].copy())
         solver._fused_step(xs, 1)
@@ -96,7 +96,7 @@ def test_shapes_without_a_split_kernel_keep_the_fp32_kernels(pa, emu_lib):
 def test_split_mode_survives_the_generic_path_and_predict(pa, emu_lib):
     """ forward-only and backward-only launches (predict, the generic step path) have no split instantiation: same results """
     g = Golden('cfg2')
-    _, solver = make_solver('cfg2', pa, gemm='bf16x3', lib=emu_lib, device='cpu')
+    _, solver = make_solver('cfg2', pa, gemm='bf16x3', _lib=emu_lib, device='cpu')
     load_params(solver, g.params)
     pts = g.points
     pred = solver.predict(*[pts[1][:, i] for i in range(pts.shape[2])])

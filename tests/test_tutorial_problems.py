@@ -120,7 +120,7 @@ def emu_lib():
 @pytest.mark.parametrize('name', NAMES)
 def test_notebook_problem_on_the_emulated_kernels(name, emu_lib):
     import pydens_amd as pa
-    _run(pa, name, dict(lib=emu_lib, device='cpu'))
+    _run(pa, name, dict(_lib=emu_lib, device='cpu'))
 
 
 @pytest.mark.gpu

@@ -40,7 +40,7 @@ for name, iters, batch in (('cfg2', 600, 4096), ('cfg4', 400, 4096), ('cfg3', 15
     for path, gemm in [(p, m) for p in (libs or [None]) for m in (('fp32', 'bf16x3') if name in ('cfg2', 'cfg4') else ('fp32',))]:
         solver = trainer
         if path is not None:
-            _, solver = make_solver(name, pa, lib=engine.bind(ctypes.CDLL(path)))
+            _, solver = make_solver(name, pa, _lib=engine.bind(ctypes.CDLL(path)))
             load_params(solver, params)
         solver.set_gemm_mode(gemm)
         solver._fused_step(torch.from_numpy(pts).cuda(), 1)

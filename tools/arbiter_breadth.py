@@ -40,7 +40,7 @@ for name in want:
         for path in libs:
             solver = trainer
             if path is not None:
-                solver = pa.Solver(cfg['equation'], **cfg['solver_kwargs'], lib=engine.bind(ctypes.CDLL(path)))
+                solver = pa.Solver(cfg['equation'], **cfg['solver_kwargs'], _lib=engine.bind(ctypes.CDLL(path)))
                 load_params(solver, params)
                 for vname in getattr(trainer.model, 'variables', {}):
                     getattr(solver.model, vname).data.copy_(getattr(trainer.model, vname).detach())

@@ -41,7 +41,7 @@ def main():
     lib = engine.bind(ctypes.CDLL(args.lib))
     torch.manual_seed(0)
     cfg = pc.make_config(args.workload, pa.D, torch, V=pa.V)
-    solver = pa.Solver(cfg['equation'], **cfg['solver_kwargs'], lib=lib)
+    solver = pa.Solver(cfg['equation'], **cfg['solver_kwargs'], _lib=lib)
     lib.pinn_debug_max_wgs_per_cu(solver.model.net.handle, args.cap)
     solver.set_gemm_mode(args.gemm)
     n = min(cfg['n_points'], 131072)

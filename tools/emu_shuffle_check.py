@@ -18,7 +18,7 @@ def grads(name, n, shuffle):
     else: os.environ.pop('PINN_EMU_SHUFFLE', None)
     torch.manual_seed(0)
     cfg = pc.make_config(name, pa.D, torch)
-    s = pa.Solver(cfg['equation'], **cfg['solver_kwargs'], lib=lib, device='cpu')
+    s = pa.Solver(cfg['equation'], **cfg['solver_kwargs'], _lib=lib, device='cpu')
     pts = torch.from_numpy(pc.sample_points(cfg, n, seed=1))
     s._fused_step(pts, 1)
     return s.grads.clone().numpy(), lib.pinn_last_kernel_name().decode()

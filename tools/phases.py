@@ -21,7 +21,7 @@ lib = engine.bind(ctypes.CDLL(lib_path))
 lib.pinn_debug_phase_buffer.argtypes = [ctypes.c_void_p]
 torch.manual_seed(0)
 cfg = pc.make_config(cfg_name, pa.D, torch)
-solver = pa.Solver(cfg['equation'], **cfg['solver_kwargs'], lib=lib)
+solver = pa.Solver(cfg['equation'], **cfg['solver_kwargs'], _lib=lib)
 n = min(cfg['n_points'], 131072)
 xs = torch.from_numpy(pc.sample_points(cfg, n, seed=1)).cuda()
 buf = torch.zeros(1024 * 8 * 16, dtype=torch.int64, device='cuda')

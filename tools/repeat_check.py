@@ -21,7 +21,7 @@ def check(workload, lib_path, cap, gemm, n, reps):
     lib = engine.bind(ctypes.CDLL(lib_path))
     torch.manual_seed(0)
     cfg = pc.make_config(workload, pa.D, torch, V=pa.V)
-    solver = pa.Solver(cfg['equation'], **cfg['solver_kwargs'], lib=lib)
+    solver = pa.Solver(cfg['equation'], **cfg['solver_kwargs'], _lib=lib)
     lib.pinn_debug_max_wgs_per_cu(solver.model.net.handle, cap)
     solver.set_gemm_mode(gemm)
     n = n or min(cfg['n_points'], 131072)

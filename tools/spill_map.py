@@ -28,6 +28,16 @@ if hp == 64:        # BASELINE config 2's fp32 kernel lives in a unit of its own
     if not (os.environ.get('SPILL_MAP_REUSE') and os.path.exists(asm2)):
         subprocess.run(cmd2, check=True, stderr=subprocess.DEVNULL)
     text += '\n' + open(asm2).read()
+# the second set of full breadth kernels (pinn_inst.inc PINN_INST_ALLACT: 1 = tile kernels, 2 = weight-gradient partners of widths >= 128) lives in
+# units of its own: SPILL_MAP_UNITS=allact adds them
+if 'allact' in os.environ.get('SPILL_MAP_UNITS', ''):
+    for part in ((1, 2) if hp >= 128 else (1,)):
+        asm3 = f'/tmp/spill_map_{hp}_allact{part}.s'
+        cmd3 = ['/opt/rocm/bin/hipcc', *build.FLAGS, *build.WIDTH_FLAGS.get(hp, []), f'-DPINN_INST_HP={hp}', f'-DPINN_INST_ALLACT={part}', '--cuda-device-only',
+                '-S', '-o', asm3, os.path.join(HERE, 'pydens_amd', 'csrc', 'pinn_inst.inc')]
+        if not (os.environ.get('SPILL_MAP_REUSE') and os.path.exists(asm3)):
+            subprocess.run(cmd3, check=True, stderr=subprocess.DEVNULL)
+        text += '\n' + open(asm3).read()
 spills = {m.group(1): int(m.group(2)) for m in re.finditer(r'\.name:\s+(\S+)\n(?:.*\n)*?\s+\.vgpr_spill_count:\s+(\d+)', text)}
 lines = text.split('\n')
 rows = []

@@ -17,7 +17,7 @@ lib = engine.bind(ctypes.CDLL(os.path.abspath(sys.argv[1]))) if len(sys.argv) > 
 for name, n in (('cfg2', 65536), ('cfg4', 131072), ('cfg2', 1000), ('cfg4', 77)):
     torch.manual_seed(0)
     cfg = pc.make_config(name, pa.D, torch)
-    solver = pa.Solver(cfg['equation'], **cfg['solver_kwargs'], lib=lib)
+    solver = pa.Solver(cfg['equation'], **cfg['solver_kwargs'], _lib=lib)
     pts = torch.from_numpy(pc.sample_points(cfg, n, seed=3)).cuda()
     res = {}
     for mode in ('fp32', 'bf16x3'):
