@@ -35,6 +35,9 @@
  * streams behind the third-order ones, S = 1 + nd + n2 + n3 + n4 (built: ONE such direction alone, packed value 73: u, u', u'', u''', u''''
  * along a column or a diagonal -- beam, Kuramoto-Sivashinsky and biharmonic operators; the host assembles
  * u_aabb = (D4_{a+b} + D4_{a-b} - 2 u_aaaa - 2 u_bbbb) / 12).
+ * Round 6: WEIGHTED diagonals 2 e_a + e_b / 2 e_a - e_b (| PINN_DIR_DOUBLE): the part of D4 along alpha e_a + e_b that is odd in b is
+ * 8 alpha^3 u_aaab + 8 alpha u_abbb, so with A = D4_{a+b} - D4_{a-b} and B = D4_{2a+b} - D4_{2a-b} the host assembles
+ * u_aaab = (B - 2 A) / 48 and u_abbb = (8 A - B) / 48 (model_torch.py:174-178 nests D in any order).
  */
 #ifndef PINN_H
 #define PINN_H
@@ -58,6 +61,7 @@ extern "C" {
 #define PINN_MAX_VARS     8    /* trainable V(...) scalars a residual program may read (user slots 0..n_vars-1) */
 
 #define PINN_DIR_MINUS    0x100  /* ORed into a diagonal's direction code: e_a - e_b instead of e_a + e_b */
+#define PINN_DIR_DOUBLE   0x200  /* ... : the FIRST column counts twice, 2 e_a + e_b / 2 e_a - e_b (round 6: u_aaab, u_abbb) */
 #define PINN_MAX_SKIPS    4    /* skip connections ('R ... +') per net */
 #define PINN_SKIP_PRE     0x100 /* ORed into skip_dst[k] / skip_src[k]: the skip ends / starts IN FRONT of that activation */
 

@@ -121,6 +121,15 @@ def make_config(name, D, torch, V=None):
         return dict(equation=equation,
                     solver_kwargs=dict(ndims=2, boundary_condition=0.0, layout='fa fa f', features=[24, 24, 1], activation='Tanh'),
                     n_points=4096, low=[0, 0], high=[1, 1])
+    if name == 'mixed31':
+        # breadth fixture (round 6): the mixed fourth-order partials u_xxxy and u_xyyy (nested D in any order, model_torch.py:174-178) --
+        # fourth Taylor coefficients along x + y, x - y and the WEIGHTED diagonals 2x + y, 2x - y (include/pinn.h PINN_DIR_DOUBLE)
+        def equation(f, x, y):
+            return (D(D(D(D(f, x), x), x), y) - 0.5 * D(D(D(D(f, y), x), y), y) + f * D(f, x)
+                    - 4.0 * torch.cos(PI * x) * torch.sin(PI * y))
+        return dict(equation=equation,
+                    solver_kwargs=dict(ndims=2, boundary_condition=0.3, layout='fa fa f', features=[24, 24, 1], activation='Tanh'),
+                    n_points=4096, low=[0, 0], high=[1, 1])
     # ---- breadth workloads: timed by `bench.py --workload ...`, not BASELINE configs -----------------------
     if name in ('skip128', 'skip256', 'sin64', 'sin128', 'gelu256', 'program', 'generic'):
         def poisson(f, x, y):

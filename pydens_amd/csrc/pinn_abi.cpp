@@ -305,11 +305,11 @@ int check_dirs(const pinn_net* net, const int* dir_cols, int nd, int n2p) {
     const int n2 = pinn_n2(n2p), n3 = pinn_n3(n2p), n4 = pinn_n4(n2p);       // packed count: seconds | thirds << 3 | fourths << 6 (include/pinn.h)
     if (nd < 0 || nd > PINN_MAX_DIRS || n2 > nd || n3 > n2 || n4 > n3 || n2p < 0) return fail("bad derivative spec nd=%d n2=%d n3=%d n4=%d", nd, n2, n3, n4);
     for (int k = 0; k < nd; ++k) {
-        // direction code: column a, or the diagonal e_a +- e_b as a | (b + 1) << 4 | PINN_DIR_MINUS (include/pinn.h)
-        if (!dir_cols || dir_cols[k] < 0 || dir_cols[k] > 511) return fail("dir_cols[%d] out of range", k);
+        // direction code: column a, or the diagonal e_a +- e_b as a | (b + 1) << 4 | PINN_DIR_MINUS, | PINN_DIR_DOUBLE: 2 e_a +- e_b (include/pinn.h)
+        if (!dir_cols || dir_cols[k] < 0 || dir_cols[k] > 1023) return fail("dir_cols[%d] out of range", k);
         const int a = dir_cols[k] & 15, b = ((dir_cols[k] >> 4) & 15) - 1;
         if (a >= net->lay.d || b >= net->lay.d || a == b) return fail("dir_cols[%d] names a column outside the %d inputs", k, net->lay.d);
-        if ((dir_cols[k] & PINN_DIR_MINUS) && b < 0) return fail("dir_cols[%d]: PINN_DIR_MINUS needs a second column", k);
+        if ((dir_cols[k] & (PINN_DIR_MINUS | PINN_DIR_DOUBLE)) && b < 0) return fail("dir_cols[%d]: PINN_DIR_MINUS / PINN_DIR_DOUBLE need a second column", k);
         // (round 5: third derivatives along diagonals too -- what mixed third-order partials are assembled from)
     }
     return 0;

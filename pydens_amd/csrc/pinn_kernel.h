@@ -474,17 +474,21 @@ PINN_DEVICE float pinn_act_d5(float sv, float d1, float d2, PinnAct act_) {
 // A differentiation direction is an input column c or a diagonal e_a + e_b / e_a - e_b of two columns (mixed partials by
 // polarisation: u_ab = (u_vv - u_aa - u_bb) / 2 with v = e_a + e_b; round 5, mixed THIRD-order partials from third derivatives along
 // both diagonals: u_aab = (D3_{a+b} - D3_{a-b} - 2 u_bbb) / 6, u_abb = (D3_{a+b} + D3_{a-b} - 2 u_aaa) / 6).
-// Code: a | (b + 1) << 4 | minus << 8, b + 1 == 0 for a single column (include/pinn.h PINN_DIR_MINUS).
+// Round 6: the WEIGHTED diagonals 2 e_a + e_b / 2 e_a - e_b (PINN_DIR_DOUBLE): the odd part in b of the fourth derivative along
+// alpha e_a + e_b is 8 alpha^3 u_aaab + 8 alpha u_abbb, so alpha = 1 and alpha = 2 separate the two:
+// u_aaab = (B - 2 A) / 48, u_abbb = (8 A - B) / 48 with A = D4_{a+b} - D4_{a-b}, B = D4_{2a+b} - D4_{2a-b}.
+// Code: a | (b + 1) << 4 | minus << 8 | double << 9, b + 1 == 0 for a single column (include/pinn.h PINN_DIR_MINUS, PINN_DIR_DOUBLE).
 PINN_DEVICE int pinn_dir_a(int code) { return code & 15; }
 PINN_DEVICE int pinn_dir_b(int code) { return ((code >> 4) & 15) - 1; }
+PINN_DEVICE float pinn_dir_wa(int code) { return (code & 0x200) ? 2.0f : 1.0f; }         // weight of column a in the direction
 PINN_DEVICE float pinn_dir_sb(int code) { return (code & 0x100) ? -1.0f : 1.0f; }        // weight of column b in the direction
 PINN_DEVICE bool pinn_dir_has(int code, int c) { return pinn_dir_a(code) == c || pinn_dir_b(code) == c; }
-// weight of input column c in the direction: 1 for a, +-1 for b, 0 otherwise
-PINN_DEVICE float pinn_dir_coef(int code, int c) { return pinn_dir_a(code) == c ? 1.0f : (pinn_dir_b(code) == c ? pinn_dir_sb(code) : 0.0f); }
-// first-layer pre-activation derivative along a direction: signed sum of the weight columns it contains
+// weight of input column c in the direction: 1 (or 2) for a, +-1 for b, 0 otherwise
+PINN_DEVICE float pinn_dir_coef(int code, int c) { return pinn_dir_a(code) == c ? pinn_dir_wa(code) : (pinn_dir_b(code) == c ? pinn_dir_sb(code) : 0.0f); }
+// first-layer pre-activation derivative along a direction: weighted sum of the weight columns it contains
 PINN_DEVICE float pinn_dir_weight(const float* w1row, int code) {
     const int b = pinn_dir_b(code);
-    return w1row[pinn_dir_a(code)] + (b >= 0 ? pinn_dir_sb(code) * w1row[b] : 0.0f);
+    return pinn_dir_wa(code) * w1row[pinn_dir_a(code)] + (b >= 0 ? pinn_dir_sb(code) * w1row[b] : 0.0f);
 }
 
 // Second-order streams. Standard form: stream 1+ND+k is d2/dx_k2 for k < N2. COMB form (N2 == 1): ONE stream
@@ -892,13 +896,14 @@ PINN_DEVICE void pinn_point_stage(const PinnKArgs& A, const float* params_, cons
         }
 #pragma unroll
         for (int k = 0; k < ND; ++k) {
-            // directional derivatives of P = prod_j p_j along v = e_a + w e_b (w = +-1): with A(t) = p_a(x_a + t), B(t) = p_b(x_b + w t)
-            // and R = prod_{j != a, b} p_j:   first = (A1 B + A B1) R,   second = (A2 B + 2 A1 B1 + A B2) R,
+            // directional derivatives of P = prod_j p_j along v = wa e_a + w e_b (w = +-1, wa = 1 or 2): with A(t) = p_a(x_a + wa t),
+            // B(t) = p_b(x_b + w t) and R = prod_{j != a, b} p_j:   first = (A1 B + A B1) R,   second = (A2 B + 2 A1 B1 + A B2) R,
             // third = 3 (A2 B1 + A1 B2) R  (every factor is quadratic in its column: A3 = B3 = 0; along a single column: 0);
-            // A1 = p1_a, A2 = p2_a, B1 = w p1_b, B2 = p2_b (columns outside the spatial block contribute nothing)
+            // A1 = wa p1_a, A2 = wa^2 p2_a, B1 = w p1_b, B2 = p2_b (columns outside the spatial block contribute nothing)
             const int ca = pinn_dir_a(SH::dir(A, k)), cb = pinn_dir_b(SH::dir(A, k));
             const float wb = SH::FIXED ? 1.0f : pinn_dir_sb(SH::dir(A, k));
-            float first = 0.0f, second = 0.0f, cross = 2.0f * wb, third = 0.0f;
+            const float wa = SH::FIXED ? 1.0f : pinn_dir_wa(SH::dir(A, k));
+            float first = 0.0f, second = 0.0f, cross = 2.0f * wa * wb, third = 0.0f;
             bool both = true;
 #pragma unroll
             for (int t = 0; t < 2; ++t) {
@@ -910,8 +915,8 @@ PINN_DEVICE void pinn_point_stage(const PinnKArgs& A, const float* params_, cons
                         if (j == c) { q1 = p1[j]; q2 = p2[j]; }
                         else rest *= p[j];
                     }
-                    first += (t == 0 ? 1.0f : wb) * q1 * rest;
-                    second += q2 * rest;
+                    first += (t == 0 ? wa : wb) * q1 * rest;
+                    second += (t == 0 ? wa * wa : 1.0f) * q2 * rest;
                 } else {
                     both = false;
                 }
@@ -928,8 +933,8 @@ PINN_DEVICE void pinn_point_stage(const PinnKArgs& A, const float* params_, cons
                         else if (j == cb) { b1 = p1[j]; b2 = p2[j]; }
                         else rab *= p[j];
                     }
-                    third = rab * (a2 * wb * b1 + a1 * b2);
-                    if (N4 > 0 && k < N4) P4[k < N4 ? k : 0] = 2.0f * rab * a2 * b2;      // fourth: 6 A2 B2 R (rab carries the 3)
+                    third = rab * (wa * wa * a2 * wb * b1 + wa * a1 * b2);
+                    if (N4 > 0 && k < N4) P4[k < N4 ? k : 0] = 2.0f * rab * wa * wa * a2 * b2;      // fourth: 6 A2 B2 R (rab carries the 3)
                 }
             }
             Pk[k] = first;
@@ -985,19 +990,21 @@ PINN_DEVICE void pinn_point_stage(const PinnKArgs& A, const float* params_, cons
 #pragma unroll
         for (int k = 0; k < ND; ++k) {
             if (pinn_dir_has(SH::dir(A, k), tcol)) {
-                // (wt: weight of the time column in the direction, -1 only as the second column of a minus diagonal; odd orders carry it)
+                // (wt: weight of the time column in the direction: -1 as the second column of a minus diagonal, 2 as the first column of a
+                //  weighted one; the derivative of order n carries wt^n)
                 const float wt = SH::FIXED ? 1.0f : pinn_dir_coef(SH::dir(A, k), tcol);
-                Gk[k] = wt * d1 * es; Gkk[k] = d2 * es * es;
+                const float wt2 = wt * wt;
+                Gk[k] = wt * d1 * es; Gkk[k] = wt2 * d2 * es * es;
                 dGk[k] = wt * es * (-tau * d2 - d1);
-                dGkk[k] = es * es * (-tau * d3 - 2.0f * d2);
+                dGkk[k] = wt2 * es * es * (-tau * d3 - 2.0f * d2);
                 if (k < N3) {
                     // G''' = s'''(tau) es^3 and its derivative with respect to log_scale (d tau / ds = -tau, d es / ds = -es)
                     const float d4 = pinn_act_d4(sg, d1, d2, PINN_ACT_SIGMOID);
-                    Gkkk[k] = wt * d3 * es * es * es;
-                    dGkkk[k] = wt * es * es * es * (-tau * d4 - 3.0f * d3);
+                    Gkkk[k] = wt2 * wt * d3 * es * es * es;
+                    dGkkk[k] = wt2 * wt * es * es * es * (-tau * d4 - 3.0f * d3);
                     if (N4 > 0 && k < N4) {
-                        // G'''' = s''''(tau) es^4 (the direction's weight enters to the fourth power: 1); d / d log_scale: -tau s^(5) es^4 - 4 s'''' es^4
-                        const float d5 = pinn_act_d5(sg, d1, d2, PINN_ACT_SIGMOID), es4 = es * es * es * es;
+                        // G'''' = s''''(tau) es^4 wt^4; d / d log_scale: -tau s^(5) es^4 - 4 s'''' es^4
+                        const float d5 = pinn_act_d5(sg, d1, d2, PINN_ACT_SIGMOID), es4 = es * es * es * es * wt2 * wt2;
                         G4[k < N4 ? k : 0] = d4 * es4;
                         dG4[k < N4 ? k : 0] = es4 * (-tau * d5 - 4.0f * d4);
                     }

@@ -393,6 +393,8 @@ class Solver:
             sc.tag(0.5 * (full[ivv] - full[iaa] - full[ibb]), ab)
         for alpha, (ip, im, ia, ib) in self.spec.mixed4.items():         # u_aabb = (D4_{a+b} + D4_{a-b} - 2 u_aaaa - 2 u_bbbb) / 12
             sc.tag((full[ip] + full[im] - 2.0 * full[ia] - 2.0 * full[ib]) / 12.0, alpha)
+        for alpha, terms in self.spec.mixed31.items():                  # u_aaab / u_abbb from D4 along a +- b and 2a +- b (round 6)
+            sc.tag(sum(coef * full[idx] for idx, coef in terms), alpha)
         for alpha, (ip, im, i3, sign) in self.spec.mixed3.items():      # u_aab = (D3_{a+b} - D3_{a-b} - 2 u_bbb) / 6, u_abb: + D3_{a-b}, - 2 u_aaa
             sc.tag((full[ip] + sign * full[im] - 2.0 * full[i3]) / 6.0, alpha)
         cols = []
@@ -422,7 +424,7 @@ class Solver:
                     if c < m.ndims_spatial and f is not None and f.requires_grad:
                         (g,) = torch.autograd.grad(f.sum(), cols[c], create_graph=True, retain_graph=True, allow_unused=True)
                         if g is not None:
-                            g = g if weight > 0 else -g
+                            g = g if weight == 1.0 else weight * g
                             total = g if total is None else total + g
                 return total
             for k, direction in enumerate(spec.dirs):

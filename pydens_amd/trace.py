@@ -37,17 +37,20 @@ class TraceUnsupported(Exception):
 # ---------------------------------------------------------------------------------------------------------------
 def dir_code(direction):
     """ ABI code of a differentiation direction: column a, the diagonal e_a + e_b as a | (b + 1) << 4, or -- a third entry -1 --
-    the minus diagonal e_a - e_b with PINN_DIR_MINUS (0x100) on top (include/pinn.h). """
+    the minus diagonal e_a - e_b with PINN_DIR_MINUS (0x100) on top, or -- a fourth entry 2 (round 6) -- the weighted diagonal
+    2 e_a +- e_b with PINN_DIR_DOUBLE (0x200) (include/pinn.h). """
     if len(direction) == 1:
         return direction[0]
-    return direction[0] | ((direction[1] + 1) << 4) | (0x100 if len(direction) > 2 and direction[2] < 0 else 0)
+    return (direction[0] | ((direction[1] + 1) << 4) | (0x100 if len(direction) > 2 and direction[2] < 0 else 0)
+            | (0x200 if len(direction) > 3 and direction[3] == 2 else 0))
 
 
 def dir_weights(direction):
-    """ [(column, weight)] of a direction tuple: (c,), (a, b) = e_a + e_b, (a, b, -1) = e_a - e_b """
+    """ [(column, weight)] of a direction tuple: (c,), (a, b) = e_a + e_b, (a, b, -1) = e_a - e_b, (a, b, +-1, 2) = 2 e_a +- e_b """
     if len(direction) == 1:
         return [(direction[0], 1.0)]
-    return [(direction[0], 1.0), (direction[1], -1.0 if len(direction) > 2 and direction[2] < 0 else 1.0)]
+    return [(direction[0], 2.0 if len(direction) > 3 and direction[3] == 2 else 1.0),
+            (direction[1], -1.0 if len(direction) > 2 and direction[2] < 0 else 1.0)]
 
 
 class StreamSpec:
@@ -69,6 +72,7 @@ class StreamSpec:
         firsts, seconds, mixed, thirds, fourths = set(), set(), set(), set(), set()
         pairs3, mixed3 = set(), {}                   # mixed THIRD-order partials (round 5): column pairs, alpha -> (pair, doubled column)
         pairs4 = set()                               # mixed FOURTH-order partials u_aabb: column pairs
+        pairs31, mixed31 = set(), {}                 # u_aaab / u_abbb (round 6): column pairs, alpha -> (pair, tripled column)
         for alpha in requested:
             if len(alpha) == 1:
                 firsts.add(alpha[0])
@@ -94,24 +98,31 @@ class StreamSpec:
                 pairs4.add((a, b))
                 for c in (a, b):
                     fourths.add(c); thirds.add(c); seconds.add(c)
+            elif len(alpha) == 4 and len(set(alpha)) == 2:
+                # u_aaab = (B - 2 A) / 48, u_abbb = (8 A - B) / 48 with A = D4_{a+b} - D4_{a-b}, B = D4_{2a+b} - D4_{2a-b}: fourth
+                # derivatives along both diagonals and both WEIGHTED diagonals of the pair (round 6; no pure fourth derivative needed)
+                a, b = sorted(set(alpha))
+                pairs31.add((a, b)); mixed31[tuple(alpha)] = ((a, b), a if alpha.count(a) == 3 else b)
             elif len(alpha) > 2:
                 raise NotImplementedError(
                     f'derivative multi-index {alpha}: the HIP kernels provide derivatives up to fourth order along single columns, mixed second- '
-                    'and third-order partials of two columns (u_xy, u_xxy) and the symmetric mixed fourth-order one (u_xxyy); partials of three '
-                    'different columns (u_xyz), u_xxxy and orders above four are not built')
+                    'and third-order partials of two columns (u_xy, u_xxy) and the mixed fourth-order ones of two columns (u_xxyy, u_xxxy, '
+                    'u_xyyy); partials of three different columns (u_xyz) and orders above four are not built')
         firsts |= seconds
         pairs3 |= pairs4                             # (a pair with a fourth-order diagonal carries the third-order ones anyway)
         # directions: fourth-order ones first, then the third-order ones (columns, then both diagonals of every pair a mixed third- /
         # fourth-order partial needs), then the other second-order columns, the remaining diagonals, the first-order rest
         def diag_pair(ab):
             return [ab, ab + (-1,)]
-        d4_dirs = [(c,) for c in sorted(fourths)] + [d for ab in sorted(pairs4) for d in diag_pair(ab)]
-        d3_dirs = [(c,) for c in sorted(thirds - fourths)] + [d for ab in sorted(pairs3 - pairs4) for d in diag_pair(ab)]
+        diag4 = pairs4 | pairs31                    # pairs whose two diagonals carry a fourth derivative
+        d4_dirs = ([(c,) for c in sorted(fourths)] + [d for ab in sorted(diag4) for d in diag_pair(ab)]
+                   + [ab + (sign, 2) for ab in sorted(pairs31) for sign in (1, -1)])
+        d3_dirs = [(c,) for c in sorted(thirds - fourths)] + [d for ab in sorted(pairs3 - diag4) for d in diag_pair(ab)]
         self.dirs = (d4_dirs + d3_dirs + [(c,) for c in sorted(seconds - thirds)]
-                     + [ab for ab in sorted(mixed) if ab not in pairs3] + [(c,) for c in sorted(firsts - seconds)])
+                     + [ab for ab in sorted(mixed) if ab not in (pairs3 | diag4)] + [(c,) for c in sorted(firsts - seconds)])
         self.n4 = len(d4_dirs)
         self.n3 = self.n4 + len(d3_dirs)
-        self.n2 = self.n3 + len(seconds - thirds) + len([ab for ab in mixed if ab not in pairs3])
+        self.n2 = self.n3 + len(seconds - thirds) + len([ab for ab in mixed if ab not in (pairs3 | diag4)])
         self.nd = len(self.dirs)
         self.n2p = self.n2 | (self.n3 << 3) | (self.n4 << 6)      # packed count of the C-ABI (include/pinn.h); only meaningful per group when large
         self.dir_cols = [dir_code(d) for d in self.dirs]
@@ -127,6 +138,8 @@ class StreamSpec:
                     self.index[(d[0],) * 3] = base3
                 if k < self.n4:
                     self.index[(d[0],) * 4] = base4
+            elif len(d) > 3:                         # weighted diagonal 2 e_a +- e_b: only its fourth derivative is asked for
+                self.index[('d4w',) + d[:3]] = base4
             else:
                 sign = -1 if len(d) > 2 else 1
                 if sign > 0:
@@ -146,6 +159,15 @@ class StreamSpec:
         # (a, a, b, b) -> streams of D4 along a + b, a - b, u_aaaa, u_bbbb
         self.mixed4 = {(a, a, b, b): (self.index[('d4', a, b, 1)], self.index[('d4', a, b, -1)], self.index[(a,) * 4], self.index[(b,) * 4])
                        for a, b in sorted(pairs4)}
+        # (a, a, a, b) / (a, b, b, b) -> [(stream, coefficient)]: streams of D4 along a + b, a - b, 2a + b, 2a - b
+        self.mixed31 = {}
+        for alpha, ((a, b), tripled) in sorted(mixed31.items()):
+            ip, im = self.index[('d4', a, b, 1)], self.index[('d4', a, b, -1)]
+            i2p, i2m = self.index[('d4w', a, b, 1)], self.index[('d4w', a, b, -1)]
+            if tripled == a:
+                self.mixed31[alpha] = [(i2p, 1.0 / 48.0), (i2m, -1.0 / 48.0), (ip, -2.0 / 48.0), (im, 2.0 / 48.0)]
+            else:
+                self.mixed31[alpha] = [(ip, 8.0 / 48.0), (im, -8.0 / 48.0), (i2p, -1.0 / 48.0), (i2m, 1.0 / 48.0)]
         # can ONE kernel call produce all of it as separate streams?
         if self.n4 > 0:
             # fourth order in ONE call: that direction alone (u'''' = f(x) beams, u_t-free fourth-order ODEs); anything else in groups

@@ -1280,6 +1280,15 @@ def _fourth_order_problems(D, torch, which):
     if which == 'time_fourth':        # fourth derivative along the TIME column: the gate's fourth derivative and its log_scale adjoint (sigmoid's fifth)
         eq = lambda f, x, t: 0.05 * D(D(D(D(f, t), t), t), t) + D(f, x) - f
         return eq, dict(ndims=2, boundary_condition=0.2, initial_condition=0.7, layout='fa fa f', features=[16, 16, 1], activation='Sigmoid')
+    if which == 'xxxt_gate':          # round 6: u_xxxt and u_xttt in (x, t) with IC + BC -- weighted diagonals 2x + t, 2x - t: the box factor's column counts
+        # twice (A1 = 2 p', A2 = 4 p''), the gate's time column carries the sign of the minus diagonals to odd orders
+        eq = lambda f, x, t: D(f, t) + 0.02 * D(D(D(D(f, x), x), x), t) - 0.01 * D(D(D(D(f, t), t), t), x) + f * D(f, x)
+        return eq, dict(ndims=2, boundary_condition=0.1, initial_condition=lambda x: torch.sin(np.pi * x), layout='fa fa f', features=[16, 16, 1],
+                        activation='Tanh')
+    if which == 'tttp_gate':          # ... u_tttp with a parameter column p behind t: the weighted diagonals 2t + p, 2t - p put weight 2 on the TIME column
+        # (the gate's n-th derivative carries 2^n, so does its log_scale adjoint)
+        eq = lambda f, x, t, p: D(f, t) + 0.01 * D(D(D(D(f, t), t), t), p) + 0.02 * D(D(D(D(f, p), p), p), t) - p * D(D(f, x), x)
+        return eq, dict(ndims=2, nparams=1, boundary_condition=0.2, initial_condition=0.5, layout='fa fa f', features=[16, 16, 1], activation='Sigmoid')
     if which == 'biharmonic':         # u_xxxx + 2 u_xxyy + u_yyyy = f: the mixed one from fourth derivatives along x + y and x - y
         eq = lambda f, x, y: D(D(D(D(f, x), x), x), x) + 2.0 * D(D(D(D(f, x), x), y), y) + D(D(D(D(f, y), y), y), y) - torch.sin(np.pi * x) * y
         return eq, dict(ndims=2, boundary_condition=0.0, layout='fa fa f', features=[16, 16, 1], activation='Tanh')
@@ -1288,7 +1297,8 @@ def _fourth_order_problems(D, torch, which):
     return eq, dict(ndims=1, boundary_condition=0.3, layout='faR fa f+a fa f', features=[12, 12, 12, 12, 1], activation=['Mish', 'Softsign', 'GELU', 'SiLU'])
 
 
-@pytest.mark.parametrize('which', ['beam_1d', 'kuramoto_sivashinsky', 'time_fourth', 'biharmonic', 'any_activation', 'beam_wide', 'beam_wide_sin'])
+@pytest.mark.parametrize('which', ['beam_1d', 'kuramoto_sivashinsky', 'time_fourth', 'biharmonic', 'any_activation', 'beam_wide', 'beam_wide_sin', 'xxxt_gate',
+                                   'tttp_gate'])
 def test_fourth_order_streams_match_the_oracle(pa, emu_lib, which):
     _fourth_order_case(pa, which, emu_kwargs(emu_lib))
 
@@ -1304,7 +1314,7 @@ def _fourth_order_case(pa, which, solver_kwargs):
     oracle = po.OracleSolver(eq_o, dtype=torch.float64, **kw)
     start = oracle32.export_params()
     oracle.import_params(start)
-    d = kw['ndims']
+    d = kw['ndims'] + kw.get('nparams', 0)
     pts = np.random.RandomState(14).rand(3, 40, d).astype(np.float32)
     ev32, g32 = oracle32.evaluate(pts[0]), oracle32.export_grads()
     ev, g_want = oracle.evaluate(pts[0]), oracle.export_grads()
@@ -1312,8 +1322,11 @@ def _fourth_order_case(pa, which, solver_kwargs):
     eq_p, kw = _fourth_order_problems(pa.D, torch, which)
     solver = pa.Solver(eq_p, **kw, **solver_kwargs)
     assert solver.spec.n4 >= 1 and solver.program is None
-    want_groups = {'beam_1d': [73], 'kuramoto_sivashinsky': [73, 0], 'time_fourth': [73, 0], 'biharmonic': [73, 73, 73, 73], 'any_activation': [73], 'beam_wide': [73], 'beam_wide_sin': [73]}[which]
+    want_groups = {'beam_1d': [73], 'kuramoto_sivashinsky': [73, 0], 'time_fourth': [73, 0], 'biharmonic': [73, 73, 73, 73], 'any_activation': [73], 'beam_wide': [73],
+                   'beam_wide_sin': [73], 'xxxt_gate': [73, 73, 73, 73, 9, 9], 'tttp_gate': [73, 73, 73, 73, 9, 9, 1]}[which]
     assert [g[1] for g in solver.spec.groups] == want_groups, solver.spec.groups
+    if which.endswith('_gate'):
+        assert [c for c in solver.spec.dir_cols if c & 0x200], solver.spec.dir_cols          # PINN_DIR_DOUBLE directions are in play
     load_params(solver, start)
     solver._generic_step(torch.from_numpy(pts[0].copy()).to(solver.device), ('equation',), [], torch.nn.MSELoss(), 1)
     lay = solver.model.net.layout

@@ -879,7 +879,7 @@ def test_prepass_with_more_registers_than_a_full_sweep_holds_on_the_gpu(pa):
     te._wide_prepass_case(pa, {})
 
 
-@pytest.mark.parametrize('name', ['nested_acts', 'mixed3', 'biharm', 'act_params'])
+@pytest.mark.parametrize('name', ['nested_acts', 'mixed3', 'biharm', 'act_params', 'mixed31'])
 def test_breadth_features_match_reference_golden_on_the_gpu(pa, name):
     """ round 5 breadth (nested skips + second-set activations, mixed third order, fourth order) against the fixtures generated from the
     unmodified reference: predict, loss, gradients, K-step trajectory (tests/test_golden_extras.py holds the case) """
@@ -887,7 +887,8 @@ def test_breadth_features_match_reference_golden_on_the_gpu(pa, name):
     tg.golden_extra_case(pa, name, {}, test='gpu_golden_extra')
 
 
-@pytest.mark.parametrize('which', ['beam_1d', 'kuramoto_sivashinsky', 'time_fourth', 'biharmonic', 'any_activation', 'beam_wide', 'beam_wide_sin'])
+@pytest.mark.parametrize('which', ['beam_1d', 'kuramoto_sivashinsky', 'time_fourth', 'biharmonic', 'any_activation', 'beam_wide', 'beam_wide_sin', 'xxxt_gate',
+                                   'tttp_gate'])
 def test_fourth_order_streams_on_the_gpu(pa, which):
     import test_emu_engine as te
     te._fourth_order_case(pa, which, {})

@@ -59,10 +59,23 @@ def test_mixed_partials_take_a_diagonal_direction():
     specb, _ = trace.discover(lambda f, x, y: D(D(D(D(f, x), x), y), y), run, 2)
     assert specb.dirs[:4] == [(0,), (1,), (0, 1), (0, 1, -1)] and specb.n4 == 4 and [g[1] for g in specb.groups] == [73, 73, 73, 73]
     assert specb.mixed4[(0, 0, 1, 1)] == (specb.index[('d4', 0, 1, 1)], specb.index[('d4', 0, 1, -1)], specb.index[(0,) * 4], specb.index[(1,) * 4])
+    # round 6: u_xxxy / u_xyyy from fourth derivatives along x + y, x - y and the WEIGHTED diagonals 2x + y, 2x - y (PINN_DIR_DOUBLE 0x200)
+    specw = trace.discover(lambda f, x, y: D(D(D(D(f, x), x), x), y) + D(D(D(D(f, x), y), y), y), run, 2)[0]
+    assert specw.dirs[:4] == [(0, 1), (0, 1, -1), (0, 1, 1, 2), (0, 1, -1, 2)] and specw.n4 == 4
+    assert specw.dir_cols[:4] == [0 | 2 << 4, 0 | 2 << 4 | 0x100, 0 | 2 << 4 | 0x200, 0 | 2 << 4 | 0x300]
+    ip, im, i2p, i2m = (specw.index[('d4', 0, 1, 1)], specw.index[('d4', 0, 1, -1)], specw.index[('d4w', 0, 1, 1)], specw.index[('d4w', 0, 1, -1)])
+    assert dict(specw.mixed31[(0, 0, 0, 1)]) == {i2p: 1 / 48, i2m: -1 / 48, ip: -2 / 48, im: 2 / 48}
+    assert dict(specw.mixed31[(0, 1, 1, 1)]) == {ip: 8 / 48, im: -8 / 48, i2p: -1 / 48, i2m: 1 / 48}
+    assert trace.dir_weights((0, 1, -1, 2)) == [(0, 2.0), (1, -1.0)]
+    # (the identity itself, on a polynomial: D4 of x^3 y + 2 x y^3 along alpha e_x + beta e_y = 4! (alpha^3 beta + 2 alpha beta^3))
+    d4 = lambda al, be: 24.0 * (al ** 3 * be + 2.0 * al * be ** 3)
+    streams = {ip: d4(1, 1), im: d4(1, -1), i2p: d4(2, 1), i2m: d4(2, -1)}
+    assert abs(sum(c * streams[i] for i, c in specw.mixed31[(0, 0, 0, 1)]) - 6.0) < 1e-12          # d4/dx3dy of x^3 y = 6
+    assert abs(sum(c * streams[i] for i, c in specw.mixed31[(0, 1, 1, 1)]) - 12.0) < 1e-12         # d4/dxdy3 of 2 x y^3 = 12
     with pytest.raises(NotImplementedError, match='orders above four'):
         trace.discover(lambda f, x: D(D(D(D(D(f, x), x), x), x), x), run, 1)
-    with pytest.raises(NotImplementedError, match='u_xxxy'):
-        trace.discover(lambda f, x, y: D(D(D(D(f, x), x), x), y), run, 2)
+    with pytest.raises(NotImplementedError, match='three different columns'):
+        trace.discover(lambda f, x, y, z: D(D(D(D(f, x), x), y), z), run, 3)
     # 3 columns + 2 diagonals = 5 directions, each with a second derivative: more than one kernel call carries -> served
     # by several calls over groups of two directions (generic path), never refused
     spec, _ = trace.discover(lambda f, x, y, z: D(D(f, x), y) + D(D(f, y), z), run, 3)

@@ -48,27 +48,61 @@ while i < len(lines):
         i += 1
         continue
     sym = m.group(1)
-    segs, cur = [], dict(mfma=0, st=0, ld=0)
+    # per barrier-delimited segment: MFMAs, scratch stores / loads, and (round 6) those of them that sit strictly BETWEEN the segment's first
+    # and last MFMA -- inside the GEMM's issue span; the others are the epilogue / staging code that shares the segment with a GEMM
+    # (a barrier-free loop -- a backward branch -- that holds MFMAs: every scratch instruction of its body is inside the span, wherever it sits in the text)
+    def fresh():
+        return dict(mfma=0, st=0, ld=0, in_st=0, in_ld=0, pend_st=0, pend_ld=0)
+    segs, cur = [], fresh()
     i += 1
+    body_start, labels, loops = i, {}, []
+    j = i
+    while not lines[j].startswith('.Lfunc_end'):
+        t = lines[j].strip()
+        lm = re.match(r'^(\.LBB\d+_\d+):', t)
+        if lm:
+            labels[lm.group(1)] = j
+        bm = re.match(r'^s_c?branch\S*\s+(\.LBB\d+_\d+)', t)
+        if bm and bm.group(1) in labels:
+            loops.append((labels[bm.group(1)], j))
+        j += 1
+    in_mfma_loop = set()
+    for lo, hi in loops:
+        body = [lines[k].strip() for k in range(lo, hi)]
+        # (a loop WITHOUT a barrier inside: a GEMM loop proper. The layer loop of the generic-depth kernels holds whole phases -- barriers, epilogues --
+        #  and is read segment by segment like straight-line code)
+        if any(t.startswith('v_mfma') for t in body) and not any(t.startswith('s_barrier') for t in body):
+            in_mfma_loop.update(range(lo, hi))
     while not lines[i].startswith('.Lfunc_end'):
         t = lines[i].strip()
+        if i in in_mfma_loop and t.startswith('scratch_'):
+            cur['in_st' if t.startswith('scratch_store') else 'in_ld'] += 1
+            cur['st' if t.startswith('scratch_store') else 'ld'] += 1
+            i += 1
+            continue
         if t.startswith('s_barrier'):
             segs.append(cur)
-            cur = dict(mfma=0, st=0, ld=0)
+            cur = fresh()
         elif t.startswith('v_mfma'):
             cur['mfma'] += 1
+            cur['in_st'] += cur['pend_st']; cur['in_ld'] += cur['pend_ld']      # (scratch code seen since the previous MFMA lies inside the span)
+            cur['pend_st'] = cur['pend_ld'] = 0
         elif t.startswith('scratch_store'):
             cur['st'] += 1
+            if cur['mfma']:
+                cur['pend_st'] += 1
         elif t.startswith('scratch_load'):
             cur['ld'] += 1
+            if cur['mfma']:
+                cur['pend_ld'] += 1
         i += 1
     segs.append(cur)
     name = subprocess.run(['c++filt', sym], capture_output=True, text=True).stdout.strip().replace('void ', '').replace('(PinnKArgs)', '')
     gemm = [s for s in segs if s['mfma'] >= 16]
     rest = [s for s in segs if s['mfma'] < 16]
-    rows.append((name, spills.get(sym, -1), sum(s['mfma'] for s in gemm), sum(s['st'] for s in gemm), sum(s['ld'] for s in gemm),
-                 sum(s['st'] for s in rest), sum(s['ld'] for s in rest)))
-print(f'width {hp}: kernel | spilled VGPRs | MFMAs | scratch stores / loads inside GEMM segments | ... outside')
+    rows.append((name, spills.get(sym, -1), sum(s['mfma'] for s in gemm), sum(s['in_st'] for s in gemm), sum(s['in_ld'] for s in gemm),
+                 sum(s['st'] for s in gemm), sum(s['ld'] for s in gemm), sum(s['st'] for s in rest), sum(s['ld'] for s in rest)))
+print(f'width {hp}: kernel | spilled VGPRs | MFMAs | scratch stores / loads BETWEEN the first and last MFMA of a GEMM segment | ... in GEMM segments in all | ... outside')
 for r in sorted(rows):
     if r[1] >= floor:
-        print('%-66s %4d   mfma %5d   gemm st %3d ld %3d   other st %3d ld %3d' % r)
+        print('%-66s %4d   mfma %5d   span st %3d ld %3d   gemm-seg st %3d ld %3d   other st %3d ld %3d' % r)
