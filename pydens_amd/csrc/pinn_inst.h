@@ -9,8 +9,10 @@ int pinn_launch_tile_hp32(int nd, int n2, const PinnKArgs* a, int grid, void* st
 int pinn_launch_tile_hp64(int nd, int n2, const PinnKArgs* a, int grid, void* stream, int query, long long* info);
 int pinn_launch_tile_hp128(int nd, int n2, const PinnKArgs* a, int grid, void* stream, int query, long long* info);
 int pinn_launch_tile_hp256(int nd, int n2, const PinnKArgs* a, int grid, void* stream, int query, long long* info);
+int pinn_launch_tile_hp512(int nd, int n2, const PinnKArgs* a, int grid, void* stream, int query, long long* info);
 
 // streamed weight-gradient kernel of the WGX tile kernels (widths >= 128): same return codes; query fills info[0] (LDS bytes),
 // info[1] (threads), info[3] (workgroups per CU)
 int pinn_launch_wgrad_hp128(int nd, int n2, int comb, int mt, const PinnKArgs* a, int grid, void* stream, int query, long long* info);
 int pinn_launch_wgrad_hp256(int nd, int n2, int comb, int mt, const PinnKArgs* a, int grid, void* stream, int query, long long* info);
+int pinn_launch_wgrad_hp512(int nd, int n2, int comb, int mt, const PinnKArgs* a, int grid, void* stream, int query, long long* info);

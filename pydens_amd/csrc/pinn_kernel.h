@@ -184,7 +184,10 @@ struct PinnCfg {
     static constexpr int PREPASS_FLOATS_PER_LANE = (O_NET - O_BUFA) / T;
     static constexpr int O_GNET = O_NET + NW * S * T;
     static constexpr int O_ACCB = O_GNET + S * T;
-    static constexpr int O_ACCW1 = O_ACCB + PINN_MAX_LAYERS * HP;   // bias-gradient rows for any depth
+    // bias-gradient rows: one per activation, for any depth the library takes -- except at width 512 (round 6), where 32 rows would be 64 KB
+    // of the 160: eight rows, i.e. nets of up to eight 512-wide hidden layers (pinn_create refuses deeper ones)
+    static constexpr int ACCB_ROWS = HP >= 512 ? 8 : PINN_MAX_LAYERS;
+    static constexpr int O_ACCW1 = O_ACCB + ACCB_ROWS * HP;
     static constexpr int O_SCAL = O_ACCW1 + HP * PINN_XS_LD;
     static constexpr int O_TBAR = O_SCAL;                       // arrival counter of the team-local barrier (PINN_TEAM_FLAGS builds): shares
                                                                 // the first slot of `scal`, which is written behind the tile loop only
@@ -802,8 +805,13 @@ struct PinnPointOut {
 // live as 64-bit lane masks in SGPRs -- the general form keeps so many of them that hipcc spills SGPRs to VGPR lanes
 // (several hundred v_readlane per tile) and the kernel needs ~95 registers more -- and the serial one-thread-per-point
 // stage shrinks to the arithmetic it needs (cfg2 kernel: 0.237 -> 0.207 ms).
-template <int SPEC, int ND>
+// Round 6: SPEC | 4 = the same shapes with a residual PROGRAM instead of the affine form (non-affine equations, trainable V(...) scalars in
+// the equation): the ansatz facts stay compile-time, the residual kind and the program come from the arguments -- so that the two-team
+// kernel of the Poisson-box shape serves them too (VAR 2048; they ran on the general one-wave-per-SIMD kernel before: 46 % MFMA-busy).
+template <int SPEC_, int ND>
 struct PinnShape {
+    static constexpr int SPEC = SPEC_ & 3;
+    static constexpr bool PROGRAM = (SPEC_ & 4) != 0;
     static constexpr bool FIXED = SPEC != 0;
     static PINN_DEVICE int d(const PinnKArgs& A) { return (SPEC == 1 || SPEC == 2) ? ND : A.d; }
     static PINN_DEVICE int nsp(const PinnKArgs& A) { return SPEC == 1 ? ND : SPEC == 2 ? ND - 1 : SPEC == 3 ? 0 : A.nsp; }
@@ -812,7 +820,7 @@ struct PinnShape {
     static PINN_DEVICE bool has_ic(const PinnKArgs& A) { return SPEC == 1 ? false : FIXED ? true : A.has_ic != 0; }
     static PINN_DEVICE int dir(const PinnKArgs& A, int k) { return FIXED ? k : A.dir_cols[k]; }
     static PINN_DEVICE int mode(const PinnKArgs& A) { return FIXED ? (int)PINN_MODE_STEP : A.mode; }
-    static PINN_DEVICE int res_kind(const PinnKArgs& A) { return FIXED ? (int)PINN_RES_AFFINE : A.res_kind; }
+    static PINN_DEVICE int res_kind(const PinnKArgs& A) { return FIXED ? (PROGRAM ? (int)PINN_RES_PROGRAM : (int)PINN_RES_AFFINE) : A.res_kind; }
     static PINN_DEVICE int s_user(const PinnKArgs& A) { return FIXED ? 99 : A.s_user; }
     static PINN_DEVICE int coef_row(const PinnKArgs& A, int s) { return FIXED ? -1 : A.coef_row[s]; }
 };
@@ -856,7 +864,7 @@ PINN_DEVICE void pinn_point_prefetch(const PinnKArgs& A, const float* params_, l
             for (int s = 0; s < S; ++s)
                 if (s < SH::s_user(A)) pre.ic[s] = (A.ic_row[s] >= 0) ? aux_[(long long)A.ic_row[s] * A.n_points + gi] : A.ic_cst[s];
         } else {
-            pre.ic[0] = (SPEC == 0 && A.ic_var1 > 0) ? params_[A.off_extra + A.ic_var1 - 1] : A.ic_const;
+            pre.ic[0] = (!SH::FIXED && A.ic_var1 > 0) ? params_[A.off_extra + A.ic_var1 - 1] : A.ic_const;
         }
     }
 }
@@ -1371,7 +1379,17 @@ PINN_DEVICE void pinn_tile_body(const PinnKArgs& A, const float* params_, float*
     // (VAR 2, two workgroups per CU: W^T of both does not fit the LDS beside the activation buffers)
     constexpr bool WTG = !SPLIT && (C::WTG || SLABL || (VAR & 2) != 0);
     constexpr int SPEC = (VAR >> 4) & 3;                   // VAR 16/32/48: training shape 1/2/3 fixed at compile time
-    using SH = PinnShape<SPEC, ND>;
+    // VAR 2048 (round 6): the shape-specialised two-team kernel with a residual PROGRAM (PinnShape: SPEC | 4) -- its program registers
+    // (PINN_MAX_REGS values + adjoints per point of a team's tile) live in the rows of the team's bias-gradient block that a static-depth
+    // net never uses (rows 8 .. PINN_MAX_LAYERS - 1 of `accB`: the team blocks of the LDS carve end in front of the program registers,
+    // and with W^T behind them the 160 KB are used up); the point stage runs on the first T threads of the team (every lane running it,
+    // PTALL, would have sixteen replicas add into the same adjoint registers)
+    constexpr bool PROG = (VAR & 2048) != 0;
+    constexpr int SPECP = SPEC | (PROG ? 4 : 0);
+    using SH = PinnShape<SPECP, ND>;
+    static_assert(!PROG || (TEAMS2 && SPEC != 0 && LHC >= 1 && LHC + 1 <= 8 && !SPLIT &&
+                            2 * PINN_MAX_REGS * T <= (C::ACCB_ROWS - 8) * HP),
+                  "program residuals on the two-team kernels: static depth, registers inside the unused bias-gradient rows");
     // two teams: everything below is written in TEAM-local terms (tid, wave, LDS block, virtual block index); the teams meet
     // at the barriers only (same trip counts by construction) and in the shared W^T
     // (the team index is wave-uniform -- NTHREADS is a multiple of 64 -- and the compiler should know: tile index, LDS block, slab and
@@ -1443,8 +1461,8 @@ PINN_DEVICE void pinn_tile_body(const PinnKArgs& A, const float* params_, float*
     float* accW1 = smem + C::O_ACCW1;
     float* scal = smem + C::O_SCAL;
     int* tbar = reinterpret_cast<int*>(smem + C::O_TBAR);
-    float* pregs = smem + C::O_PREG;
-    float* padj = smem + C::O_PADJ;
+    float* pregs = PROG ? accB + 8 * HP : smem + C::O_PREG;
+    float* padj = PROG ? accB + 8 * HP + PINN_MAX_REGS * T : smem + C::O_PADJ;       // (zeroed with accB below)
 
     // -DPINN_FIT_PROF (experiment builds, pinn_fit_kernel.h): clock ticks of thread 0 between marks of this function
 #if defined(PINN_FIT_PROF) && !defined(PINN_EMU)
@@ -1461,7 +1479,7 @@ PINN_DEVICE void pinn_tile_body(const PinnKArgs& A, const float* params_, float*
     }
     for (int i = tid; i < HP; i += NTHREADS) { b1s[i] = params_[A.off_b1 + i]; WLs[i] = params_[A.off_wl + i]; }
     if (tid == 0) tbar[0] = 0;
-    for (int i = tid; i < PINN_MAX_LAYERS * HP; i += NTHREADS) accB[i] = 0.0f;
+    for (int i = tid; i < C::ACCB_ROWS * HP; i += NTHREADS) accB[i] = 0.0f;
     float* WTs = (TEAMS2 || VWG) ? smem_all + TEAMS * TEAM_FLOATS : smem + C::O_WT;
     const float* wtg = A.wt + (SLABL ? (size_t)PINN_BID * (size_t)lh * HP * HP : (size_t)0);
     if (SLABL && train) {
@@ -1852,14 +1870,14 @@ PINN_DEVICE void pinn_tile_body(const PinnKArgs& A, const float* params_, float*
         // less. Same-box A/B (round 5, profiles/r05_headline_ab.txt): -1.1 % on BASELINE config 2 (16-point tiles, Dirichlet box: the
         // point stage is ~40 instructions), +6.8 % on config 4 (32-point tiles: two points per lane and the IC gate's exponentials in
         // every wave) -- so only where the stage is small: PinnShape 1, one row tile, at most four waves per team
-        constexpr bool PTALL = (PINN_PTALL == 2 && SPEC != 0) || (PINN_PTALL == 1 && SPEC == 1 && MT == 1 && NW <= 4);
+        constexpr bool PTALL = !PROG && ((PINN_PTALL == 2 && SPEC != 0) || (PINN_PTALL == 1 && SPEC == 1 && MT == 1 && NW <= 4));
         PinnPointPre<ND, N2> ppre, ppre_all[PTALL ? MT : 1];
         if constexpr (PTALL) {
 #pragma unroll
             for (int mt = 0; mt < MT; ++mt)
-                pinn_point_prefetch<ND, N2, SPEC>(A, params_, base + mt * 16 + lr, base + mt * 16 + lr < A.n_points, pregs, T, ppre_all[mt], aux_);
+                pinn_point_prefetch<ND, N2, SPECP>(A, params_, base + mt * 16 + lr, base + mt * 16 + lr < A.n_points, pregs, T, ppre_all[mt], aux_);
         } else {
-            if (pt_thread) pinn_point_prefetch<ND, N2, SPEC>(A, params_, base + ptid, base + ptid < A.n_points, pregs + ptid, T, ppre, aux_);
+            if (pt_thread) pinn_point_prefetch<ND, N2, SPECP>(A, params_, base + ptid, base + ptid < A.n_points, pregs + ptid, T, ppre, aux_);
         }
         PH(0)
 
@@ -2223,7 +2241,7 @@ PINN_DEVICE void pinn_tile_body(const PinnKArgs& A, const float* params_, float*
                     net[s] = v;
                 }
                 PinnPointOut<ND, N2> po;
-                pinn_point_stage<ND, N2, false, COMB, SPEC>(A, params_, net, xs_t + pt * PINN_XS_LD, base + pt, base + pt < A.n_points,
+                pinn_point_stage<ND, N2, false, COMB, SPECP>(A, params_, net, xs_t + pt * PINN_XS_LD, base + pt, base + pt < A.n_points,
                                                             pregs, padj, T, ppre_all[mt], po, es_gate);
 #pragma unroll
                 for (int s = 0; s < S; ++s) gnet_r[PTALL ? mt : 0][s] = po.gnet[s];
@@ -2252,7 +2270,7 @@ PINN_DEVICE void pinn_tile_body(const PinnKArgs& A, const float* params_, float*
             }
 #endif
             PinnPointOut<ND, N2> po;
-            pinn_point_stage<ND, N2, SPEC == 0, COMB, SPEC>(A, params_, net, xs_t + pt * PINN_XS_LD, base + pt, base + pt < A.n_points,
+            pinn_point_stage<ND, N2, SPEC == 0 || PROG, COMB, SPECP>(A, params_, net, xs_t + pt * PINN_XS_LD, base + pt, base + pt < A.n_points,
                                      pregs + pt, padj + pt, T, ppre, po, es_gate);
 #pragma unroll
             for (int s = 0; s < S; ++s) gnetb[s * T + pt] = po.gnet[s];
@@ -2914,12 +2932,12 @@ PINN_DEVICE void pinn_tile_body(const PinnKArgs& A, const float* params_, float*
                 put(part + A.off_bl, tot_bl);
                 if (!add)
                     for (int i = A.off_loss + 1; i < A.p_core; ++i) part[i] = 0.0f;
-                if (SPEC == 0 && SH::mode(A) == PINN_MODE_STEP && A.res_kind == PINN_RES_PROGRAM) {
+                if ((SPEC == 0 || PROG) && SH::mode(A) == PINN_MODE_STEP && SH::res_kind(A) == PINN_RES_PROGRAM) {
                     const int vbase = S + d + A.n_aux;
                     for (int k = 0; k < A.n_vars; ++k) {
                         float g = 0.0f;
                         for (int i = 0; i < T; ++i) g += padj[(vbase + k) * T + i];
-                        part[A.off_extra + k] = g;
+                        put(part + A.off_extra + k, g);          // (two teams: the second one adds on top)
                     }
                 }
                 if (SPEC == 0 && A.ic_var1 > 0 && SH::mode(A) == PINN_MODE_STEP) {

@@ -30,13 +30,18 @@ struct PinnWgCfg {
     static constexpr int LDK = KC + 4;               // row stride of the unit-major operand buffers: rows 4 units apart land
                                                      // 16 banks apart (ds_write_b32 of lanes lq, lq + 1), b128 rows stay aligned
     static constexpr int WM = 2, WN = 4;             // wave grid over the output
-    static constexpr int AM = HP / 16 / WM, BN = HP / 16 / WN;    // 16 x 16 output tiles per wave (8 x 4 at 256, 4 x 2 at 128)
-    static constexpr int OPER = HP * LDK;            // one operand buffer (floats)
+    // width 512 (round 6): the HP x HP accumulator is 2 048 registers per lane -- the output goes in NBLK x NBLK blocks of HB x HB = 256 x 256,
+    // one after the other; a block pass stages the HB units of gz_a of its row block and the HB units of h_{a-1} of its column block (every
+    // operand is read from HBM NBLK times: twice)
+    static constexpr int HB = HP > 256 ? 256 : HP, NBLK = HP / HB;
+    static constexpr int AM = HB / 16 / WM, BN = HB / 16 / WN;    // 16 x 16 output tiles per wave (8 x 4 at 256 / 512, 4 x 2 at 128)
+    static constexpr int OPER = HB * LDK;            // one operand buffer (floats)
     // split-bf16 form (round 3): TWO stages (K = 32 (stream, point) slots) per MFMA step; an operand buffer = three bf16 planes
     // of [HP units][32 k] = rows of 64 bytes, k slot 2 * point + stage: the two stages' values of a thread share one dword,
     // written by one ds_write_b32 per plane; 16-byte chunk index XORed with 3 * ((unit >> 2) & 1): ds_read_b128 of the fragments
     // conflict-free, the writes two-way (free for ds_write_b32). Two such buffer pairs (double buffering) fit at width 128
     // (96 KB), one at width 256 (96 KB: the staging of the next pair then waits for the MFMAs of this one).
+    static_assert(!SPLIT || NBLK == 1, "split-bf16 weight gradients: widths up to 256");
     static constexpr int SP_PLANE_F = HP * 16;       // floats of one plane
     static constexpr int SP_OPER_F = 3 * SP_PLANE_F; // one operand (hi, mid, lo)
     static constexpr int SP_NBUF = (2 * 2 * SP_OPER_F * 4 + HP * PINN_XS_LD * 4 <= 160 * 1024) ? 2 : 1;
@@ -86,7 +91,13 @@ pinn_wgrad_kernel(const PinnKArgs A) {
     const long long t_first = A.tile_begin + PINN_BID, t_step = PINN_NBLK;
     auto unit0 = [&](int j) { return (wave * NTW + j) * 16 + 4 * lq; };
 
-    for (int li = 0; li < lh; ++li) {
+    constexpr int NBLK = W::NBLK, HB = W::HB;
+    // (width 512: waves [0, NW / 2) hold the units of block 0 in the tile kernel's lane-private layout, the others those of block 1)
+    const int my_blk = (NBLK > 1) ? (wave * NTW * 16) / HB : 0;
+    for (int li = 0; li < lh; ++li)
+    for (int mb = 0; mb < NBLK; ++mb)
+    for (int nb = 0; nb < NBLK; ++nb) {
+        const bool need_g = (NBLK == 1) || my_blk == mb, need_h = (NBLK == 1) || my_blk == nb;
         // layer a = li + 1: A operand gz_a, B operand h_{a-1} = h of activation index li
         const PinnAct act(pinn_act_code(A.act_codes, li) & (HEAVY ? (ALLACT ? 15 : 7) : 1), HEAVY ? A.act_par[li] : 0.0f);
         int sk_in = -1;                   // skip that joins behind activation li
@@ -106,14 +117,15 @@ pinn_wgrad_kernel(const PinnKArgs A) {
             const f32x4* gzp = A.gzslab + tl * gz_tile + (((size_t)(li * S + s) * NTW) * MT + mt) * NTHREADS;
             const f32x4* svp = A.slab + tl * sv_tile + (((size_t)(li * S + s) * NTW) * MT + mt) * NTHREADS;
             const unsigned t = (unsigned)tid;
-            if (SKIPS && sk_in >= 0) {
+            if (SKIPS && sk_in >= 0 && need_h) {
                 const f32x4* skp = A.slab + tl * sv_tile + (((size_t)((lh + 1 + sk_in) * S + s) * NTW) * MT + mt) * NTHREADS;
 #pragma unroll
                 for (int j = 0; j < NTW; ++j) skr[SKIPS ? j : 0] = pinn_ld4_stream<(HP >= PINN_SLAB_NT_MIN_HP)>(skp + (size_t)j * MT * NTHREADS + t);
             }
 #pragma unroll
             for (int j = 0; j < NTW; ++j) {
-                gzr[j] = pinn_ld4_stream<(HP >= PINN_SLAB_NT_MIN_HP)>(gzp + (size_t)j * MT * NTHREADS + t);
+                if (need_g) gzr[j] = pinn_ld4_stream<(HP >= PINN_SLAB_NT_MIN_HP)>(gzp + (size_t)j * MT * NTHREADS + t);
+                if (!need_h) continue;
                 if (li > 0 || s == 0) {
                     svr[j] = pinn_ld4_stream<(HP >= PINN_SLAB_NT_MIN_HP)>(svp + (size_t)j * MT * NTHREADS + t);
                 } else {
@@ -177,8 +189,9 @@ pinn_wgrad_kernel(const PinnKArgs A) {
             for (int j = 0; j < NTW; ++j)
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
-                    buf[(unit0(j) + r) * LDK + lr] = gzr[j][r];
-                    buf[OPER + (unit0(j) + r) * LDK + lr] = hv[j][r];
+                    const int row = unit0(j) + r - my_blk * HB;          // (this lane's unit inside its block)
+                    if (need_g) buf[row * LDK + lr] = gzr[j][r];
+                    if (need_h) buf[OPER + row * LDK + lr] = hv[j][r];
                 }
         };
 
@@ -329,7 +342,7 @@ pinn_wgrad_kernel(const PinnKArgs A) {
         int p = 0;
         if (t_first < A.tile_end) {
             load_raw(t_first, 0, 0, gzr, svr, skr);
-            transform(0, svr, hv, skr);
+            if (need_h) transform(0, svr, hv, skr);
             write_stage(smem, gzr, hv);
         }
         PINN_SYNC();
@@ -346,7 +359,7 @@ pinn_wgrad_kernel(const PinnKArgs A) {
                     if (has_next && !PINN_DBG(A, 32)) load_raw(ntile, nmt, ns, gzr, svr, skr);
                     mfma_stage(smem + p * 2 * OPER);
                     if (has_next && !PINN_DBG(A, 16)) {
-                        transform(ns, svr, hv, skr);
+                        if (need_h) transform(ns, svr, hv, skr);
                         write_stage(smem + (p ^ 1) * 2 * OPER, gzr, hv);
                     }
                     if (!PINN_DBG(A, 8)) PINN_SYNC();
@@ -359,7 +372,8 @@ pinn_wgrad_kernel(const PinnKArgs A) {
         // (one 32-bit lane offset + a pointer per output tile row i; rows r and column tiles jn sit at immediate offsets below 4 KB: left
         //  to itself the compiler hoists all AM * BN * 4 sixty-four-bit element offsets out of the layer loop and parks them in scratch
         //  -- 200 spilled registers at width 256, none of them inside a stage, but 800 B of scratch per lane for nothing)
-        float* dst = part + A.off_wh + (size_t)li * A.hidden_stride + (unsigned)((m0 + 4 * lq) * HP + n0 + lr);
+        if (NBLK > 1) PINN_SYNC();          // (the next block pass restages both LDS buffers from their start)
+        float* dst = part + A.off_wh + (size_t)li * A.hidden_stride + (unsigned)((mb * HB + m0 + 4 * lq) * HP + nb * HB + n0 + lr);
 #pragma unroll
         for (int i = 0; i < AM; ++i) {
             float* row = dst + (unsigned)(16 * i * HP);

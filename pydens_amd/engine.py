@@ -138,8 +138,7 @@ def bind(lib):
     lib.pinn_debug_fit_persistent.argtypes = [vp, ctypes.c_int]
     lib.pinn_fit_chunk_status.argtypes = []
     lib.pinn_fit_chunk_status.restype = ctypes.c_int
-    if hasattr(lib, 'pinn_debug_fit_onecu_rounds'):              # (experiment builds of older sources, tools/variant.sh, lack the knob)
-        lib.pinn_debug_fit_onecu_rounds.argtypes = [vp, ctypes.c_int]
+    lib.pinn_debug_fit_onecu_rounds.argtypes = [vp, ctypes.c_int]       # (a required symbol like the others: ABI_SYMBOLS)
     lib.pinn_last_launch_info.argtypes = [ctypes.POINTER(ctypes.c_int32)]
     lib.pinn_debug_fit_graph_stats.argtypes = [ctypes.POINTER(ctypes.c_int32)]
     for name in ('pinn_create', 'pinn_create_ex', 'pinn_destroy', 'pinn_layout', 'pinn_jet_forward', 'pinn_jet_forward_ws', 'pinn_jet_backward',
@@ -267,7 +266,11 @@ class Net:
         if os.environ.get('PYDENS_AMD_FIT_PERSIST') in ('0', '1', '2'):
             self.lib.pinn_debug_fit_persistent(self.handle, int(os.environ['PYDENS_AMD_FIT_PERSIST']))
         if os.environ.get('PYDENS_AMD_FIT_ROUNDS'):
-            self.lib.pinn_debug_fit_onecu_rounds(self.handle, int(os.environ['PYDENS_AMD_FIT_ROUNDS']))
+            try:
+                rounds = int(os.environ['PYDENS_AMD_FIT_ROUNDS'])
+            except ValueError:
+                raise ValueError(f"PYDENS_AMD_FIT_ROUNDS={os.environ['PYDENS_AMD_FIT_ROUNDS']!r}: expected an integer") from None
+            self.lib.pinn_debug_fit_onecu_rounds(self.handle, rounds)
         if os.environ.get('PYDENS_AMD_TANH'):
             self.set_tanh_mode(os.environ['PYDENS_AMD_TANH'])
         if os.environ.get('PYDENS_AMD_WGX_CHUNK_MB'):           # experiments: slab budget of the widths >= 128 (pinn_debug_wgx_chunk_bytes)

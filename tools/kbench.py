@@ -17,7 +17,7 @@ def bench(cfg_name, lib_path, n=None, reps=None, rounds=3):
     reps = reps or (8 if cfg_name in ('cfg3', 'cfg5') else 30)
     lib = engine.bind(ctypes.CDLL(lib_path))
     torch.manual_seed(0)
-    cfg = pc.make_config(cfg_name, pa.D, torch)
+    cfg = pc.make_config(cfg_name, pa.D, torch, V=pa.V)
     solver = pa.Solver(cfg['equation'], **cfg['solver_kwargs'], _lib=lib)
     n = n or (cfg['n_points'] if cfg_name == 'cfg3' else min(cfg['n_points'], 131072))
     xs = torch.from_numpy(pc.sample_points(cfg, n, seed=1)).cuda()
