@@ -51,6 +51,10 @@ WORKLOADS = {
     'sin64': (65536, 16384, "breadth: 2D Poisson, 4x64 MLP with activation 'Sin' -- breadth kernels (VAR 8)"),
     'program': (65536, 16384, 'breadth: u_xx+u_yy+k u^2=5sin(pi(x+y)) with a trainable V(k), 4x64 Tanh -- residual program + its reverse sweep'),
     'generic': (65536, 16384, 'breadth: BASELINE cfg2 on the GENERIC step path (pinn_jet_forward -> torch autograd over the equation -> pinn_jet_backward)'),
+    # round 6
+    'burgers64': (65536, 16384, 'breadth: viscous Burgers u_t+u u_x=0.05 u_xx (x,t), IC sin(pi x), BC 0, 4x64 Tanh -- evolution shape with a residual program on the two-team kernel (VAR 256 | 32 | 2048)'),
+    'heat64': (65536, 16384, 'breadth: 1-D heat u_t=0.3 u_xx+2e^{-t}sin(pi x) (x,t), IC sin(pi x), BC 0, 4x64 Tanh -- evolution shape, affine residual, two-team kernel (VAR 256 | 32)'),
+    'poisson512': (65536, 4096, 'breadth: BASELINE cfg2 problem on a 4x512 Tanh MLP -- hidden width 512: generic step path, one kernel call of S = 3 streams per second-order direction, weight gradients in four 256 x 256 block passes'),
 }
 BASELINE_WORKLOADS = ('cfg2', 'cfg3', 'cfg4', 'cfg5')
 
@@ -394,8 +398,8 @@ def main():
     cfg = pc.make_config(args.workload, pa.D, torch, V=pa.V)
     extra = dict(_lib=pa.engine._LIB) if on_cpu else {}
     solver = pa.Solver(cfg['equation'], **cfg['solver_kwargs'], device=device, **extra)
-    assert solver.program is not None, solver.program_error
-    generic = args.workload == 'generic'
+    generic = args.workload in ('generic', 'poisson512')     # (width 512: S <= 3 streams per call -- the Laplacian runs in direction groups on the generic path)
+    assert generic or solver.program is not None, solver.program_error
     if generic:
         solver.program = None                   # what a user gets whose equation the tracer cannot lower
     solver.set_gemm_mode(args.gemm)

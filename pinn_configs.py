@@ -131,6 +131,20 @@ def make_config(name, D, torch, V=None):
                     solver_kwargs=dict(ndims=2, boundary_condition=0.3, layout='fa fa f', features=[24, 24, 1], activation='Tanh'),
                     n_points=4096, low=[0, 0], high=[1, 1])
     # ---- breadth workloads: timed by `bench.py --workload ...`, not BASELINE configs -----------------------
+    if name in ('burgers64', 'heat64', 'poisson512'):           # round 6 breadth workloads
+        if name == 'burgers64':                                  # viscous Burgers in (x, t) on the 4 x 64 Tanh net: residual program, IC + BC (PinnShape 2)
+            def burgers(f, x, t):
+                return D(f, t) + f * D(f, x) - 0.05 * D(D(f, x), x)
+            return dict(equation=burgers, solver_kwargs=dict(ndims=2, boundary_condition=0, initial_condition=lambda x: torch.sin(PI * x), **mlp(4, 64)),
+                        n_points=65536, low=[0, 0], high=[1, 1])
+        if name == 'heat64':                                     # 1-D heat equation with a source, same net: affine residual, IC + BC
+            def heat(f, x, t):
+                return D(f, t) - 0.3 * D(D(f, x), x) - 2.0 * torch.exp(-t) * torch.sin(PI * x)
+            return dict(equation=heat, solver_kwargs=dict(ndims=2, boundary_condition=0, initial_condition=lambda x: torch.sin(PI * x), **mlp(4, 64)),
+                        n_points=65536, low=[0, 0], high=[1, 1])
+        def poisson512(f, x, y):                                 # BASELINE config 2's problem on a 4 x 512 net: width 512, generic path, one call per direction
+            return D(D(f, x), x) + D(D(f, y), y) - 5 * torch.sin(PI * (x + y))
+        return dict(equation=poisson512, solver_kwargs=dict(ndims=2, boundary_condition=1, **mlp(4, 512)), n_points=65536, low=[0, 0], high=[1, 1])
     if name in ('skip128', 'skip256', 'sin64', 'sin128', 'gelu256', 'program', 'generic'):
         def poisson(f, x, y):
             return D(D(f, x), x) + D(D(f, y), y) - 5 * torch.sin(PI * (x + y))

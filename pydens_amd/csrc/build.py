@@ -14,7 +14,8 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 PKG = os.path.dirname(HERE)
 OUT = os.path.join(PKG, 'libpinn_hip.so')
 OBJ = os.path.join(HERE, '_obj')
-WIDTHS = (16, 32, 64, 128, 256)
+WIDTHS = (16, 32, 64, 128, 256, 512)
+ALLACT_WIDTHS = (16, 32, 64, 128, 256)           # (width 512, round 6: plain kernels + the first set of full breadth kernels only)
 FLAGS = ['--offload-arch=gfx950', '-O3', '-std=c++17', '-fPIC', '-x', 'hip', '-Wno-unused-result', '-I', HERE]
 # per-width scheduler choice (same-box A/B of hipcc's -amdgpu-sched-strategy values on the BASELINE kernels, DESIGN.md
 # section 6): the width-256 kernels (256 VGPRs, spilling) run 4.9 % faster under `iterative-maxocc` (4.1 % under
@@ -23,7 +24,8 @@ FLAGS = ['--offload-arch=gfx950', '-O3', '-std=c++17', '-fPIC', '-x', 'hip', '-W
 # round 2 (two-team width-64 kernels, streamed weight gradients): width 64 gains 1.5 % on cfg4 under `iterative-ilp` (cfg2 +-0);
 # width 256 is within 0.3 % between the default and `iterative-maxocc` now (`iterative-ilp` costs its weight-gradient kernel 27 %);
 # width 128 is within 1 % everywhere
-WIDTH_FLAGS = {256: ['-mllvm', '-amdgpu-sched-strategy=iterative-maxocc'], 64: ['-mllvm', '-amdgpu-sched-strategy=iterative-ilp']}
+WIDTH_FLAGS = {256: ['-mllvm', '-amdgpu-sched-strategy=iterative-maxocc'], 64: ['-mllvm', '-amdgpu-sched-strategy=iterative-ilp'],
+               512: ['-mllvm', '-amdgpu-sched-strategy=iterative-maxocc']}       # (width 512: register-bound like 256; not measured separately)
 # split-bf16 twins of the two BASELINE width-64 kernels (same-box A/B, round 3): 1 = the S = 4 Poisson-box kernel, fastest with the
 # SLP vectoriser on (packed fp32 ops: fewer instructions to issue) and -- it sits at the 256-register limit of two waves per SIMD --
 # without operand prefetch in its forward / data-gradient GEMMs (40 spilled registers otherwise), 2 = the S = 2 ODE-family kernel,
@@ -106,7 +108,7 @@ def _build(force, verbose, extra_flags, widths):
                            os.path.join(HERE, 'pinn_inst.inc'), '-o', obj]))
     # second set of full breadth kernels (round 5: all sixteen activations, nested skips -- pinn_inst.inc PINN_INST_ALLACT): a unit of
     # its own per width, so that the build's wall time stays that of its longest unit
-    for hp in WIDTHS:
+    for hp in ALLACT_WIDTHS:
         for part in ((1, 2) if hp >= 128 else (1,)):         # 1: tile kernels (+ the stub of the partner launcher below width 128), 2: weight-gradient partners
             obj = os.path.join(OBJ, f'inst_hp{hp}_allact{part}.o')
             jobs.append((obj, [hipcc, *FLAGS, *WIDTH_FLAGS.get(hp, []), *extra_flags, *([] if hp in widths else ['-DPINN_ONLY_BASELINE']),
@@ -160,7 +162,7 @@ def _build(force, verbose, extra_flags, widths):
         return obj
 
     # (the widest units take longest: start them first so that the pool's tail is short)
-    order = sorted(range(len(jobs)), key=lambda i: (0 if 'hp256' in jobs[i][0] else 1 if 'hp128' in jobs[i][0] else 2, i))
+    order = sorted(range(len(jobs)), key=lambda i: (0 if ('hp256' in jobs[i][0] or 'hp512' in jobs[i][0]) else 1 if 'hp128' in jobs[i][0] else 2, i))
     with ThreadPoolExecutor(max_workers=min(len(jobs), os.cpu_count() or 4)) as pool:
         done = dict(zip(order, pool.map(run, [jobs[i] for i in order])))
     objs = [done[i] for i in range(len(jobs))]

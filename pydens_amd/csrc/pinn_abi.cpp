@@ -104,6 +104,7 @@ wgrad_fn wgrad_launcher_for(int hp) {
     switch (hp) {
         case 128: return pinn_launch_wgrad_hp128;
         case 256: return pinn_launch_wgrad_hp256;
+        case 512: return pinn_launch_wgrad_hp512;
         default: return nullptr;
     }
 }
@@ -119,6 +120,7 @@ launch_fn launcher_for(int hp) {
         case 64: return pinn_launch_tile_hp64;
         case 128: return pinn_launch_tile_hp128;
         case 256: return pinn_launch_tile_hp256;
+        case 512: return pinn_launch_tile_hp512;
         default: return nullptr;
     }
 }
@@ -181,7 +183,7 @@ struct Plan {
 int make_plan(const pinn_net* net, int64_t n_points, int nd, int n2, Plan* plan, int mode = PINN_MODE_FORWARD,
               int res_kind = PINN_RES_PROGRAM, int comb = 0, const PinnKArgs* hint = nullptr) {
     plan->fn = launcher_for(net->lay.hp);
-    if (!plan->fn) return fail("no kernel for padded hidden width %d (supported: 16, 32, 64, 128, 256)", net->lay.hp);
+    if (!plan->fn) return fail("no kernel for padded hidden width %d (supported: 16, 32, 64, 128, 256, 512)", net->lay.hp);
     plan->n2k = comb ? 1 : pick_n2(nd, n2);
     if (comb && (n2 != 1 || nd < 2 || nd > 4)) return fail("combined second-order stream needs n2 == 1 and nd in {2, 3, 4}");
     if (plan->n2k < 0) return fail("unsupported derivative spec nd=%d n2=%d n3=%d n4=%d (nd <= 3 with n2 <= nd, nd = 4 with n2 = 0 / one combined second-order stream, one third-order direction with nd <= 2, or one fourth-order direction alone)", nd, pinn_n2(n2), pinn_n3(n2), pinn_n4(n2));
@@ -588,8 +590,11 @@ int pinn_create_ex(const int* layer_dims, int n_layers, const int* acts, int n_s
     if (hp == 48) hp = 64;
     if (hp > 64 && hp < 128) hp = 128;
     if (hp > 128 && hp <= 256) hp = 256;
-    if (hp > 256) return fail("hidden width %d > 256 is not supported by this build", hmax);
+    if (hp > 256 && hp <= 512) hp = 512;
+    if (hp > 512) return fail("hidden width %d > 512 is not supported by this build", hmax);
     const int lh = n_layers - 2;
+    // (width 512, round 6: eight bias-gradient rows in the LDS carve -- PinnCfg::ACCB_ROWS -- i.e. up to eight hidden layers)
+    if (hp == 512 && lh + 1 > 8) return fail("hidden width %d (padded to 512): at most 8 hidden layers at this width, got %d", hmax, lh + 1);
     pinn_net* net = new (std::nothrow) pinn_net();
     if (!net) return fail("out of memory");
     memset(net, 0, sizeof(*net));

@@ -1192,7 +1192,7 @@ PINN_DEVICE void pinn_point_stage(const PinnKArgs& A, const float* params_, cons
 #if defined(PINN_PROFILE_PHASES) && !defined(PINN_EMU)
 #define PH_DECL long long ph_acc[16] = {0}; long long ph_last = __builtin_readcyclecounter();
 #define PH(i) { PINN_SCHED_BARRIER(); const long long ph_now = __builtin_readcyclecounter(); ph_acc[i] += ph_now - ph_last; ph_last = ph_now; PINN_SCHED_BARRIER(); }
-#define PH_FLUSH if (A.prof && lane == 0) { for (int i = 0; i < 16; ++i) A.prof[((size_t)rowid * NW + wave) * 16 + i] = ph_acc[i]; }
+#define PH_FLUSH if (A.prof && lane == 0) { for (int i = 0; i < 16; ++i) A.prof[((size_t)vbid * NW + wave) * 16 + i] = ph_acc[i]; }      /* (a row per TEAM: vbid) */
 #else
 #define PH_DECL
 #define PH(i)

@@ -182,8 +182,19 @@ class StreamSpec:
                                (self.nd == 4 and self.n2 == 0)
         if allact and self.n4 == 0:
             self.single_call = (self.nd <= 2) if self.n3 == 0 else (self.n3 == 1 and self.n2 == 1 and self.nd == 1)
+        self.hp = hp
+        if hp == 512:
+            # width 512 (round 6): one 16-point tile of S streams is 33 KB x S of LDS activations -- S <= 3 per kernel call: the value with ONE
+            # direction and its second derivative, or with two first-order directions; everything else in direction groups of that size
+            if self.n3 > 0:
+                raise NotImplementedError('third- and fourth-order derivatives at hidden width 512 are not built (three derivative streams per '
+                                          'kernel call at that width); widths up to 256 carry them')
+            if allact:
+                raise NotImplementedError('hidden width 512: the second set of full breadth kernels (activation codes above 7, nested skips) is '
+                                          'not built at that width')
+            self.single_call = self.nd <= 1 or (self.nd == 2 and self.n2 == 0)
         # ... or as [u, firsts, one combined second-order stream] (affine residuals only)
-        self.combinable = 2 <= self.nd <= (3 if allact else MAX_DIRS) and self.n2 >= 1 and self.n3 == 0
+        self.combinable = 2 <= self.nd <= (3 if allact else MAX_DIRS) and self.n2 >= 1 and self.n3 == 0 and hp != 512
         # groups for the generic path: (direction codes, packed n2 of the group, stream index of each of the group's streams)
         self.groups = []
         if self.single_call:
@@ -192,6 +203,9 @@ class StreamSpec:
             # every third- / fourth-order direction in a call of its own (those kernels carry one such direction), the rest in pairs
             rest = list(range(self.n3, self.nd))
             chunks = [[k] for k in range(self.n3)] + [rest[i:i + 2] for i in range(0, len(rest), 2)]
+            if hp == 512:       # second-order directions one per call, the first-order rest in pairs
+                rest = list(range(self.n2, self.nd))
+                chunks = [[k] for k in range(self.n2)] + [rest[i:i + 2] for i in range(0, len(rest), 2)]
         for ks in chunks:
             n2g = sum(1 for k in ks if k < self.n2)
             n3g = sum(1 for k in ks if k < self.n3)
@@ -761,6 +775,13 @@ def _worth_combining(weights, spec):
 
 
 def combine_second_order(plan, spec):
+    # (width 512: no combined second-order stream -- S <= 3 streams per call at that width, StreamSpec)
+    if getattr(spec, 'hp', None) == 512:
+        return False
+    return _combine_second_order(plan, spec)
+
+
+def _combine_second_order(plan, spec):
     """ Affine residual whose second derivatives enter only as  sum_k c_k u_kk  with CONSTANT c_k (Laplacian, wave,
     heat operators): propagate that one combination instead of n2 separate streams. Rewrites the plan in place to the
     stream layout [u, firsts (nd), combined] and returns True; otherwise leaves it alone. """

@@ -13,7 +13,8 @@ OUT = os.path.join(BUILD, 'libpinn_emu.so')
 CXX = '/opt/rocm/lib/llvm/bin/clang++'
 FLAGS = ['-x', 'c++', '-DPINN_EMU', '-O1', '-std=c++17', '-fPIC', '-I', HERE, '-I', CSRC, '-Wno-unknown-pragmas',
          '-Wno-pass-failed']
-WIDTHS = (16, 32, 64, 128, 256)
+WIDTHS = (16, 32, 64, 128, 256, 512)
+ALLACT_WIDTHS = (16, 32, 64, 128, 256)       # (width 512: no second set of full breadth kernels, pydens_amd/csrc/build.py)
 
 
 def _deps():
@@ -58,7 +59,7 @@ def _build(force, extra_flags, tag, widths):
         jobs.append([CXX, *FLAGS, '-DPINN_INST_HP=64', '-DPINN_INST_OWN=1', '-c', os.path.join(CSRC, 'pinn_inst.inc'), '-o',
                      os.path.join(BUILD, 'inst_hp64_own1.o')])          # (BASELINE config 2's fp32 kernel: a unit of its own in the product build)
         jobs += [[CXX, *FLAGS, f'-DPINN_INST_HP={hp}', f'-DPINN_INST_ALLACT={part}', '-c', os.path.join(CSRC, 'pinn_inst.inc'), '-o',
-                  os.path.join(BUILD, f'inst_hp{hp}_allact{part}.o')] for hp in WIDTHS for part in ((1, 2) if hp >= 128 else (1,))]
+                  os.path.join(BUILD, f'inst_hp{hp}_allact{part}.o')] for hp in ALLACT_WIDTHS for part in ((1, 2) if hp >= 128 else (1,))]
         jobs.append([CXX, *FLAGS, '-c', os.path.join(CSRC, 'pinn_abi.cpp'), '-o', os.path.join(BUILD, 'abi.o')])
         jobs.append([CXX, *FLAGS, '-c', os.path.join(HERE, 'emu_runtime.cpp'), '-o', os.path.join(BUILD, 'emu_runtime.o')])
         with ThreadPoolExecutor(max_workers=os.cpu_count() or 4) as pool:
@@ -84,7 +85,7 @@ def _build(force, extra_flags, tag, widths):
         objs += [os.path.join(BUILD, f'inst_hp64_split{n}.o') for n in (1, 2)]
     objs += [os.path.join(BUILD, f'inst_hp{hp}_split.o') for hp in (128, 256)]
     objs.append(os.path.join(BUILD, 'inst_hp64_own1.o'))
-    objs += [os.path.join(BUILD, f'inst_hp{hp}_allact{part}.o') for hp in WIDTHS for part in ((1, 2) if hp >= 128 else (1,))]   # (second set of full breadth kernels: the default build's)
+    objs += [os.path.join(BUILD, f'inst_hp{hp}_allact{part}.o') for hp in ALLACT_WIDTHS for part in ((1, 2) if hp >= 128 else (1,))]   # (second set of full breadth kernels: the default build's)
     objs += [os.path.join(BUILD, 'abi.o'), os.path.join(BUILD, 'emu_runtime.o')]
     _run([CXX, '-shared', '-fPIC', *objs, '-o', tout])
     return tout

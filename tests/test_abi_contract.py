@@ -35,7 +35,8 @@ def _ptr(t):
 
 def test_create_rejects_what_the_kernels_do_not_instantiate(lib):
     from pydens_amd import engine
-    for dims, kw, needle in (((2, 300, 1), {}, 'width'),                      # wider than 256
+    for dims, kw, needle in (((2, 600, 1), {}, 'width'),                      # wider than 512
+                             ((2,) + (300,) * 9 + (1,), {}, 'at most 8 hidden layers'),     # width 512: eight bias-gradient rows in the LDS carve (round 6)
                              ((2,) + (8,) * 33 + (1,), {}, 'layer'),           # more than PINN_MAX_LAYERS (32) linear layers
                              ((9, 8, 1), dict(ndims=9), 'ndims+nparams'),     # more than PINN_MAX_INPUTS columns
                              ((2, 8, 2), {}, 'one unit')):                     # not a scalar field
@@ -46,6 +47,17 @@ def test_create_rejects_what_the_kernels_do_not_instantiate(lib):
         engine.Net([2, 8, 1], 'hardswish', 2, lib=lib)           # (an activation outside the sixteen codes of include/pinn.h)
     # round 5: ReLU & co. exist -- ReLU (code 7) with the first set of full breadth kernels, codes above 7 on the second set
     assert not engine.Net([2, 8, 1], 'relu', 2, lib=lib).allact and engine.Net([2, 8, 1], 'elu', 2, lib=lib).allact
+    # round 6: widths 257 .. 512 exist (padded to 512); what that width does not carry is refused where the streams are planned
+    wide = _net(lib, (2, 300, 300, 1))
+    assert wide.layout.hp == 512
+    from pydens_amd import trace
+    spec = trace.StreamSpec({(0,), (0, 0), (1,), (1, 1), (2,)}, hp=512)
+    assert [g[1] for g in spec.groups] == [1, 1, 0] and [len(g[0]) for g in spec.groups] == [1, 1, 1] and not spec.single_call and not spec.combinable
+    assert trace.StreamSpec({(0,), (0, 0)}, hp=512).single_call and trace.StreamSpec({(0,), (1,)}, hp=512).single_call
+    with pytest.raises(NotImplementedError, match='width 512'):
+        trace.StreamSpec({(0,), (0, 0), (0, 0, 0)}, hp=512)
+    with pytest.raises(NotImplementedError, match='second set'):
+        trace.StreamSpec({(0,)}, hp=512, allact=True)
     bad = (ctypes.c_int * 3)(2, 8, 1)
     assert lib.pinn_create_ex(bad, 2, None, 0, None, None, 2, 0, 0, 0, None, None, 0.0, None) != 0
 

@@ -1162,6 +1162,110 @@ def test_sin_net_of_depth_four_takes_the_static_kernel(pa, emu_lib, bc):
         assert params_close(got, want, 2e-5)
 
 
+def _wide512_problems(D, torch, which):
+    """ hidden widths beyond 256 (the reference takes any `features`, model_torch.py:158-168): padded to 512 """
+    if which == 'ode_fused':          # one direction with its second derivative: ONE kernel call (S = 3), fused step path
+        eq = lambda f, x: D(D(f, x), x) + f - torch.sin(3.0 * x)
+        return eq, dict(ndims=1, boundary_condition=0.2, layout='fa fa f', features=[300, 300, 1], activation='Tanh'), 'fused'
+    if which == 'poisson_groups':     # two second-order directions: one kernel call each (generic path)
+        eq = lambda f, x, y: D(D(f, x), x) + D(D(f, y), y) - 5 * torch.sin(np.pi * (x + y))
+        return eq, dict(ndims=2, boundary_condition=1, layout='fa fa fa f', features=[264, 320, 264, 1], activation='Tanh'), 'generic'
+    if which == 'heat_sigmoid':       # IC + BC, a second-order and a first-order direction (two calls), Sigmoid
+        eq = lambda f, x, t: D(f, t) - 0.2 * D(D(f, x), x)
+        return eq, dict(ndims=2, boundary_condition=0.0, initial_condition=lambda x: torch.sin(np.pi * x), layout='fa fa f', features=[512, 512, 1],
+                        activation='Sigmoid'), 'generic'
+    # first breadth set: Sin / GELU layers and a skip connection at width 512
+    eq = lambda f, x, y: D(f, x) + 0.5 * D(f, y) - f * f
+    return eq, dict(ndims=2, boundary_condition=0.3, layout='faR fa fa+ f', features=[288, 288, 288, 1], activation=['Sin', 'GELU', 'Tanh']), 'fused'
+
+
+@pytest.mark.parametrize('which', ['ode_fused', 'poisson_groups', 'heat_sigmoid', 'advection_breadth'])
+def test_hidden_width_512_matches_the_oracle(pa, emu_lib, which):
+    # (a 512-wide net costs the emulator minutes per tile: two cases in the CPU tier, all four with PYDENS_AMD_SLOW_EMU=1 -- and on the device,
+    #  tests/test_gpu_parity.py::test_hidden_width_512_on_the_gpu)
+    if which in ('poisson_groups', 'advection_breadth') and os.environ.get('PYDENS_AMD_SLOW_EMU') != '1':
+        pytest.skip('slow on the emulator: PYDENS_AMD_SLOW_EMU=1, or the -m gpu twin')
+    _wide512_case(pa, which, emu_kwargs(emu_lib), 16)
+
+
+def _wide512_case(pa, which, solver_kwargs, n):
+    """ round 6: widths 257 .. 512 run on kernels of their own -- S <= 3 streams per call (LDS), anything larger in direction groups, eight
+    bias-gradient rows, the streamed weight-gradient kernel in four 256 x 256 block passes """
+    from oracle import pinn_oracle as po
+    torch.manual_seed(53)
+    eq_o, kw, path = _wide512_problems(po.D, torch, which)
+    oracle32 = po.OracleSolver(eq_o, **kw)
+    oracle = po.OracleSolver(eq_o, dtype=torch.float64, **kw)
+    start = oracle32.export_params()
+    oracle.import_params(start)
+    eq_p, kw, _ = _wide512_problems(pa.D, torch, which)
+    solver = pa.Solver(eq_p, **kw, **solver_kwargs)
+    assert solver.model.net.layout.hp == 512
+    assert (solver.program is not None) == (path == 'fused'), solver.program_error
+    load_params(solver, start)
+    d = kw['ndims']
+    pts = np.random.RandomState(21).rand(3, n, d).astype(np.float32)
+    ev32, g32 = oracle32.evaluate(pts[0]), oracle32.export_grads()
+    ev, g_want = oracle.evaluate(pts[0]), oracle.export_grads()
+    xs = torch.from_numpy(pts[0].copy()).to(solver.device)
+    if path == 'fused':
+        solver._fused_step(xs, 1)
+    else:
+        solver._generic_step(xs, ('equation',), [], torch.nn.MSELoss(), 1)
+    lay = solver.model.net.layout
+    loss = float(solver.grads[lay.off_loss])
+    assert abs(loss - ev['loss']) <= max(2 * abs(ev32['loss'] - ev['loss']), 1e-5 * ev['loss']), (loss, ev['loss'], ev32['loss'])
+    for got, want, w32 in zip(export_grads(solver), g_want, g32):
+        if want is not None:
+            err = np.linalg.norm(np.asarray(got, dtype=np.float64) - want)
+            assert err <= max(2 * np.linalg.norm(np.asarray(w32, dtype=np.float64) - want), 1e-5 * np.linalg.norm(want)), (which, err)
+    oracle32.fit(niters=2, batch_size=n, points=pts[1:], lr=0.002)
+    solver.fit(niters=2, batch_size=n, sampler=FixedBatches(pts[1:]), lr=0.002)
+    assert solver.last_fit_path == path
+    np.testing.assert_allclose([float(v) for v in solver.losses], [float(v) for v in oracle32.losses], rtol=5e-5)
+    for got, want in zip(export_params(solver), oracle32.export_params()):
+        assert params_close(got, want, 5e-5, atol=5e-6)
+    cols = [pts[0][:, i] for i in range(d)]
+    assert np.abs(solver.predict(*cols) - oracle32.predict(*cols)).max() < 2e-5
+
+
+def _evolution_problems(D, torch, which):
+    """ (x, t) problems on a 4 x 64 Tanh net: boundary binding in x, initial condition in t (PinnShape 2) """
+    kw = dict(ndims=2, boundary_condition=0.1, initial_condition=lambda x: torch.sin(np.pi * x), layout='fa fa fa fa f', features=[64, 64, 64, 64, 1],
+              activation='Tanh')
+    if which == 'heat':           # affine residual, one second derivative beside u_t: the combined second-order stream
+        return (lambda f, x, t: D(f, t) - 0.3 * D(D(f, x), x) - 2.0 * torch.exp(-t) * torch.sin(np.pi * x)), kw
+    if which == 'wave':           # second derivatives in both columns
+        return (lambda f, x, t: D(D(f, t), t) - 0.5 * D(D(f, x), x)), kw
+    return (lambda f, x, t: D(f, t) + f * D(f, x) - 0.05 * D(D(f, x), x)), kw            # viscous Burgers: residual program
+
+
+@pytest.mark.parametrize('which', ['heat', 'wave', 'burgers'])
+def test_evolution_shape_in_x_t_takes_the_two_team_kernels(pa, emu_lib, which):
+    _evolution_case(pa, which, emu_kwargs(emu_lib), 50, emu_lib)
+
+
+def _evolution_case(pa, which, solver_kwargs, n, lib=None):
+    """ round 6: heat / wave / Burgers in one space dimension on the 4 x 64 Tanh net run on two-team twins of the Poisson-box kernel
+    (VAR 256 | 32: PinnShape 2; | 2048 with a residual program) instead of the general one-wave-per-SIMD kernel """
+    from oracle import pinn_oracle as po
+    torch.manual_seed(31)
+    eq_o, kw = _evolution_problems(po.D, torch, which)
+    oracle = po.OracleSolver(eq_o, **kw)
+    eq_p, kw = _evolution_problems(pa.D, torch, which)
+    solver = pa.Solver(eq_p, **kw, **solver_kwargs)
+    assert solver.program is not None, solver.program_error
+    load_params(solver, oracle.export_params())
+    pts = np.random.RandomState(12).rand(2, n, 2).astype(np.float32)
+    oracle.fit(niters=2, batch_size=n, points=pts, lr=0.005)
+    solver.fit(niters=2, batch_size=n, sampler=FixedBatches(pts), lr=0.005)
+    name = (lib or solver.model.net.lib).pinn_last_kernel_name().decode()
+    assert name == ('pinn_tile_kernel<64,2,1,1,3,0,true,2336>' if which == 'burgers' else 'pinn_tile_kernel<64,2,1,1,3,0,true,288>'), name
+    np.testing.assert_allclose([float(v) for v in solver.losses], [float(v) for v in oracle.losses], rtol=2e-5)
+    for got, want in zip(export_params(solver), oracle.export_params()):
+        assert params_close(got, want, 2e-5)
+
+
 @pytest.mark.parametrize('name', ['w16_program', 'w32_affine', 'w32_generic', 'w32_third_order', 'w100_heat', 'program', 'generic'])
 def test_the_large_batch_gpu_cases_on_a_few_points(pa, emu_lib, name):
     """ tests/test_gpu_occupancy.py runs these problems at 131 072 points on full grids of the device; here the same body (oracle

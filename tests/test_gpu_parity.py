@@ -1101,6 +1101,19 @@ def test_accurate_tanh_mode_on_a_trained_state(pa):
     assert max(ratios) <= 1.4, ratios
 
 
+@pytest.mark.parametrize('which', ['heat', 'wave', 'burgers'])
+def test_evolution_shape_in_x_t_on_the_two_team_kernels(pa, which):
+    import test_emu_engine as te
+    te._evolution_case(pa, which, {}, 3000)
+
+
+@pytest.mark.parametrize('which', ['ode_fused', 'poisson_groups', 'heat_sigmoid', 'advection_breadth'])
+def test_hidden_width_512_on_the_gpu(pa, which):
+    """ round 6: hidden widths 257 .. 512 (S <= 3 streams per kernel call, direction groups beyond, block passes of the weight-gradient kernel) """
+    import test_emu_engine as te
+    te._wide512_case(pa, which, {}, 4000)
+
+
 def test_sin_net_of_depth_four_on_the_static_kernel(pa):
     """ the 4 x 64 'Sin' breadth workload of bench.py (static-depth kernel with the Dirichlet-box facts fixed) against the oracle """
     from oracle import pinn_oracle as po

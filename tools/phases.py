@@ -20,7 +20,7 @@ if len(sys.argv) > 3 and sys.argv[3] == 'chain':      # pinn_chain_kernel
 lib = engine.bind(ctypes.CDLL(lib_path))
 lib.pinn_debug_phase_buffer.argtypes = [ctypes.c_void_p]
 torch.manual_seed(0)
-cfg = pc.make_config(cfg_name, pa.D, torch)
+cfg = pc.make_config(cfg_name, pa.D, torch, V=pa.V)
 solver = pa.Solver(cfg['equation'], **cfg['solver_kwargs'], _lib=lib)
 n = min(cfg['n_points'], 131072)
 xs = torch.from_numpy(pc.sample_points(cfg, n, seed=1)).cuda()
@@ -38,6 +38,14 @@ b = buf.cpu().numpy().reshape(-1, 16)
 b = b[b.sum(axis=1) > 0]
 if len(sys.argv) > 3 and sys.argv[3] == 'chain':
     b = b[b[:, 2] > 0]          # chain waves only (the wgrad waves report their total under 'epilogue')
+if len(sys.argv) > 3 and sys.argv[3] == 'teams':
+    # two-team kernels (round 6): rows are (workgroup, team, wave) -- the phase totals of team 0 and team 1 side by side
+    t = b.reshape(-1, 2, 4, 16)
+    print(f'{cfg_name}: {t.shape[0]} workgroups; cycles per wave and launch, team 0 | team 1 (mean over waves and workgroups)')
+    for i, name in enumerate(NAMES):
+        print(f'  {name:22s} {t[:, 0, :, i].mean():10.0f} | {t[:, 1, :, i].mean():10.0f}')
+    print(f'  {"total":22s} {t[:, 0].sum(axis=-1).mean():10.0f} | {t[:, 1].sum(axis=-1).mean():10.0f}')
+    sys.exit(0)
 nw = b.shape[0]
 tot = b.sum(axis=1).mean()
 print(f'{cfg_name}: {nw} waves reported, mean total cycles/wave {tot:.0f}')
