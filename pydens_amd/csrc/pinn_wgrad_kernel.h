@@ -108,9 +108,11 @@ pinn_wgrad_kernel(const PinnKArgs A) {
 #pragma unroll
             for (int jn = 0; jn < BN; ++jn) acc[i][jn] = f32x4{0.f, 0.f, 0.f, 0.f};
 
+        // (the lambdas below are forced inline: at width 512 -- four unit tiles per lane -- hipcc's inliner left load_raw / transform as
+        //  FUNCTIONS, their array arguments and the by-value kernel arguments in scratch: 12 ms instead of 2.6 for 65 536 points, round 6)
         // raw operands of a stage, straight from HBM (the tile kernel's lane-private layout: this thread reads what the
         // thread with the same id stored)
-        auto load_raw = [&](long long tile, int mt, int s, f32x4 (&gzr)[NTW], f32x4 (&svr)[NTW], f32x4 (&skr)[SKIPS ? NTW : 1]) {
+        auto load_raw = [&](long long tile, int mt, int s, f32x4 (&gzr)[NTW], f32x4 (&svr)[NTW], f32x4 (&skr)[SKIPS ? NTW : 1]) PINN_INLINE_LAMBDA {
             // (uniform 64-bit base per slot + this thread's 32-bit index: scalar address arithmetic, one VGPR of offset)
             // (debug flag 2, timing experiments only: every stage re-reads the first tile -- operands from L2 instead of HBM)
             const size_t tl = PINN_DBG(A, 2) ? 0 : (size_t)(tile - A.tile_begin);
@@ -142,7 +144,7 @@ pinn_wgrad_kernel(const PinnKArgs A) {
         f32x4 z1v[N3n > 0 ? N3n : 1][NTW], z2v[N3n > 0 ? N3n : 1][NTW];      // first / second streams of the third-order directions
         f32x4 s0v[KEEP0 ? NTW : 1];                                           // what was saved of the value stream (third / fourth derivative of the activation)
         f32x4 z3v[N4n > 0 ? N4n : 1][NTW];                                    // third streams of the fourth-order directions
-        auto transform = [&](int s, const f32x4 (&svr)[NTW], f32x4 (&hv)[NTW], const f32x4 (&skr)[SKIPS ? NTW : 1]) {
+        auto transform = [&](int s, const f32x4 (&svr)[NTW], f32x4 (&hv)[NTW], const f32x4 (&skr)[SKIPS ? NTW : 1]) PINN_INLINE_LAMBDA {
 #pragma unroll
             for (int j = 0; j < NTW; ++j) {
 #pragma unroll
@@ -184,7 +186,7 @@ pinn_wgrad_kernel(const PinnKArgs A) {
                 if (SKIPS && sk_in >= 0) hv[j] += skr[SKIPS ? j : 0];
             }
         };
-        auto write_stage = [&](float* buf, const f32x4 (&gzr)[NTW], const f32x4 (&hv)[NTW]) {
+        auto write_stage = [&](float* buf, const f32x4 (&gzr)[NTW], const f32x4 (&hv)[NTW]) PINN_INLINE_LAMBDA {
 #pragma unroll
             for (int j = 0; j < NTW; ++j)
 #pragma unroll
@@ -198,7 +200,7 @@ pinn_wgrad_kernel(const PinnKArgs A) {
         // stages of this workgroup in order: (tile, mt, s), s fastest and unrolled (the jet formulas branch on s). Stage i
         // computes from LDS buffer p while the raw operands of stage i + 1 are in flight from HBM; they are turned into
         // buffer p ^ 1 right behind the MFMAs, one barrier per stage.
-        auto mfma_stage = [&](const float* bg) {
+        auto mfma_stage = [&](const float* bg) PINN_INLINE_LAMBDA {
             // B fragments of the whole stage up front; A fragment of output tile row i + 1 in flight while the 4 * BN MFMAs
             // of row i issue (pinned with sched barriers: left alone the scheduler hoists every fragment load to the top
             // and the 128 accumulators no longer fit beside them)
