@@ -38,6 +38,8 @@
  * Round 6: WEIGHTED diagonals 2 e_a + e_b / 2 e_a - e_b (| PINN_DIR_DOUBLE): the part of D4 along alpha e_a + e_b that is odd in b is
  * 8 alpha^3 u_aaab + 8 alpha u_abbb, so with A = D4_{a+b} - D4_{a-b} and B = D4_{2a+b} - D4_{2a-b} the host assembles
  * u_aaab = (B - 2 A) / 48 and u_abbb = (8 A - B) / 48 (model_torch.py:174-178 nests D in any order).
+ * THREE-column directions e_a +- e_b +- e_c (| (c + 1) << 10, | PINN_DIR_MINUS_C): the third derivatives along the four sign pairs give the
+ * partial of three different columns, u_abc = [D3_{+,+} - D3_{+,-} - D3_{-,+} + D3_{-,-}] / 24 (up to third order along such a direction).
  */
 #ifndef PINN_H
 #define PINN_H
@@ -62,6 +64,7 @@ extern "C" {
 
 #define PINN_DIR_MINUS    0x100  /* ORed into a diagonal's direction code: e_a - e_b instead of e_a + e_b */
 #define PINN_DIR_DOUBLE   0x200  /* ... : the FIRST column counts twice, 2 e_a + e_b / 2 e_a - e_b (round 6: u_aaab, u_abbb) */
+#define PINN_DIR_MINUS_C  0x4000 /* a THIRD column c rides in bits 10..13 as (c + 1) << 10: e_a +- e_b + e_c, with this bit - e_c (round 6: u_abc) */
 #define PINN_MAX_SKIPS    4    /* skip connections ('R ... +') per net */
 #define PINN_SKIP_PRE     0x100 /* ORed into skip_dst[k] / skip_src[k]: the skip ends / starts IN FRONT of that activation */
 

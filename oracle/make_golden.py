@@ -22,7 +22,8 @@ from oracle.reference_loader import load_reference          # noqa: E402
 GOLDEN_N = dict(cfg1=100, cfg2=256, cfg3=128, cfg4=256, cfg5=64, ode_sigmoid=128, mixed=128, heat3d=128, kdv=128, resnet3=128,
                 nested_acts=128, mixed3=128, biharm=128,     # round 5 breadth fixtures (tests/test_golden_extras.py)
                 act_params=128,                              # round 6: activation instances with non-default parameters
-                mixed31=128)                                 # round 6: u_xxxy, u_xyyy (weighted diagonals)
+                mixed31=128,                                 # round 6: u_xxxy, u_xyyy (weighted diagonals)
+                mixed111=128)                                # round 6: u_xyz (three-column directions)
 K_STEPS = 5
 LR = 0.005
 

@@ -131,6 +131,14 @@ def make_config(name, D, torch, V=None):
                     solver_kwargs=dict(ndims=2, boundary_condition=0.3, layout='fa fa f', features=[24, 24, 1], activation='Tanh'),
                     n_points=4096, low=[0, 0], high=[1, 1])
     # ---- breadth workloads: timed by `bench.py --workload ...`, not BASELINE configs -----------------------
+    if name == 'mixed111':
+        # breadth fixture (round 6): u_xyz, the partial of THREE different columns (model_torch.py:174-178), all three inside the boundary factor --
+        # third Taylor coefficients along x +- y +- z (include/pinn.h PINN_DIR_MINUS_C)
+        def equation(f, x, y, z):
+            return D(D(D(f, x), y), z) + f * D(f, x) - 0.2 * D(D(f, z), z) - 3.0 * torch.sin(PI * x) * torch.cos(PI * y) * z
+        return dict(equation=equation,
+                    solver_kwargs=dict(ndims=3, boundary_condition=0.2, layout='fa fa f', features=[24, 24, 1], activation='Tanh'),
+                    n_points=4096, low=[0, 0, 0], high=[1, 1, 1])
     if name in ('burgers64', 'heat64', 'poisson512'):           # round 6 breadth workloads
         if name == 'burgers64':                                  # viscous Burgers in (x, t) on the 4 x 64 Tanh net: residual program, IC + BC (PinnShape 2)
             def burgers(f, x, t):

@@ -308,10 +308,17 @@ int check_dirs(const pinn_net* net, const int* dir_cols, int nd, int n2p) {
     if (nd < 0 || nd > PINN_MAX_DIRS || n2 > nd || n3 > n2 || n4 > n3 || n2p < 0) return fail("bad derivative spec nd=%d n2=%d n3=%d n4=%d", nd, n2, n3, n4);
     for (int k = 0; k < nd; ++k) {
         // direction code: column a, or the diagonal e_a +- e_b as a | (b + 1) << 4 | PINN_DIR_MINUS, | PINN_DIR_DOUBLE: 2 e_a +- e_b (include/pinn.h)
-        if (!dir_cols || dir_cols[k] < 0 || dir_cols[k] > 1023) return fail("dir_cols[%d] out of range", k);
-        const int a = dir_cols[k] & 15, b = ((dir_cols[k] >> 4) & 15) - 1;
-        if (a >= net->lay.d || b >= net->lay.d || a == b) return fail("dir_cols[%d] names a column outside the %d inputs", k, net->lay.d);
+        if (!dir_cols || dir_cols[k] < 0 || dir_cols[k] > 0x7fff) return fail("dir_cols[%d] out of range", k);
+        const int a = dir_cols[k] & 15, b = ((dir_cols[k] >> 4) & 15) - 1, c = ((dir_cols[k] >> 10) & 15) - 1;
+        if (a >= net->lay.d || b >= net->lay.d || c >= net->lay.d || a == b || (c >= 0 && (c == a || c == b)))
+            return fail("dir_cols[%d] names a column outside the %d inputs (or one column twice)", k, net->lay.d);
         if ((dir_cols[k] & (PINN_DIR_MINUS | PINN_DIR_DOUBLE)) && b < 0) return fail("dir_cols[%d]: PINN_DIR_MINUS / PINN_DIR_DOUBLE need a second column", k);
+        if (c >= 0 && (b < 0 || (dir_cols[k] & PINN_DIR_DOUBLE))) return fail("dir_cols[%d]: a third column needs a plain second one", k);
+        if ((dir_cols[k] & PINN_DIR_MINUS_C) && c < 0) return fail("dir_cols[%d]: PINN_DIR_MINUS_C needs a third column", k);
+        if (c >= 0 && k < n4) return fail("dir_cols[%d]: three-column directions carry derivatives up to third order", k);
+        // (the kernels decode these extensions only in the stream shapes that can carry them: pinn_dir_x, pinn_kernel.h)
+        if (c >= 0 && n3 == 0) return fail("dir_cols[%d]: a three-column direction needs a third-order stream in the call (n3 > 0)", k);
+        if ((dir_cols[k] & PINN_DIR_DOUBLE) && n4 == 0) return fail("dir_cols[%d]: PINN_DIR_DOUBLE needs a fourth-order stream in the call (n4 > 0)", k);
         // (round 5: third derivatives along diagonals too -- what mixed third-order partials are assembled from)
     }
     return 0;

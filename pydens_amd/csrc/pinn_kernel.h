@@ -483,15 +483,26 @@ PINN_DEVICE float pinn_act_d5(float sv, float d1, float d2, PinnAct act_) {
 // Code: a | (b + 1) << 4 | minus << 8 | double << 9, b + 1 == 0 for a single column (include/pinn.h PINN_DIR_MINUS, PINN_DIR_DOUBLE).
 PINN_DEVICE int pinn_dir_a(int code) { return code & 15; }
 PINN_DEVICE int pinn_dir_b(int code) { return ((code >> 4) & 15) - 1; }
-PINN_DEVICE float pinn_dir_wa(int code) { return (code & 0x200) ? 2.0f : 1.0f; }         // weight of column a in the direction
 PINN_DEVICE float pinn_dir_sb(int code) { return (code & 0x100) ? -1.0f : 1.0f; }        // weight of column b in the direction
-PINN_DEVICE bool pinn_dir_has(int code, int c) { return pinn_dir_a(code) == c || pinn_dir_b(code) == c; }
-// weight of input column c in the direction: 1 (or 2) for a, +-1 for b, 0 otherwise
-PINN_DEVICE float pinn_dir_coef(int code, int c) { return pinn_dir_a(code) == c ? pinn_dir_wa(code) : (pinn_dir_b(code) == c ? pinn_dir_sb(code) : 0.0f); }
+// The two extensions of round 6 only exist where the host can send them: weighted diagonals with a FOURTH-order stream (pinn_n4 > 0), a
+// third column with a THIRD-order stream (pinn_n3 > 0). Every helper takes that as a compile-time mask X (bit 0: weighted, bit 1: third
+// column; pinn_dir_x(N2P) of the instantiation), so that the kernels of every other stream shape compile the decoding away (the third
+// column's terms cost the width-256 program kernel of bench.py `gelu256` 2.8 % when they were unconditional).
+PINN_HOST_DEVICE constexpr int pinn_dir_x(int n2p) { return (pinn_n4(n2p) > 0 ? 1 : 0) | (pinn_n3(n2p) > 0 ? 2 : 0); }
+template <int X = 3> PINN_DEVICE float pinn_dir_wa(int code) { return ((X & 1) && (code & 0x200)) ? 2.0f : 1.0f; }         // weight of column a
+// ... and a THIRD column, e_a +- e_b +- e_c (round 6: partials of three different columns, u_abc = [D3_{+,+} - D3_{+,-} - D3_{-,+} + D3_{-,-}] / 24
+// over the four sign pairs of b and c): (c + 1) << 10, PINN_DIR_MINUS_C for -e_c
+template <int X = 3> PINN_DEVICE int pinn_dir_c(int code) { return (X & 2) ? ((code >> 10) & 15) - 1 : -1; }
+PINN_DEVICE float pinn_dir_sc(int code) { return (code & 0x4000) ? -1.0f : 1.0f; }
+template <int X = 3> PINN_DEVICE bool pinn_dir_has(int code, int c) { return pinn_dir_a(code) == c || pinn_dir_b(code) == c || pinn_dir_c<X>(code) == c; }
+// weight of input column c in the direction: 1 (or 2) for a, +-1 for b and for the third column, 0 otherwise
+template <int X = 3> PINN_DEVICE float pinn_dir_coef(int code, int c) {
+    return pinn_dir_a(code) == c ? pinn_dir_wa<X>(code) : (pinn_dir_b(code) == c ? pinn_dir_sb(code) : (pinn_dir_c<X>(code) == c ? pinn_dir_sc(code) : 0.0f));
+}
 // first-layer pre-activation derivative along a direction: weighted sum of the weight columns it contains
-PINN_DEVICE float pinn_dir_weight(const float* w1row, int code) {
-    const int b = pinn_dir_b(code);
-    return pinn_dir_wa(code) * w1row[pinn_dir_a(code)] + (b >= 0 ? pinn_dir_sb(code) * w1row[b] : 0.0f);
+template <int X = 3> PINN_DEVICE float pinn_dir_weight(const float* w1row, int code) {
+    const int b = pinn_dir_b(code), c = pinn_dir_c<X>(code);
+    return pinn_dir_wa<X>(code) * w1row[pinn_dir_a(code)] + (b >= 0 ? pinn_dir_sb(code) * w1row[b] : 0.0f) + (c >= 0 ? pinn_dir_sc(code) * w1row[c] : 0.0f);
 }
 
 // Second-order streams. Standard form: stream 1+ND+k is d2/dx_k2 for k < N2. COMB form (N2 == 1): ONE stream
@@ -880,6 +891,7 @@ PINN_DEVICE void pinn_point_stage(const PinnKArgs& A, const float* params_, cons
     using J = PinnJet<ND, N2P, COMB>;
     using SH = PinnShape<SPEC, ND>;
     constexpr int NIN = SH::FIXED ? (ND > 0 ? ND : 1) : PINN_MAX_INPUTS;   // input columns the box factors may range over
+    constexpr int DX = pinn_dir_x(N2P);                                    // which direction-code extensions this stream shape can meet
     const float* cw = A.comb_w;
     // ---- BC factor P and its direction derivatives --------------------------------------------------------
     float P = 1.0f, Pk[ND > 0 ? ND : 1], Pkk[ND > 0 ? ND : 1], Pkkk[N3 > 0 ? N3 : 1], P4[N4 > 0 ? N4 : 1];
@@ -910,7 +922,7 @@ PINN_DEVICE void pinn_point_stage(const PinnKArgs& A, const float* params_, cons
             // A1 = wa p1_a, A2 = wa^2 p2_a, B1 = w p1_b, B2 = p2_b (columns outside the spatial block contribute nothing)
             const int ca = pinn_dir_a(SH::dir(A, k)), cb = pinn_dir_b(SH::dir(A, k));
             const float wb = SH::FIXED ? 1.0f : pinn_dir_sb(SH::dir(A, k));
-            const float wa = SH::FIXED ? 1.0f : pinn_dir_wa(SH::dir(A, k));
+            const float wa = SH::FIXED ? 1.0f : pinn_dir_wa<DX>(SH::dir(A, k));
             float first = 0.0f, second = 0.0f, cross = 2.0f * wa * wb, third = 0.0f;
             bool both = true;
 #pragma unroll
@@ -943,6 +955,32 @@ PINN_DEVICE void pinn_point_stage(const PinnKArgs& A, const float* params_, cons
                     }
                     third = rab * (wa * wa * a2 * wb * b1 + wa * a1 * b2);
                     if (N4 > 0 && k < N4) P4[k < N4 ? k : 0] = 2.0f * rab * wa * wa * a2 * b2;      // fourth: 6 A2 B2 R (rab carries the 3)
+                }
+            }
+            if (!SH::FIXED && (DX & 2)) {
+                // a THIRD spatial column in the direction, C(t) = p_c(x_c + wc t), wc = +-1 (round 6). On top of the pair's terms:
+                //   first  += C1 (A B) R
+                //   second += C2 (A B) R + 2 C1 (A1 B + A B1) R
+                //   third  += 3 C1 (A2 B + A B2 + 2 A1 B1) R + 3 C2 (A1 B + A B1) R           (A3 = B3 = C3 = 0)
+                // with A, B standing for 1 where that column is not a spatial one; fourth order along such a direction is not asked for
+                const int cc = pinn_dir_c<DX>(SH::dir(A, k));
+                if (cc >= 0 && cc < SH::nsp(A)) {
+                    const float wc = pinn_dir_sc(SH::dir(A, k));
+                    const bool a_sp = ca >= 0 && ca < SH::nsp(A), b_sp = cb >= 0 && cb < SH::nsp(A);
+                    float rest = 1.0f, c0 = 1.0f, c1 = 0.0f, c2 = 0.0f, a0 = 1.0f, a1 = 0.0f, a2 = 0.0f, b0 = 1.0f, b1 = 0.0f, b2 = 0.0f;
+#pragma unroll
+                    for (int j = 0; j < NIN; ++j) {
+                        if (j == cc) { c0 = p[j]; c1 = wc * p1[j]; c2 = p2[j]; }
+                        else if (j == ca && a_sp) { a0 = p[j]; a1 = wa * p1[j]; a2 = wa * wa * p2[j]; }
+                        else if (j == cb && b_sp) { b0 = p[j]; b1 = wb * p1[j]; b2 = p2[j]; }
+                        else rest *= p[j];
+                    }
+                    const float ab0 = a0 * b0, ab1 = a1 * b0 + a0 * b1, ab2 = a2 * b0 + a0 * b2 + 2.0f * a1 * b1;
+                    // (the pair's own terms above were taken with the third column's factor inside `rest`: they carry C already)
+                    first += c1 * ab0 * rest;
+                    second += (c2 * ab0 + 2.0f * c1 * ab1) * rest;
+                    third += 3.0f * (c1 * ab2 + c2 * ab1) * rest;
+                    (void)c0;
                 }
             }
             Pk[k] = first;
@@ -997,10 +1035,10 @@ PINN_DEVICE void pinn_point_stage(const PinnKArgs& A, const float* params_, cons
         dG = -tau * d1;
 #pragma unroll
         for (int k = 0; k < ND; ++k) {
-            if (pinn_dir_has(SH::dir(A, k), tcol)) {
+            if (pinn_dir_has<DX>(SH::dir(A, k), tcol)) {
                 // (wt: weight of the time column in the direction: -1 as the second column of a minus diagonal, 2 as the first column of a
                 //  weighted one; the derivative of order n carries wt^n)
-                const float wt = SH::FIXED ? 1.0f : pinn_dir_coef(SH::dir(A, k), tcol);
+                const float wt = SH::FIXED ? 1.0f : pinn_dir_coef<DX>(SH::dir(A, k), tcol);
                 const float wt2 = wt * wt;
                 Gk[k] = wt * d1 * es; Gkk[k] = wt2 * d2 * es * es;
                 dGk[k] = wt * es * (-tau * d2 - d1);
@@ -1956,7 +1994,7 @@ PINN_DEVICE void pinn_tile_body(const PinnKArgs& A, const float* params_, float*
                     }
                     z[0] = z0;
 #pragma unroll
-                    for (int k = 0; k < ND; ++k) z[1 + k] = pinn_dir_weight(W1s + n * PINN_XS_LD, SH::dir(A, k));
+                    for (int k = 0; k < ND; ++k) z[1 + k] = pinn_dir_weight<pinn_dir_x(N2)>(W1s + n * PINN_XS_LD, SH::dir(A, k));
 #pragma unroll
                     for (int s = 1 + ND; s < S; ++s) z[s] = 0.0f;              // z_kk = z_kkk = 0 in the first layer
                     pinn_jet_fwd<ND, N2, COMB>(z, with_poly(act0), h, cw);
@@ -2299,7 +2337,7 @@ PINN_DEVICE void pinn_tile_body(const PinnKArgs& A, const float* params_, float*
                         for (int r = 0; r < 4; ++r) {
 #pragma unroll
                             for (int k = 0; k < ND; ++k)
-                                dst[j][mt][1 + k][r] = pinn_dir_weight(W1s + (unit0(j) + r) * PINN_XS_LD, SH::dir(A, k));
+                                dst[j][mt][1 + k][r] = pinn_dir_weight<pinn_dir_x(N2)>(W1s + (unit0(j) + r) * PINN_XS_LD, SH::dir(A, k));
 #pragma unroll
                             for (int s = 1 + ND; s < S; ++s) dst[j][mt][s][r] = 0.0f;
                         }
@@ -2806,7 +2844,7 @@ PINN_DEVICE void pinn_tile_body(const PinnKArgs& A, const float* params_, float*
                                 accW1r[REGB ? c : 0][j] += gz[j][mt][0] * xs_t[(mt * 16 + lr) * PINN_XS_LD + c];
 #pragma unroll
                                 for (int k = 0; k < ND; ++k)
-                                    if (pinn_dir_has(SH::dir(A, k), c)) accW1r[REGB ? c : 0][j] += (SH::FIXED ? 1.0f : pinn_dir_coef(SH::dir(A, k), c)) * gz[j][mt][1 + k];
+                                    if (pinn_dir_has<pinn_dir_x(N2)>(SH::dir(A, k), c)) accW1r[REGB ? c : 0][j] += (SH::FIXED ? 1.0f : pinn_dir_coef<pinn_dir_x(N2)>(SH::dir(A, k), c)) * gz[j][mt][1 + k];
                             }
                         }
                     }
@@ -2823,7 +2861,7 @@ PINN_DEVICE void pinn_tile_body(const PinnKArgs& A, const float* params_, float*
                         v += gz[j][mt][0] * xs_t[(mt * 16 + lr) * PINN_XS_LD + c];
 #pragma unroll
                         for (int k = 0; k < ND; ++k)
-                            if (pinn_dir_has(SH::dir(A, k), c)) v += (SH::FIXED ? 1.0f : pinn_dir_coef(SH::dir(A, k), c)) * gz[j][mt][1 + k];
+                            if (pinn_dir_has<pinn_dir_x(N2)>(SH::dir(A, k), c)) v += (SH::FIXED ? 1.0f : pinn_dir_coef<pinn_dir_x(N2)>(SH::dir(A, k), c)) * gz[j][mt][1 + k];
                     }
                     v = pinn_row_sum16_v4(v);
                     if (lr == 0) {

@@ -134,7 +134,7 @@ pinn_wgrad_kernel(const PinnKArgs A) {
                     // first layer: only tanh(z) was saved; z_k = W1[:, col_k] (+ the diagonal partner), z_kk = 0
 #pragma unroll
                     for (int r = 0; r < 4; ++r)
-                        svr[j][r] = (s <= ND) ? pinn_dir_weight(W1s + (unit0(j) + r) * PINN_XS_LD, A.dir_cols[s - 1 < 0 ? 0 : s - 1]) : 0.0f;
+                        svr[j][r] = (s <= ND) ? pinn_dir_weight<pinn_dir_x(N2)>(W1s + (unit0(j) + r) * PINN_XS_LD, A.dir_cols[s - 1 < 0 ? 0 : s - 1]) : 0.0f;
                 }
             }
         };

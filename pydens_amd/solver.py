@@ -275,7 +275,7 @@ class Solver:
         try:
             root = trace.symbolic(self.equation, self.ctx.run, total, variable_slot=self._variable_slot)
             ic_root = self._symbolic_initial_condition()
-            if self.spec.mixed3 or self.spec.n4 > 0:
+            if self.spec.mixed3 or self.spec.n4 > 0 or self.spec.mixed111:
                 raise trace.TraceUnsupported('mixed third-order partials / fourth-order derivatives run on the generic path')
             plan = trace.lower_residual(root, self.spec, total, ic_root=ic_root)
             trace.combine_second_order(plan, self.spec)
@@ -393,7 +393,8 @@ class Solver:
             sc.tag(0.5 * (full[ivv] - full[iaa] - full[ibb]), ab)
         for alpha, (ip, im, ia, ib) in self.spec.mixed4.items():         # u_aabb = (D4_{a+b} + D4_{a-b} - 2 u_aaaa - 2 u_bbbb) / 12
             sc.tag((full[ip] + full[im] - 2.0 * full[ia] - 2.0 * full[ib]) / 12.0, alpha)
-        for alpha, terms in self.spec.mixed31.items():                  # u_aaab / u_abbb from D4 along a +- b and 2a +- b (round 6)
+        for alpha, terms in list(self.spec.mixed31.items()) + list(self.spec.mixed111.items()):
+            # u_aaab / u_abbb from D4 along a +- b and 2a +- b; u_abc from D3 along a +- b +- c (round 6)
             sc.tag(sum(coef * full[idx] for idx, coef in terms), alpha)
         for alpha, (ip, im, i3, sign) in self.spec.mixed3.items():      # u_aab = (D3_{a+b} - D3_{a-b} - 2 u_bbb) / 6, u_abb: + D3_{a-b}, - 2 u_aaa
             sc.tag((full[ip] + sign * full[im] - 2.0 * full[i3]) / 6.0, alpha)

@@ -38,19 +38,27 @@ class TraceUnsupported(Exception):
 def dir_code(direction):
     """ ABI code of a differentiation direction: column a, the diagonal e_a + e_b as a | (b + 1) << 4, or -- a third entry -1 --
     the minus diagonal e_a - e_b with PINN_DIR_MINUS (0x100) on top, or -- a fourth entry 2 (round 6) -- the weighted diagonal
-    2 e_a +- e_b with PINN_DIR_DOUBLE (0x200) (include/pinn.h). """
+    2 e_a +- e_b with PINN_DIR_DOUBLE (0x200), or -- six entries (a, b, sb, 1, c, sc) -- the three-column direction e_a +- e_b +- e_c with
+    (c + 1) << 10 and PINN_DIR_MINUS_C (0x4000) (include/pinn.h). """
     if len(direction) == 1:
         return direction[0]
-    return (direction[0] | ((direction[1] + 1) << 4) | (0x100 if len(direction) > 2 and direction[2] < 0 else 0)
+    code = (direction[0] | ((direction[1] + 1) << 4) | (0x100 if len(direction) > 2 and direction[2] < 0 else 0)
             | (0x200 if len(direction) > 3 and direction[3] == 2 else 0))
+    if len(direction) > 5:
+        code |= ((direction[4] + 1) << 10) | (0x4000 if direction[5] < 0 else 0)
+    return code
 
 
 def dir_weights(direction):
-    """ [(column, weight)] of a direction tuple: (c,), (a, b) = e_a + e_b, (a, b, -1) = e_a - e_b, (a, b, +-1, 2) = 2 e_a +- e_b """
+    """ [(column, weight)] of a direction tuple: (c,), (a, b) = e_a + e_b, (a, b, -1) = e_a - e_b, (a, b, +-1, 2) = 2 e_a +- e_b,
+    (a, b, sb, 1, c, sc) = e_a + sb e_b + sc e_c """
     if len(direction) == 1:
         return [(direction[0], 1.0)]
-    return [(direction[0], 2.0 if len(direction) > 3 and direction[3] == 2 else 1.0),
-            (direction[1], -1.0 if len(direction) > 2 and direction[2] < 0 else 1.0)]
+    out = [(direction[0], 2.0 if len(direction) > 3 and direction[3] == 2 else 1.0),
+           (direction[1], -1.0 if len(direction) > 2 and direction[2] < 0 else 1.0)]
+    if len(direction) > 5:
+        out.append((direction[4], -1.0 if direction[5] < 0 else 1.0))
+    return out
 
 
 class StreamSpec:
@@ -73,6 +81,7 @@ class StreamSpec:
         pairs3, mixed3 = set(), {}                   # mixed THIRD-order partials (round 5): column pairs, alpha -> (pair, doubled column)
         pairs4 = set()                               # mixed FOURTH-order partials u_aabb: column pairs
         pairs31, mixed31 = set(), {}                 # u_aaab / u_abbb (round 6): column pairs, alpha -> (pair, tripled column)
+        triples = set()                              # u_abc (round 6): partials of three different columns
         for alpha in requested:
             if len(alpha) == 1:
                 firsts.add(alpha[0])
@@ -82,6 +91,9 @@ class StreamSpec:
                 mixed.add(tuple(alpha)); seconds.update(alpha)
             elif len(alpha) == 3 and alpha[0] == alpha[1] == alpha[2]:
                 thirds.add(alpha[0]); seconds.add(alpha[0])
+            elif len(alpha) == 3 and len(set(alpha)) == 3:
+                # u_abc = [D3_{+,+} - D3_{+,-} - D3_{-,+} + D3_{-,-}] / 24: third derivatives along e_a +- e_b +- e_c (the terms odd in b AND in c)
+                triples.add(tuple(sorted(alpha)))
             elif len(alpha) == 3 and len(set(alpha)) == 2:
                 # u_aab = (D3_{a+b} - D3_{a-b} - 2 u_bbb) / 6,  u_abb = (D3_{a+b} + D3_{a-b} - 2 u_aaa) / 6: third derivatives along both
                 # diagonals of the pair and along the column that occurs ONCE
@@ -107,7 +119,8 @@ class StreamSpec:
                 raise NotImplementedError(
                     f'derivative multi-index {alpha}: the HIP kernels provide derivatives up to fourth order along single columns, mixed second- '
                     'and third-order partials of two columns (u_xy, u_xxy) and the mixed fourth-order ones of two columns (u_xxyy, u_xxxy, '
-                    'u_xyyy); partials of three different columns (u_xyz) and orders above four are not built')
+                    'u_xyyy) and the third-order partial of three columns (u_xyz); fourth-order partials of three or more different columns and '
+                    'orders above four are not built')
         firsts |= seconds
         pairs3 |= pairs4                             # (a pair with a fourth-order diagonal carries the third-order ones anyway)
         # directions: fourth-order ones first, then the third-order ones (columns, then both diagonals of every pair a mixed third- /
@@ -117,7 +130,8 @@ class StreamSpec:
         diag4 = pairs4 | pairs31                    # pairs whose two diagonals carry a fourth derivative
         d4_dirs = ([(c,) for c in sorted(fourths)] + [d for ab in sorted(diag4) for d in diag_pair(ab)]
                    + [ab + (sign, 2) for ab in sorted(pairs31) for sign in (1, -1)])
-        d3_dirs = [(c,) for c in sorted(thirds - fourths)] + [d for ab in sorted(pairs3 - diag4) for d in diag_pair(ab)]
+        d3_dirs = ([(c,) for c in sorted(thirds - fourths)] + [d for ab in sorted(pairs3 - diag4) for d in diag_pair(ab)]
+                   + [(a, b, sb, 1, c, sc) for a, b, c in sorted(triples) for sb in (1, -1) for sc in (1, -1)])
         self.dirs = (d4_dirs + d3_dirs + [(c,) for c in sorted(seconds - thirds)]
                      + [ab for ab in sorted(mixed) if ab not in (pairs3 | diag4)] + [(c,) for c in sorted(firsts - seconds)])
         self.n4 = len(d4_dirs)
@@ -138,6 +152,8 @@ class StreamSpec:
                     self.index[(d[0],) * 3] = base3
                 if k < self.n4:
                     self.index[(d[0],) * 4] = base4
+            elif len(d) > 5:                         # three-column direction e_a +- e_b +- e_c: its third derivative
+                self.index[('d3t', d[0], d[1], d[4], d[2], d[5])] = base3
             elif len(d) > 3:                         # weighted diagonal 2 e_a +- e_b: only its fourth derivative is asked for
                 self.index[('d4w',) + d[:3]] = base4
             else:
@@ -168,6 +184,8 @@ class StreamSpec:
                 self.mixed31[alpha] = [(i2p, 1.0 / 48.0), (i2m, -1.0 / 48.0), (ip, -2.0 / 48.0), (im, 2.0 / 48.0)]
             else:
                 self.mixed31[alpha] = [(ip, 8.0 / 48.0), (im, -8.0 / 48.0), (i2p, -1.0 / 48.0), (i2m, 1.0 / 48.0)]
+        # (a, b, c) -> [(stream, coefficient)]: third derivatives along e_a +- e_b +- e_c
+        self.mixed111 = {abc: [(self.index[('d3t',) + abc + (sb, sc)], sb * sc / 24.0) for sb in (1, -1) for sc in (1, -1)] for abc in sorted(triples)}
         # can ONE kernel call produce all of it as separate streams?
         if self.n4 > 0:
             # fourth order in ONE call: that direction alone (u'''' = f(x) beams, u_t-free fourth-order ODEs); anything else in groups

@@ -13,7 +13,7 @@ GOLDEN_NAMES = ('cfg1', 'cfg2', 'cfg3', 'cfg4', 'cfg5', 'ode_sigmoid', 'mixed', 
 # round 5 breadth fixtures (nested skips + second-set activations, mixed third order, fourth order): the restatement is pinned on them like
 # on the others; the fp64 jet restatement (oracle/jet_f64.py) does not go there -- the KERNELS are checked against them directly
 # (tests/test_golden_extras.py; -m gpu twin in test_gpu_parity.py)
-GOLDEN_EXTRA = ('nested_acts', 'mixed3', 'biharm', 'act_params', 'mixed31')
+GOLDEN_EXTRA = ('nested_acts', 'mixed3', 'biharm', 'act_params', 'mixed31', 'mixed111')
 
 
 def pytest_configure(config):

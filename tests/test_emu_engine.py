@@ -918,7 +918,7 @@ def test_third_order_streams_match_the_oracle(pa, emu_lib, which):
 
 
 @pytest.mark.parametrize('which', ['two_third_order_columns', 'third_beside_second', 'mixed_third_space', 'mixed_third_time',
-                                   'mixed_third_both'])
+                                   'mixed_third_both', 'three_columns_time'])
 def test_third_order_beyond_one_call_runs_in_direction_groups(pa, emu_lib, which):
     _direction_groups_case(pa, which, emu_kwargs(emu_lib))
 
@@ -939,6 +939,10 @@ def _direction_groups_case(pa, which, solver_kwargs):
         elif which == 'mixed_third_time':
             # u_xtt: the minus diagonal x - t carries the time column with weight -1 through the IC gate and its log_scale adjoint
             eq = lambda f, x, y, t: D(D(D(f, t), x), t) * 0.05 + D(f, t) - D(D(f, y), y)
+        elif which == 'three_columns_time':
+            # round 6: u_xyt -- the partial of THREE different columns, from third derivatives along x +- y +- t (PINN_DIR_MINUS_C): the box
+            # factor's pair (x, y) beside the time column, which rides through the IC gate with weight +-1
+            eq = lambda f, x, y, t: D(f, t) + 0.2 * D(D(D(f, x), y), t) - 0.1 * D(D(f, x), x) + f * D(f, y)
         elif which == 'mixed_third_both':
             # u_xxy and u_xyy of the same pair (they share the two diagonals), a mixed second-order partial of it as well
             eq = lambda f, x, y, t: D(f, t) + 0.1 * D(D(D(f, x), y), x) - 0.07 * D(D(D(f, y), y), x) + 0.3 * D(D(f, x), y)
@@ -959,7 +963,8 @@ def _direction_groups_case(pa, which, solver_kwargs):
     solver = pa.Solver(eq_p, **kw, **solver_kwargs)
     assert solver.program is None and not solver.spec.single_call
     want_groups = {'two_third_order_columns': [9, 9, 0], 'third_beside_second': [9, 1], 'mixed_third_space': [9, 9, 9, 1],
-                   'mixed_third_time': [9, 9, 9, 2], 'mixed_third_both': [9, 9, 9, 9, 0]}[which]      # (intermediate D(D(f, x), x) of a nest counts)
+                   'mixed_third_time': [9, 9, 9, 2], 'mixed_third_both': [9, 9, 9, 9, 0],
+                   'three_columns_time': [9, 9, 9, 9, 2, 1]}[which]      # (intermediate D(D(f, x), x) of a nest counts)
     assert [g[1] for g in solver.spec.groups] == want_groups, solver.spec.groups
     load_params(solver, start)
     solver._generic_step(torch.from_numpy(pts[0].copy()).to(solver.device), ('equation',), [], torch.nn.MSELoss(), 1)
@@ -1181,9 +1186,9 @@ def _wide512_problems(D, torch, which):
 
 @pytest.mark.parametrize('which', ['ode_fused', 'poisson_groups', 'heat_sigmoid', 'advection_breadth'])
 def test_hidden_width_512_matches_the_oracle(pa, emu_lib, which):
-    # (a 512-wide net costs the emulator minutes per tile: two cases in the CPU tier, all four with PYDENS_AMD_SLOW_EMU=1 -- and on the device,
+    # (a 512-wide net costs the emulator a minute or more per tile: ONE case in the CPU tier, all four with PYDENS_AMD_SLOW_EMU=1 -- and on the device,
     #  tests/test_gpu_parity.py::test_hidden_width_512_on_the_gpu)
-    if which in ('poisson_groups', 'advection_breadth') and os.environ.get('PYDENS_AMD_SLOW_EMU') != '1':
+    if which != 'ode_fused' and os.environ.get('PYDENS_AMD_SLOW_EMU') != '1':
         pytest.skip('slow on the emulator: PYDENS_AMD_SLOW_EMU=1, or the -m gpu twin')
     _wide512_case(pa, which, emu_kwargs(emu_lib), 16)
 

@@ -4,6 +4,7 @@
     mixed3        u_xxy and u_xyy next to u_t (third Taylor coefficients along x + y and x - y)
     biharm        u_xxxx + 2 u_xxyy + u_yyyy (fourth Taylor coefficients, the mixed one polarised)
     mixed31       u_xxxy and u_xyyy (round 6: fourth Taylor coefficients along x + y, x - y and the weighted diagonals 2x + y, 2x - y)
+    mixed111      u_xyz (round 6: third Taylor coefficients along the three-column directions x +- y +- z)
 
 The restatement (oracle/pinn_oracle.py) is pinned on them by tests/test_oracle_vs_golden.py (same `golden` fixture). Here the KERNELS
 are: predict, loss, every parameter gradient and the K-step Adam trajectory of `Solver.fit`. The survey's bar (1e-5 gradients, 2e-5
@@ -24,6 +25,7 @@ EXPECT = {  # name: (fit path, [packed second/third/fourth-order counts of the k
     'mixed3': ('generic', None, False),
     'biharm': ('generic', [73, 73, 73, 73], False),
     'mixed31': ('generic', [73, 73, 73, 73, 9, 1], False),     # (+ the intermediates the nesting passes through: u_xxx / u_xx, u_yy)
+    'mixed111': ('generic', None, False),
     'act_params': ('fused', None, True),        # round 6: Softplus(beta) / ELU(alpha) / LeakyReLU(negative_slope) instances
 }
 FIT_RTOL = 2e-5

@@ -879,7 +879,7 @@ def test_prepass_with_more_registers_than_a_full_sweep_holds_on_the_gpu(pa):
     te._wide_prepass_case(pa, {})
 
 
-@pytest.mark.parametrize('name', ['nested_acts', 'mixed3', 'biharm', 'act_params', 'mixed31'])
+@pytest.mark.parametrize('name', ['nested_acts', 'mixed3', 'biharm', 'act_params', 'mixed31', 'mixed111'])
 def test_breadth_features_match_reference_golden_on_the_gpu(pa, name):
     """ round 5 breadth (nested skips + second-set activations, mixed third order, fourth order) against the fixtures generated from the
     unmodified reference: predict, loss, gradients, K-step trajectory (tests/test_golden_extras.py holds the case) """
@@ -894,7 +894,7 @@ def test_fourth_order_streams_on_the_gpu(pa, which):
     te._fourth_order_case(pa, which, {})
 
 
-@pytest.mark.parametrize('which', ['two_third_order_columns', 'third_beside_second', 'mixed_third_space', 'mixed_third_time', 'mixed_third_both'])
+@pytest.mark.parametrize('which', ['two_third_order_columns', 'third_beside_second', 'mixed_third_space', 'mixed_third_time', 'mixed_third_both', 'three_columns_time'])
 def test_third_order_direction_groups_on_the_gpu(pa, which):
     """ equations with more third-order content than one kernel call carries: generic path, one call per third-order column """
     import test_emu_engine as te

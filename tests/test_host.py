@@ -120,9 +120,13 @@ def test_hip_library_exports_every_declared_symbol():
     assert lib.pinn_layout(handle, ctypes.byref(lay)) == 0
     assert (lay.hp, lay.lh, lay.d, lay.p_core) == (64, 3, 2, 64 * 2 + 64 + 3 * (64 * 64 + 64) + 64 + 4)
     lib.pinn_destroy(handle)
-    bad = (ctypes.c_int * 3)(2, 512, 1)
+    bad = (ctypes.c_int * 3)(2, 600, 1)          # (round 6: widths up to 512 exist)
     assert lib.pinn_create(bad, 2, 0, 2, 0, 0, 0, None, None, 0.0, ctypes.byref(handle)) != 0
-    assert b'512' in lib.pinn_last_error()
+    assert b'600' in lib.pinn_last_error()
+    wide = (ctypes.c_int * 3)(2, 300, 1)
+    assert lib.pinn_create(wide, 2, 0, 2, 0, 0, 0, None, None, 0.0, ctypes.byref(handle)) == 0
+    assert lib.pinn_layout(handle, ctypes.byref(lay)) == 0 and lay.hp == 512
+    lib.pinn_destroy(handle)
 
 
 def test_host_constants_of_a_constraint_are_cached_on_the_device_by_content():

@@ -49,9 +49,14 @@ def test_mixed_partials_take_a_diagonal_direction():
     assert (ip, im, i3, sign) == (specm.index[('d3', 0, 1, 1)], specm.index[('d3', 0, 1, -1)], specm.index[(1, 1, 1)], -1.0)
     assert [g[1] for g in specm.groups] == [9, 9, 9, 1]
     assert trace.discover(lambda f, x, y: D(D(D(f, y), x), y), run, 2)[0].mixed3[(0, 1, 1)][3] == 1.0     # u_xyy: + D3_{x-y}, - 2 u_xxx
-    # three different columns (u_xyz) and orders above three stay refused, loudly
-    with pytest.raises(NotImplementedError, match='three different columns'):
-        trace.discover(lambda f, x, y, z: D(D(D(f, x), y), z), run, 3)
+    # round 6: the partial of three different columns, u_xyz = [D3_{+,+} - D3_{+,-} - D3_{-,+} + D3_{-,-}] / 24 over the directions x +- y +- z
+    spect = trace.discover(lambda f, x, y, z: D(D(D(f, x), y), z), run, 3)[0]
+    assert spect.dirs[:4] == [(0, 1, 1, 1, 2, 1), (0, 1, 1, 1, 2, -1), (0, 1, -1, 1, 2, 1), (0, 1, -1, 1, 2, -1)] and spect.n3 == 4
+    assert spect.dir_cols[:4] == [0xc20, 0x4c20, 0xd20, 0x4d20]          # a | (b + 1) << 4 | (c + 1) << 10, PINN_DIR_MINUS 0x100, PINN_DIR_MINUS_C 0x4000
+    assert [c for _, c in spect.mixed111[(0, 1, 2)]] == [1 / 24, -1 / 24, -1 / 24, 1 / 24]
+    assert trace.dir_weights((0, 1, -1, 1, 2, -1)) == [(0, 1.0), (1, -1.0), (2, -1.0)]
+    # (the identity on the monomial x y z: D3 along (1, sb, sc) = 6 sb sc)
+    assert abs(sum(c * 6.0 * sb * sc for (_, c), (sb, sc) in zip(spect.mixed111[(0, 1, 2)], ((1, 1), (1, -1), (-1, 1), (-1, -1)))) - 1.0) < 1e-12
     # round 5: fourth order along a column (one direction with second, third and fourth derivative: packed count 1 | 1 << 3 | 1 << 6 = 73) and
     # the symmetric mixed one, u_xxyy = (D4_{x+y} + D4_{x-y} - 2 u_xxxx - 2 u_yyyy) / 12
     spec4, _ = trace.discover(lambda f, x: D(D(D(D(f, x), x), x), x), run, 1)
@@ -74,7 +79,7 @@ def test_mixed_partials_take_a_diagonal_direction():
     assert abs(sum(c * streams[i] for i, c in specw.mixed31[(0, 1, 1, 1)]) - 12.0) < 1e-12         # d4/dxdy3 of 2 x y^3 = 12
     with pytest.raises(NotImplementedError, match='orders above four'):
         trace.discover(lambda f, x: D(D(D(D(D(f, x), x), x), x), x), run, 1)
-    with pytest.raises(NotImplementedError, match='three different columns'):
+    with pytest.raises(NotImplementedError, match='three or more different columns'):
         trace.discover(lambda f, x, y, z: D(D(D(D(f, x), x), y), z), run, 3)
     # 3 columns + 2 diagonals = 5 directions, each with a second derivative: more than one kernel call carries -> served
     # by several calls over groups of two directions (generic path), never refused

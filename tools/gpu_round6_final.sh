@@ -5,7 +5,7 @@
 # line carries `baseline_configs` + `sustained`), the breadth lines, fit rates, the GPU suite last.
 # usage: bash tools/gpu_round6_final.sh <tag>   -> gpurun_out/<tag>/ ; copy into profiles/ with tools/collect_round6.sh <tag>
 TAG=${1:-r6z}; OUT=/root/repo/gpurun_out/$TAG; mkdir -p $OUT; cd /root/repo; export TMPDIR=/tmp
-BREADTH="program sin64 sin128 generic skip128 skip256 gelu256"
+BREADTH="program sin64 sin128 generic skip128 skip256 gelu256 burgers64 heat64"
 for c in cfg2 cfg4 cfg3 cfg5; do
   timeout 420 bash tools/profile_bench.sh $c $TAG "" > /dev/null 2>&1
   timeout 420 bash tools/profile_bench.sh $c $TAG _split --gemm bf16x3 > /dev/null 2>&1
@@ -28,10 +28,12 @@ for w in $BREADTH; do
   timeout 300 python bench.py --workload $w --no-cpu-baseline --no-strong > $OUT/bench_$w.txt 2> $OUT/bench_$w.err
   echo "$w: $(grep 'bench\] gpu' $OUT/bench_$w.err) parity $(python -c "import json; print(json.loads(open('$OUT/bench_$w.txt').read().strip().splitlines()[-1]).get('parity_checked', {}).get('ok'))" 2>/dev/null)"
 done
-timeout 500 python tools/fit_rate.py > $OUT/fit_rate.txt 2>&1; tail -8 $OUT/fit_rate.txt
+timeout 400 python bench.py --workload poisson512 --no-cpu-baseline --no-strong > $OUT/bench_poisson512.txt 2> $OUT/bench_poisson512.err; echo "poisson512: $(grep 'bench\] gpu' $OUT/bench_poisson512.err)"
+timeout 300 python tools/wide512_rate.py > $OUT/wide512_rate.txt 2>&1; tail -n 3 $OUT/wide512_rate.txt
+timeout 500 python tools/fit_rate.py > $OUT/fit_rate.txt 2>&1; tail -n 8 $OUT/fit_rate.txt
 timeout 400 python tools/small_fit_rate.py > $OUT/small_fit_rate.txt 2>&1; cat $OUT/small_fit_rate.txt
 timeout 600 python tools/cfg4_bl_probe.py 99 100 101 > $OUT/cfg4_bl_probe.txt 2>&1
 timeout 1800 python -m pytest tests -m gpu -q --durations=12 > $OUT/pytest_gpu.log 2>&1; echo "pytest exit $?" >> $OUT/pytest_gpu.log
-grep -E "passed|failed|exit" $OUT/pytest_gpu.log | tail -4
+grep -E "passed|failed|exit" $OUT/pytest_gpu.log | tail -n 4
 cp gpurun_out/grad_margins.txt $OUT/grad_margins.txt 2>/dev/null
-timeout 300 python -c "import __graft_entry__ as g; g.smoke()" > $OUT/smoke.txt 2>&1; tail -1 $OUT/smoke.txt
+timeout 300 python -c "import __graft_entry__ as g; g.smoke()" > $OUT/smoke.txt 2>&1; tail -n 1 $OUT/smoke.txt
