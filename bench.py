@@ -596,6 +596,14 @@ def main():
         plan = solver.residual_plan
         s_exec = (2 + spec.nd) if (plan is not None and plan.comb_w is not None and not generic) else spec.n_streams
         f_exec = flops_per_point(model.layer_dims, s_exec)
+        roof_note = None
+        if generic and len(spec.groups) > 1:
+            # direction groups (width 512, many directions): kernel_ms is the LAST backward launch -- one group's streams -- so the FLOPs it is
+            # priced with are that group's too (the whole-step count over one launch's time read 1.09 of the peak on poisson512)
+            s_exec = len(spec.groups[-1][2])
+            f_pt = f_exec = flops_per_point(model.layer_dims, s_exec)
+            roof_note = ('generic path in %d direction groups: kernel_ms, flops_per_point and frac describe the LAST pinn_jet_backward launch '
+                         '(the %d streams of its group); `value` is the whole step' % (len(spec.groups), s_exec))
         kernels_ms = tile_ms + (wgrad_ms or 0.0)
         achieved = f_pt * n / (kernels_ms * 1e-3) / 1e12
         traffic, traffic_src = hbm_traffic(args.workload, kernel, n)
@@ -609,6 +617,8 @@ def main():
                 'hbm_gbps': (traffic / (kernels_ms * 1e-3) / 1e9) if traffic else None,
                 'traffic_source': ((f'{traffic_src}: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command, committed, same kernel '
                                     'sources (content hash); NOT measured in this run') if traffic else traffic_src) if traffic_src else None}
+        if roof_note:
+            roof['what'] = roof_note
         if kernel_variant(kernel):
             # split-bf16 kernel: the matrix pipe executes SIX bf16 MFMA flops per fp32-equivalent flop (products a_i b_j, i + j <= 2)
             # and its bound is the dense bf16 MFMA peak; the fp32-equivalent figures stay alongside (they may exceed the fp32

@@ -5,8 +5,10 @@ and -- =0 -- as launch graphs (round 4). One fresh process per line: python tool
 import os, subprocess, sys, time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 CASES = ('cfg1', 'cfg1_256', 'ode_tanh', 'poisson_10', 'ode_family', 'heat_sigmoid')
+if len(sys.argv) == 2:                 # python tools/small_fit_rate.py cfg1,cfg1_nosrc : just these cases
+    CASES = tuple(sys.argv[1].split(','))
 
-if len(sys.argv) > 1:
+if len(sys.argv) > 2:
     sys.path.insert(0, ROOT)
     import numpy as np, torch
     import pinn_configs as pc
@@ -22,6 +24,9 @@ if len(sys.argv) > 1:
     if name in ('cfg1', 'cfg1_256'):      # BASELINE config 1 (README.md:36-53) at its 100 points; at 256 points (16 tiles: two sweeps of 8)
         cfg = pc.make_config('cfg1', pa.D, torch)
         solver, batch = pa.Solver(cfg['equation'], **cfg['solver_kwargs']), (100 if name == 'cfg1' else 256)
+    elif name == 'cfg1_nosrc':            # the same net and batch on an equation WITHOUT an x-only term (no pre-pass program): what the fp64 pre-pass costs the one-CU form
+        cfg = pc.make_config('cfg1', pa.D, torch)
+        solver, batch = pa.Solver(lambda f, x, y: D(D(f, x), x) + D(D(f, y), y) - 1.0, **cfg['solver_kwargs']), 100
     elif name == 'ode_tanh':              # tutorial cells 12-14
         solver, batch = pa.Solver(lambda f, x: D(f, x) - 2 * np.pi * torch.cos(2 * np.pi * x), ndims=1, initial_condition=.5, activation='Tanh',
                                   layout='fafaf', features=[12, 10, 1]), 400
