@@ -718,15 +718,17 @@ PINN_DEVICE void pinn_sincos_f64(double x, double& sn, double& cs) {
 PINN_DEVICE double pinn_sin_f64(double x) { if (!(fabs(x) < 1e5)) return sin(x); double s, c; pinn_sincos_f64(x, s, c); return s; }
 PINN_DEVICE double pinn_cos_f64(double x) { if (!(fabs(x) < 1e5)) return cos(x); double s, c; pinn_sincos_f64(x, s, c); return c; }
 
-PINN_DEVICE double pinn_prepass_op(int op, double xa, double xb, double cb) {
+// The pre-pass runs ONCE per workgroup (or, in the one-launch fit chunk of the narrow nets, once per iteration) between code that fills
+// the instruction cache with something else, and its fp64 library forms (exp, log, tanh, pow, the large-argument sin / cos) are each
+// hundreds of instructions: laid out as one switch the dispatch of a seven-operation source term walked a 10 KB region and paid
+// ~1 000 cycles per OPERATION -- 7.4 K ticks (3.2 us) per pass, half of what the tile loop of a 16-wide net takes (phase clocks of the
+// fit chunk, round 6: profiles/r06_fit_chunk_phases.txt). The operations source terms are made of -- sums, products, sines and cosines of
+// moderate arguments -- therefore sit in front, compact; everything else is marked unlikely so that the compiler places it behind them.
+PINN_DEVICE double pinn_prepass_rare(int op, double xa, double xb, double cb) {
     switch (op) {
-        case PINN_OP_ADD: return xa + xb;
-        case PINN_OP_SUB: return xa - xb;
-        case PINN_OP_MUL: return xa * xb;
         case PINN_OP_DIV: return xa / xb;
-        case PINN_OP_NEG: return -xa;
-        case PINN_OP_SIN: return pinn_sin_f64(xa);
-        case PINN_OP_COS: return pinn_cos_f64(xa);
+        case PINN_OP_SIN: return sin(xa);           // (|x| >= 1e5: the library's reduction)
+        case PINN_OP_COS: return cos(xa);
         case PINN_OP_EXP: return exp(xa);
         case PINN_OP_LOG: return log(xa);
         case PINN_OP_TANH: return tanh(xa);
@@ -738,20 +740,41 @@ PINN_DEVICE double pinn_prepass_op(int op, double xa, double xb, double cb) {
         default: return xa;    // COPY
     }
 }
+PINN_DEVICE double pinn_prepass_op(int op, double xa, double xb, double cb) {
+    if (op == PINN_OP_ADD) return xa + xb;
+    if (op == PINN_OP_MUL) return xa * xb;
+    if (op == PINN_OP_SUB) return xa - xb;
+    if (op == PINN_OP_NEG) return -xa;
+    if ((op == PINN_OP_SIN || op == PINN_OP_COS) && __builtin_expect(fabs(xa) < 1e5, 1)) {
+        double sn, cs;
+        pinn_sincos_f64(xa, sn, cs);
+        return op == PINN_OP_SIN ? sn : cs;
+    }
+    if (op == PINN_OP_COPY) return xa;
+    return pinn_prepass_rare(op, xa, xb, cb);
+}
 PINN_DEVICE void pinn_prepass_point(const pinn_program_t& pg, const PinnPreConsts& c64, const float* x, int d, float* aux, long long n,
                                     long long gi, double* regs, int T) {
     // `regs`: from ONE address space per call site (round 5: a select between the LDS carve and a private array made every register
     // access a flat instruction)
     for (int c = 0; c < d; ++c) regs[c * T] = (double)x[c];
     unsigned w_next = pg.n_ops > 0 ? pg.code[0] : 0u;          // (the next op word is fetched one op ahead: a scalar load per op otherwise)
+    // (round 6: the value an operation just produced is what the next one usually reads -- forwarded in a register, so that the chain of
+    //  operations is not also a chain of LDS write -> read round trips; the register file itself is written all the same)
+    double last = 0.0;
+    int last_dst = -1;
     for (int i = 0; i < pg.n_ops; ++i) {
         const unsigned w = w_next;
         if (i + 1 < pg.n_ops) w_next = pg.code[i + 1];
         const int op = w & 255, dst = (w >> 8) & 255, a = (w >> 16) & 255, b = (w >> 24) & 255;
-        if (op == PINN_OP_STORE) { aux[(long long)b * n + gi] = (float)regs[a * T]; continue; }
-        if (op == PINN_OP_CONST) { regs[dst * T] = c64.v[a]; continue; }
+        if (op == PINN_OP_STORE) { aux[(long long)b * n + gi] = (float)((a == last_dst) ? last : regs[a * T]); continue; }
+        if (op == PINN_OP_CONST) { last = c64.v[a]; last_dst = dst; regs[dst * T] = last; continue; }
         const bool b_is_reg = op == PINN_OP_ADD || op == PINN_OP_SUB || op == PINN_OP_MUL || op == PINN_OP_DIV;
-        regs[dst * T] = pinn_prepass_op(op, regs[a * T], b_is_reg ? regs[b * T] : 0.0, op == PINN_OP_POW ? c64.v[b] : 0.0);
+        const double xa = (a == last_dst) ? last : regs[a * T];
+        const double xb = b_is_reg ? ((b == last_dst) ? last : regs[b * T]) : 0.0;
+        last = pinn_prepass_op(op, xa, xb, op == PINN_OP_POW ? c64.v[b] : 0.0);
+        last_dst = dst;
+        regs[dst * T] = last;
     }
 }
 
