@@ -37,7 +37,7 @@ def launch_info(solver):
 
 def _problem(name, D, V):
     """ (equation, solver kwargs, oracle dtype, path, expects several workgroups per CU) """
-    if name in ('skip128', 'skip256', 'sin64', 'program', 'generic', 'burgers64', 'heat64'):
+    if name in ('skip128', 'skip256', 'sin64', 'sin128', 'program', 'generic', 'burgers64', 'heat64'):
         cfg = pc.make_config(name, D, torch, V=V)
         return cfg['equation'], cfg['solver_kwargs'], torch.float32, ('generic' if name == 'generic' else 'fused'), False
     if name == 'w16_program':         # one wave per workgroup; Burgers: residual program
@@ -67,7 +67,8 @@ def _problem(name, D, V):
 
 
 CASES = ['w16_program', 'w32_affine', 'w32_generic', 'w32_third_order', 'w100_heat', 'skip128', 'skip256', 'sin64', 'program', 'generic',
-         'burgers64', 'heat64']          # (round 6: the (x, t) evolution shape on the two-team kernels)
+         'burgers64', 'heat64',          # (round 6: the (x, t) evolution shape on the two-team kernels)
+         'sin128']                       # (round 6: the static-activation Sin kernel of the streamed widths)
 
 
 def run_case(pa, name, n_points, solver_kwargs=None, on_device=True):
