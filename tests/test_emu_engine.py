@@ -1139,24 +1139,30 @@ def test_chunked_fit_equals_the_per_iteration_loop(pa, emu_lib):
 
 
 def test_wide_sin_net_takes_the_static_activation_kernel(pa, emu_lib):
+    _wide_sin_case(pa, 128, emu_kwargs(emu_lib), 40, emu_lib)
+
+
+def _wide_sin_case(pa, hp, solver_kwargs, n, lib=None):
     """ round 6: 'Sin' nets of the streamed widths (>= 128) without skips on the Dirichlet-box shape run on a tile kernel with the activation fixed at compile
     time (VAR 16 | 128, ACTC = Sin) instead of the full breadth kernel's run-time activation code; the weight gradients come from the HEAVY partner as before """
     from oracle import pinn_oracle as po
+    feats = [72, 100, 72, 1] if hp == 128 else [200, 256, 136, 1]
 
     def problem(D):
         eq = lambda f, x, y: D(D(f, x), x) + D(D(f, y), y) - 5 * torch.sin(np.pi * (x + y))
-        return eq, dict(ndims=2, boundary_condition=1, layout='fa fa fa f', features=[72, 100, 72, 1], activation='Sin')
+        return eq, dict(ndims=2, boundary_condition=1, layout='fa fa fa f', features=feats, activation='Sin')
     torch.manual_seed(6)
     eq_o, kw = problem(po.D)
     oracle = po.OracleSolver(eq_o, **kw)
     eq_p, kw = problem(pa.D)
-    solver = pa.Solver(eq_p, **kw, **emu_kwargs(emu_lib))
+    solver = pa.Solver(eq_p, **kw, **solver_kwargs)
     load_params(solver, oracle.export_params())
-    pts = np.random.RandomState(9).rand(2, 40, 2).astype(np.float32)
-    oracle.fit(niters=2, batch_size=40, points=pts, lr=0.005)
-    solver.fit(niters=2, batch_size=40, sampler=FixedBatches(pts), lr=0.005)
-    assert emu_lib.pinn_last_kernel_name().decode() == 'pinn_tile_kernel<128,2,1,1,-1,2,true,144>', emu_lib.pinn_last_kernel_name().decode()
-    assert emu_lib.pinn_last_wgrad_kernel_name().decode().startswith('pinn_wgrad_kernel<128,2,1,true,1,false,true,true')
+    pts = np.random.RandomState(9).rand(2, n, 2).astype(np.float32)
+    oracle.fit(niters=2, batch_size=n, points=pts, lr=0.005)
+    solver.fit(niters=2, batch_size=n, sampler=FixedBatches(pts), lr=0.005)
+    lib = lib or solver.model.net.lib
+    assert lib.pinn_last_kernel_name().decode() == f'pinn_tile_kernel<{hp},2,1,1,-1,2,true,144>', lib.pinn_last_kernel_name().decode()
+    assert lib.pinn_last_wgrad_kernel_name().decode().startswith(f'pinn_wgrad_kernel<{hp},2,1,true,1,false,true,true')
     np.testing.assert_allclose([float(v) for v in solver.losses], [float(v) for v in oracle.losses], rtol=2e-5)
     for got, want in zip(export_params(solver), oracle.export_params()):
         assert params_close(got, want, 2e-5)

@@ -1114,6 +1114,12 @@ def test_hidden_width_512_on_the_gpu(pa, which):
     te._wide512_case(pa, which, {}, 4000)
 
 
+@pytest.mark.parametrize('hp', [128, 256])
+def test_wide_sin_nets_on_the_static_activation_kernel(pa, hp):
+    import test_emu_engine as te
+    te._wide_sin_case(pa, hp, {}, 3000)
+
+
 def test_sin_net_of_depth_four_on_the_static_kernel(pa):
     """ the 4 x 64 'Sin' breadth workload of bench.py (static-depth kernel with the Dirichlet-box facts fixed) against the oracle """
     from oracle import pinn_oracle as po
