@@ -223,12 +223,24 @@ class _ModelForward(torch.autograd.Function):
         return None, None, None
 
 
+class InputProbe(Exception):
+    """ raised by `model.conv_block` while the solver asks a custom forward() what it hands to the network (Solver._input_map) """
+    def __init__(self, arg):
+        super().__init__('conv_block input probe')
+        self.arg = arg
+
+
+PROBE = object()        # `model.raw_field` while that question is being asked
+
+
 class KernelBlock(nn.Sequential):
     """ `model.conv_block` (reference model_torch.py:164-172): holds the layers' parameters as views of the flat kernel buffer; CALLED
     -- which only a subclass with its own forward() does -- it returns the network value computed by the HIP kernels: inside an
     equation evaluation the value stream the solver already has (tagged, so that `D` finds the derivative streams), elsewhere
-    (predict, constraints) a value-only kernel forward that is differentiable with respect to the parameters. The argument must
-    be the batch of points itself: inputs transformed before the net are outside what the kernels compute. """
+    (predict, constraints) a value-only kernel forward that is differentiable with respect to the parameters. Inside an equation
+    evaluation the argument must be the batch of points itself or a fixed per-column affine map of it (`2 * xs - 1`, `(xs - mean) / std`:
+    the solver asked beforehand -- Solver._input_map -- evaluated the kernels THERE and scales the derivative streams by the chain
+    rule); any other transform in front of the net needs derivative seeds the kernels do not take. """
     def __init__(self, model):
         super().__init__()
         object.__setattr__(self, '_model', model)
@@ -237,19 +249,23 @@ class KernelBlock(nn.Sequential):
         model = self._model
         model.conv_block_calls += 1
         field = model.raw_field
+        if field is PROBE:
+            raise InputProbe(xs)
         if field is not None:
-            pts, value = field
-            if xs is not pts:
+            pts, value, expect = field
+            want = pts if expect is None else expect
+            if xs is not want:
                 # a forward() that hands over a view or a copy of its argument. The SAME MEMORY seen through the same shape and strides
-                # (`xs[:, :]`, `xs.view_as(xs)`) is the batch by construction: no compare. A real copy (`xs.clone()`, `torch.cat(cols, 1)`)
-                # is another buffer whose content only a compare can vouch for -- in every call: the caching allocator hands a fresh
-                # temporary the address of the last one, so a remembered verdict would keep accepting `xs * self.scale` after `scale`
-                # moved away from 1 (the compare is an N x d pass + a device sync, paid only by forwards that copy)
-                same_memory = (xs.data_ptr() == pts.data_ptr() and xs.shape == pts.shape and xs.stride() == pts.stride()
+                # (`xs[:, :]`, `xs.view_as(xs)`) is the batch by construction: no compare. A real copy (`xs.clone()`, `torch.cat(cols, 1)`,
+                # `2 * xs - 1`) is another buffer whose content only a compare can vouch for -- in every call: the caching allocator hands
+                # a fresh temporary the address of the last one, so a remembered verdict would keep accepting `xs * self.scale` after `scale`
+                # moved (the compare is an N x d pass + a device sync, paid only by forwards that copy)
+                same_memory = (expect is None and xs.data_ptr() == pts.data_ptr() and xs.shape == pts.shape and xs.stride() == pts.stride()
                                and xs.dtype == pts.dtype and xs.device == pts.device)
-                if not same_memory and (xs.shape != pts.shape or not torch.equal(xs.detach(), pts.detach())):
-                    raise NotImplementedError('a custom forward() may call self.conv_block only on the batch of points it was given '
-                                              '(inputs transformed in front of the net are not what the HIP kernels compute)')
+                if not same_memory and (xs.shape != want.shape or not torch.equal(xs.detach().to(want.dtype), want.detach())):
+                    raise NotImplementedError('a custom forward() may call self.conv_block only on the batch of points it was given or on a '
+                                              'fixed per-column affine map of it (other inputs transformed in front of the net are not what '
+                                              'the HIP kernels compute)')
             return value
         xs = xs.to(device=model.flat.device, dtype=torch.float32).contiguous()
         return _ModelForward.apply(model._anchor, xs, model)

@@ -13,6 +13,7 @@ Data parallelism: if torch.distributed is initialised, every rank steps on its o
 gradient buffer (loss slot included) is summed with one all-reduce (RCCL) per iteration.
 """
 import contextlib
+import math
 import os
 from contextvars import copy_context
 
@@ -22,9 +23,12 @@ from torch import nn
 from tqdm import tqdm
 
 from . import engine, trace
-from .model import ConvBlockModel
+from .model import ConvBlockModel, InputProbe, PROBE
 from . import tokens
 from .tokens import current_model
+
+
+UNSET = object()        # Solver._imap outside a step: a custom forward()'s input map has not been asked for
 
 
 class FlatAdam:
@@ -106,12 +110,14 @@ class Solver:
         # change how the fully connected net / the ansatz parameters are set up run on the HIP kernels; a subclass that
         # replaces `forward` may put its own torch code AROUND the network -- `self.anzatc(self.conv_block(xs), xs) * g(xs)`, another
         # output transform, no ansatz at all: `self.conv_block(xs)` is then the bare network on the kernels and the rest runs as torch
-        # ops on its value and derivative streams (generic step path; `D` applies the chain rule). Anything else -- a model that is
-        # not a ConvBlockModel, inputs transformed in front of the net -- is arbitrary torch code the kernels cannot see: refused
+        # ops on its value and derivative streams (generic step path; `D` applies the chain rule); inputs normalised in front of the net
+        # by a fixed per-column affine map are followed too (_input_map). Anything else -- a model that is not a ConvBlockModel, a feature
+        # map or a trainable scale in front of the net -- is arbitrary torch code the kernels cannot see: refused
         if not isinstance(self.model, ConvBlockModel):
             raise NotImplementedError('Solver(model=...): only ConvBlockModel and its subclasses (fully connected layouts; a custom '
                                       'forward() may wrap torch code around self.conv_block(xs)) are backed by the HIP kernels')
         self.custom_forward = self.model.custom_forward
+        self._imap = UNSET                                                # custom forward(): (points the kernels see, per-column scale) of the running step
         current_model.set(self.model)                                     # :316-317
         self.ctx = copy_context()
         self.device = self.model.flat.device
@@ -153,20 +159,61 @@ class Solver:
         instead of 1.7 - 1.9x, for +2.5 % kernel time (include/pinn.h pinn_set_tanh_mode). Process-wide: PYDENS_AMD_TANH. """
         self.model.net.set_tanh_mode(mode)
 
+    def _input_map(self, pts, inside=False):
+        """ custom forward(): what does it hand to `self.conv_block`? None = the batch itself; (ys, scale) = a fixed per-column affine map
+        `ys[:, k] = a_k * pts[:, k] + b_k` of it (input normalisation, `2 * xs - 1`): the kernels then evaluate the network and its
+        derivative streams AT ys, and a derivative of multi-index alpha with respect to the solver's own columns is the stream times
+        prod_{k in alpha} a_k (chain rule; _eval_equation). Anything else the reference's seam takes in front of the net (model_torch.py:52-54:
+        feature maps, trainable scales, columns mixed) would need derivative seeds the kernels do not take: NotImplementedError. """
+        model = self.model
+        pts = pts.detach()
+        model.raw_field = PROBE
+        try:
+            model.forward(pts) if inside else self.ctx.run(model.forward, pts)         # (inside: the caller runs in self.ctx already)
+        except InputProbe as probe:
+            ys = probe.arg
+        else:
+            raise NotImplementedError('Solver(model=...): this forward() never calls self.conv_block(xs) -- a model that is not the '
+                                      'fully connected net of its layout is arbitrary torch code the HIP kernels cannot see')
+        finally:
+            model.raw_field = None
+        if not torch.is_tensor(ys):
+            raise NotImplementedError('a custom forward() must call self.conv_block on a tensor of points')
+        if (ys.data_ptr() == pts.data_ptr() and ys.shape == pts.shape and ys.stride() == pts.stride() and ys.dtype == pts.dtype
+                and ys.device == pts.device):
+            return None
+        refusal = ('a custom forward() may call self.conv_block only on the batch of points it was given or on a fixed per-column affine '
+                   'map of it (other inputs transformed in front of the net are not what the HIP kernels compute)')
+        if ys.requires_grad:
+            raise NotImplementedError(refusal + ': this one depends on trainable parameters')
+        if ys.shape != pts.shape:
+            raise NotImplementedError(refusal + f': shape {tuple(ys.shape)} from points of shape {tuple(pts.shape)}')
+        x64, y64 = pts.double(), ys.detach().double()
+        lo, hi = x64.argmin(dim=0), x64.argmax(dim=0)
+        k = torch.arange(x64.shape[1], device=x64.device)
+        span = x64[hi, k] - x64[lo, k]
+        flat = span <= 0                                    # a column without two different values: only the identity is recognisable
+        a = torch.where(flat, torch.ones_like(span), (y64[hi, k] - y64[lo, k]) / torch.where(flat, torch.ones_like(span), span))
+        b = y64[lo, k] - a * x64[lo, k]
+        # (fp32 arithmetic of the user's map: a few ulp of its largest intermediate)
+        err = (y64 - (a * x64 + b)).abs() - 1e-5 * ((a * x64).abs() + b.abs() + y64.abs())
+        if float(err.max()) > 0.0 or not bool(torch.isfinite(a).all()):
+            raise NotImplementedError(refusal)
+        return ys.detach().to(torch.float32).contiguous(), [float(v) for v in a.tolist()]
+
     def _equation_of_the_network(self, net_value, *cols):
         """ custom forward(): the equation as a function of the BARE network's value (tagged: `D` finds its derivative streams)
         and the input columns -- u_hat = model.forward(points) is torch code around it (reference model_torch.py:437-447) """
         model = self.model
         pts = torch.cat(cols, dim=1)                        # = reshape_and_concat of [N,1] columns (:345-362)
-        model.raw_field = (pts, net_value)
-        calls = model.conv_block_calls
+        imap = self._imap
+        if imap is UNSET:                                   # (the fake run of the tracer: no kernel has run, the question is asked here)
+            imap = self._input_map(pts, inside=True)
+        model.raw_field = (pts, net_value, None if imap is None else imap[0])
         try:
             u_hat = model.forward(pts)
         finally:
             model.raw_field = None
-        if model.conv_block_calls == calls:
-            raise NotImplementedError('Solver(model=...): this forward() never calls self.conv_block(xs) -- a model that is not the '
-                                      'fully connected net of its layout is arbitrary torch code the HIP kernels cannot see')
         return self.equation(u_hat, *cols)
 
     def _trace_equation(self):
@@ -176,7 +223,10 @@ class Solver:
         self.spec, self.needs_x_grad = trace.discover(self._eq, self.ctx.run, self.model.total, self.device,
                                                       hp=self.model.net.layout.hp, allact=self.model.net.allact)
         if self.custom_forward:
-            # torch code between the network and the equation: generic step path only
+            # torch code between the network and the equation: generic step path only. (What the forward() hands to the network is
+            # asked in every step; asked here on more points than the tracer's three, a feature map in front of the net is refused
+            # at construction and not in the first fit call.)
+            self._input_map(torch.rand((64, self.model.total), device=self.device))
             self.needs_x_grad = True
             self.ic_var_slot, self.ic_trainable, self.residual_plan = None, False, None
             self.program, self.program_error = None, 'the model has its own forward(): torch code around the network (generic path)'
@@ -381,6 +431,14 @@ class Solver:
         """ run the user's callable on stream tensors [S,N] (+ optional IC streams), D resolves to streams. """
         total = self.model.total
         sc = trace.StreamContext(total)
+        imap = self._imap if self.custom_forward else None
+        scale = None if imap in (None, UNSET) or all(a == 1.0 for a in imap[1]) else imap[1]
+
+        def tag(t, alpha):
+            # streams taken at an affine map of the points (custom forward(), _input_map): chain rule back to the solver's columns
+            if scale is not None and alpha:
+                t = t * math.prod(scale[c] for c in alpha)
+            return sc.tag(t, alpha)
         full = {}
         for alpha, idx in self.spec.index.items():
             t = streams[idx].view(-1, 1)
@@ -388,16 +446,16 @@ class Solver:
                 t = t + ic_streams[idx]
             full[idx] = t
             if all(isinstance(c, int) for c in alpha):          # ('d', a, b) diagonal streams are not user-visible
-                sc.tag(t, alpha)
+                tag(t, alpha)
         for ab, (ivv, iaa, ibb) in self.spec.mixed.items():      # u_ab = (u_vv - u_aa - u_bb) / 2
-            sc.tag(0.5 * (full[ivv] - full[iaa] - full[ibb]), ab)
+            tag(0.5 * (full[ivv] - full[iaa] - full[ibb]), ab)
         for alpha, (ip, im, ia, ib) in self.spec.mixed4.items():         # u_aabb = (D4_{a+b} + D4_{a-b} - 2 u_aaaa - 2 u_bbbb) / 12
-            sc.tag((full[ip] + full[im] - 2.0 * full[ia] - 2.0 * full[ib]) / 12.0, alpha)
+            tag((full[ip] + full[im] - 2.0 * full[ia] - 2.0 * full[ib]) / 12.0, alpha)
         for alpha, terms in list(self.spec.mixed31.items()) + list(self.spec.mixed111.items()):
             # u_aaab / u_abbb from D4 along a +- b and 2a +- b; u_abc from D3 along a +- b +- c (round 6)
-            sc.tag(sum(coef * full[idx] for idx, coef in terms), alpha)
+            tag(sum(coef * full[idx] for idx, coef in terms), alpha)
         for alpha, (ip, im, i3, sign) in self.spec.mixed3.items():      # u_aab = (D3_{a+b} - D3_{a-b} - 2 u_bbb) / 6, u_abb: + D3_{a-b}, - 2 u_aaa
-            sc.tag((full[ip] + sign * full[im] - 2.0 * full[i3]) / 6.0, alpha)
+            tag((full[ip] + sign * full[im] - 2.0 * full[i3]) / 6.0, alpha)
         cols = []
         for c in range(total):
             col = xs[:, c:c + 1]
@@ -917,15 +975,20 @@ class Solver:
             # the global batch) is weighted by that share and the constraint terms, which every rank evaluates, by 1 / world
             n_global = self._global_batch if (world > 1 and getattr(self, '_global_batch', None)) else xs.shape[0] * world
             w_eq, w_con = xs.shape[0] / n_global, 1.0 / world
+            kpts = xs                              # where the kernels evaluate the network: the batch, or what a custom forward() maps it to
             if 'equation' in loss_terms:
+                if self.custom_forward:
+                    self._imap = self._input_map(xs)
+                    if self._imap is not None:
+                        kpts = self._imap[0]
                 if len(spec.groups) == 1:
-                    leaf = model.net.jet_forward(model.flat, xs, spec.dir_cols, spec.n2p,
+                    leaf = model.net.jet_forward(model.flat, kpts, spec.dir_cols, spec.n2p,
                                                  ic_const=model.kernel_ic_const()).requires_grad_()
                 else:
                     # more directions than one kernel call carries: one forward per group of directions (u comes with each)
                     leaf = torch.empty((spec.n_streams, xs.shape[0]), dtype=torch.float32, device=self.device)
                     for num, (dirs_g, n2g, idx) in enumerate(spec.groups):
-                        part = model.net.jet_forward(model.flat, xs, dirs_g, n2g, ic_const=model.kernel_ic_const())
+                        part = model.net.jet_forward(model.flat, kpts, dirs_g, n2g, ic_const=model.kernel_ic_const())
                         leaf.index_copy_(0, self._group_rows(num, idx), part)
                     leaf.requires_grad_()
                 ic_streams = None
@@ -946,7 +1009,7 @@ class Solver:
             if leaf is not None and leaf.grad is not None:
                 if len(spec.groups) == 1:
                     ws = model.workspace(xs.shape[0], spec.nd, spec.n2p)
-                    model.net.jet_backward(model.flat, xs, leaf.grad.contiguous(), self.grads, ws, spec.dir_cols, spec.n2p,
+                    model.net.jet_backward(model.flat, kpts, leaf.grad.contiguous(), self.grads, ws, spec.dir_cols, spec.n2p,
                                            ic_const=model.kernel_ic_const(), accumulate=True)
                 else:
                     # the parameter gradient is linear in the upstream stream gradients: one backward per group, the
@@ -956,7 +1019,7 @@ class Solver:
                         if num > 0:
                             gin[0].zero_()
                         ws = model.workspace(xs.shape[0], len(dirs_g), n2g)
-                        model.net.jet_backward(model.flat, xs, gin, self.grads, ws, dirs_g, n2g,
+                        model.net.jet_backward(model.flat, kpts, gin, self.grads, ws, dirs_g, n2g,
                                                ic_const=model.kernel_ic_const(), accumulate=True)
             for name, (off, n) in model.variables.items():
                 p = getattr(model, name)
@@ -970,6 +1033,7 @@ class Solver:
             self.grads[lay.off_loss] = loss.detach()
         finally:
             model.grad_sink = None
+            self._imap = UNSET
 
     def predict(self, *xs):
         """ reference model_torch.py:466-487 -> ndarray [N,1]. """

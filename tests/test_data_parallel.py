@@ -71,7 +71,7 @@ def _problem(path, pa, lib):
         # its log_scale gradient from autograd) and an output factor as torch code, generic step path -- under data parallelism
         class Scaled(pa.ConvBlockModel):
             def forward(self, xs):
-                return self.anzatc(self.conv_block(xs), xs) * (1.0 + 0.5 * xs[:, :1])
+                return self.anzatc(self.conv_block(2.0 * xs - 1.0), xs) * (1.0 + 0.5 * xs[:, :1])      # (inputs normalised in front of the net: Solver._input_map)
         torch.manual_seed(5)
         eq = lambda f, x, t: pa.D(f, t) - 0.1 * pa.D(pa.D(f, x), x) + f * f
         solver = pa.Solver(eq, ndims=2, boundary_condition=0.2, initial_condition=lambda x: torch.sin(np.pi * x), model=Scaled,

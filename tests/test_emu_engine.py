@@ -1030,7 +1030,7 @@ def _combined_program_case(pa, which, solver_kwargs):
         assert abs(float(solver.model.k.detach()) - float(oracle.model.k.detach())) < 1e-5
 
 
-@pytest.mark.parametrize('which', ['scaled_ansatz', 'no_ansatz_head', 'with_constraint'])
+@pytest.mark.parametrize('which', ['scaled_ansatz', 'no_ansatz_head', 'with_constraint', 'normalised_inputs', 'normalised_mixed'])
 def test_model_subclass_with_its_own_forward(pa, emu_lib, which):
     _custom_forward_case(pa, which, emu_kwargs(emu_lib))
 
@@ -1050,11 +1050,24 @@ def _custom_forward_case(pa, which, solver_kwargs):
         class Head(base):
             def forward(self, xs):
                 return torch.tanh(self.conv_block(xs)) * xs[:, :1] * (1 - xs[:, :1]) + 0.3
+
+        class Normalised(base):
+            # inputs normalised in front of the net (round 6): a fixed per-column affine map; the kernels evaluate the network at the
+            # mapped points and the solver scales the derivative streams by the chain rule
+            def forward(self, xs):
+                ys = 2.0 * xs - 1.0 if which == 'normalised_inputs' else (xs - torch.tensor([0.5, 0.25], device=xs.device)) / torch.tensor([0.29, 1.7], device=xs.device)
+                return self.anzatc(self.conv_block(ys), xs)
+        if which.startswith('normalised'):
+            return Normalised
         return Head if which == 'no_ansatz_head' else Scaled
 
     def problem(D):
         if which == 'no_ansatz_head':
             return (lambda f, x: D(D(f, x), x) + f * D(f, x) - torch.sin(3 * x)), dict(ndims=1)
+        if which == 'normalised_mixed':
+            # a mixed partial and a third derivative: every multi-index picks up its own product of scales
+            eq = lambda f, x, t: D(f, t) - 0.1 * D(D(f, x), x) + 0.05 * D(D(f, x), t) + 0.01 * D(D(D(f, x), x), x) + f * D(f, x)
+            return eq, dict(ndims=2, boundary_condition=0.2, initial_condition=lambda x: torch.sin(np.pi * x))
         eq = lambda f, x, t: D(f, t) - 0.1 * D(D(f, x), x) + f * f
         return eq, dict(ndims=2, boundary_condition=0.2, initial_condition=lambda x: torch.sin(np.pi * x))
     net = dict(layout='fa fa f', features=[20, 20, 1], activation='Tanh')
@@ -1085,6 +1098,20 @@ def _custom_forward_case(pa, which, solver_kwargs):
             return self.conv_block(torch.sin(xs))
     with pytest.raises(NotImplementedError):
         pa.Solver(eq_p, **kw, **net, model=Fourier, **solver_kwargs)
+    # ... and so are a map that mixes columns and one that depends on a trainable parameter
+    class Mixing(pa.ConvBlockModel):
+        def forward(self, xs):
+            return self.conv_block(xs + 0.5 * xs.flip(1)) if xs.shape[1] > 1 else self.conv_block(xs * xs)
+    with pytest.raises(NotImplementedError):
+        pa.Solver(eq_p, **kw, **net, model=Mixing, **solver_kwargs)
+    class Trainable(pa.ConvBlockModel):
+        def __init__(self, *args, **kwargs):
+            super().__init__(*args, **kwargs)
+            self.stretch = torch.nn.Parameter(torch.tensor(2.0, device=self.flat.device))
+        def forward(self, xs):
+            return self.conv_block(xs * self.stretch)
+    with pytest.raises(NotImplementedError, match='trainable'):
+        pa.Solver(eq_p, **kw, **net, model=Trainable, **solver_kwargs)
 
 
 def test_breadth_streams_and_gradients_match_the_fp64_jets(pa, emu_lib):

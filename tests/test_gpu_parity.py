@@ -856,7 +856,7 @@ def test_known_answers_of_the_tutorial(pa):
     assert abs(v - 2.0) < 0.05 and err < 0.1, (v, err)              # (reference: V = 1.997 .. 2.004, error 0.006 .. 0.02)
 
 
-@pytest.mark.parametrize('which', ['scaled_ansatz', 'no_ansatz_head', 'with_constraint'])
+@pytest.mark.parametrize('which', ['scaled_ansatz', 'no_ansatz_head', 'with_constraint', 'normalised_inputs', 'normalised_mixed'])
 def test_model_subclass_with_its_own_forward_on_the_gpu(pa, which):
     import test_emu_engine as te
     te._custom_forward_case(pa, which, {})
