@@ -194,7 +194,7 @@ class Solver:
         span = x64[hi, k] - x64[lo, k]
         flat = span <= 0                                    # a column without two different values: only the identity is recognisable
         a = torch.where(flat, torch.ones_like(span), (y64[hi, k] - y64[lo, k]) / torch.where(flat, torch.ones_like(span), span))
-        b = y64[lo, k] - a * x64[lo, k]
+        b = torch.where(flat, torch.zeros_like(span), y64[lo, k] - a * x64[lo, k])     # (such a column must come through unchanged)
         # (fp32 arithmetic of the user's map: a few ulp of its largest intermediate)
         err = (y64 - (a * x64 + b)).abs() - 1e-5 * ((a * x64).abs() + b.abs() + y64.abs())
         if float(err.max()) > 0.0 or not bool(torch.isfinite(a).all()):

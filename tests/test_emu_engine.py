@@ -1112,6 +1112,10 @@ def _custom_forward_case(pa, which, solver_kwargs):
             return self.conv_block(xs * self.stretch)
     with pytest.raises(NotImplementedError, match='trainable'):
         pa.Solver(eq_p, **kw, **net, model=Trainable, **solver_kwargs)
+    if which == 'normalised_inputs':
+        # a batch that cannot tell the scale (one point): refused rather than guessed
+        with pytest.raises(NotImplementedError):
+            solver._input_map(torch.full((1, d), 0.3, device=solver.device))
 
 
 def test_breadth_streams_and_gradients_match_the_fp64_jets(pa, emu_lib):
