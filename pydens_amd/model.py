@@ -7,7 +7,7 @@ from abc import ABC, abstractmethod
 import torch
 from torch import nn
 
-from . import engine
+from . import engine, trace
 
 
 def default_device():
@@ -238,9 +238,10 @@ class KernelBlock(nn.Sequential):
     -- which only a subclass with its own forward() does -- it returns the network value computed by the HIP kernels: inside an
     equation evaluation the value stream the solver already has (tagged, so that `D` finds the derivative streams), elsewhere
     (predict, constraints) a value-only kernel forward that is differentiable with respect to the parameters. Inside an equation
-    evaluation the argument must be the batch of points itself or a fixed per-column affine map of it (`2 * xs - 1`, `(xs - mean) / std`:
-    the solver asked beforehand -- Solver._input_map -- evaluated the kernels THERE and scales the derivative streams by the chain
-    rule); any other transform in front of the net needs derivative seeds the kernels do not take. """
+    evaluation the argument must be the batch of points itself or a fixed map of it, point by point, onto as many columns (`2 * xs - 1`,
+    `torch.sin(xs)`, a time warp, a rotation: the solver asked beforehand -- Solver._input_map --, evaluated the kernels THERE and applies
+    the chain rule: scaled streams for per-column affine maps, the map's Jacobian by autograd otherwise); maps that depend on trainable
+    parameters, on the batch as a whole or that change the number of columns are refused. """
     def __init__(self, model):
         super().__init__()
         object.__setattr__(self, '_model', model)
@@ -264,8 +265,11 @@ class KernelBlock(nn.Sequential):
                                and xs.dtype == pts.dtype and xs.device == pts.device)
                 if not same_memory and (xs.shape != want.shape or not torch.equal(xs.detach().to(want.dtype), want.detach())):
                     raise NotImplementedError('a custom forward() may call self.conv_block only on the batch of points it was given or on a '
-                                              'fixed per-column affine map of it (other inputs transformed in front of the net are not what '
-                                              'the HIP kernels compute)')
+                                              'fixed pointwise map of it (the argument differs from what the same forward() handed over when '
+                                              'the solver asked)')
+            sc = trace.active_streams.get()
+            if sc is not None and sc.ymap is not None:
+                sc.ymap['ys'] = xs              # (connected to the solver's columns by the forward()'s own torch ops: the Jacobian comes from there)
             return value
         xs = xs.to(device=model.flat.device, dtype=torch.float32).contiguous()
         return _ModelForward.apply(model._anchor, xs, model)

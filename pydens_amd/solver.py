@@ -110,14 +110,15 @@ class Solver:
         # change how the fully connected net / the ansatz parameters are set up run on the HIP kernels; a subclass that
         # replaces `forward` may put its own torch code AROUND the network -- `self.anzatc(self.conv_block(xs), xs) * g(xs)`, another
         # output transform, no ansatz at all: `self.conv_block(xs)` is then the bare network on the kernels and the rest runs as torch
-        # ops on its value and derivative streams (generic step path; `D` applies the chain rule); inputs normalised in front of the net
-        # by a fixed per-column affine map are followed too (_input_map). Anything else -- a model that is not a ConvBlockModel, a feature
-        # map or a trainable scale in front of the net -- is arbitrary torch code the kernels cannot see: refused
+        # ops on its value and derivative streams (generic step path; `D` applies the chain rule); a fixed map of each point onto as many
+        # columns in front of the net is followed too (_input_map). Anything else -- a model that is not a ConvBlockModel, a map in front
+        # of the net that is trainable, changes the number of columns or looks at the whole batch -- is refused
         if not isinstance(self.model, ConvBlockModel):
             raise NotImplementedError('Solver(model=...): only ConvBlockModel and its subclasses (fully connected layouts; a custom '
                                       'forward() may wrap torch code around self.conv_block(xs)) are backed by the HIP kernels')
         self.custom_forward = self.model.custom_forward
-        self._imap = UNSET                                                # custom forward(): (points the kernels see, per-column scale) of the running step
+        self._imap = UNSET                                                # custom forward(): _input_map of the running step
+        self._map_pattern, self._map_affine = None, False                 # ... and what _check_input_map found at construction
         current_model.set(self.model)                                     # :316-317
         self.ctx = copy_context()
         self.device = self.model.flat.device
@@ -159,14 +160,9 @@ class Solver:
         instead of 1.7 - 1.9x, for +2.5 % kernel time (include/pinn.h pinn_set_tanh_mode). Process-wide: PYDENS_AMD_TANH. """
         self.model.net.set_tanh_mode(mode)
 
-    def _input_map(self, pts, inside=False):
-        """ custom forward(): what does it hand to `self.conv_block`? None = the batch itself; (ys, scale) = a fixed per-column affine map
-        `ys[:, k] = a_k * pts[:, k] + b_k` of it (input normalisation, `2 * xs - 1`): the kernels then evaluate the network and its
-        derivative streams AT ys, and a derivative of multi-index alpha with respect to the solver's own columns is the stream times
-        prod_{k in alpha} a_k (chain rule; _eval_equation). Anything else the reference's seam takes in front of the net (model_torch.py:52-54:
-        feature maps, trainable scales, columns mixed) would need derivative seeds the kernels do not take: NotImplementedError. """
+    def _conv_block_argument(self, pts, inside=False):
+        """ run the custom forward() up to its call of `self.conv_block` and return that call's argument """
         model = self.model
-        pts = pts.detach()
         model.raw_field = PROBE
         try:
             model.forward(pts) if inside else self.ctx.run(model.forward, pts)         # (inside: the caller runs in self.ctx already)
@@ -179,16 +175,36 @@ class Solver:
             model.raw_field = None
         if not torch.is_tensor(ys):
             raise NotImplementedError('a custom forward() must call self.conv_block on a tensor of points')
+        return ys
+
+    def _input_map(self, pts, inside=False):
+        """ custom forward(): what does it hand to `self.conv_block`? Asked in every step (a probe call of the forward()).
+          None               the batch itself;
+          (ys, scale, None)  a fixed per-column affine map `ys[:, k] = a_k * pts[:, k] + b_k` (input normalisation, `2 * xs - 1`): the kernels
+                             evaluate the network and its derivative streams AT ys, and a derivative of multi-index alpha with respect to the
+                             solver's own columns is the stream times prod_{k in alpha} a_k (_eval_equation);
+          (ys, None, pattern) any other fixed map of a point onto as many columns (`torch.sin(xs)`, a time warp, columns mixed): streams at ys
+                             with respect to the network's input columns, chain rule with the map's Jacobian by torch autograd
+                             (trace.StreamContext._through_map; pattern[k][c] = "ys_k depends on column c", found at construction).
+        What the reference's seam (model_torch.py:52-54) also takes and this does not: a map that depends on trainable parameters (its
+        gradient would need the streams' own derivatives), on the batch as a whole, or that changes the number of columns (the reference
+        builds `conv_block` for `total` inputs, :167): NotImplementedError. """
+        pts = pts.detach()
+        ys = self._conv_block_argument(pts, inside)
         if (ys.data_ptr() == pts.data_ptr() and ys.shape == pts.shape and ys.stride() == pts.stride() and ys.dtype == pts.dtype
                 and ys.device == pts.device):
             return None
-        refusal = ('a custom forward() may call self.conv_block only on the batch of points it was given or on a fixed per-column affine '
-                   'map of it (other inputs transformed in front of the net are not what the HIP kernels compute)')
+        refusal = 'a custom forward() may call self.conv_block only on the batch of points it was given or on a fixed pointwise map of it '
         if ys.requires_grad:
-            raise NotImplementedError(refusal + ': this one depends on trainable parameters')
+            raise NotImplementedError(refusal + '(this one depends on trainable parameters)')
         if ys.shape != pts.shape:
-            raise NotImplementedError(refusal + f': shape {tuple(ys.shape)} from points of shape {tuple(pts.shape)}')
+            raise NotImplementedError(refusal + f'onto as many columns (shape {tuple(ys.shape)} from points of shape {tuple(pts.shape)})')
+        ys32 = ys.detach().to(torch.float32).contiguous()
+        if self._map_pattern is not None:                   # (known since construction to be more than a per-column affine map)
+            return ys32, None, self._map_pattern
         x64, y64 = pts.double(), ys.detach().double()
+        if not bool(torch.isfinite(y64).all()):
+            raise NotImplementedError(refusal + '(not finite on this batch)')
         lo, hi = x64.argmin(dim=0), x64.argmax(dim=0)
         k = torch.arange(x64.shape[1], device=x64.device)
         span = x64[hi, k] - x64[lo, k]
@@ -197,9 +213,38 @@ class Solver:
         b = torch.where(flat, torch.zeros_like(span), y64[lo, k] - a * x64[lo, k])     # (such a column must come through unchanged)
         # (fp32 arithmetic of the user's map: a few ulp of its largest intermediate)
         err = (y64 - (a * x64 + b)).abs() - 1e-5 * ((a * x64).abs() + b.abs() + y64.abs())
-        if float(err.max()) > 0.0 or not bool(torch.isfinite(a).all()):
-            raise NotImplementedError(refusal)
-        return ys.detach().to(torch.float32).contiguous(), [float(v) for v in a.tolist()]
+        if float(err.max()) <= 0.0:
+            return ys32, [float(v) for v in a.tolist()], None
+        if self._map_affine:
+            raise NotImplementedError(refusal + '(per-column affine on the points of the construction, not on this batch: a column without two '
+                                      'different values cannot tell its scale)')
+        return ys32, None, None
+
+    def _check_input_map(self):
+        """ construction: what kind of map does the custom forward() put in front of the network (refusals happen here and not in the first
+        fit call), is it a map of each point by itself, and -- if it is not per-column affine -- which input column of the network depends
+        on which column of the solver. """
+        total = self.model.total
+        self._map_pattern, self._map_affine = None, False
+        pts = torch.rand((64, total), device=self.device)
+        imap = self._input_map(pts)
+        if imap is None:
+            return
+        self._map_affine = imap[1] is not None
+        part = self._input_map(pts[:23].contiguous())
+        if part is None or not torch.allclose(part[0], imap[0][:23], rtol=1e-6, atol=1e-7):
+            raise NotImplementedError('a custom forward() may call self.conv_block only on a map of each point by itself (this one depends on '
+                                      'the batch as a whole: the reference differentiates such a map across the rows of the batch, the '
+                                      'kernels see one point at a time)')
+        if imap[1] is not None:
+            return
+        p = pts.clone().requires_grad_()
+        ys = self._conv_block_argument(p)
+        pattern = []
+        for k in range(total):
+            g = torch.autograd.grad(ys[:, k].sum(), p, retain_graph=True, allow_unused=True)[0] if ys.requires_grad else None
+            pattern.append([False] * total if g is None else [bool(v) for v in (g != 0).any(dim=0).tolist()])
+        self._map_pattern = pattern
 
     def _equation_of_the_network(self, net_value, *cols):
         """ custom forward(): the equation as a function of the BARE network's value (tagged: `D` finds its derivative streams)
@@ -209,6 +254,10 @@ class Solver:
         imap = self._imap
         if imap is UNSET:                                   # (the fake run of the tracer: no kernel has run, the question is asked here)
             imap = self._input_map(pts, inside=True)
+        if imap is not None and imap[1] is None:
+            # a general map in front of the net: the streams are derivatives with respect to the NETWORK's input columns; `D` goes through
+            # the map's Jacobian (trace.StreamContext._through_map), taken from the graph this very forward() call builds
+            trace.active_streams.get().ymap = {'cols': cols, 'pattern': imap[2], 'ys': None, 'jac': {}}
         model.raw_field = (pts, net_value, None if imap is None else imap[0])
         try:
             u_hat = model.forward(pts)
@@ -220,13 +269,12 @@ class Solver:
         """ which streams does the equation need, and can it be lowered to a residual program? (construction, and again at
         the start of a fit call whenever the cached lowering no longer reproduces the live callable) """
         self._eq = self._equation_of_the_network if self.custom_forward else self.equation
+        if self.custom_forward:
+            self._check_input_map()
         self.spec, self.needs_x_grad = trace.discover(self._eq, self.ctx.run, self.model.total, self.device,
                                                       hp=self.model.net.layout.hp, allact=self.model.net.allact)
         if self.custom_forward:
-            # torch code between the network and the equation: generic step path only. (What the forward() hands to the network is
-            # asked in every step; asked here on more points than the tracer's three, a feature map in front of the net is refused
-            # at construction and not in the first fit call.)
-            self._input_map(torch.rand((64, self.model.total), device=self.device))
+            # torch code between the network and the equation: generic step path only
             self.needs_x_grad = True
             self.ic_var_slot, self.ic_trainable, self.residual_plan = None, False, None
             self.program, self.program_error = None, 'the model has its own forward(): torch code around the network (generic path)'
@@ -432,7 +480,7 @@ class Solver:
         total = self.model.total
         sc = trace.StreamContext(total)
         imap = self._imap if self.custom_forward else None
-        scale = None if imap in (None, UNSET) or all(a == 1.0 for a in imap[1]) else imap[1]
+        scale = None if imap is None or imap is UNSET or imap[1] is None or all(a == 1.0 for a in imap[1]) else imap[1]
 
         def tag(t, alpha):
             # streams taken at an affine map of the points (custom forward(), _input_map): chain rule back to the solver's columns
@@ -446,7 +494,10 @@ class Solver:
                 t = t + ic_streams[idx]
             full[idx] = t
             if all(isinstance(c, int) for c in alpha):          # ('d', a, b) diagonal streams are not user-visible
-                tag(t, alpha)
+                # (a node of its own in the autograd graph: the combinations below are built from `full`, NOT from tagged tensors -- `D` of an
+                #  expression asks autograd for the partial derivative with respect to every tagged stream, and a mixed partial that hung
+                #  below the tagged u_aa would be counted in d / d u_aa a second time)
+                tag(t.view_as(t), alpha)
         for ab, (ivv, iaa, ibb) in self.spec.mixed.items():      # u_ab = (u_vv - u_aa - u_bb) / 2
             tag(0.5 * (full[ivv] - full[iaa] - full[ibb]), ab)
         for alpha, (ip, im, ia, ib) in self.spec.mixed4.items():         # u_aabb = (D4_{a+b} + D4_{a-b} - 2 u_aaaa - 2 u_bbbb) / 12

@@ -246,6 +246,10 @@ class StreamContext:
         self.spec = None
         self.discovering = False
         self.used_autograd_fallback = False
+        # a custom forward() that hands `self.conv_block` a (non-affine or column-mixing) map ys = phi(points) of the batch: the streams are
+        # derivatives with respect to the NETWORK's input columns, taken at ys; a derivative with respect to a column of the solver is
+        # sum_k stream_{alpha + k} * d ys_k / d x_col (chain rule; the Jacobian of phi by torch autograd on the user's few pointwise ops)
+        self.ymap = None           # {'cols': the solver's column tensors, 'pattern': [k][col] "ys_k depends on x_col", 'ys': None, 'jac': {}}
 
     def tag(self, tensor, alpha):
         tensor._pinn_alpha = alpha
@@ -254,6 +258,25 @@ class StreamContext:
         return tensor
 
     def derivative(self, alpha, col):
+        if self.ymap is not None:
+            return self._through_map(alpha, col)
+        return self._stream(alpha, col)
+
+    def _through_map(self, alpha, col):
+        m = self.ymap
+        if m['ys'] is None:
+            raise NotImplementedError('D(...) of the network before the forward() of the model has called self.conv_block')
+        total = None
+        for k, row in enumerate(m['pattern']):
+            if not row[col]:
+                continue
+            if (k, col) not in m['jac']:
+                m['jac'][(k, col)] = torch.autograd.grad(m['ys'][:, k].sum(), m['cols'][col], retain_graph=True, create_graph=True)[0]
+            term = m['jac'][(k, col)] * self._stream(alpha, k)
+            total = term if total is None else total + term
+        return total if total is not None else torch.zeros_like(self.tensors[()])
+
+    def _stream(self, alpha, col):
         new = tuple(sorted(alpha + (col,)))
         self.requested.add(new)
         if new in self.tensors:

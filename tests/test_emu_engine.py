@@ -388,6 +388,12 @@ def _mixed_affine_problem(D, torch):
     return eq, dict(ndims=2, boundary_condition=0.5, layout='fafaf', features=[16, 16, 1], activation='Tanh')
 
 
+def _D_of_a_mixed_partial_problem(D, torch):
+    def eq(f, x, y):                                 # D of an EXPRESSION that holds a mixed partial (which the solver builds from u_vv, u_xx, u_yy)
+        return D(f * D(D(f, x), y), x) + D(D(f, y), y) - torch.sin(3 * x * y)
+    return eq, dict(ndims=2, boundary_condition=0.5, layout='fafaf', features=[16, 16, 1], activation='Tanh')
+
+
 def _mixed_nonlinear_problem(D, torch):
     def eq(f, x, t):                                 # mixed space-time partial under a callable IC, nonlinear in f
         return D(f, t) + f * D(D(f, x), t) - 0.1 * D(D(f, x), x) - x * t
@@ -428,16 +434,22 @@ def test_residual_kinds_match_the_oracle(pa, emu_lib, problem, kind):
         assert params_close(got, want, 3e-5)
 
 
-@pytest.mark.parametrize('problem', ['mixed', 'composite'])
+@pytest.mark.parametrize('problem', ['mixed', 'composite', 'D_of_mixed'])
 def test_mixed_partial_and_composite_D_generic_path(pa, emu_lib, problem):
     """ generic path (kernel streams -> the user's torch code -> kernel backward): D(D(f, x), y) seen as
-    u_xy = (u_vv - u_xx - u_yy) / 2 built from the streams; D(f * f, x) by the chain rule over the streams """
+    u_xy = (u_vv - u_xx - u_yy) / 2 built from the streams; D(f * f, x) by the chain rule over the streams; `D_of_mixed` (round 6):
+    D of an expression that holds u_xy -- the chain rule takes d expr / d stream for every tagged stream by autograd, so u_xy must
+    not hang below the tagged u_xx / u_yy in the graph (it did: d / d u_xx then counted the path through u_xy a second time) """
+    _generic_D_case(pa, problem, emu_kwargs(emu_lib))
+
+
+def _generic_D_case(pa, problem, solver_kwargs):
     from oracle import pinn_oracle as po
-    make = _mixed_affine_problem if problem == 'mixed' else _conservative_burgers_problem
+    make = {'mixed': _mixed_affine_problem, 'composite': _conservative_burgers_problem, 'D_of_mixed': _D_of_a_mixed_partial_problem}[problem]
     eq_o, kw = make(po.D, torch)
     oracle = po.OracleSolver(eq_o, **kw)
     eq_p, kw = make(pa.D, torch)
-    solver = pa.Solver(eq_p, **kw, **emu_kwargs(emu_lib))
+    solver = pa.Solver(eq_p, **kw, **solver_kwargs)
     solver.program = None
     load_params(solver, oracle.export_params())
     pts = np.random.RandomState(9).rand(3, 40, 2).astype(np.float32)
@@ -1030,7 +1042,8 @@ def _combined_program_case(pa, which, solver_kwargs):
         assert abs(float(solver.model.k.detach()) - float(oracle.model.k.detach())) < 1e-5
 
 
-@pytest.mark.parametrize('which', ['scaled_ansatz', 'no_ansatz_head', 'with_constraint', 'normalised_inputs', 'normalised_mixed'])
+@pytest.mark.parametrize('which', ['scaled_ansatz', 'no_ansatz_head', 'with_constraint', 'normalised_inputs', 'normalised_mixed',
+                                   'map_sine', 'map_mixing', 'map_time_warp', 'map_mixing_third'])
 def test_model_subclass_with_its_own_forward(pa, emu_lib, which):
     _custom_forward_case(pa, which, emu_kwargs(emu_lib))
 
@@ -1059,13 +1072,28 @@ def _custom_forward_case(pa, which, solver_kwargs):
                 return self.anzatc(self.conv_block(ys), xs)
         if which.startswith('normalised'):
             return Normalised
+
+        class Mapped(base):
+            # any fixed map of a point onto as many columns in front of the net (round 6): streams with respect to the network's input
+            # columns at the mapped points, chain rule with the map's Jacobian by autograd -- elementwise, mixing columns, one column only
+            def forward(self, xs):
+                if which == 'map_sine':
+                    ys = torch.sin(2.0 * xs)
+                elif which.startswith('map_mixing'):
+                    ys = xs + 0.5 * xs.flip(1) * xs
+                else:
+                    ys = torch.cat([xs[:, :1], torch.log1p(3.0 * xs[:, 1:])], dim=1)
+                return self.anzatc(self.conv_block(ys), xs)
+        if which.startswith('map_'):
+            return Mapped
         return Head if which == 'no_ansatz_head' else Scaled
 
     def problem(D):
         if which == 'no_ansatz_head':
             return (lambda f, x: D(D(f, x), x) + f * D(f, x) - torch.sin(3 * x)), dict(ndims=1)
-        if which == 'normalised_mixed':
-            # a mixed partial and a third derivative: every multi-index picks up its own product of scales
+        if which in ('normalised_mixed', 'map_mixing_third'):
+            # a mixed partial and a third derivative: every multi-index picks up its own product of scales (a map that mixes columns: every
+            # partial of the network's two inputs up to third order, u_yyz / u_yzz included)
             eq = lambda f, x, t: D(f, t) - 0.1 * D(D(f, x), x) + 0.05 * D(D(f, x), t) + 0.01 * D(D(D(f, x), x), x) + f * D(f, x)
             return eq, dict(ndims=2, boundary_condition=0.2, initial_condition=lambda x: torch.sin(np.pi * x))
         eq = lambda f, x, t: D(f, t) - 0.1 * D(D(f, x), x) + f * f
@@ -1092,18 +1120,18 @@ def _custom_forward_case(pa, which, solver_kwargs):
     for got, want in zip(export_params(solver), oracle.export_params()):
         assert params_close(got, want, 3e-5)
     assert np.abs(solver.predict(*xs) - oracle.predict(*xs)).max() < 2e-5
-    # inputs transformed in front of the net are not what the kernels compute: refused where it happens
-    class Fourier(pa.ConvBlockModel):
+    # what stays refused, where it happens: a map in front of the net that changes the number of columns, that depends on the batch as a
+    # whole, or on a trainable parameter
+    class Wider(pa.ConvBlockModel):
         def forward(self, xs):
-            return self.conv_block(torch.sin(xs))
-    with pytest.raises(NotImplementedError):
-        pa.Solver(eq_p, **kw, **net, model=Fourier, **solver_kwargs)
-    # ... and so are a map that mixes columns and one that depends on a trainable parameter
-    class Mixing(pa.ConvBlockModel):
+            return self.conv_block(torch.cat([torch.sin(xs), torch.cos(xs)], dim=1))
+    with pytest.raises(NotImplementedError, match='as many columns'):
+        pa.Solver(eq_p, **kw, **net, model=Wider, **solver_kwargs)
+    class BatchStatistics(pa.ConvBlockModel):
         def forward(self, xs):
-            return self.conv_block(xs + 0.5 * xs.flip(1)) if xs.shape[1] > 1 else self.conv_block(xs * xs)
-    with pytest.raises(NotImplementedError):
-        pa.Solver(eq_p, **kw, **net, model=Mixing, **solver_kwargs)
+            return self.conv_block((xs - xs.mean(dim=0)) / xs.std(dim=0))
+    with pytest.raises(NotImplementedError, match='batch as a whole'):
+        pa.Solver(eq_p, **kw, **net, model=BatchStatistics, **solver_kwargs)
     class Trainable(pa.ConvBlockModel):
         def __init__(self, *args, **kwargs):
             super().__init__(*args, **kwargs)

@@ -856,7 +856,14 @@ def test_known_answers_of_the_tutorial(pa):
     assert abs(v - 2.0) < 0.05 and err < 0.1, (v, err)              # (reference: V = 1.997 .. 2.004, error 0.006 .. 0.02)
 
 
-@pytest.mark.parametrize('which', ['scaled_ansatz', 'no_ansatz_head', 'with_constraint', 'normalised_inputs', 'normalised_mixed'])
+@pytest.mark.parametrize('problem', ['mixed', 'composite', 'D_of_mixed'])
+def test_mixed_partial_and_composite_D_generic_path_on_the_gpu(pa, problem):
+    import test_emu_engine as te
+    te._generic_D_case(pa, problem, {})
+
+
+@pytest.mark.parametrize('which', ['scaled_ansatz', 'no_ansatz_head', 'with_constraint', 'normalised_inputs', 'normalised_mixed',
+                                   'map_sine', 'map_mixing', 'map_time_warp', 'map_mixing_third'])
 def test_model_subclass_with_its_own_forward_on_the_gpu(pa, which):
     import test_emu_engine as te
     te._custom_forward_case(pa, which, {})
