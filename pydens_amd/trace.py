@@ -593,14 +593,24 @@ def symbolic_constraint(constraint, ctx_run, n_inputs, to_points, variable_slot=
     return root, calls[0]
 
 
+def kernel_stream_shift(nd, n2p):
+    """ extra second-derivative streams of the kernel instantiation that serves (nd, n2): mirror of pick_n2 in csrc/pinn_abi.cpp (the
+    compiled second-order shapes per nd; third / fourth order: exact instantiations only) """
+    if n2p > 7:
+        return 0
+    avail = {0: (0,), 1: (0, 1), 2: (0, 2), 3: (2, 3), 4: (0,)}.get(nd, ())
+    fits = [k for k in avail if k >= n2p]
+    return (min(fits) - n2p) if fits else 0
+
+
 class _Emitter:
     """ register-code emitter shared by the pre-pass and the main program. Main programs are single-assignment (the
     reverse sweep of the interpreter relies on it); the pre-pass has no reverse sweep, so with `reuse=True` its code is
     emitted over virtual registers and `finish()` maps them onto the MAX_REGS physical ones, recycling a register after
     its last use (an initial condition with its derivatives easily takes more ops than there are registers). """
-    def __init__(self, first_temp, reuse=False):
+    def __init__(self, first_temp, reuse=False, limit=MAX_REGS):
         self.first_temp, self.code, self.consts, self.memo, self._cidx = first_temp, [], [], {}, {}
-        self.reuse = reuse
+        self.reuse, self.limit = reuse, limit
         # the memo is keyed by id(node): every visited node is kept alive here, or a node created later (the derivatives of a callable
         # IC, emitted after the residual's own rows) can be handed the id of a temporary that is gone -- and with it that temporary's
         # register. (Round 5: the tutorial's heat equation with a parameter column lost its lowered IC that way -- the validation against
@@ -621,7 +631,7 @@ class _Emitter:
 
     def emit(self, op, a=0, b=0):
         dst = self.first_temp + sum(1 for c in self.code if c[0] != OPS['STORE'])
-        if (dst >= MAX_REGS and not self.reuse) or len(self.code) >= MAX_OPS:
+        if (dst >= self.limit and not self.reuse) or len(self.code) >= MAX_OPS:
             raise TraceUnsupported('residual program too long')
         self.code.append((OPS[op], dst, a, b))
         return dst
@@ -1022,7 +1032,11 @@ def lower_residual(root, spec, n_inputs, ic_root=None):
             find_vars(a, seen)
     find_vars(root, set())
     n_vars = max(slots) + 1 if slots else 0
-    main = _Emitter(first_temp=S + n_inputs + n_aux + n_vars)
+    # (the library runs the step on the smallest COMPILED stream shape that holds this one and re-bases every register behind the streams
+    #  by the difference -- pinn_abi.cpp pick_n2 / "re-basing": the budget of a program is what is left after that shift. Round 6: a
+    #  random-equation soak met a 38-register program on an (nd, n2) = (2, 1) spec, which runs on the (2, 2) kernels: refused by the library
+    #  inside the first fit call instead of here, where a refusal means the generic path)
+    main = _Emitter(first_temp=S + n_inputs + n_aux + n_vars, limit=MAX_REGS - kernel_stream_shift(spec.nd, spec.n2p))
 
     def main_leaf(node):
         if id(node) in aux_of:

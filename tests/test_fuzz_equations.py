@@ -191,6 +191,74 @@ def test_random_third_order_equations_on_the_gpu():
     _run(pa, {}, n_trees=40 * SCALE, batch=523, third=True)
 
 
+def _composite_equation(trees, cols, D):
+    """ D of EXPRESSIONS (round 6): residual = D(E1, a) + D(D(E2, b), c) + E0 with random trees E1 over (u, u_x, u_t, x, t), E2 over (u, x, t) --
+    the chain rule of `D` over the streams (symbolic on the fused path, torch autograd over the tagged streams on the generic one), mixed
+    second and third partials of two columns included; the reference nests torch.autograd.grad (model_torch.py:174-178) """
+    e0, e1, e2 = trees
+    a, b, c = cols
+
+    def equation(u, x, t):
+        env = {'u': u, 'x': x, 't': t}
+        xs = {'x': x, 't': t}
+        if any(_uses(e, 'ux') for e in trees):
+            env['ux'] = D(u, x)
+        if any(_uses(e, 'ut') for e in trees):
+            env['ut'] = D(u, t)
+        first = D(_ev(e1, env) + u, xs[a])
+        second = D(D(_ev(e2, env) + 0.3 * u * u, xs[b]), xs[c])
+        return 0.5 * first + 0.1 * second + _ev(e0, env) + 0.05 * u + 0.37
+    return equation
+
+
+def _run_composite(pa, extra, n_trees, batch, test):
+    from oracle import pinn_oracle as po
+    rng = np.random.RandomState(23)
+    kw = dict(ndims=2, initial_condition=lambda x: torch.sin(np.pi * x), boundary_condition=0.0, layout='fafaf',
+              features=[16, 16, 1], activation='Tanh')
+    paths, done = {'fused': 0, 'generic': 0}, 0
+    for trial in range(n_trees):
+        trees = (_gen(rng, 2, ['u', 'ux', 'ut', 'x', 't', 'c']), _gen(rng, 2, ['u', 'ux', 'ut', 'x', 't', 'c']), _gen(rng, 2, ['u', 'x', 't', 'c']))
+        cols = tuple('xt'[rng.randint(2)] for _ in range(3))
+        torch.manual_seed(trial)
+        # (the reference's arithmetic in fp64 from the same fp32 start: two and three nested fp32 autograd sweeps of a random expression
+        #  are 1e-4 noisy -- as for the third-order trees above)
+        oracle = po.OracleSolver(_composite_equation(trees, cols, po.D), dtype=torch.float64, **kw)
+        start = [np.asarray(p, dtype=np.float32) for p in po.OracleSolver(_composite_equation(trees, cols, po.D), **kw).export_params()]
+        oracle.import_params(start)
+        pts = np.random.RandomState(trial).rand(2, batch, 2).astype(np.float32)
+        solver = pa.Solver(_composite_equation(trees, cols, pa.D), **kw, **extra)
+        load_params(solver, start)
+        oracle.fit(niters=2, batch_size=batch, points=pts, lr=0.01)
+        want = np.array([float(v) for v in oracle.losses])
+        if not np.all(np.isfinite(want)) or want.max() > 1e4:
+            continue
+        solver.fit(niters=2, batch_size=batch, sampler=FixedBatches(pts), lr=0.01)
+        np.testing.assert_allclose([float(v) for v in solver.losses], want, rtol=1e-4, err_msg=str((trees, cols, solver.last_fit_path)))
+        for got, ref in zip(export_params(solver), oracle.export_params()):
+            assert params_close(got, ref, 2e-4, atol=1e-5), (trees, cols, solver.last_fit_path)
+        paths[solver.last_fit_path] += 1
+        done += 1
+    assert done >= n_trees * 3 // 4 and paths['generic'] >= 3, (done, paths)
+
+
+def test_random_composite_D_on_the_emulated_kernels():
+    import ctypes
+    import os
+    import sys
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), 'emu'))
+    import build_emu
+    import pydens_amd as pa
+    from pydens_amd import engine
+    _run_composite(pa, dict(_lib=engine.bind(ctypes.CDLL(build_emu.build())), device='cpu'), n_trees=24, batch=23, test='emu')
+
+
+@pytest.mark.gpu
+def test_random_composite_D_on_the_gpu():
+    import pydens_amd as pa
+    _run_composite(pa, {}, n_trees=40 * SCALE, batch=523, test='gpu')
+
+
 def _random_net(rng, wmax=41):
     """ a random fully connected layout of the reference's Block vocabulary: 1-5 hidden layers of 5-40 units (padded to
     16 / 32 / 64 inside), Tanh / Sigmoid / Sin / Softplus / SiLU / GELU per layer (or one name), sometimes a hidden layer without activation,

@@ -276,6 +276,32 @@ def test_D_of_composite_expressions_is_differentiated_symbolically():
         trace.symbolic(lambda f, x, y: D(x * D(D(f, x), x), y), run, 2)
 
 
+def test_register_budget_of_a_program_counts_the_kernel_shape():
+    """ the library runs an (nd, n2) = (2, 1) step on the compiled (2, 2) kernels and re-bases the program's registers behind the streams
+    by one (pinn_abi.cpp pick_n2): a program the tracer accepts must still fit AFTER that shift -- round 6's random-equation soak found one
+    that did not and was refused inside the first fit call instead of at construction, where a refusal means the generic path """
+    assert [trace.kernel_stream_shift(*a) for a in [(1, 0), (1, 1), (2, 0), (2, 1), (2, 2), (3, 0), (3, 1), (3, 3), (4, 0), (2, 9), (1, 73)]] == \
+           [0, 0, 0, 1, 0, 2, 1, 0, 0, 0, 0]
+    accepted = refused = 0
+    for length in range(20, 40):
+        def eq(f, x, t, length=length):
+            acc = D(f, t) * f + D(D(f, x), x) * D(f, x)
+            for i in range(length):
+                acc = torch.sin(acc) if i % 2 else acc * f
+            return acc
+        spec, _ = trace.discover(eq, run, 2)
+        assert (spec.nd, spec.n2p) == (2, 1)
+        try:
+            plan = trace.lower_residual(trace.symbolic(eq, run, 2), spec, 2)
+        except trace.TraceUnsupported:
+            refused += 1
+            continue
+        code = plan.program[0]
+        assert max(c[1] for c in code) + trace.kernel_stream_shift(spec.nd, spec.n2p) < trace.MAX_REGS, length
+        accepted += 1
+    assert accepted >= 3 and refused >= 3
+
+
 def test_random_expression_trees_survive_the_lowering():
     """ fuzz: 600 random residual expressions over u, u_x, u_t, u_xx, the coordinates and constants (arithmetic, sin / cos /
     exp / tanh / sigmoid / abs, squares and cubes) -- affine ones with x-dependent coefficients and source terms included --
