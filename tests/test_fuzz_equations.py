@@ -433,3 +433,78 @@ def test_random_problem_shapes_on_the_emulated_kernels():
 def test_random_problem_shapes_on_the_gpu():
     import pydens_amd as pa
     _run_problems(pa, {}, n_problems=40 * SCALE, max_batch=3000)
+
+
+def _random_ic_problem(rng, D):
+    """ a random CALLABLE initial condition (round 6): a smooth expression tree of the spatial columns -- the tracer lowers it, with its
+    derivatives along every direction of the equation, to rows of the x-only pre-pass (fused path), the generic path differentiates it by
+    torch autograd -- under an evolution equation with first, second and (sometimes) mixed space-time derivatives; boundary binding or not """
+    nsp = int(rng.randint(1, 3))
+    smooth = [name for name in UNARY if name != 'abs']
+    tree = _gen(rng, 3, ['x', 'y', 'c'][:nsp] + ['x', 'c'], smooth)
+    if not any(_uses(tree, name) for name in ('x', 'y')):
+        tree = ('add', tree, ('sin', ('x',)))
+    mixed, burgers = bool(rng.rand() < 0.4), bool(rng.rand() < 0.5)
+    c = float(np.round(rng.uniform(0.05, 0.5), 2))
+
+    def ic(*cols):
+        return _ev(tree, dict(zip('xy', cols)))
+
+    def equation(u, *args):
+        xs, t = args[:nsp], args[nsp]
+        r = D(u, t) + 0.37
+        for i, x in enumerate(xs):
+            ux = D(u, x)
+            r = r - c * D(ux, x) + (u * ux if burgers and i == 0 else 0.3 * ux)
+            if mixed and i == 0:
+                r = r + 0.2 * D(ux, t)
+        return r
+    kw = dict(ndims=nsp + 1, initial_condition=ic, layout='fafaf', features=[16, 16, 1], activation='Tanh')
+    if rng.rand() < 0.6:
+        kw['boundary_condition'] = float(np.round(rng.uniform(-1, 1), 2))
+    return equation, kw, tree
+
+
+def _run_ics(pa, extra, n_problems, batch):
+    from oracle import pinn_oracle as po
+    paths = {'fused': 0, 'generic': 0}
+    for trial in range(n_problems):
+        eq_o, kw, tree = _random_ic_problem(np.random.RandomState(500 + trial), po.D)
+        eq_p, kw_p, _ = _random_ic_problem(np.random.RandomState(500 + trial), pa.D)
+        torch.manual_seed(trial)
+        oracle = po.OracleSolver(eq_o, **kw)
+        solver = pa.Solver(eq_p, **kw_p, **extra)
+        start = oracle.export_params()
+        load_params(solver, start)
+        pts = np.random.RandomState(trial).rand(2, batch, kw['ndims']).astype(np.float32)
+
+        def oracle64(trial=trial, start=start, pts=pts):
+            eq64, kw64, _ = _random_ic_problem(np.random.RandomState(500 + trial), po.D)
+            o = po.OracleSolver(eq64, dtype=torch.float64, **kw64)
+            o.import_params(start)
+            o.fit(niters=2, batch_size=batch, points=pts, lr=0.01)
+            return o
+        oracle.fit(niters=2, batch_size=batch, points=pts, lr=0.01)
+        want = [float(v) for v in oracle.losses]
+        if not np.all(np.isfinite(want)) or max(want) > 1e4:
+            continue
+        solver.fit(niters=2, batch_size=batch, sampler=FixedBatches(pts), lr=0.01)
+        _fit_close('random_initial_conditions', (trial, tree), solver, oracle, oracle64, adam_move=2 * 0.01)
+        paths[solver.last_fit_path] += 1
+    assert paths['fused'] >= n_problems // 2, paths
+
+
+def test_random_initial_conditions_on_the_emulated_kernels():
+    import ctypes
+    import sys
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), 'emu'))
+    import build_emu
+    import pydens_amd as pa
+    from pydens_amd import engine
+    _run_ics(pa, dict(_lib=engine.bind(ctypes.CDLL(build_emu.build())), device='cpu'), n_problems=16, batch=23)
+
+
+@pytest.mark.gpu
+def test_random_initial_conditions_on_the_gpu():
+    import pydens_amd as pa
+    _run_ics(pa, {}, n_problems=40 * SCALE, batch=523)
