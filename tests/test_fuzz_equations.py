@@ -508,3 +508,90 @@ def test_random_initial_conditions_on_the_emulated_kernels():
 def test_random_initial_conditions_on_the_gpu():
     import pydens_amd as pa
     _run_ics(pa, {}, n_problems=40 * SCALE, batch=523)
+
+
+def _random_forward_problem(rng, D, base):
+    """ a random model subclass with its own forward() (round 6; the reference's plug-in seam, model_torch.py:52-54): a random fixed map of
+    each point in FRONT of the network (none / per-column affine / an expression tree per column / columns mixed) and a random smooth
+    head around it (an expression tree of the network value and the columns, inside or instead of the ansatz) """
+    smooth = [name for name in UNARY if name != 'abs']
+    kind = ['none', 'affine', 'columns', 'mixing'][rng.randint(4)]
+    a, b = rng.uniform(0.5, 2.5, size=2).round(2), rng.uniform(-1, 1, size=2).round(2)
+    col_trees = [_gen(rng, 2, ['x', 'x', 'c'], smooth) for _ in range(2)]
+    mix = float(np.round(rng.uniform(0.2, 0.8), 2))
+    head = _gen(rng, 2, ['n', 'n', 'x', 't', 'c'], smooth)
+    if not _uses(head, 'n'):
+        head = ('add', head, ('n',))
+    with_ansatz = bool(rng.rand() < 0.6)
+
+    class Model(base):
+        def forward(self, xs):
+            if kind == 'none':
+                ys = xs
+            elif kind == 'affine':
+                ys = xs * torch.tensor([float(a[0]), float(a[1])], device=xs.device) + torch.tensor([float(b[0]), float(b[1])], device=xs.device)
+            elif kind == 'columns':
+                ys = torch.cat([_ev(col_trees[k], {'x': xs[:, k:k + 1]}) + 0.5 * xs[:, k:k + 1] for k in range(2)], dim=1)
+            else:
+                ys = xs + mix * xs.flip(1) * xs
+            n = self.conv_block(ys)
+            out = _ev(head, {'n': n, 'x': xs[:, :1], 't': xs[:, 1:2]})
+            return self.anzatc(out, xs) if with_ansatz else out
+    mixed = bool(rng.rand() < 0.4)
+    c = float(np.round(rng.uniform(0.05, 0.5), 2))
+
+    def equation(u, x, t):
+        ux = D(u, x)
+        r = D(u, t) - c * D(ux, x) + u * ux + 0.37
+        return r + 0.2 * D(ux, t) if mixed else r
+    kw = dict(ndims=2, initial_condition=lambda x: torch.sin(np.pi * x), boundary_condition=0.2, layout='fafaf', features=[16, 16, 1],
+              activation='Tanh', model=Model)
+    return equation, kw, (kind, head, col_trees if kind == 'columns' else None, with_ansatz, mixed)
+
+
+def _run_forwards(pa, extra, n_problems, batch):
+    from oracle import pinn_oracle as po
+    kinds = {}
+    for trial in range(n_problems):
+        eq_o, kw, what = _random_forward_problem(np.random.RandomState(900 + trial), po.D, po.OracleModel)
+        eq_p, kw_p, _ = _random_forward_problem(np.random.RandomState(900 + trial), pa.D, pa.ConvBlockModel)
+        torch.manual_seed(trial)
+        oracle = po.OracleSolver(eq_o, **kw)
+        solver = pa.Solver(eq_p, **kw_p, **extra)
+        start = oracle.export_params()
+        load_params(solver, start)
+        pts = np.random.RandomState(trial).rand(2, batch, 2).astype(np.float32)
+
+        def oracle64(trial=trial, start=start, pts=pts):
+            eq64, kw64, _ = _random_forward_problem(np.random.RandomState(900 + trial), po.D, po.OracleModel)
+            o = po.OracleSolver(eq64, dtype=torch.float64, **kw64)
+            o.import_params(start)
+            o.fit(niters=2, batch_size=batch, points=pts, lr=0.01)
+            return o
+        oracle.fit(niters=2, batch_size=batch, points=pts, lr=0.01)
+        want = [float(v) for v in oracle.losses]
+        if not np.all(np.isfinite(want)) or max(want) > 1e4:
+            continue
+        solver.fit(niters=2, batch_size=batch, sampler=FixedBatches(pts), lr=0.01)
+        assert solver.last_fit_path == 'generic'
+        _fit_close('random_forwards', (trial, what), solver, oracle, oracle64, adam_move=2 * 0.01)
+        xs = [pts[0][:, i] for i in range(2)]
+        assert np.abs(solver.predict(*xs) - oracle.predict(*xs)).max() < 2e-5, what
+        kinds[what[0]] = kinds.get(what[0], 0) + 1
+    assert len(kinds) == 4, kinds
+
+
+def test_random_forwards_on_the_emulated_kernels():
+    import ctypes
+    import sys
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), 'emu'))
+    import build_emu
+    import pydens_amd as pa
+    from pydens_amd import engine
+    _run_forwards(pa, dict(_lib=engine.bind(ctypes.CDLL(build_emu.build())), device='cpu'), n_problems=16, batch=23)
+
+
+@pytest.mark.gpu
+def test_random_forwards_on_the_gpu():
+    import pydens_amd as pa
+    _run_forwards(pa, {}, n_problems=40 * SCALE, batch=523)
