@@ -595,3 +595,94 @@ def test_random_forwards_on_the_emulated_kernels():
 def test_random_forwards_on_the_gpu():
     import pydens_amd as pa
     _run_forwards(pa, {}, n_problems=40 * SCALE, batch=523)
+
+
+def _random_variable_problem(rng, D, V):
+    """ random trainable variables and constraint terms (round 6; reference model_torch.py:180-188, :441-457): 1-3 scalar V(...) in random places
+    of a random residual tree (program registers on the fused path, torch autograd on the generic one), sometimes as the initial value,
+    0-2 constraint terms on fixed points (values of the solution, sometimes against a variable), several fit calls with different
+    loss_terms -- the reference creates a variable where it is first met and hands it to the optimizer of the NEXT fit call """
+    n_vars = int(rng.randint(1, 4))
+    names = ['va', 'vb', 'vc'][:n_vars]
+    init = {name: float(np.round(rng.uniform(0.3, 1.5), 2)) for name in names}
+    smooth = [name for name in UNARY if name != 'abs']
+    tree = _gen(rng, 3, ['u', 'ux', 'ut', 'uxx', 'x', 't', 'c'] + names + names, smooth)
+    if not any(_uses(tree, name) for name in names):
+        tree = ('add', tree, ('mul', (names[0],), ('u',)))
+    ic_var = bool(rng.rand() < 0.3)
+    n_con = int(rng.randint(0, 3))
+    con_pts = [(float(np.round(rng.uniform(0.1, 0.9), 2)), float(np.round(rng.uniform(0.1, 0.9), 2))) for _ in range(n_con)]
+    con_var = [bool(rng.rand() < 0.5) for _ in range(n_con)]
+    con_tgt = [float(np.round(rng.uniform(-0.5, 0.5), 2)) for _ in range(n_con)]
+
+    def var(name):
+        return V(name, data=torch.Tensor([init[name]]))
+
+    def equation(u, x, t):
+        env = {'u': u, 'x': x, 't': t}
+        env.update({name: var(name) for name in names if _uses(tree, name)})
+        env['ux'] = D(u, x)
+        if _uses(tree, 'uxx'):
+            env['uxx'] = D(env['ux'], x)
+        if _uses(tree, 'ut'):
+            env['ut'] = D(u, t)
+        return _ev(tree, env) + 0.05 * u + 0.1 * env['ux'] + 0.37
+
+    def constraint(k):
+        def con(f, x, t):
+            value = f(torch.tensor([con_pts[k][0]]), torch.tensor([con_pts[k][1]]))
+            return value - (var(names[k % n_vars]) * 0.5 if con_var[k] else con_tgt[k])
+        return con
+    kw = dict(ndims=2, boundary_condition=0.0, layout='fafaf', features=[16, 16, 1], activation='Tanh',
+              initial_condition=(lambda x: V('v_init', data=torch.Tensor([0.6]))) if ic_var else (lambda x: torch.sin(np.pi * x)),
+              constraints=[constraint(k) for k in range(n_con)] or None)
+    terms = [['equation'] + [f'constraint_{k}' for k in range(n_con)], 'equation'] + ([[f'constraint_{n_con - 1}']] if n_con else [])
+    return equation, kw, terms, names + (['v_init'] if ic_var else []), (tree, ic_var, n_con, con_var)
+
+
+def _run_variables(pa, extra, n_problems, batch):
+    from oracle import pinn_oracle as po
+    paths = {'fused': 0, 'generic': 0}
+    for trial in range(n_problems):
+        eq_o, kw, terms, names, what = _random_variable_problem(np.random.RandomState(1300 + trial), po.D, po.V)
+        eq_p, kw_p, _, _, _ = _random_variable_problem(np.random.RandomState(1300 + trial), pa.D, pa.V)
+        torch.manual_seed(trial)
+        oracle = po.OracleSolver(eq_o, **kw)
+        solver = pa.Solver(eq_p, **kw_p, **extra)
+        load_params(solver, oracle.export_params())
+        if trial % 2:
+            solver.use_fused = False            # every other problem on the generic path (the tracer lowers nearly all of them)
+        pts = np.random.RandomState(trial).rand(2 * len(terms), batch, 2).astype(np.float32)
+        bad = False
+        for k, lt in enumerate(terms):
+            oracle.fit(niters=2, batch_size=batch, points=pts[2 * k:2 * k + 2], lr=0.01, loss_terms=lt)
+            if not np.all(np.isfinite([float(v) for v in oracle.losses])) or max(float(v) for v in oracle.losses) > 1e4:
+                bad = True
+                break
+            solver.fit(niters=2, batch_size=batch, sampler=FixedBatches(pts[2 * k:2 * k + 2]), lr=0.01, loss_terms=lt)
+            paths[solver.last_fit_path] += 1
+        if bad:
+            continue
+        np.testing.assert_allclose([float(v) for v in solver.losses], [float(v) for v in oracle.losses], rtol=5e-5, err_msg=str((trial, what)))
+        for name in names:
+            if hasattr(oracle.model, name) or hasattr(solver.model, name):
+                assert abs(float(getattr(solver.model, name).detach()) - float(getattr(oracle.model, name).detach())) < 2e-5, (trial, name, what)
+        for got, want in zip(export_params(solver), oracle.export_params()):
+            assert params_close(got, want, 1e-4, atol=2e-5), (trial, what)
+    assert paths['fused'] >= 3 and paths['generic'] >= 3, paths
+
+
+def test_random_variables_and_constraints_on_the_emulated_kernels():
+    import ctypes
+    import sys
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), 'emu'))
+    import build_emu
+    import pydens_amd as pa
+    from pydens_amd import engine
+    _run_variables(pa, dict(_lib=engine.bind(ctypes.CDLL(build_emu.build())), device='cpu'), n_problems=16, batch=23)
+
+
+@pytest.mark.gpu
+def test_random_variables_and_constraints_on_the_gpu():
+    import pydens_amd as pa
+    _run_variables(pa, {}, n_problems=40 * SCALE, batch=523)
