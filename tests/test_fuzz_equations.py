@@ -686,3 +686,76 @@ def test_random_variables_and_constraints_on_the_emulated_kernels():
 def test_random_variables_and_constraints_on_the_gpu():
     import pydens_amd as pa
     _run_variables(pa, {}, n_problems=40 * SCALE, batch=523)
+
+
+HIGH = {2: [('x', 'x', 'x'), ('x', 'x', 'y'), ('x', 'y', 'y'), ('y', 'y', 'y'), ('x', 'x', 'x', 'x'), ('x', 'x', 'y', 'y'), ('x', 'x', 'x', 'y'), ('x', 'y', 'y', 'y')],
+        3: [('x', 'y', 'z'), ('x', 'x', 'z'), ('y', 'z', 'z'), ('x', 'x', 'x')]}
+
+
+def _random_high_order_problem(rng, D):
+    """ random equations over third- and fourth-order partials (round 6: u_xxxy / u_xyyy / u_xyz joined u_xxx, u_xxy, u_xxxx, u_xxyy): 1-3 of
+    them as leaves of a smooth expression tree beside u and the coordinates, D nested in a random order of the columns, on a random
+    activation, with or without the boundary binding; direction groups and polarisation identities of the generic path """
+    nd = int(rng.choice([2, 2, 3]))
+    picks = [HIGH[nd][i] for i in rng.choice(len(HIGH[nd]), size=int(rng.randint(1, 4)), replace=False)]
+    names = ['d%d' % i for i in range(len(picks))]
+    smooth = [name for name in UNARY if name not in ('abs', 'exps', 'cube')]
+    tree = _gen(rng, 2, ['u', 'x', 'y', 'c'] + names + names, smooth)
+    orders = [list(rng.permutation(len(p))) for p in picks]
+
+    def equation(u, *cols):
+        col = dict(zip('xyz', cols))
+        env = {'u': u, 'x': cols[0], 'y': cols[1]}
+        total = 0.0
+        for name, alpha, order in zip(names, picks, orders):
+            v = u
+            for i in order:
+                v = D(v, col[alpha[i]])
+            env[name] = v
+            total = total + 0.01 * v
+        return _ev(tree, env) + total + 0.1 * u + 0.37
+    kw = dict(ndims=nd, layout='fafaf', features=[12, 12, 1], activation=['Tanh', 'Sin', 'Sigmoid', 'SiLU'][rng.randint(4)])
+    if rng.rand() < 0.5:
+        kw['boundary_condition'] = float(np.round(rng.uniform(-1, 1), 2))
+    return equation, kw, (picks, tree)
+
+
+def _run_high_order(pa, extra, n_problems, batch):
+    from oracle import pinn_oracle as po
+    seen = set()
+    for trial in range(n_problems):
+        eq_o, kw, what = _random_high_order_problem(np.random.RandomState(1700 + trial), po.D)
+        eq_p = _random_high_order_problem(np.random.RandomState(1700 + trial), pa.D)[0]
+        torch.manual_seed(trial)
+        start = [np.asarray(p, dtype=np.float32) for p in po.OracleSolver(eq_o, **kw).export_params()]
+        oracle = po.OracleSolver(eq_o, dtype=torch.float64, **kw)             # (four nested fp32 sweeps of the reference are noise: fp64 from the same start)
+        oracle.import_params(start)
+        solver = pa.Solver(eq_p, **kw, **extra)
+        load_params(solver, start)
+        pts = np.random.RandomState(trial).rand(2, batch, kw['ndims']).astype(np.float32)
+        oracle.fit(niters=2, batch_size=batch, points=pts, lr=0.01)
+        want = np.array([float(v) for v in oracle.losses])
+        if not np.all(np.isfinite(want)) or want.max() > 1e4:
+            continue
+        solver.fit(niters=2, batch_size=batch, sampler=FixedBatches(pts), lr=0.01)
+        np.testing.assert_allclose([float(v) for v in solver.losses], want, rtol=2e-4, err_msg=str((trial, what, solver.last_fit_path)))
+        for got, ref in zip(export_params(solver), oracle.export_params()):
+            assert params_close(got, ref, 5e-4, atol=2e-5), (trial, what, solver.last_fit_path)
+        seen.update(what[0])
+    assert len(seen) >= 8, seen
+
+
+def test_random_high_order_equations_on_the_emulated_kernels():
+    import ctypes
+    import sys
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), 'emu'))
+    import build_emu
+    import pydens_amd as pa
+    from pydens_amd import engine
+    _run_high_order(pa, dict(_lib=engine.bind(ctypes.CDLL(build_emu.build())), device='cpu'), n_problems=16, batch=17)
+
+
+@pytest.mark.gpu
+def test_random_high_order_equations_on_the_gpu():
+    import pydens_amd as pa
+    _run_high_order(pa, {}, n_problems=30 * SCALE, batch=311)
