@@ -262,6 +262,24 @@ def test_random_composite_D_on_the_gpu():
     _run_composite(pa, {}, n_trees=40 * SCALE, batch=523, test='gpu')
 
 
+def _all_activations(rng, depth):
+    """ one activation per hidden layer out of the whole vocabulary of the kernels (round 6): names, module instances configured away from torch's
+    defaults (LeakyReLU slope, ELU alpha, Softplus beta, GELU tanh form), the smooth ones more often than the kinked ones """
+    from torch import nn
+    smooth = ['Tanh', 'Sigmoid', 'Sin', 'Softplus', 'SiLU', 'GELU', 'Softsign', 'Mish', 'Tanhshrink', 'LogSigmoid', 'SELU', 'ELU']
+    made = []
+    for _ in range(depth):
+        r = rng.rand()
+        if r < 0.55:
+            made.append(smooth[rng.randint(len(smooth))])
+        elif r < 0.85:
+            made.append([lambda: nn.Softplus(beta=float(np.round(rng.uniform(0.5, 3.0), 2))), lambda: nn.ELU(alpha=float(np.round(rng.uniform(0.3, 2.0), 2))),
+                         lambda: nn.GELU(approximate='tanh'), lambda: nn.LeakyReLU(float(np.round(rng.uniform(0.05, 0.4), 2)))][rng.randint(4)]())
+        else:
+            made.append(['ReLU', 'LeakyReLU'][rng.randint(2)])
+    return made
+
+
 def _random_net(rng, wmax=41):
     """ a random fully connected layout of the reference's Block vocabulary: 1-5 hidden layers of 5-40 units (padded to
     16 / 32 / 64 inside), Tanh / Sigmoid / Sin / Softplus / SiLU / GELU per layer (or one name), sometimes a hidden layer without activation,
@@ -290,10 +308,11 @@ def _random_net(rng, wmax=41):
     return dict(layout=' '.join(letters) + ' f', features=widths + [1], activation=activation if isinstance(activation, str) else acts)
 
 
-def _run_layouts(pa, extra, n_nets, batch, wide=False):
-    """ wide: widths up to 200 (the 128- and 256-wide kernels with the streamed weight gradient; the device only) """
+def _run_layouts(pa, extra, n_nets, batch, wide=False, all_acts=False):
+    """ wide: widths up to 200 (the 128- and 256-wide kernels with the streamed weight gradient; the device only); all_acts: the activations
+    drawn from the whole vocabulary incl. configured instances (_all_activations) """
     from oracle import pinn_oracle as po
-    rng = np.random.RandomState(4)
+    rng = np.random.RandomState(44 if all_acts else 4)
 
     def problems(D):
         return [
@@ -305,6 +324,8 @@ def _run_layouts(pa, extra, n_nets, batch, wide=False):
     seen = set()
     for trial in range(n_nets):
         net = _random_net(rng, 201 if wide and trial % 4 == 3 else 41)
+        if all_acts:
+            net['activation'] = _all_activations(rng, net['layout'].count('a'))
         which = trial % 3
         eq_o, kw = problems(po.D)[which]
         eq_p, _ = problems(pa.D)[which]
@@ -323,11 +344,11 @@ def _run_layouts(pa, extra, n_nets, batch, wide=False):
         oracle.fit(niters=2, batch_size=batch, points=pts, lr=0.01)
         solver.fit(niters=2, batch_size=batch, sampler=FixedBatches(pts), lr=0.01)
         assert solver.last_fit_path == 'fused', (net, solver.program_error)
-        _fit_close('random_layouts' + ('_wide' if wide else ''), net, solver, oracle, oracle64, adam_move=2 * 0.01)
+        _fit_close('random_layouts' + ('_wide' if wide else '') + ('_all_acts' if all_acts else ''), str(net), solver, oracle, oracle64, adam_move=2 * 0.01)
         grid = [np.linspace(0.1, 0.9, 5).astype(np.float32)] * 2
         assert np.abs(solver.predict(*grid) - oracle.predict(*grid)).max() < 2e-5, net
         seen.add(('R' in net['layout'], isinstance(net['activation'], list)))
-    assert len(seen) >= 3                                          # with / without skips, one name / per-layer lists
+    assert len(seen) >= (2 if all_acts else 3)                     # with / without skips, one name / per-layer lists
 
 
 def test_random_layouts_on_the_emulated_kernels():
@@ -339,6 +360,22 @@ def test_random_layouts_on_the_emulated_kernels():
     import pydens_amd as pa
     from pydens_amd import engine
     _run_layouts(pa, dict(_lib=engine.bind(ctypes.CDLL(build_emu.build())), device='cpu'), n_nets=20, batch=21)
+
+
+def test_random_layouts_with_every_activation_on_the_emulated_kernels():
+    import ctypes
+    import sys
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), 'emu'))
+    import build_emu
+    import pydens_amd as pa
+    from pydens_amd import engine
+    _run_layouts(pa, dict(_lib=engine.bind(ctypes.CDLL(build_emu.build())), device='cpu'), n_nets=12, batch=23, all_acts=True)
+
+
+@pytest.mark.gpu
+def test_random_layouts_with_every_activation_on_the_gpu():
+    import pydens_amd as pa
+    _run_layouts(pa, {}, n_nets=30 * SCALE, batch=523, wide=True, all_acts=True)
 
 
 @pytest.mark.gpu
