@@ -52,15 +52,43 @@ class FlatAdam:
         self.exp_avg, self.exp_avg_sq, self.step_count = state
         self.t = 0                  # host copy of the step counter (the fused single-rank step passes it by value)
         self.mask = None
+        self.members = None         # what this optimizer was built over (reference :420: the parameters that required grad THEN)
+        # torch's Adam counts steps PER PARAMETER, and one the loss does not reach is not stepped; the kernel has one count for the whole
+        # buffer. Per fit call and trainable scalar (log_scale, V(...) slots): was it reached? -> the step count it has in the reference
+        self.calls = []             # (step count at its start, set of unreached offsets) per fit call this optimizer served
 
-    def refresh(self):
+    def refresh(self, unreached=()):
+        """ unreached: offsets of scalars (log_scale, V(...) slots) the loss terms of the coming fit call do not reach: the reference's backward
+        leaves them without a gradient and Adam SKIPS them -- moments, step count and value stay. With fresh moments a zero gradient does the
+        same; a reused optimizer (`optimizer=None`) would walk on along the old momentum (Solver._unreached_scalars). """
         new = self.model.trainable_mask()
+        if self.members is None:
+            self.members = new.clone()
+        else:
+            new = new & self.members        # (`fit(optimizer=None)` after unfreeze_trainable: the reused optimizer never heard of that parameter)
+        for off in unreached:
+            new[off] = 0
         buf = getattr(self.model, '_adam_mask', None)         # (same address from fit to fit, like the moment buffers)
         if buf is None or buf.shape != new.shape or buf.device != new.device:
             self.model._adam_mask = buf = new
         else:
             buf.copy_(new)
         self.mask = buf
+        self.calls.append((self.t, set(unreached)))
+
+    def _served(self):
+        """ (iterations, unreached offsets) of every fit call so far; the running one last """
+        ends = [t0 for t0, _ in self.calls[1:]] + [self.t]
+        return [(end - t0, skipped) for (t0, skipped), end in zip(self.calls, ends)]
+
+    def lagging(self, offsets):
+        """ scalars that the coming call reaches but some earlier call of this optimizer did not: their step count in the reference is behind
+        the buffer's (other bias corrections) -- what one count for the whole buffer cannot express (Solver._fit hands over to torch's Adam) """
+        past = self._served()[:-1]
+        return [off for off in offsets if off not in self.calls[-1][1] and any(off in skipped and n > 0 for n, skipped in past)]
+
+    def steps_of(self, off):
+        return sum(n for n, skipped in self._served() if off not in skipped)
 
     def step(self, grads, loss_out=None, stream=None):
         """ loss_out: device address that receives grads[off_loss] in the same launch (the fit's loss history) """
@@ -77,12 +105,39 @@ class TorchOptimizerAdapter:
         self.params = model.optimizer_parameters()
         self.opt = getattr(torch.optim, name)(self.params, lr=lr, **kwargs)
 
+    @classmethod
+    def continuing(cls, adam):
+        """ torch.optim.Adam carrying on where a FlatAdam stands: same members, moments and -- per parameter -- step counts (FlatAdam.lagging) """
+        model = adam.model
+        self = cls.__new__(cls)
+        self.model = model
+        members = adam.members
+        self.params = [p for p in model.parameters() if bool(members.as_strided(tuple(p.shape), tuple(p.stride()), p.storage_offset()).any())]
+        self.opt = torch.optim.Adam(self.params, lr=adam.lr, betas=adam.betas, eps=adam.eps)
+        for p in self.params:
+            steps = adam.steps_of(p.storage_offset()) if p.numel() == 1 else adam.t
+            if steps > 0:
+                view = lambda buf: buf.as_strided(tuple(p.shape), tuple(p.stride()), p.storage_offset()).clone()
+                self.opt.state[p] = {'step': torch.tensor(float(steps)), 'exp_avg': view(adam.exp_avg), 'exp_avg_sq': view(adam.exp_avg_sq)}
+        return self
+
     def refresh(self):
         pass
 
     def step(self, grads, loss_out=None, stream=None):
+        # Parameters WITHOUT a gradient are skipped by torch's optimizers -- no weight decay, no momentum step, no step count -- and the
+        # reference's backward leaves `.grad = None` on (a) a parameter frozen since this optimizer was built (`fit(optimizer=None)` after
+        # freeze_trainable) and (b) a scalar the loss of this call does not reach: `log_scale` without an initial condition, a V(...) of the
+        # equation in a constraint-only call (round 6's fit-sequence fuzz: AdamW decayed such a variable). The kernels deliver a flat buffer
+        # with an exact 0.0 there; a one-entry parameter whose gradient is exactly zero is taken for unreached (one small read-back per step).
+        scalars = [p for p in self.params if p.numel() == 1 and p.requires_grad]
+        zero = set()
+        if scalars:
+            values = torch.stack([grads[p.storage_offset()] for p in scalars]).tolist()
+            zero = {id(p) for p, v in zip(scalars, values) if v == 0.0}
         for p in self.params:
-            p.grad = grads.as_strided(tuple(p.shape), tuple(p.stride()), p.storage_offset())
+            reached = p.requires_grad and id(p) not in zero
+            p.grad = grads.as_strided(tuple(p.shape), tuple(p.stride()), p.storage_offset()) if reached else None
         self.opt.step()
         for p in self.params:
             p.grad = None
@@ -737,6 +792,24 @@ class Solver:
         self._all_reduce(stream)
         self.optimizer.step(self.grads, loss_out=loss_out, stream=stream)
 
+    def _unreached_scalars(self, offsets, loss_terms, nums_constraints, criterion):
+        """ offsets of the trainable scalars (log_scale, V(...) slots) that the loss of these terms does not depend on -- the equation's
+        variable in a constraint-only call, log_scale without an initial condition: one dry evaluation of the terms on a few random points
+        through the generic step (torch autograd tells), read back once per fit call of a model with variables (FlatAdam.refresh). """
+        model = self.model
+        if not any(term == 'equation' or 'constraint' in term for term in loss_terms):
+            return []
+        keep = self.grads.clone()
+        try:
+            gen = torch.Generator(device=self.device)           # (its own stream: the solver's sampling seeds come from torch's global one)
+            gen.manual_seed(5)
+            self._generic_step(torch.rand((5, model.total), device=self.device, generator=gen), loss_terms,
+                               [num for num in nums_constraints if num < len(self.constraints)], criterion, 1)
+            values = self.grads[torch.tensor(offsets, device=self.device)].tolist()
+        finally:
+            self.grads.copy_(keep)
+        return [off for off, v in zip(offsets, values) if v == 0.0]
+
     def fit(self, niters, batch_size, sampler=None, loss_terms='equation', optimizer='Adam',
             criterion=nn.MSELoss(), lr=0.005, **kwargs):
         """ reference model_torch.py:364-464. Under torch.distributed `batch_size` stays the GLOBAL number of points per
@@ -755,13 +828,22 @@ class Solver:
                               else TorchOptimizerAdapter(model, optimizer, lr, **kwargs))
         elif self.optimizer is None:
             raise ValueError('optimizer=None reuses the optimizer of a previous fit call; there is none yet')
-        self.optimizer.refresh()
         self._generic_graph = None          # launch graphs of the generic step are recorded per fit call (closure constants may have changed)
         model.train()
         loss_terms = loss_terms if isinstance(loss_terms, (tuple, list)) else (loss_terms, )
         nums_constraints = [int(term.replace('constraint', '').replace('_', ''))
                             for term in loss_terms if 'constraint' in term]
         self._refresh_traces(set(nums_constraints))
+        if isinstance(self.optimizer, FlatAdam) and model.variables:
+            # (trainable V(...) scalars: which of them the terms of THIS call reach decides what torch's Adam does with them; one dry
+            #  evaluation per fit call. Without variables nothing changes from call to call: log_scale is reached iff there is an IC)
+            lay = model.net.layout
+            scalars = [lay.off_log_scale] + [off + i for off, n in model.variables.values() for i in range(n)]
+            self.optimizer.refresh(self._unreached_scalars(scalars, loss_terms, nums_constraints, criterion))
+            if optimizer is None and self.optimizer.lagging(scalars):
+                self.optimizer = TorchOptimizerAdapter.continuing(self.optimizer)
+        else:
+            self.optimizer.refresh()
         self._constraints_seen |= {num for num in nums_constraints if num < len(self.constraints)}
         mse_mean = isinstance(criterion, nn.MSELoss) and criterion.reduction == 'mean'
         lowered = all(num < len(self.constraint_plans) and self.constraint_plans[num] is not None

@@ -798,3 +798,71 @@ def test_random_high_order_equations_on_the_emulated_kernels():
 def test_random_high_order_equations_on_the_gpu():
     import pydens_amd as pa
     _run_high_order(pa, {}, n_problems=30 * SCALE, batch=311)
+
+
+def _run_fit_sequences(pa, extra, n_sequences, batch):
+    """ random SEQUENCES of fit calls on one solver (round 6; reference model_torch.py:364-464): optimizer by name with keyword arguments
+    (plain Adam on the HIP kernel, everything else through the adapter), `optimizer=None` (the optimizer of the call before keeps its
+    moments), lr, criterion (MSE on the fused path, anything else generic), loss_terms, a variable frozen / unfrozen in between (the
+    reference hands the optimizer the parameters that require grad when the call starts, :420) """
+    from torch import nn
+    from oracle import pinn_oracle as po
+
+    def problem(D, V):
+        def eq(u, x, t):
+            return D(u, t) - V('nu', data=torch.Tensor([0.3])) * D(D(u, x), x) + u * D(u, x)
+
+        def con(f, x, t):
+            return f(torch.tensor([0.4]), torch.tensor([0.6])) - 0.2
+        return eq, con
+    kw = dict(ndims=2, initial_condition=lambda x: torch.sin(np.pi * x), boundary_condition=0.0, layout='fafaf', features=[16, 16, 1],
+              activation='Tanh')
+    optimizers = [('Adam', {}), ('Adam', {}), ('Adam', dict(weight_decay=0.01)), ('Adam', dict(amsgrad=True)), ('Adam', dict(betas=(0.8, 0.95))),
+                  ('SGD', dict(momentum=0.9)), ('RMSprop', {}), ('AdamW', {}), ('Adagrad', {}), (None, {}), (None, {})]
+    seen = set()
+    for trial in range(n_sequences):
+        rng = np.random.RandomState(2100 + trial)
+        eq_o, con_o = problem(po.D, po.V)
+        eq_p, con_p = problem(pa.D, pa.V)
+        torch.manual_seed(trial)
+        oracle = po.OracleSolver(eq_o, constraints=con_o, **kw)
+        solver = pa.Solver(eq_p, constraints=con_p, **kw, **extra)
+        load_params(solver, oracle.export_params())
+        n_calls = int(rng.randint(3, 6))
+        pts = np.random.RandomState(trial).rand(2 * n_calls, batch, 2).astype(np.float32)
+        frozen, log = False, []
+        for k in range(n_calls):
+            name, okw = optimizers[rng.randint(len(optimizers))] if k > 0 else optimizers[rng.randint(len(optimizers) - 2)]
+            crit = [nn.MSELoss, nn.MSELoss, nn.L1Loss, nn.SmoothL1Loss][rng.randint(4)]
+            terms = [['equation', 'constraint_0'], 'equation', ['equation', 'constraint_0'], ['constraint_0']][rng.randint(4)]
+            lr = float([0.01, 0.003, 0.02][rng.randint(3)])
+            if rng.rand() < 0.3:
+                frozen = not frozen
+                oracle.model.nu.requires_grad = not frozen
+                (solver.model.freeze_trainable if frozen else solver.model.unfreeze_trainable)(variables=['nu'])
+            call = dict(loss_terms=terms, optimizer=name, criterion=crit(), lr=lr, **okw)
+            log.append((name, okw, crit.__name__, terms, lr, frozen))
+            oracle.fit(niters=2, batch_size=batch, points=pts[2 * k:2 * k + 2], **{**call, 'criterion': crit()})
+            solver.fit(niters=2, batch_size=batch, sampler=FixedBatches(pts[2 * k:2 * k + 2]), **call)
+            seen.add((name, tuple(okw), crit.__name__, solver.last_fit_path))
+        np.testing.assert_allclose([float(v) for v in solver.losses], [float(v) for v in oracle.losses], rtol=1e-4, err_msg=str((trial, log)))
+        assert abs(float(solver.model.nu.detach()) - float(oracle.model.nu.detach())) < 5e-5, (trial, log)
+        for got, want in zip(export_params(solver), oracle.export_params()):
+            assert params_close(got, want, 2e-4, atol=4e-5), (trial, log)
+    assert len({s[0] for s in seen}) >= 5 and {'fused', 'generic'} <= {s[3] for s in seen}, seen
+
+
+def test_random_fit_call_sequences_on_the_emulated_kernels():
+    import ctypes
+    import sys
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), 'emu'))
+    import build_emu
+    import pydens_amd as pa
+    from pydens_amd import engine
+    _run_fit_sequences(pa, dict(_lib=engine.bind(ctypes.CDLL(build_emu.build())), device='cpu'), n_sequences=12, batch=23)
+
+
+@pytest.mark.gpu
+def test_random_fit_call_sequences_on_the_gpu():
+    import pydens_amd as pa
+    _run_fit_sequences(pa, {}, n_sequences=20 * SCALE, batch=523)
