@@ -24,6 +24,7 @@ import argparse
 import json
 import os
 import sys
+import contextlib
 import time
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
@@ -105,6 +106,22 @@ def cpu_baseline(workload, n_points, budget_s=15.0):
 def nn_mse():
     import torch.nn as nn
     return nn.MSELoss()
+
+
+@contextlib.contextmanager
+def quiet_collector():
+    """ timed regions run with Python's cyclic garbage collector paused, as `timeit` does: a full collection in a process that has torch
+    loaded stops the launching thread for ~40 ms (measured on `Solver.fit` of BASELINE config 4, round 6: tools/fit_one.py), which the GPU
+    then spends idle -- a property of the host interpreter at the moment of the measurement, not of the step """
+    import gc
+    gc.collect()
+    was = gc.isenabled()
+    gc.disable()
+    try:
+        yield
+    finally:
+        if was:
+            gc.enable()
 
 
 def parity_check(workload, solver, generic, mse, n_points=4096, seed=99, cache=None):
@@ -249,10 +266,11 @@ def baseline_configs(device, no_parity=False, steps=20, warmup=5):
     solver.fit(niters=512, batch_size=100)
     torch.cuda.synchronize()
     iters = 4096
-    t0 = time.perf_counter()
-    solver.fit(niters=iters, batch_size=100)
-    torch.cuda.synchronize()
-    dt = time.perf_counter() - t0
+    with quiet_collector():
+        t0 = time.perf_counter()
+        solver.fit(niters=iters, batch_size=100)
+        torch.cuda.synchronize()
+        dt = time.perf_counter() - t0
     out['cfg1'] = {'points_per_gpu': 100, 'fit_iterations': iters, 'fit_it_per_s': iters / dt, 'us_per_iteration': dt / iters * 1e6,
                    'value': 100 * iters / dt, 'kernel': solver.model.net.lib.pinn_last_kernel_name().decode(),
                    'parity_ok': None if parity is None else parity['ok'],
@@ -459,17 +477,18 @@ def main():
         if world > 1:
             dist.barrier()
         sync()
-        t0 = time.perf_counter()
-        if not on_cpu:
-            ev0.record()
-        for i in range(n_steps):
-            step(i, pts)
-        if not on_cpu:
-            ev1.record()
-        if world > 1:
-            dist.barrier()
-        sync()
-        host = time.perf_counter() - t0
+        with quiet_collector():
+            t0 = time.perf_counter()
+            if not on_cpu:
+                ev0.record()
+            for i in range(n_steps):
+                step(i, pts)
+            if not on_cpu:
+                ev1.record()
+            if world > 1:
+                dist.barrier()
+            sync()
+            host = time.perf_counter() - t0
         t = torch.tensor([host if on_cpu else ev0.elapsed_time(ev1) * 1e-3, host], dtype=torch.float64, device=device)
         if world > 1:
             # every rank's own figure too (rank 0 prints min / max: the first multi-GPU run should say WHERE a shortfall sits)

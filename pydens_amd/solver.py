@@ -63,7 +63,13 @@ class FlatAdam:
         same; a reused optimizer (`optimizer=None`) would walk on along the old momentum (Solver._unreached_scalars). """
         new = self.model.trainable_mask()
         if self.members is None:
-            self.members = new.clone()
+            # (a buffer of the MODEL, like the mask and the moments: a fresh allocation per fit call shifted what the allocator hands the rest
+            #  of the call and cost BASELINE config 4's fit 40 ms per call -- tools/fit_one.py, measured)
+            kept = getattr(self.model, '_adam_members', None)
+            if kept is None or kept.shape != new.shape or kept.device != new.device:
+                self.model._adam_members = kept = torch.empty_like(new)
+            kept.copy_(new)
+            self.members = kept
         else:
             new = new & self.members        # (`fit(optimizer=None)` after unfreeze_trainable: the reused optimizer never heard of that parameter)
         for off in unreached:

@@ -15,10 +15,16 @@ solver = pa.Solver(cfg['equation'], **cfg['solver_kwargs'])
 sampler = pa.NumpySampler('uniform') & pa.NumpySampler('uniform', low=1, high=5) if name == 'cfg4' else None
 solver.fit(niters=20, batch_size=n, sampler=sampler)
 torch.cuda.synchronize()
+# (as `timeit` does: a full collection of Python's cyclic garbage collector stops the launching thread for ~40 ms in a process with torch loaded;
+#  whether one falls into the 64 ms this call of BASELINE config 4 takes depended on the allocation count of the host code -- round 6)
+import gc
+gc.collect()
+gc.disable()
 t0 = time.perf_counter()
 solver.fit(niters=iters, batch_size=n, sampler=sampler)
 torch.cuda.synchronize()
 dt = time.perf_counter() - t0
+gc.enable()
 losses = solver.losses
 print(f'{name}: Solver.fit {iters / dt:9.1f} it/s  {n * iters / dt:12.4g} points/s  ({dt / iters * 1e3:.3f} ms/it, batch {n}, path {solver.last_fit_path}, '
       f'loss {float(losses[20]):.4g} -> {float(losses[-1]):.4g})')

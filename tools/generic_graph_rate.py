@@ -30,6 +30,7 @@ else:
 iters = 2000 if batch <= 1000 else 600
 solver.fit(niters=30, batch_size=batch, lr=0.005)
 torch.cuda.synchronize()
+import gc; gc.collect(); gc.disable()          # (as timeit does: tools/fit_one.py)
 t0 = time.perf_counter()
 solver.fit(niters=iters, batch_size=batch, lr=0.005, optimizer=None)
 torch.cuda.synchronize()

@@ -43,10 +43,12 @@ if len(sys.argv) > 2:
         sampler = pa.NumpySampler('u', dim=2) & pa.NumpySampler('u', low=0, high=.5) & pa.NumpySampler('u', low=.1, high=4)
     solver.fit(niters=300, batch_size=batch, sampler=sampler)
     torch.cuda.synchronize()
+    import gc; gc.collect(); gc.disable()          # (as timeit does: tools/fit_one.py)
     t0 = time.perf_counter()
     solver.fit(niters=iters, batch_size=batch, sampler=sampler)
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
+    gc.enable()
     print(f'{name:14s} batch {batch:5d} width {solver.model.net.layout.hp:3d}  {iters / dt:10.0f} it/s  ({dt / iters * 1e6:7.2f} us/it)  '
           f'{solver.model.net.lib.pinn_last_kernel_name().decode()}  loss {float(solver.losses[300]):.4g} -> {float(solver.losses[-1]):.4g}')
     sys.exit(0)
