@@ -108,13 +108,26 @@ def nn_mse():
     return nn.MSELoss()
 
 
+_FROZEN = []
+
+
+def freeze_once():
+    """ once per process (main calls it first): what is alive now (torch, the modules) goes to the collector's permanent generation -- later
+    collections stay short, and no timed region is preceded by 40 ms of idle GPU (which would cost the clocks the settle load has brought up) """
+    import gc
+    if not _FROZEN:
+        gc.collect()
+        gc.freeze()
+        _FROZEN.append(True)
+
+
 @contextlib.contextmanager
 def quiet_collector():
     """ timed regions run with Python's cyclic garbage collector paused, as `timeit` does: a full collection in a process that has torch
     loaded stops the launching thread for ~40 ms (measured on `Solver.fit` of BASELINE config 4, round 6: tools/fit_one.py), which the GPU
     then spends idle -- a property of the host interpreter at the moment of the measurement, not of the step """
     import gc
-    gc.collect()
+    freeze_once()
     was = gc.isenabled()
     gc.disable()
     try:
@@ -263,10 +276,10 @@ def baseline_configs(device, no_parity=False, steps=20, warmup=5):
     cfg = pc.make_config('cfg1', pa.D, torch, V=pa.V)
     solver = pa.Solver(cfg['equation'], **cfg['solver_kwargs'], device=device)
     parity = None if no_parity else parity_check('cfg1', solver, False, None, n_points=100)
-    solver.fit(niters=512, batch_size=100)
-    torch.cuda.synchronize()
     iters = 4096
     with quiet_collector():
+        solver.fit(niters=512, batch_size=100)
+        torch.cuda.synchronize()
         t0 = time.perf_counter()
         solver.fit(niters=iters, batch_size=100)
         torch.cuda.synchronize()
@@ -365,6 +378,7 @@ def main():
     ap.add_argument('--unfused', action='store_true',
                     help='diagnostic: run the N > 1 step path (step, all-reduce, Adam as separate launches) at N = 1')
     args = ap.parse_args()
+    freeze_once()
 
     import pydens_amd as pa
     if args.lib:
@@ -470,14 +484,14 @@ def main():
     def timed(pts, n_warm, n_steps):
         """ n_warm untimed steps, then EXACTLY n_steps between two HIP events on the launch stream, barrier + device
         synchronise on both sides; -> (seconds by the events, seconds by the host clock), MAX over the ranks """
-        for i in range(n_warm):
-            step(i, pts)
-        if not on_cpu:
-            ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        if world > 1:
-            dist.barrier()
-        sync()
         with quiet_collector():
+            for i in range(n_warm):
+                step(i, pts)
+            if not on_cpu:
+                ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            if world > 1:
+                dist.barrier()
+            sync()
             t0 = time.perf_counter()
             if not on_cpu:
                 ev0.record()

@@ -13,13 +13,14 @@ torch.manual_seed(0)
 cfg = pc.make_config(name, pa.D, torch)
 solver = pa.Solver(cfg['equation'], **cfg['solver_kwargs'])
 sampler = pa.NumpySampler('uniform') & pa.NumpySampler('uniform', low=1, high=5) if name == 'cfg4' else None
+import gc
+gc.collect()            # (in front of the warm-up: the collection itself leaves the GPU idle for 40 ms, which costs the clocks)
+gc.freeze()
+gc.disable()
 solver.fit(niters=20, batch_size=n, sampler=sampler)
 torch.cuda.synchronize()
 # (as `timeit` does: a full collection of Python's cyclic garbage collector stops the launching thread for ~40 ms in a process with torch loaded;
 #  whether one falls into the 64 ms this call of BASELINE config 4 takes depended on the allocation count of the host code -- round 6)
-import gc
-gc.collect()
-gc.disable()
 t0 = time.perf_counter()
 solver.fit(niters=iters, batch_size=n, sampler=sampler)
 torch.cuda.synchronize()

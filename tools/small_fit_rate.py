@@ -41,9 +41,9 @@ if len(sys.argv) > 2:
                                   initial_condition=lambda x, y: 10 * x * y * (1 - x) * (1 - y), boundary_condition=0, layout='fafaf',
                                   features=[30, 24, 1], activation='Sigmoid'), 1500
         sampler = pa.NumpySampler('u', dim=2) & pa.NumpySampler('u', low=0, high=.5) & pa.NumpySampler('u', low=.1, high=4)
+    import gc; gc.collect(); gc.disable()          # (as timeit does, in front of the warm-up: tools/fit_one.py)
     solver.fit(niters=300, batch_size=batch, sampler=sampler)
     torch.cuda.synchronize()
-    import gc; gc.collect(); gc.disable()          # (as timeit does: tools/fit_one.py)
     t0 = time.perf_counter()
     solver.fit(niters=iters, batch_size=batch, sampler=sampler)
     torch.cuda.synchronize()
