@@ -812,6 +812,8 @@ class Solver:
             self._generic_step(torch.rand((5, model.total), device=self.device, generator=gen), loss_terms,
                                [num for num in nums_constraints if num < len(self.constraints)], criterion, 1)
             values = self.grads[torch.tensor(offsets, device=self.device)].tolist()
+        except Exception:                                       # (an equation that cannot be evaluated on U[0, 1) points: the fit itself will say;
+            return []                                           #  every scalar counts as reached, the behaviour before this check existed)
         finally:
             self.grads.copy_(keep)
         return [off for off, v in zip(offsets, values) if v == 0.0]
